@@ -1,0 +1,244 @@
+// Linear attention (feature map elu(x)+1) -- there is no QK^T matrix and no softmax here:
+//   reduce:  KV[g,h] = sum_s K'_s^T (V_s / S),  Ksum[g,h] = sum_s K'_s      (d x d and d per head)
+//   apply :  out_q   = (Q'_q KV) / (Q'_q . Ksum + eps) * S
+// d = D / heads is 4..32, so the d x d accumulator of one (group, head) lives in the registers of
+// one wave: lane = (key lane, row chunk); the cross-lane sum over key lanes is a butterfly of
+// wavefront shuffles.  Which keys form a group (a ToF zone's 16 samples, a ws x ws window with
+// its zero padding, the sub-sampled global keys, the inside-zone rectangle) is pure addressing.
+#include "common.h"
+
+namespace {
+
+struct KvP {
+  const void* k; const void* v;
+  float* kv; float* ksum; float* ws;
+  int k_ld, v_ld;
+  int NB, Hk, Wk, th, tw, gy, gx;
+  int cy0, cy1, cx0, cx1;
+  int count_pad, heads, d, nsplit;
+  float inv_len;
+};
+
+// IC rows of the d x d accumulator per lane; TPK = d / IC lanes per key; KL = 64 / TPK key lanes.
+template <int D> struct KvCfg;
+template <> struct KvCfg<4>  { static constexpr int IC = 4; };
+template <> struct KvCfg<8>  { static constexpr int IC = 8; };
+template <> struct KvCfg<16> { static constexpr int IC = 4; };
+template <> struct KvCfg<32> { static constexpr int IC = 2; };
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void kv_reduce_kernel(KvP p) {
+  constexpr int IC = KvCfg<D>::IC;
+  constexpr int TPK = D / IC;
+  constexpr int KL = 64 / TPK;
+  const T* __restrict__ K = reinterpret_cast<const T*>(p.k);
+  const T* __restrict__ V = reinterpret_cast<const T*>(p.v);
+  const int g = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int ip = lane % TPK, kl = lane / TPK;
+
+  const int gpb = p.gy * p.gx;
+  const int b = g / gpb, gi = g % gpb;
+  const int ty = gi / p.gx, tx = gi % p.gx;
+  // key rectangle of this group: tile, clipped to the grid and to the clip rectangle
+  const int y0 = max(max(ty * p.th, p.cy0), 0), y1 = min(min((ty + 1) * p.th, p.cy1), p.Hk);
+  const int x0 = max(max(tx * p.tw, p.cx0), 0), x1 = min(min((tx + 1) * p.tw, p.cx1), p.Wk);
+  const int rh = max(y1 - y0, 0), rw = max(x1 - x0, 0);
+  const int S = rh * rw;
+  const int per = (S + p.nsplit - 1) / p.nsplit;
+  const int s_begin = sp * per, s_end = min(S, s_begin + per);
+
+  float acc[IC][D];
+  float ks[IC];
+#pragma unroll
+  for (int i = 0; i < IC; ++i) {
+    ks[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) acc[i][j] = 0.f;
+  }
+  for (int s = s_begin + kl; s < s_end; s += KL) {
+    const int yy = y0 + s / rw, xx = x0 + s % rw;
+    const long long row = ((long long)b * p.Hk + yy) * p.Wk + xx;
+    const T* kp = K + row * p.k_ld + h * D + ip * IC;
+    const T* vp = V + row * p.v_ld + h * D;
+    float kf[IC], vf[D];
+#pragma unroll
+    for (int i = 0; i < IC; ++i) kf[i] = elu1(to_f32<T>(kp[i]));
+#pragma unroll
+    for (int j = 0; j < D; ++j) vf[j] = to_f32<T>(vp[j]) * p.inv_len;
+#pragma unroll
+    for (int i = 0; i < IC; ++i) {
+      ks[i] += kf[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[i][j] = fmaf(kf[i], vf[j], acc[i][j]);
+    }
+  }
+  // butterfly over the key lanes (lanes with equal ip)
+#pragma unroll
+  for (int o = TPK; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < IC; ++i) {
+      ks[i] += __shfl_xor(ks[i], o, 64);
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[i][j] += __shfl_xor(acc[i][j], o, 64);
+    }
+  }
+  if (kl == 0) {
+    // zero-padded window positions: K' = elu(0)+1 = 1, V = 0 (only the first split adds them)
+    float padk = 0.f;
+    if (p.count_pad && sp == 0) padk = (float)(p.th * p.tw - S);
+    float* dkv; float* dks;
+    if (p.nsplit == 1) {
+      dkv = p.kv + ((long long)g * p.heads + h) * D * D;
+      dks = p.ksum + ((long long)g * p.heads + h) * D;
+    } else {
+      float* base = p.ws + (((long long)g * p.heads + h) * p.nsplit + sp) * (D * D + D);
+      dkv = base; dks = base + D * D;
+    }
+#pragma unroll
+    for (int i = 0; i < IC; ++i) {
+      dks[ip * IC + i] = ks[i] + padk;
+#pragma unroll
+      for (int j = 0; j < D; ++j) dkv[(ip * IC + i) * D + j] = acc[i][j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restrict__ ws, float* __restrict__ kv,
+                                                          float* __restrict__ ksum, int nsplit, int d, long long items) {
+  // one thread per element of [group*head][d*d + d]
+  const int per = d * d + d;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items * per; i += (long long)gridDim.x * 256) {
+    long long gh = i / per;
+    int e = (int)(i % per);
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += ws[(gh * nsplit + j) * per + e];
+    if (e < d * d) kv[gh * d * d + e] = s; else ksum[gh * d + (e - d * d)] = s;
+  }
+}
+
+struct ApP {
+  const void* q; const float* kv; const float* ksum; void* out;
+  int q_ld, out_ld, NB, Hq, Wq, qth, qtw, ggy, ggx;
+  int ey0, ey1, ex0, ex1, heads;
+  float v_length, eps;
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_apply_kernel(ApP p) {
+  const T* __restrict__ Q = reinterpret_cast<const T*>(p.q);
+  T* __restrict__ O = reinterpret_cast<T*>(p.out);
+  const long long total = (long long)p.NB * p.Hq * p.Wq * p.heads;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int h = (int)(i % p.heads);
+    const long long tok = i / p.heads;
+    const int x = (int)(tok % p.Wq);
+    const long long t = tok / p.Wq;
+    const int y = (int)(t % p.Hq);
+    const int b = (int)(t / p.Hq);
+    T* op = O + tok * p.out_ld + h * D;
+    float o[D];
+    if (y >= p.ey0 && y < p.ey1 && x >= p.ex0 && x < p.ex1) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = 0.f;
+    } else {
+      const long long g = ((long long)b * p.ggy + y / p.qth) * p.ggx + x / p.qtw;
+      const float* kv = p.kv + (g * p.heads + h) * D * D;
+      const float* ks = p.ksum + (g * p.heads + h) * D;
+      const T* qp = Q + tok * p.q_ld + h * D;
+      float z = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int ii = 0; ii < D; ++ii) {
+        const float qv = elu1(to_f32<T>(qp[ii]));
+        z = fmaf(qv, ks[ii], z);
+#pragma unroll
+        for (int j = 0; j < D; ++j) o[j] = fmaf(qv, kv[ii * D + j], o[j]);
+      }
+      const float zi = 1.f / (z + p.eps);
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = o[j] * zi * p.v_length;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) op[j] = from_f32<T>(o[j]);
+  }
+}
+
+int pick_nsplit(int S, long long groups_heads) {
+  // enough waves to cover the chip, at least ~64 keys per wave
+  long long want = (2048 + groups_heads - 1) / groups_heads;
+  int by_keys = (S + 63) / 64;
+  long long n = want < by_keys ? want : by_keys;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return (int)n;
+}
+
+}  // namespace
+
+extern "C" size_t cfp_attn_kv_ws_floats(int NB, int Hk, int Wk, int th, int tw, int heads, int d) {
+  if (NB <= 0 || Hk <= 0 || Wk <= 0 || th <= 0 || tw <= 0 || heads <= 0 || d <= 0) return 0;
+  long long groups = (long long)NB * cdiv(Hk, th) * cdiv(Wk, tw);
+  int S = (th < Hk ? th : Hk) * (tw < Wk ? tw : Wk);
+  int ns = pick_nsplit(S, groups * heads);
+  return (size_t)(groups * heads * ns * (d * d + d));
+}
+
+extern "C" int cfp_attn_kv_reduce(const void* k, int k_ld, const void* v, int v_ld, float* kv, float* ksum, float* ws,
+                                  int NB, int Hk, int Wk, int th, int tw, int cy0, int cy1, int cx0, int cx1,
+                                  int count_pad, float v_length, int heads, int d, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_attn_kv_reduce: bad dtype");
+  CFP_REQUIRE(k && v && kv && ksum, CFP_EINVAL, "cfp_attn_kv_reduce: null pointer");
+  CFP_REQUIRE(NB > 0 && Hk > 0 && Wk > 0 && th > 0 && tw > 0 && heads > 0 && (d == 4 || d == 8 || d == 16 || d == 32) &&
+                  k_ld >= heads * d && v_ld >= heads * d && v_length > 0.f,
+              CFP_ESHAPE, "cfp_attn_kv_reduce: bad shape (head dim must be 4, 8, 16 or 32)");
+  KvP p;
+  p.k = k; p.v = v; p.kv = kv; p.ksum = ksum; p.ws = ws; p.k_ld = k_ld; p.v_ld = v_ld;
+  p.NB = NB; p.Hk = Hk; p.Wk = Wk; p.th = th; p.tw = tw; p.gy = cdiv(Hk, th); p.gx = cdiv(Wk, tw);
+  p.cy0 = cy0; p.cy1 = cy1; p.cx0 = cx0; p.cx1 = cx1; p.count_pad = count_pad; p.heads = heads; p.d = d;
+  p.inv_len = 1.0f / v_length;
+  long long groups = (long long)NB * p.gy * p.gx;
+  int S = (th < Hk ? th : Hk) * (tw < Wk ? tw : Wk);
+  p.nsplit = pick_nsplit(S, groups * heads);
+  CFP_REQUIRE(p.nsplit == 1 || ws, CFP_EINVAL, "cfp_attn_kv_reduce: workspace required");
+  CFP_REQUIRE(groups < (1ll << 31) && heads <= 65535, CFP_ESHAPE, "cfp_attn_kv_reduce: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)groups, heads, p.nsplit);
+#define KV_LAUNCH(T, D) hipLaunchKernelGGL((kv_reduce_kernel<T, D>), grid, dim3(64), 0, s, p)
+#define KV_SWITCH(T) switch (d) { case 4: KV_LAUNCH(T, 4); break; case 8: KV_LAUNCH(T, 8); break; \
+                                  case 16: KV_LAUNCH(T, 16); break; default: KV_LAUNCH(T, 32); break; }
+  if (dtype == CFP_BF16) { KV_SWITCH(bf16_t) } else { KV_SWITCH(float) }
+#undef KV_SWITCH
+#undef KV_LAUNCH
+  if (p.nsplit > 1) {
+    long long items = groups * heads;
+    long long total = items * (d * d + d);
+    int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(kv_finalize_kernel, dim3(blocks), dim3(256), 0, s, ws, kv, ksum, p.nsplit, d, items);
+  }
+  return cfp_check_launch("cfp_attn_kv_reduce");
+}
+
+extern "C" int cfp_attn_apply(const void* q, int q_ld, const float* kv, const float* ksum, void* out, int out_ld,
+                              int NB, int Hq, int Wq, int qth, int qtw, int ey0, int ey1, int ex0, int ex1,
+                              float v_length, float eps, int heads, int d, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_attn_apply: bad dtype");
+  CFP_REQUIRE(q && kv && ksum && out, CFP_EINVAL, "cfp_attn_apply: null pointer");
+  CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && heads > 0 && (d == 4 || d == 8 || d == 16 || d == 32) &&
+                  q_ld >= heads * d && out_ld >= heads * d, CFP_ESHAPE, "cfp_attn_apply: bad shape");
+  ApP p;
+  p.q = q; p.kv = kv; p.ksum = ksum; p.out = out; p.q_ld = q_ld; p.out_ld = out_ld;
+  p.NB = NB; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
+  p.ey0 = ey0; p.ey1 = ey1; p.ex0 = ex0; p.ex1 = ex1; p.heads = heads; p.v_length = v_length; p.eps = eps;
+  long long total = (long long)NB * Hq * Wq * heads;
+  int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define AP_LAUNCH(T, D) hipLaunchKernelGGL((attn_apply_kernel<T, D>), dim3(blocks), dim3(256), 0, s, p)
+#define AP_SWITCH(T) switch (d) { case 4: AP_LAUNCH(T, 4); break; case 8: AP_LAUNCH(T, 8); break; \
+                                  case 16: AP_LAUNCH(T, 16); break; default: AP_LAUNCH(T, 32); break; }
+  if (dtype == CFP_BF16) { AP_SWITCH(bf16_t) } else { AP_SWITCH(float) }
+#undef AP_SWITCH
+#undef AP_LAUNCH
+  return cfp_check_launch("cfp_attn_apply");
+}

@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, 16-byte vector accesses).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/cfpnet_hip.h"
+
+typedef unsigned short bf16_t;  // storage type of a bf16 element
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// One 16-byte vector of T: 4 x f32 or 8 x bf16.
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(p);
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) {
+    f32x4 x = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = x;
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    u32x4 x = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(x[i] << 16);
+      v[2 * i + 1] = __uint_as_float(x[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    u32x4 x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = x;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case CFP_ACT_RELU: return x > 0.f ? x : 0.f;
+    case CFP_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
+    case CFP_ACT_SILU: return x / (1.f + __expf(-x));
+    case CFP_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case CFP_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }  // elu(x)+1
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side -------------------------------------------------------------------------
+void cfp_set_error(const std::string& msg);
+int cfp_check_launch(const char* what);
+
+#define CFP_REQUIRE(cond, code, msg)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      cfp_set_error(std::string(msg));      \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int vec_elems(int dtype) { return dtype == CFP_BF16 ? 8 : 4; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,420 @@
+// Bandwidth-bound helper kernels: reductions over H*W, the SE gate, LayerNorm, bilinear
+// resampling (with the zone crop / scatter folded into its addressing), broadcast adds, layout
+// conversion.  All of them move 16 bytes per lane per access along the channel axis.
+#include "common.h"
+
+namespace {
+
+// ---- channel sums: partial[b][s][c] = sum over the s-th slice of the HW rows ------------
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ in, int in_ld, float* __restrict__ partial,
+                                                          int HW, int C, int nsplit) {
+  constexpr int VE = Vec<T>::N;
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.y, s = blockIdx.x;
+  const int CV = C / VE;
+  const int rows_per = (HW + nsplit - 1) / nsplit;
+  const int r_begin = s * rows_per;
+  const int r_end = min(HW, r_begin + rows_per);
+  const int lanes_r = 256 / CV > 0 ? 256 / CV : 1;   // row lanes when CV <= 256
+  // channel vectors are walked in chunks of up to 256
+  for (int cv0 = 0; cv0 < CV; cv0 += 256) {
+    const int ncv = min(256, CV - cv0);
+    const int rl = 256 / ncv;                 // row lanes for this chunk
+    const int cv = threadIdx.x % ncv, rr = threadIdx.x / ncv;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (rr < rl) {
+      for (int r = r_begin + rr; r < r_end; r += rl) {
+        float v[VE];
+        Vec<T>::load(in + ((long long)b * HW + r) * in_ld + (cv0 + cv) * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] += v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < ncv) {
+      float t[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) t[e] = 0.f;
+      for (int j = 0; j < rl; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) t[e] += red[(j * ncv + threadIdx.x) * 8 + e];
+      float* dst = partial + ((long long)b * nsplit + s) * C + (cv0 + threadIdx.x) * VE;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) dst[e] = t[e];
+    }
+    __syncthreads();
+  }
+  (void)lanes_r;
+}
+
+// ---- SE gate: one workgroup per batch element --------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
+                                                      const float* __restrict__ wr, const float* __restrict__ br,
+                                                      const float* __restrict__ we, const float* __restrict__ be,
+                                                      float* __restrict__ gate, int C, int R) {
+  extern __shared__ float sm[];   // mean[C] then hidden[R]
+  float* mean = sm;
+  float* hid = sm + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += partial[((long long)b * nsplit + j) * C + c];
+    mean[c] = s * inv_hw;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(mean[c], wr[(long long)r * C + c], s);
+    s = wave_sum(s);
+    if (lane == 0) hid[r] = apply_act(s + br[r], CFP_ACT_SILU);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = be[c];
+    for (int r = 0; r < R; ++r) s = fmaf(hid[r], we[(long long)c * R + r], s);
+    gate[(long long)b * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int ld, const float* __restrict__ gate,
+                                                             int HW, int C, long long total) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long long row = i / CV;
+    int b = (int)(row / HW);
+    float v[VE];
+    T* p = x + row * ld + cv * VE;
+    Vec<T>::load(p, v);
+    const float* g = gate + (long long)b * C + cv * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] *= g[e];
+    Vec<T>::store(p, v);
+  }
+}
+
+// ---- LayerNorm: LPR lanes per row, each lane one 16-byte vector -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ in, int in_ld, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        const T* __restrict__ res, int res_ld, T* __restrict__ out,
+                                                        int out_ld, int rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int LPR = C / VE;               // power of two, <= 64
+  const int rows_per_block = 256 / LPR;
+  const int lr = threadIdx.x % LPR;
+  const int rb = threadIdx.x / LPR;
+  float g[VE], bt[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { g[e] = gamma[lr * VE + e]; bt[e] = beta[lr * VE + e]; }
+  const float inv_c = 1.f / (float)C;
+  for (long long row0 = (long long)blockIdx.x * rows_per_block; row0 < rows; row0 += (long long)gridDim.x * rows_per_block) {
+    long long row = row0 + rb;
+    bool ok = row < rows;
+    float v[VE];
+    if (ok) Vec<T>::load(in + row * in_ld + lr * VE, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s += v[e];
+    for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { float d = v[e] - mean; q = fmaf(d, d, q); }
+    for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    if (ok) {
+      float o_[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o_[e] = (v[e] - mean) * rstd * g[e] + bt[e];
+      if (res) {
+        float r_[VE];
+        Vec<T>::load(res + row * res_ld + lr * VE, r_);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o_[e] += r_[e];
+      }
+      Vec<T>::store(out + row * out_ld + lr * VE, o_);
+    }
+  }
+}
+
+// ---- bilinear resampling, align_corners=True ---------------------------------------------
+struct ResizeP {
+  const void* src; void* dst; const uint8_t* zone_valid;
+  int src_ld, Hs, Ws, sy0, sx0, sh, sw;
+  int dst_ld, Hd, Wd, dy0, dx0, dh, dw;
+  int zn, p1, p2, accumulate, B, C;
+  float scale_y, scale_x;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_kernel(ResizeP p) {
+  constexpr int VE = Vec<T>::N;
+  const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+  T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
+  const int CV = p.C / VE;
+  const long long total = (long long)p.B * p.dh * p.dw * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long long t = i / CV;
+    int dx = (int)(t % p.dw); t /= p.dw;
+    int dy = (int)(t % p.dh);
+    int b = (int)(t / p.dh);
+    const int oy = p.dy0 + dy, ox = p.dx0 + dx;
+    if (oy < 0 || oy >= p.Hd || ox < 0 || ox >= p.Wd) continue;
+    // source coordinate inside the source rectangle (torch: src = scale * dst_index)
+    const float fy = p.scale_y * (float)dy, fx = p.scale_x * (float)dx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.sh - 1 ? 1 : 0), x1 = x0 + (x0 < p.sw - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    float tap[4][VE];
+    const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int ry = ys[a], rx = xs[c];              // rectangle coordinates
+        const int gy = p.sy0 + ry, gx = p.sx0 + rx;    // source-map coordinates
+        float* tp = tap[a * 2 + c];
+        bool ok = gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws;
+        if (ok && p.zone_valid) ok = p.zone_valid[(long long)b * p.zn * p.zn + (ry / p.p1) * p.zn + rx / p.p2] != 0;
+        if (ok) Vec<T>::load(src + ((long long)(b * p.Hs + gy) * p.Ws + gx) * p.src_ld + cv * VE, tp);
+        else {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) tp[e] = 0.f;
+        }
+      }
+    float o[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+      o[e] = ly0 * (lx0 * tap[0][e] + lx1 * tap[1][e]) + ly1 * (lx0 * tap[2][e] + lx1 * tap[3][e]);
+    T* dp = dst + ((long long)(b * p.Hd + oy) * p.Wd + ox) * p.dst_ld + cv * VE;
+    if (p.accumulate) {
+      float d[VE];
+      Vec<T>::load(dp, d);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o[e] += d[e];
+    }
+    Vec<T>::store(dp, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_rowtable_kernel(const T* __restrict__ in, int in_ld, const float* __restrict__ table,
+                                                           T* __restrict__ out, int out_ld, long long rows, int C, int H, int W,
+                                                           int Wt, int oy, int ox) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long long r = i / CV;
+    long long trow = ((r / W) % H + oy) * (long long)Wt + (r % W) + ox;
+    float v[VE];
+    Vec<T>::load(in + r * in_ld + cv * VE, v);
+    const float* tp = table + trow * C + cv * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] += tp[e];
+    Vec<T>::store(out + r * out_ld + cv * VE, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ in, int in_ld, T* __restrict__ out, int out_ld,
+                                                        long long rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int cv = (int)(i % CV);
+    long long r = i / CV;
+    *reinterpret_cast<u32x4*>(out + r * out_ld + cv * VE) = *reinterpret_cast<const u32x4*>(in + r * in_ld + cv * VE);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restrict__ rgb, T* __restrict__ out, int HW, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long b = i / HW, hw = i % HW;
+    const float* p = rgb + b * 3 * HW + hw;
+    float v[8] = {p[0], p[HW], p[2 * (long long)HW], 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(out) + i * 8, v);
+    else { Vec<float>::store(reinterpret_cast<float*>(out) + i * 8, v); Vec<float>::store(reinterpret_cast<float*>(out) + i * 8 + 4, v + 4); }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scalar_to_rows8_kernel(const float* __restrict__ in, T* __restrict__ out, long long rows) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
+    float v[8] = {in[i], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(out) + i * 8, v);
+    else { Vec<float>::store(reinterpret_cast<float*>(out) + i * 8, v); Vec<float>::store(reinterpret_cast<float*>(out) + i * 8 + 4, v + 4); }
+  }
+}
+
+inline int ew_blocks(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define CHECK_DTYPE(name) CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, name ": bad dtype")
+
+extern "C" int cfp_channel_sum(const void* in, int in_ld, float* partial, int B, int HW, int C, int nsplit, int dtype,
+                               cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_channel_sum");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(in && partial && aligned16(in), CFP_EINVAL, "cfp_channel_sum: bad pointer");
+  CFP_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && in_ld >= C && nsplit > 0 && nsplit <= 65535,
+              CFP_ESHAPE, "cfp_channel_sum: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, s, (const bf16_t*)in, in_ld, partial, HW, C, nsplit);
+  else
+    hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nsplit, B), dim3(256), 0, s, (const float*)in, in_ld, partial, HW, C, nsplit);
+  return cfp_check_launch("cfp_channel_sum");
+}
+
+extern "C" int cfp_se_gate(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                           const float* w_expand, const float* b_expand, float* gate, int B, int C, int R,
+                           cfp_stream_t stream) {
+  CFP_REQUIRE(partial && w_reduce && b_reduce && w_expand && b_expand && gate, CFP_EINVAL, "cfp_se_gate: null pointer");
+  CFP_REQUIRE(B > 0 && C > 0 && R > 0 && nsplit > 0 && (size_t)(C + R) * 4 <= 64 * 1024, CFP_ESHAPE, "cfp_se_gate: bad shape");
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + R) * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                     partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand, b_expand, gate, C, R);
+  return cfp_check_launch("cfp_se_gate");
+}
+
+extern "C" int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_scale_channels");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(x && gate && aligned16(x), CFP_EINVAL, "cfp_scale_channels: bad pointer");
+  CFP_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0 && ld % ve == 0 && ld >= C, CFP_ESHAPE, "cfp_scale_channels: bad shape");
+  long long total = (long long)B * HW * (C / ve);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(scale_channels_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (bf16_t*)x, ld, gate, HW, C, total);
+  else
+    hipLaunchKernelGGL(scale_channels_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (float*)x, ld, gate, HW, C, total);
+  return cfp_check_launch("cfp_scale_channels");
+}
+
+extern "C" int cfp_layernorm(const void* in, int in_ld, const float* gamma, const float* beta, float eps,
+                             const void* residual, int res_ld, void* out, int out_ld, int rows, int C, int dtype,
+                             cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_layernorm");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(in && gamma && beta && out && aligned16(in) && aligned16(out) && aligned16(residual), CFP_EINVAL,
+              "cfp_layernorm: bad pointer");
+  const int lpr = C / ve;
+  CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && in_ld % ve == 0 && out_ld % ve == 0 &&
+                  in_ld >= C && out_ld >= C && (!residual || (res_ld % ve == 0 && res_ld >= C)),
+              CFP_ESHAPE, "cfp_layernorm: C / vector width must be a power of two <= 64");
+  const int rpb = 256 / lpr;
+  long long blocks = ((long long)rows + rpb - 1) / rpb;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)in, in_ld, gamma, beta, eps,
+                       (const bf16_t*)residual, res_ld, (bf16_t*)out, out_ld, rows, C);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in, in_ld, gamma, beta, eps,
+                       (const float*)residual, res_ld, (float*)out, out_ld, rows, C);
+  return cfp_check_launch("cfp_layernorm");
+}
+
+extern "C" int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, int sy0, int sx0, int sh, int sw,
+                                   void* dst, int dst_ld, int Hd, int Wd, int dy0, int dx0, int dh, int dw,
+                                   const uint8_t* zone_valid, int zn, int p1, int p2, int accumulate, int B, int C,
+                                   int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_resize_bilinear");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(src && dst && aligned16(src) && aligned16(dst), CFP_EINVAL, "cfp_resize_bilinear: bad pointer");
+  CFP_REQUIRE(B > 0 && C > 0 && C % 8 == 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 &&
+                  src_ld % ve == 0 && dst_ld % ve == 0 && src_ld >= C && dst_ld >= C,
+              CFP_ESHAPE, "cfp_resize_bilinear: bad shape");
+  CFP_REQUIRE(!zone_valid || (zn > 0 && p1 > 0 && p2 > 0 && sh <= zn * p1 && sw <= zn * p2), CFP_ESHAPE,
+              "cfp_resize_bilinear: zone grid smaller than the source rectangle");
+  ResizeP p;
+  p.src = src; p.dst = dst; p.zone_valid = zone_valid;
+  p.src_ld = src_ld; p.Hs = Hs; p.Ws = Ws; p.sy0 = sy0; p.sx0 = sx0; p.sh = sh; p.sw = sw;
+  p.dst_ld = dst_ld; p.Hd = Hd; p.Wd = Wd; p.dy0 = dy0; p.dx0 = dx0; p.dh = dh; p.dw = dw;
+  p.zn = zn; p.p1 = p1; p.p2 = p2; p.accumulate = accumulate; p.B = B; p.C = C;
+  p.scale_y = dh > 1 ? (float)(sh - 1) / (float)(dh - 1) : 0.f;
+  p.scale_x = dw > 1 ? (float)(sw - 1) / (float)(dw - 1) : 0.f;
+  long long total = (long long)B * dh * dw * (C / ve);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(resize_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(resize_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
+  return cfp_check_launch("cfp_resize_bilinear");
+}
+
+extern "C" int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C,
+                                int H, int W, int Wt, int oy, int ox, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_add_rowtable");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(in && table && out && aligned16(in) && aligned16(out), CFP_EINVAL, "cfp_add_rowtable: bad pointer");
+  CFP_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && Wt >= W + ox && oy >= 0 && ox >= 0 && in_ld % ve == 0 &&
+                  out_ld % ve == 0 && in_ld >= C && out_ld >= C, CFP_ESHAPE, "cfp_add_rowtable: bad shape");
+  long long total = (long long)rows * (C / ve);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(add_rowtable_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, table,
+                       (bf16_t*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
+  else
+    hipLaunchKernelGGL(add_rowtable_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, table,
+                       (float*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
+  return cfp_check_launch("cfp_add_rowtable");
+}
+
+extern "C" int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, int C, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_copy_rows");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(in && out && aligned16(in) && aligned16(out), CFP_EINVAL, "cfp_copy_rows: bad pointer");
+  CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && in_ld % ve == 0 && out_ld % ve == 0 && in_ld >= C && out_ld >= C, CFP_ESHAPE,
+              "cfp_copy_rows: bad shape");
+  long long total = (long long)rows * (C / ve);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, (bf16_t*)out, out_ld, (long long)rows, C);
+  else
+    hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, (long long)rows, C);
+  return cfp_check_launch("cfp_copy_rows");
+}
+
+extern "C" int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_rgb_to_nhwc8");
+  CFP_REQUIRE(rgb && out && aligned16(out), CFP_EINVAL, "cfp_rgb_to_nhwc8: bad pointer");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0, CFP_ESHAPE, "cfp_rgb_to_nhwc8: bad shape");
+  long long total = (long long)B * H * W;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(rgb_to_nhwc8_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (bf16_t*)out, H * W, total);
+  else hipLaunchKernelGGL(rgb_to_nhwc8_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (float*)out, H * W, total);
+  return cfp_check_launch("cfp_rgb_to_nhwc8");
+}
+
+extern "C" int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_scalar_to_rows8");
+  CFP_REQUIRE(in && out && aligned16(out), CFP_EINVAL, "cfp_scalar_to_rows8: bad pointer");
+  CFP_REQUIRE(rows > 0, CFP_ESHAPE, "cfp_scalar_to_rows8: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(scalar_to_rows8_kernel<bf16_t>, dim3(ew_blocks(rows)), dim3(256), 0, s, in, (bf16_t*)out, (long long)rows);
+  else hipLaunchKernelGGL(scalar_to_rows8_kernel<float>, dim3(ew_blocks(rows)), dim3(256), 0, s, in, (float*)out, (long long)rows);
+  return cfp_check_launch("cfp_scalar_to_rows8");
+}

@@ -1,0 +1,494 @@
+"""Inference engine: `Deltar.forward` as a sequence of HIP kernel launches.
+
+The reference's forward (`/root/reference/src/models/deltar.py:34-67`) is ~1000 eager PyTorch
+ops.  Here the same computation is a static launch list over NHWC buffers:
+
+  * parameters are packed once (BatchNorm folded into per-channel scale/shift, conv weights
+    re-laid [Cout][kh][kw][Cin], q/k/v projections concatenated, storage dtype bf16 or f32);
+  * every `rearrange 'b (h w) c <-> b c h w'` of the reference disappears (tokens ARE NHWC);
+  * every `torch.cat` disappears: producers write into channel slices of the consumer's buffer;
+  * the zone crop / per-zone regrouping / boolean-mask scatter of `fusion.py:103-157` and the
+    window partition of `transformer.py:104-115` are kernel addressing (see geometry.py);
+  * the whole list can be captured into one HIP graph (`capture()` / `replay()`), because no
+    step needs a device->host sync (the reference syncs 6x per forward, transformer.py:218).
+
+torch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip, ops, spec
+from .geometry import FusionGeometry, gsa_keys
+from .ops import Act
+
+_BN_EPS = 1e-5
+
+
+def _same_pad(size: int, k: int, s: int) -> Tuple[int, int]:
+    total = max((math.ceil(size / s) - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
+class Engine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, layer_names: Sequence[str], n_bins: int = 256,
+                 min_val: float = 1e-3, max_val: float = 10.0, norm: str = "linear", change_embedding: bool = True,
+                 no_skip_inside: bool = False, stem_act: bool = False, dtype=torch.bfloat16, device="cuda:0",
+                 zone_sample_num: int = 16):
+        hip.load()   # fail loudly if the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("cfpnet_amd.Engine needs a GPU: the product path has no CPU fallback")
+        assert dtype in (torch.bfloat16, torch.float32)
+        self.layer_names = list(layer_names)
+        self.n_bins, self.min_val, self.max_val = n_bins, float(min_val), float(max_val)
+        self.norm = {"linear": 0, "softmax": 1, "sigmoid": 2}[norm]
+        self.change_embedding, self.no_skip_inside, self.stem_act = change_embedding, no_skip_inside, stem_act
+        self.dtype, self.device = dtype, torch.device(device)
+        self.zone_sample_num = zone_sample_num
+        self.ve = 8 if dtype == torch.bfloat16 else 4
+        self.P: Dict[str, torch.Tensor] = {}
+        self._plans: Dict[tuple, dict] = {}
+        self._graph = None
+        self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------------------ packing
+    def _dev(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=dtype or torch.float32).contiguous()
+
+    def _pack_conv(self, w: torch.Tensor) -> torch.Tensor:
+        """[Co,Ci,kh,kw] or [Co,Ci] or [Co,Ci,1] -> [Co, kh*kw*Ci_padded] in the storage dtype."""
+        w = w.detach().float()
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        elif w.dim() == 3:
+            w = w[:, :, :, None]
+        co, ci, kh, kw = w.shape
+        cip = (ci + 7) // 8 * 8
+        if cip != ci:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cip - ci))
+        return self._dev(w.permute(0, 2, 3, 1).reshape(co, kh * kw * cip), self.dtype)
+
+    def _fold_bn(self, sd, bn: Optional[str], bias: Optional[torch.Tensor], co: int, eps: float):
+        """y = conv*scale + shift  ==  BN(conv + bias)"""
+        if bn is None:
+            scale = torch.ones(co)
+            shift = bias.detach().float().clone() if bias is not None else torch.zeros(co)
+        else:
+            g, b = sd[bn + ".weight"].float(), sd[bn + ".bias"].float()
+            m, v = sd[bn + ".running_mean"].float(), sd[bn + ".running_var"].float()
+            scale = g / torch.sqrt(v + eps)
+            shift = b - m * scale
+            if bias is not None:
+                shift = shift + bias.detach().float() * scale
+        return self._dev(scale), self._dev(shift)
+
+    def _conv(self, sd, name: str, wkey: str, bkey: Optional[str] = None, bn: Optional[str] = None, eps: float = _BN_EPS):
+        w = sd[wkey]
+        self.P[name + ".w"] = self._pack_conv(w)
+        s, t = self._fold_bn(sd, bn, sd[bkey] if bkey else None, w.shape[0], eps)
+        self.P[name + ".s"], self.P[name + ".t"] = s, t
+
+    def _loftr_pack(self, sd, p: str, self_attn: bool):
+        D = sd[p + ".q_proj.weight"].shape[0]
+        if self_attn:
+            self.P[p + ".qkv"] = self._pack_conv(torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0))
+        else:
+            self.P[p + ".q"] = self._pack_conv(sd[p + ".q_proj.weight"])
+            self.P[p + ".kv"] = self._pack_conv(torch.cat([sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0))
+        self.P[p + ".merge"] = self._pack_conv(sd[p + ".merge.weight"])
+        self.P[p + ".mlp0"] = self._pack_conv(sd[p + ".mlp.0.weight"])
+        self.P[p + ".mlp2"] = self._pack_conv(sd[p + ".mlp.2.weight"])
+        for n in ("norm1", "norm2"):
+            self.P[f"{p}.{n}.g"], self.P[f"{p}.{n}.b"] = self._dev(sd[f"{p}.{n}.weight"]), self._dev(sd[f"{p}.{n}.bias"])
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Pack a reference-layout state dict for the kernels."""
+        self.P.clear()
+        self._graph = None
+        e = "img_encoder"
+        EPS = spec.ENC_BN_EPS
+        self._conv(sd, "stem", f"{e}.conv0.0.weight", bn=f"{e}.conv0.1", eps=EPS)
+        for b in spec.ENC_BLOCKS:
+            q = f"{e}.{b.prefix}"
+            if b.kind == "cn":
+                self._conv(sd, q + ".conv", q + ".conv.weight", bn=q + ".bn1", eps=EPS)
+            elif b.kind == "er":
+                self._conv(sd, q + ".exp", q + ".conv_exp.weight", bn=q + ".bn1", eps=EPS)
+                self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn2", eps=EPS)
+            else:
+                self._conv(sd, q + ".pw", q + ".conv_pw.weight", bn=q + ".bn1", eps=EPS)
+                wd = sd[q + ".conv_dw.weight"].float()
+                self.P[q + ".dw.w"] = self._dev(wd.reshape(wd.shape[0], 9).t(), self.dtype)
+                self.P[q + ".dw.s"], self.P[q + ".dw.t"] = self._fold_bn(sd, q + ".bn2", None, wd.shape[0], EPS)
+                self.P[q + ".se.wr"] = self._dev(sd[q + ".se.conv_reduce.weight"].reshape(b.se_rd, b.mid))
+                self.P[q + ".se.br"] = self._dev(sd[q + ".se.conv_reduce.bias"])
+                self.P[q + ".se.we"] = self._dev(sd[q + ".se.conv_expand.weight"].reshape(b.mid, b.se_rd))
+                self.P[q + ".se.be"] = self._dev(sd[q + ".se.conv_expand.bias"])
+                self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn3", eps=EPS)
+        for ex in (1, 2, 3):
+            q = f"hist_encoder.hist_extractor{ex}.pointnet_encoder"
+            for j in (1, 2, 3):
+                self._conv(sd, f"{q}.l{j}", f"{q}.conv{j}.weight", f"{q}.conv{j}.bias", bn=f"{q}.bn{j}")
+        d = "decoder"
+        self._conv(sd, d + ".conv4", d + ".conv4.weight", d + ".conv4.bias")
+        for i in (1, 2, 3, 4):
+            q = f"{d}.up{i}._net"
+            self._conv(sd, f"{d}.up{i}.a", q + ".0.weight", q + ".0.bias", bn=q + ".1")
+            self._conv(sd, f"{d}.up{i}.b", q + ".3.weight", q + ".3.bias", bn=q + ".4")
+        for n in ("conv3", "conv2", "conv1", "conv0"):
+            self._conv(sd, f"{d}.{n}", f"{d}.{n}.weight", f"{d}.{n}.bias")
+        for name in spec.FUSION:
+            q = f"{d}.{name}"
+            self.P[q + ".pe"] = self._dev(sd[q + ".positional_encodings"])
+            self.P[q + ".pe2"] = self._dev(sd[q + ".positional_encodings2"])
+            for i, ln in enumerate(self.layer_names):
+                l = f"{q}.layers.{i}"
+                if ln == "hist2image":
+                    self._loftr_pack(sd, l, False)
+                elif ln == "image":
+                    self._loftr_pack(sd, l + ".lga.encoder_layer", True)
+                    self._loftr_pack(sd, l + ".gsa.encoder_layer", False)
+                    self._conv(sd, l + ".gsa.sr", l + ".gsa.sr.weight", l + ".gsa.sr.bias")
+                    self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"] = self._dev(sd[l + ".gsa.norm.weight"]), self._dev(sd[l + ".gsa.norm.bias"])
+                elif ln == "combine1":
+                    t = l + ".transformer_path"
+                    self.P[t + ".qkv"] = self._pack_conv(torch.cat([sd[t + ".q_proj.weight"], sd[t + ".k_proj.weight"], sd[t + ".v_proj.weight"]], 0))
+                    self._conv(sd, t + ".conv1", t + ".conv1.weight", bn=t + ".bn1")
+                    self._conv(sd, t + ".conv2", t + ".conv2.weight", bn=t + ".bn2")
+                    k = l + ".large_kernel_path"
+                    wd = sd[k + ".dwconv2.weight"].float()
+                    kk = wd.shape[-1]
+                    self.P[k + ".dw.w"] = self._dev(wd.reshape(wd.shape[0], kk * kk).t())     # f32 [k*k][C]
+                    self.P[k + ".dw.s"], self.P[k + ".dw.t"] = self._fold_bn(sd, k + ".bn1", sd[k + ".dwconv2.bias"], wd.shape[0], _BN_EPS)
+                    self.P[k + ".norm.g"], self.P[k + ".norm.b"] = self._dev(sd[k + ".norm.weight"]), self._dev(sd[k + ".norm.bias"])
+                    self._conv(sd, k + ".pw1", k + ".pwconv1.weight", k + ".pwconv1.bias")
+                    self._conv(sd, k + ".pw2", k + ".pwconv2.weight", k + ".pwconv2.bias")
+                else:
+                    raise NotImplementedError(ln)
+        h = "depth_head"
+        self._conv(sd, h + ".conv3x3", h + ".conv3x3.weight", h + ".conv3x3.bias")
+        self.P[h + ".w1x1"] = self._dev(sd[h + ".conv1x1.weight"].reshape(128, 128))
+        for i in (0, 2, 4):
+            self.P[f"{h}.r{i}.w"], self.P[f"{h}.r{i}.b"] = self._dev(sd[f"{h}.regressor.{i}.weight"]), self._dev(sd[f"{h}.regressor.{i}.bias"])
+        self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias")
+
+    # ------------------------------------------------------------------------------ buffers
+    def _act(self, plan, key: str, rows: int, C: int, ld: Optional[int] = None, zero: bool = False) -> Act:
+        bufs = plan["bufs"]
+        if key not in bufs:
+            bufs[key] = ops.new_act(rows, C, self.dtype, self.device, ld, zero)
+        a = bufs[key]
+        assert a.rows == rows and a.ld == (ld or C), key
+        return Act(a.buf, 0, C)
+
+    def _f32(self, plan, key: str, n: int) -> torch.Tensor:
+        bufs = plan["bufs"]
+        if key not in bufs:
+            bufs[key] = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        assert bufs[key].numel() >= n, key
+        return bufs[key]
+
+    # ------------------------------------------------------------------------------ layers
+    def _cv(self, name, x: Act, out: Act, B, H, W, k, stride=1, pads=None, act=hip.ACT_NONE, residual=None):
+        if pads is None:
+            p = (k - 1) // 2
+            pt = pl = p
+            Ho, Wo = (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+        else:
+            (pt, pb), (pl, pr) = pads
+            Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
+        ops.conv2d(x, self.P[name + ".w"], self.P[name + ".s"], self.P[name + ".t"], out, B, H, W, k, k, stride, pt, pl,
+                   Ho, Wo, act, residual)
+        return Ho, Wo
+
+    def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None):
+        ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual)
+
+    def _encoder(self, plan, rgb: torch.Tensor, B, H, W, taps):
+        """encoder.py:71-79 over timm tf_efficientnetv2_b3 blocks; returns the five tap Acts."""
+        e = "img_encoder"
+        x8 = self._act(plan, "rgb8", B * H * W, 8)
+        ops.rgb_to_nhwc8(rgb, x8, B, H, W)
+        pads = (_same_pad(H, 3, 2), _same_pad(W, 3, 2))
+        h, w = math.ceil(H / 2), math.ceil(W / 2)
+        x = self._act(plan, "stem", B * h * w, spec.ENC_STEM_OUT)
+        self._cv("stem", x8, x, B, H, W, 3, 2, pads, hip.ACT_SILU if self.stem_act else hip.ACT_NONE)
+        tap_acts: List[Act] = []
+        for bi, b in enumerate(spec.ENC_BLOCKS):
+            q = f"{e}.{b.prefix}"
+            ho, wo = math.ceil(h / b.stride), math.ceil(w / b.stride)
+            pads = (_same_pad(h, 3, b.stride), _same_pad(w, 3, b.stride))
+            if bi in spec.ENC_TAPS:
+                out = plan["tap_dst"][spec.ENC_TAPS[bi]]
+            else:
+                out = self._act(plan, f"enc{bi}", B * ho * wo, b.cout)
+            res = x if b.skip else None
+            if b.kind == "cn":
+                self._cv(q + ".conv", x, out, B, h, w, 3, b.stride, pads, hip.ACT_SILU, res)
+            elif b.kind == "er":
+                mid = self._act(plan, f"enc{bi}.mid", B * ho * wo, b.mid)
+                self._cv(q + ".exp", x, mid, B, h, w, 3, b.stride, pads, hip.ACT_SILU)
+                self._cv(q + ".pwl", mid, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
+            else:
+                mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
+                self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
+                mid2 = self._act(plan, f"enc{bi}.dw", B * ho * wo, b.mid)
+                ops.dwconv3x3(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, B, h, w, b.stride,
+                              pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
+                ns = max(1, min(64, (ho * wo) // 64))
+                part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
+                gate = self._f32(plan, f"enc{bi}.gate", B * b.mid)
+                ops.channel_sum(mid2, part, B, ho * wo, ns)
+                ops.se_gate(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], self.P[q + ".se.we"],
+                            self.P[q + ".se.be"], gate, B, b.mid, b.se_rd)
+                ops.scale_channels(mid2, gate, B, ho * wo)
+                self._cv(q + ".pwl", mid2, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
+            x, h, w = out, ho, wo
+            if bi in spec.ENC_TAPS:
+                tap_acts.append(out)
+                if taps is not None:
+                    taps[f"enc{spec.ENC_TAPS[bi]}"] = self._nchw(out, B, h, w)
+        return tap_acts
+
+    def _hist_encoder(self, plan, hist: torch.Tensor, R: int, taps):
+        x = self._act(plan, "hist.in", R, 8)
+        ops.scalar_to_rows8(hist, x, R)
+        outs = []
+        for ex, c in zip((1, 2, 3), spec.HIST_CHANNELS):
+            q = f"hist_encoder.hist_extractor{ex}.pointnet_encoder"
+            for j in (1, 2, 3):
+                y = self._act(plan, f"hist.{ex}.{j}", R, c)
+                self._lin(f"{q}.l{j}.w", x, y, R, hip.ACT_RELU, None, f"{q}.l{j}")
+                x = y
+            outs.append(x)
+            if taps is not None:
+                taps[f"hist{ex - 1}"] = x.torch().float().cpu()
+        return outs
+
+    # -- LoFTR encoder layer (transformer.py:41-71) on tokens living in xb[:, 0:D] of a [rows, 2D] buffer
+    def _loftr(self, plan, tag, p, xb: Act, rows_q, src: Optional[Act], rows_s, heads, out: Act, kvmode: dict, apmode: dict):
+        D = xb.C // 2
+        d = D // heads
+        x = xb.slice(0, D)
+        qb = self._act(plan, f"{tag}.qkv", rows_q, 3 * D)
+        if src is None:       # self attention: one GEMM for q|k|v
+            self._lin(p + ".qkv", x, qb, rows_q)
+            kA, vA = qb.slice(D, D), qb.slice(2 * D, D)
+        else:
+            self._lin(p + ".q", x, qb.slice(0, D), rows_q)
+            kvb = self._act(plan, f"{tag}.kvsrc", rows_s, 2 * D)
+            self._lin(p + ".kv", src, kvb, rows_s)
+            kA, vA = kvb.slice(0, D), kvb.slice(D, D)
+        G = kvmode["groups"]
+        kv = self._f32(plan, f"{tag}.kv", G * heads * d * d)
+        ks = self._f32(plan, f"{tag}.ks", G * heads * d)
+        nws = ops.attn_kv_ws_floats(kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"], heads, d)
+        ws = self._f32(plan, f"{tag}.kvws", nws)
+        ops.attn_kv_reduce(kA, vA, kv, ks, ws, kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"],
+                           kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
+        msg = self._act(plan, f"{tag}.msg", rows_q, D)
+        ops.attn_apply(qb.slice(0, D), kv, ks, msg, apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"],
+                       (0, 0, 0, 0), kvmode["v_length"], heads, d)
+        m2 = self._act(plan, f"{tag}.m2", rows_q, D)
+        self._lin(p + ".merge", msg, m2, rows_q)
+        ops.layernorm(m2, self.P[p + ".norm1.g"], self.P[p + ".norm1.b"], 1e-5, xb.slice(D, D), rows_q)
+        hid = self._act(plan, f"{tag}.hid", rows_q, 2 * D)
+        self._lin(p + ".mlp0", xb, hid, rows_q, hip.ACT_RELU)
+        self._lin(p + ".mlp2", hid, m2, rows_q)
+        ops.layernorm(m2, self.P[p + ".norm2.g"], self.P[p + ".norm2.b"], 1e-5, out, rows_q, residual=x)
+
+    def _fusion(self, plan, name: str, x: Act, feat1: Act, zone_valid: torch.Tensor, geo: FusionGeometry, B, H, W, out: Act,
+                pos_offset, taps):
+        """fusion.py:52-188."""
+        D, (Hm, Wm), lk = spec.FUSION[name]
+        p = f"decoder.{name}"
+        ws = spec.window_size((Hm, Wm))
+        M = B * H * W
+        Z = geo.zone_num * geo.zone_num
+        N = self.zone_sample_num
+        tok = [self._act(plan, f"{name}.tokA", M, 2 * D), self._act(plan, f"{name}.tokB", M, 2 * D)]
+        cur = 0
+        oy, ox = pos_offset
+        ops.add_rowtable(x, self.P[p + ".pe"], tok[0].slice(0, D), M, H, W, Wm, oy, ox)
+        emb0 = None
+        if not self.change_embedding:
+            emb0 = self._act(plan, f"{name}.emb0", M, D)
+            ops.copy_rows(tok[0].slice(0, D), emb0, M)
+        src = self._act(plan, f"{name}.src", B * Z * N, D)
+        ops.add_rowtable(feat1, self.P[p + ".pe2"], src, B * Z * N, 1, N, N, 0, 0)
+        gh, gw = geo.grid_h, geo.grid_w
+        Mz = B * gh * gw
+        y0, y1, x0, x1 = geo.clipped(H, W)
+        rect = (geo.sy_wo, geo.sx_wo, geo.tzh, geo.tzw)
+
+        for i, ln in enumerate(self.layer_names):
+            l = f"{p}.layers.{i}"
+            tag = f"{name}.L{i}"
+            if ln == "hist2image":
+                zin = self._act(plan, f"{name}.zin", Mz, 2 * D)
+                zsrc = tok[cur].slice(0, D) if self.change_embedding else emb0
+                ops.resize_bilinear(zsrc, H, W, rect, zin.slice(0, D), gh, gw, (0, 0, gh, gw), B)
+                zout = self._act(plan, f"{name}.zout", Mz, D)
+                self._loftr(plan, f"{name}.x2i", l, zin, Mz, src, B * Z * N, spec.X2I_HEADS, zout,
+                            dict(groups=B * Z, NB=B * Z, Hk=1, Wk=N, th=1, tw=N, clip=(0, 1, 0, N), count_pad=False, v_length=float(N)),
+                            dict(NB=B, Hq=gh, Wq=gw, qth=geo.p1, qtw=geo.p2))
+                ops.resize_bilinear(zout, gh, gw, (0, 0, gh, gw), tok[cur].slice(0, D), H, W, rect, B, zone_valid=zone_valid,
+                                    zn=geo.zone_num, p1=geo.p1, p2=geo.p2, accumulate=not self.no_skip_inside)
+            elif ln == "image":
+                nh, nw = math.ceil(H / ws), math.ceil(W / ws)
+                self._loftr(plan, f"{name}.lsa", l + ".lga.encoder_layer", tok[cur], M, None, 0, spec.TWINS_HEADS, tok[cur ^ 1].slice(0, D),
+                            dict(groups=B * nh * nw, NB=B, Hk=H, Wk=W, th=ws, tw=ws, clip=(0, H, 0, W), count_pad=True, v_length=float(ws * ws)),
+                            dict(NB=B, Hq=H, Wq=W, qth=ws, qtw=ws))
+                cur ^= 1
+                hk, wk = gsa_keys(H, W, ws)
+                kraw = self._act(plan, f"{name}.gsa.kraw", B * hk * wk, D)
+                ops.conv2d(tok[cur].slice(0, D), self.P[l + ".gsa.sr.w"], self.P[l + ".gsa.sr.s"], self.P[l + ".gsa.sr.t"], kraw,
+                           B, H, W, ws, ws, ws, 0, 0, hk, wk)
+                keys = self._act(plan, f"{name}.gsa.keys", B * hk * wk, D)
+                ops.layernorm(kraw, self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5, keys, B * hk * wk)
+                S = hk * wk
+                self._loftr(plan, f"{name}.gsa", l + ".gsa.encoder_layer", tok[cur], M, keys, B * S, spec.TWINS_HEADS, tok[cur ^ 1].slice(0, D),
+                            dict(groups=B, NB=B, Hk=1, Wk=S, th=1, tw=S, clip=(0, 1, 0, S), count_pad=False, v_length=float(S)),
+                            dict(NB=B, Hq=H, Wq=W, qth=H, qtw=W))
+                cur ^= 1
+            elif ln == "combine1":
+                # DAPM (transformer.py:204-248)
+                t = l + ".transformer_path"
+                heads = spec.X2I_HEADS
+                d = D // heads
+                xin = tok[cur]
+                qb = self._act(plan, f"{name}.dapm.qkv", M, 3 * D)
+                self._lin(t + ".qkv", xin.slice(0, D), qb, M)
+                n_in = (y1 - y0) * (x1 - x0)
+                kv = self._f32(plan, f"{name}.dapm.kv", B * heads * d * d)
+                ks = self._f32(plan, f"{name}.dapm.ks", B * heads * d)
+                wsb = self._f32(plan, f"{name}.dapm.ws", ops.attn_kv_ws_floats(B, H, W, H, W, heads, d))
+                ops.attn_kv_reduce(qb.slice(D, D), qb.slice(2 * D, D), kv, ks, wsb, B, H, W, H, W, (y0, y1, x0, x1), False,
+                                   float(max(n_in, 1)), heads, d)
+                ops.attn_apply(qb.slice(0, D), kv, ks, xin.slice(D, D), B, H, W, H, W, (y0, y1, x0, x1), float(max(n_in, 1)), heads, d)
+                c1 = self._act(plan, f"{name}.dapm.c1", M, D)
+                self._cv(t + ".conv1", xin, c1, B, H, W, 3)
+                self._cv(t + ".conv2", c1, tok[cur ^ 1].slice(0, D), B, H, W, 3, residual=xin.slice(0, D))
+                cur ^= 1
+                # LKPM (convnext.py:42-58)
+                k = l + ".large_kernel_path"
+                xin = tok[cur]
+                t1 = self._act(plan, f"{name}.lk.t1", M, D)
+                ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
+                t2 = self._act(plan, f"{name}.lk.t2", M, D)
+                ops.layernorm(t1, self.P[k + ".norm.g"], self.P[k + ".norm.b"], 1e-6, t2, M)
+                h4 = self._act(plan, f"{name}.lk.h4", M, 4 * D)
+                self._lin(k + ".pw1.w", t2, h4, M, hip.ACT_GELU, None, k + ".pw1")
+                self._lin(k + ".pw2.w", h4, tok[cur ^ 1].slice(0, D), M, hip.ACT_NONE, xin.slice(0, D), k + ".pw2")
+                cur ^= 1
+            else:
+                raise NotImplementedError(ln)
+            if taps is not None:
+                taps[f"{p}.layers.{i}"] = tok[cur].slice(0, D).torch().float().cpu().reshape(B, H * W, D)
+        ops.copy_rows(tok[cur].slice(0, D), out, M)
+
+    def _nchw(self, a: Act, B, H, W) -> torch.Tensor:
+        return a.torch().float().cpu().reshape(B, H, W, a.C).permute(0, 3, 1, 2).contiguous()
+
+    # ------------------------------------------------------------------------------ forward
+    def _plan(self, B, H, W) -> dict:
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = {"bufs": {}}
+        return self._plans[key]
+
+    @torch.no_grad()
+    def forward(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None,
+                taps: Optional[dict] = None, img_features: Optional[Sequence[torch.Tensor]] = None):
+        """Eval-mode forward.  Returns (bin_edges [B,n+1] f32, pred [B,1,H/2,W/2] f32, prob [B,n,H/2,W/2] | None)."""
+        rgb = input_data["rgb"]
+        add = input_data["additional"]
+        B, _, H, W = rgb.shape
+        assert H % 32 == 0 and W % 32 == 0, "input height/width must be multiples of 32"
+        dev = self.device
+        plan = self._plan(B, H, W)
+        pos_offsets = pos_offsets or {}
+        hs = [H // 2, H // 4, H // 8, H // 16, H // 32]
+        wsz = [W // 2, W // 4, W // 8, W // 16, W // 32]
+        e, c = spec.DEC_ENC_CH, spec.DEC_CH
+        # concatenation buffers: [upsampled decoder features | encoder skip]
+        cat = [None,
+               self._act(plan, "cat1", B * hs[3] * wsz[3], c[0] + e[1]),
+               self._act(plan, "cat2", B * hs[2] * wsz[2], c[1] + e[2]),
+               self._act(plan, "cat3", B * hs[1] * wsz[1], c[2] + e[3]),
+               self._act(plan, "cat4", B * hs[0] * wsz[0], c[3] + e[4])]
+        b4 = self._act(plan, "tap4", B * hs[4] * wsz[4], e[0])
+        plan["tap_dst"] = [cat[4].slice(c[3], e[4]), cat[3].slice(c[2], e[3]), cat[2].slice(c[1], e[2]),
+                           cat[1].slice(c[0], e[1]), b4]
+        if img_features is not None:      # test hook: bypass the RGB encoder with given NCHW features
+            for f, dst in zip(img_features, plan["tap_dst"]):
+                dst.torch().copy_(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).to(device=dev, dtype=self.dtype))
+        else:
+            self._encoder(plan, rgb.to(device=dev, dtype=torch.float32).contiguous(), B, H, W, taps)
+
+        hist = add["hist_data"].to(device=dev, dtype=torch.float32).contiguous()
+        Z, N = hist.shape[1], hist.shape[2]
+        hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
+        zone_valid = add["mask"].to(device=dev).to(torch.uint8).contiguous()
+        pinfo = add["patch_info"]
+
+        def fuse(name, x, feat, hh, ww, out):
+            Wm = spec.FUSION[name][1][1]
+            geo = FusionGeometry.from_patch_info(pinfo, 640 / Wm)
+            assert geo.zone_num * geo.zone_num == Z
+            self._fusion(plan, name, x, feat, zone_valid, geo, B, hh, ww, out, pos_offsets.get(name, (0, 0)), taps)
+
+        def up(i, src: Act, hs_, ws_, hd, wd):
+            ops.resize_bilinear(src, hs_, ws_, (0, 0, hs_, ws_), cat[i].slice(0, src.C), hd, wd, (0, 0, hd, wd), B)
+            M = B * hd * wd
+            t1 = self._act(plan, f"up{i}.a", M, c[i])
+            self._cv(f"decoder.up{i}.a", cat[i], t1, B, hd, wd, 3, act=hip.ACT_LRELU)
+            t2 = self._act(plan, f"up{i}.b", M, c[i])
+            self._cv(f"decoder.up{i}.b", t1, t2, B, hd, wd, 3, act=hip.ACT_LRELU)
+            return t2
+
+        xd4 = self._act(plan, "xd4", B * hs[4] * wsz[4], c[0])
+        self._cv("decoder.conv4", b4, xd4, B, hs[4], wsz[4], 1)
+        x = xd4
+        ph, pw = hs[4], wsz[4]
+        for i, (fname, feat) in enumerate((("cross_atten3", hfeat[2]), ("cross_atten2", hfeat[1]), ("cross_atten1", hfeat[0])), start=1):
+            hh, ww = hs[4 - i], wsz[4 - i]
+            t = up(i, x, ph, pw, hh, ww)
+            if taps is not None:
+                taps[f"up{i}"] = self._nchw(t, B, hh, ww)
+            D = c[i + 1]
+            dcat = self._act(plan, f"dcat{i}", B * hh * ww, 2 * D)
+            self._cv(f"decoder.conv{4 - i}", t, dcat.slice(0, D), B, hh, ww, 1)
+            fuse(fname, dcat.slice(0, D), feat, hh, ww, dcat.slice(D, D))
+            if taps is not None:
+                taps[f"conv{4 - i}"] = self._nchw(dcat.slice(0, D), B, hh, ww)
+                taps[fname] = self._nchw(dcat.slice(D, D), B, hh, ww)
+            x, ph, pw = dcat, hh, ww
+        t = up(4, x, ph, pw, hs[0], wsz[0])
+        Mh = B * hs[0] * wsz[0]
+        HWh = hs[0] * wsz[0]
+        unet = self._act(plan, "unet", Mh, 128)
+        self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
+        ram = self._act(plan, "ram", Mh, 128)
+        self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
+        ns = max(1, min(256, HWh // 256))
+        part = self._f32(plan, "head.sum", B * ns * 128)
+        ops.channel_sum(unet, part, B, HWh, ns)
+        edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
+        centers = self._f32(plan, "head.centers", B * self.n_bins)
+        h = "depth_head"
+        ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
+                          self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
+                          edges, centers, B, 128, 256, self.n_bins)
+        logits = self._act(plan, "logits", Mh, self.n_bins)
+        self._lin("conv_out.w", ram, logits, Mh, hip.ACT_NONE, None, "conv_out")
+        pred = torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
+        prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
+        ops.bin_softmax(logits, centers, prob, pred, B, HWh, self.n_bins)
+        if taps is not None:
+            taps["unet_out"] = self._nchw(unet, B, hs[0], wsz[0])
+            taps["ram"] = self._nchw(ram, B, hs[0], wsz[0])
+        return edges, pred, prob

@@ -1,0 +1,84 @@
+"""ctypes binding of libcfpnet_hip.so (the C ABI declared in include/cfpnet_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a symbol is absent this
+module raises at import/first use, and every non-zero return code becomes a RuntimeError
+carrying `cfp_last_error()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfpnet_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
+
+_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/cfpnet_hip.h
+SIGNATURES = {
+    "cfp_version": (_i, []),
+    "cfp_last_error": (C.c_char_p, []),
+    "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p]),
+    "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),
+    "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
+    "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_se_gate": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "cfp_scale_channels": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "cfp_layernorm": (_i, [_p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "cfp_attn_kv_ws_floats": (_sz, [_i] * 7),
+    "cfp_attn_kv_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p] + [_i] * 10 + [_f, _i, _i, _i, _p]),
+    "cfp_attn_apply": (_i, [_p, _i, _p, _p, _p, _i] + [_i] * 9 + [_f, _f, _i, _i, _i, _p]),
+    "cfp_resize_bilinear": (_i, [_p, _i] + [_i] * 6 + [_p, _i] + [_i] * 6 + [_p] + [_i] * 7 + [_p]),
+    "cfp_add_rowtable": (_i, [_p, _i, _p, _p, _i] + [_i] * 8 + [_p]),
+    "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "cfp_rgb_to_nhwc8": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "cfp_scalar_to_rows8": (_i, [_p, _p, _i, _i, _p]),
+    "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
+    "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            f"(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C cfpnet_amd/csrc`). "
+            "There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().cfp_last_error().decode()
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {last_error()}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

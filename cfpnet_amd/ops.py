@@ -1,0 +1,159 @@
+"""Thin tensor-level wrappers over the C ABI: one Python function per HIP entry point.
+
+Activations are `Act` handles: a channel slice [c0, c0+C) of a row-major [rows, ld] device
+buffer (NHWC with an explicit pitch), which is how producers write straight into concatenation
+buffers.  torch is used for device memory and the stream only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+
+DT = {torch.float32: hip.F32, torch.bfloat16: hip.BF16}
+
+
+@dataclass
+class Act:
+    buf: torch.Tensor      # [rows, ld], contiguous, float32 or bfloat16, on the GPU
+    c0: int
+    C: int
+
+    @property
+    def rows(self) -> int:
+        return self.buf.shape[0]
+
+    @property
+    def ld(self) -> int:
+        return self.buf.shape[1]
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    @property
+    def dt(self) -> int:
+        return DT[self.buf.dtype]
+
+    def slice(self, c0: int, C: int) -> "Act":
+        assert 0 <= c0 and c0 + C <= self.C
+        return Act(self.buf, self.c0 + c0, C)
+
+    def torch(self) -> torch.Tensor:
+        return self.buf[:, self.c0:self.c0 + self.C]
+
+
+def new_act(rows: int, C: int, dtype, device, ld: Optional[int] = None, zero: bool = False) -> Act:
+    ld = ld or C
+    f = torch.zeros if zero else torch.empty
+    return Act(f((rows, ld), dtype=dtype, device=device), 0, C)
+
+
+def _s():
+    return hip.current_stream()
+
+
+def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo,
+           act=hip.ACT_NONE, residual: Optional[Act] = None):
+    assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
+    assert w.dtype == x.buf.dtype and w.shape == (out.C, KH * KW * x.C), (w.shape, out.C, KH, KW, x.C)
+    hip.call("cfp_conv2d_nhwc", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
+             residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
+             B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+
+
+def linear(x: Act, w: torch.Tensor, scale, shift, out: Act, rows: int, act=hip.ACT_NONE, residual: Optional[Act] = None):
+    conv2d(x, w, scale, shift, out, 1, 1, rows, 1, 1, 1, 0, 0, 1, rows, act, residual)
+
+
+def dwconv3x3(x: Act, w, scale, shift, out: Act, B, H, W, stride, pad_t, pad_l, Ho, Wo, act):
+    hip.call("cfp_dwconv3x3_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
+             B, H, W, x.C, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+
+
+def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
+    hip.call("cfp_dwconv_large_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
+             B, H, W, x.C, k, act, x.dt, _s())
+
+
+def channel_sum(x: Act, partial: torch.Tensor, B, HW, nsplit):
+    assert partial.dtype == torch.float32 and partial.numel() >= B * nsplit * x.C
+    hip.call("cfp_channel_sum", x.ptr, x.ld, partial.data_ptr(), B, HW, x.C, nsplit, x.dt, _s())
+
+
+def se_gate(partial, nsplit, inv_hw, wr, br, we, be, gate, B, C, R):
+    hip.call("cfp_se_gate", partial.data_ptr(), nsplit, float(inv_hw), wr.data_ptr(), br.data_ptr(), we.data_ptr(),
+             be.data_ptr(), gate.data_ptr(), B, C, R, _s())
+
+
+def scale_channels(x: Act, gate, B, HW):
+    hip.call("cfp_scale_channels", x.ptr, x.ld, gate.data_ptr(), B, HW, x.C, x.dt, _s())
+
+
+def layernorm(x: Act, gamma, beta, eps, out: Act, rows, residual: Optional[Act] = None):
+    hip.call("cfp_layernorm", x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), float(eps),
+             residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld, rows, x.C, x.dt, _s())
+
+
+def attn_kv_ws_floats(NB, Hk, Wk, th, tw, heads, d) -> int:
+    return int(hip.load().cfp_attn_kv_ws_floats(NB, Hk, Wk, th, tw, heads, d))
+
+
+def attn_kv_reduce(k: Act, v: Act, kv, ksum, ws, NB, Hk, Wk, th, tw, clip, count_pad, v_length, heads, d):
+    cy0, cy1, cx0, cx1 = clip
+    hip.call("cfp_attn_kv_reduce", k.ptr, k.ld, v.ptr, v.ld, kv.data_ptr(), ksum.data_ptr(), hip.ptr(ws),
+             NB, Hk, Wk, th, tw, cy0, cy1, cx0, cx1, int(count_pad), float(v_length), heads, d, k.dt, _s())
+
+
+def attn_apply(q: Act, kv, ksum, out: Act, NB, Hq, Wq, qth, qtw, excl, v_length, heads, d, eps=1e-6):
+    ey0, ey1, ex0, ex1 = excl
+    hip.call("cfp_attn_apply", q.ptr, q.ld, kv.data_ptr(), ksum.data_ptr(), out.ptr, out.ld,
+             NB, Hq, Wq, qth, qtw, ey0, ey1, ex0, ex1, float(v_length), float(eps), heads, d, q.dt, _s())
+
+
+def resize_bilinear(src: Act, Hs, Ws, srect, dst: Act, Hd, Wd, drect, B, zone_valid=None, zn=0, p1=0, p2=0,
+                    accumulate=False):
+    sy0, sx0, sh, sw = srect
+    dy0, dx0, dh, dw = drect
+    assert src.C == dst.C
+    hip.call("cfp_resize_bilinear", src.ptr, src.ld, Hs, Ws, sy0, sx0, sh, sw, dst.ptr, dst.ld, Hd, Wd, dy0, dx0, dh, dw,
+             hip.ptr(zone_valid), zn, p1, p2, int(accumulate), B, src.C, src.dt, _s())
+
+
+def add_rowtable(x: Act, table, out: Act, rows, H, W, Wt, oy, ox):
+    assert table.dtype == torch.float32 and table.shape[1] == x.C
+    hip.call("cfp_add_rowtable", x.ptr, x.ld, table.data_ptr(), out.ptr, out.ld, rows, x.C, H, W, Wt, oy, ox, x.dt, _s())
+
+
+def copy_rows(x: Act, out: Act, rows):
+    hip.call("cfp_copy_rows", x.ptr, x.ld, out.ptr, out.ld, rows, x.C, x.dt, _s())
+
+
+def rgb_to_nhwc8(rgb: torch.Tensor, out: Act, B, H, W):
+    assert rgb.dtype == torch.float32 and rgb.is_contiguous() and out.C == 8 and out.ld == 8
+    hip.call("cfp_rgb_to_nhwc8", rgb.data_ptr(), out.ptr, B, H, W, out.dt, _s())
+
+
+def scalar_to_rows8(x: torch.Tensor, out: Act, rows):
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.C == 8 and out.ld == 8
+    hip.call("cfp_scalar_to_rows8", x.data_ptr(), out.ptr, rows, out.dt, _s())
+
+
+def bin_regressor(partial, nsplit, inv_hw, w1x1, w0, b0, w1, b1, w2, b2, min_val, max_val, norm, edges, centers, B, C,
+                  hidden, nbins):
+    hip.call("cfp_bin_regressor", partial.data_ptr(), nsplit, float(inv_hw), w1x1.data_ptr(), w0.data_ptr(), b0.data_ptr(),
+             w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), float(min_val), float(max_val), norm,
+             edges.data_ptr(), centers.data_ptr(), B, C, hidden, nbins, _s())
+
+
+def bin_softmax(logits: Act, centers, prob, pred, B, HW, nbins):
+    hip.call("cfp_bin_softmax", logits.ptr, logits.ld, centers.data_ptr(), hip.ptr(prob), pred.data_ptr(), B, HW, nbins,
+             logits.dt, _s())
+
+
+def bin_head_fused(x: Act, w, bias, centers, prob, pred, B, HW):
+    hip.call("cfp_bin_head_fused", x.ptr, x.ld, w.data_ptr(), bias.data_ptr(), centers.data_ptr(), hip.ptr(prob),
+             pred.data_ptr(), B, HW, x.C, x.dt, _s())

@@ -1,0 +1,162 @@
+/*
+ * libcfpnet_hip.so -- C ABI of the MI355X (gfx950) CFPNet hot path.
+ *
+ * The reference (denyingmxd/CFPNet) is pure PyTorch: its "operator interface" for this path is
+ * the set of torch ops `Deltar.forward` issues (src/models/deltar.py:34-67).  Each entry point
+ * below replaces one family of those ops with a hand-written HIP kernel; the comment on every
+ * declaration names the reference lines it stands in for.  The host side
+ * (cfpnet_amd/engine.py, via ctypes -- see INTEGRATION.md) strings them together.
+ *
+ * Conventions
+ *   - every pointer is a caller-owned DEVICE pointer; nothing is allocated or freed here
+ *   - activations are NHWC ("tokens": [rows = B*H*W][channels]) with an explicit row pitch
+ *     `*_ld` in ELEMENTS, so producers can write straight into a channel slice of a wider
+ *     (concatenation) buffer; channel counts, pitches and slice offsets are multiples of
+ *     8 elements (bf16) / 4 elements (f32) so that every access is a 16-byte vector
+ *   - dtype: CFP_F32 or CFP_BF16 storage; all arithmetic accumulates in f32
+ *   - all calls are asynchronous on `stream` (a hipStream_t), stateless and re-entrant
+ *   - return 0 on success, a negative CFP_E* code otherwise; `cfp_last_error()` gives the
+ *     message (thread-local).  No C++ exception crosses this boundary.
+ */
+#ifndef CFPNET_HIP_H
+#define CFPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cfp_stream_t; /* hipStream_t */
+
+enum { CFP_OK = 0, CFP_EINVAL = -1, CFP_ESHAPE = -2, CFP_EHIP = -3 };
+enum { CFP_F32 = 0, CFP_BF16 = 1 };
+enum { CFP_ACT_NONE = 0, CFP_ACT_RELU = 1, CFP_ACT_LRELU = 2, CFP_ACT_SILU = 3, CFP_ACT_GELU = 4, CFP_ACT_SIGMOID = 5 };
+
+int cfp_version(void);
+const char* cfp_last_error(void);
+
+/* Dense convolution / linear layer as an implicit GEMM on the matrix cores:
+ *   out[m, n] = act( (sum_k A[m,k] * w[n,k]) * scale[n] + shift[n] ) + residual[m, n]
+ * with m = (b, ho, wo), k = (kh, kw, ci), w packed [Cout][KH][KW][Cin].
+ * Replaces nn.Conv2d 3x3 / 1x1 (+ folded BatchNorm + activation + skip add):
+ *   decoder.py:43-58,70-80 (UpSampleBN, conv0..conv4), decoder.py:13 (depth_head.conv3x3),
+ *   transformer.py:197-200,240-244 (DAPM convs), transformer.py:132 (GSA sr conv),
+ *   nn.Linear in transformer.py:24-36 / convnext.py:32-34 / encoder.py:10-12 (KH=KW=1, H=1),
+ *   and the encoder's conv_stem / conv / conv_exp / conv_pw / conv_pwl (encoder.py:57-69).
+ * scale/shift may be NULL (1 / 0).  residual may be NULL.  Cin % 8 == 0 (bf16) or % 4 (f32). */
+int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                    const void* residual, int res_ld, void* out, int out_ld,
+                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
+
+/* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused
+ * BatchNorm scale/shift + activation.  w packed [9][C].  HBM-bandwidth-bound.
+ * Replaces timm InvertedResidual.conv_dw + bn2 + SiLU (encoder.py:66-69, 24 convs). */
+int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                       void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
+                       int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
+
+/* Large-kernel depthwise convolution (k = 7 / 15 / 31, stride 1, "same"), fused bias + BatchNorm +
+ * ReLU.  w packed [k*k][C] as f32.  Vector-FMA-bound.  Replaces Block14.dwconv2 + bn1 + relu
+ * (convnext.py:30,45-47). */
+int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float* scale, const float* shift,
+                          void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
+                          cfp_stream_t stream);
+
+/* Per-(batch, channel) sums over H*W, split in `nsplit` row slices: partial[b][s][c] (f32).
+ * Consumers divide by H*W.  Replaces x.mean((2,3)) in the SE block and `.mean([2,3])` of
+ * DepthRegression (decoder.py:24-25; conv1x1 and mean commute). */
+int cfp_channel_sum(const void* in, int in_ld, float* partial, int B, int HW, int C, int nsplit, int dtype,
+                    cfp_stream_t stream);
+
+/* Squeeze-excite gate: mean -> FC(C->R)+bias -> SiLU -> FC(R->C)+bias -> sigmoid, f32 weights.
+ * gate[b][c] f32.  Replaces timm SqueezeExcite (inside encoder.py:66-69 blocks). */
+int cfp_se_gate(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                const float* w_expand, const float* b_expand, float* gate, int B, int C, int R, cfp_stream_t stream);
+
+/* x[b, hw, c] *= gate[b, c] in place. */
+int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream);
+
+/* Row LayerNorm over C with affine, optional residual add afterwards:
+ *   out[r,:] = LN(in[r,:]) * gamma + beta (+ residual[r,:])
+ * Replaces nn.LayerNorm in transformer.py:38-39,63,68,70 and convnext.py:31,49. */
+int cfp_layernorm(const void* in, int in_ld, const float* gamma, const float* beta, float eps,
+                  const void* residual, int res_ld, void* out, int out_ld, int rows, int C, int dtype,
+                  cfp_stream_t stream);
+
+/* Linear attention, reduction half (attention.py:31-43):  for every key group g and head h
+ *   KV[g,h] = sum_s (elu(K_s)+1)^T (V_s / v_length),   Ksum[g,h] = sum_s (elu(K_s)+1)
+ * Keys live on an [NB, Hk, Wk] grid (row pitch ld); group (b, gy, gx) owns the th x tw tile
+ * clipped to [cy0,cy1) x [cx0,cx1).  With count_pad != 0, tile positions outside the grid count
+ * as zero-feature tokens (K = 1, V = 0): the zero-padded windows of transformer.py:101-107.
+ * Covers hist2image (tile 1x16), LSA windows, GSA (one tile per batch) and DAPM (inside rectangle).
+ * ws: f32 scratch of cfp_attn_kv_ws_floats() floats. */
+size_t cfp_attn_kv_ws_floats(int NB, int Hk, int Wk, int th, int tw, int heads, int d);
+int cfp_attn_kv_reduce(const void* k, int k_ld, const void* v, int v_ld, float* kv, float* ksum, float* ws,
+                       int NB, int Hk, int Wk, int th, int tw, int cy0, int cy1, int cx0, int cx1,
+                       int count_pad, float v_length, int heads, int d, int dtype, cfp_stream_t stream);
+
+/* Linear attention, query half (attention.py:48-49):
+ *   out[q,h,:] = (Q_q,h . KV[g(q),h]) / (Q_q,h . Ksum[g(q),h] + eps) * v_length,  Q = elu(q)+1
+ * Queries live on an [NB, Hq, Wq] grid; g(q) = (b, y / qth, x / qtw).  Queries inside the
+ * exclusion rectangle [ey0,ey1) x [ex0,ex1) get 0 (DAPM: only outside-zone tokens receive a
+ * message, transformer.py:233-234). */
+int cfp_attn_apply(const void* q, int q_ld, const float* kv, const float* ksum, void* out, int out_ld,
+                   int NB, int Hq, int Wq, int qth, int qtw, int ey0, int ey1, int ex0, int ex1,
+                   float v_length, float eps, int heads, int d, int dtype, cfp_stream_t stream);
+
+/* Bilinear resampling (align_corners=True) of a rectangle of an NHWC map into a rectangle of
+ * another one.  The source rectangle may overhang the source map (reads 0 there: F.pad in
+ * fusion.py:136).  If zone_valid != NULL, source texel (y,x) is multiplied by
+ * zone_valid[b][(y/p1)*zn + x/p2] (fusion.py:144).  accumulate: 0 dst = v, 1 dst += v.
+ * Only destination pixels inside the destination map are written.
+ * Replaces F.interpolate in decoder.py:56 and fusion.py:141,148, the crop of fusion.py:138, the
+ * zone regrouping of fusion.py:142,147,151 (which is pure addressing) and the masked
+ * scatter-add of fusion.py:154-157. */
+int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, int sy0, int sx0, int sh, int sw,
+                        void* dst, int dst_ld, int Hd, int Wd, int dy0, int dx0, int dh, int dw,
+                        const uint8_t* zone_valid, int zn, int p1, int p2, int accumulate,
+                        int B, int C, int dtype, cfp_stream_t stream);
+
+/* out[r,:] = in[r,:] + table[((r / W) % H + oy) * Wt + (r % W) + ox, :]   (table f32 [*, C])
+ * Positional encodings: fusion.py:92-96 (H x W window of the [Hmax*Wmax, D] table) and
+ * fusion.py:123-124 (H=1, W=Wt=16). */
+int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C,
+                     int H, int W, int Wt, int oy, int ox, int dtype, cfp_stream_t stream);
+
+/* Strided row copy out[r, 0:C] = in[r, 0:C]. */
+int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, int C, int dtype, cfp_stream_t stream);
+
+/* rgb f32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] (channels 3..7 zero) in `dtype`. */
+int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream);
+/* f32 scalars [rows] -> [rows][8] with the value in column 0 (ToF sample depths, deltar.py:40). */
+int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_stream_t stream);
+
+/* Bin-width regressor + bin edges/centres, one workgroup per batch element, all f32:
+ *   mean -> conv1x1 (no bias) -> Linear/LeakyReLU x2 -> Linear -> norm -> widths -> cumsum
+ * norm: 0 linear (relu + 0.1, L1-normalise), 1 softmax, 2 sigmoid (L1-normalise).
+ * edges [B][nbins+1], centers [B][nbins].  Replaces decoder.py:23-36 + deltar.py:53-59. */
+int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw, const float* w1x1,
+                      const float* w0, const float* b0, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float min_val, float max_val, int norm,
+                      float* edges, float* centers, int B, int C, int hidden, int nbins, cfp_stream_t stream);
+
+/* Per-pixel softmax over nbins logits + expectation over bin centres:
+ *   prob[b, n, hw] = softmax_n(logits[b*HW + hw, n]);  pred[b, hw] = sum_n prob * centers[b, n]
+ * prob (NCHW, `dtype`) may be NULL.  pred is f32.  Replaces nn.Softmax(dim=1) of deltar.py:19
+ * and deltar.py:61. */
+int cfp_bin_softmax(const void* logits, int ld, const float* centers, void* prob, float* pred,
+                    int B, int HW, int nbins, int dtype, cfp_stream_t stream);
+
+/* Fused bin head: logits = x @ w^T + bias never leave the chip:
+ *   1x1 conv (Cin -> 256) on the matrix cores, row softmax, expectation, optional prob write.
+ * Replaces conv_out (deltar.py:18-19,51) + deltar.py:61.  bf16 only; nbins == 256. */
+int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
+                       void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFPNET_HIP_H */

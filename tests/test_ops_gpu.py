@@ -1,0 +1,349 @@
+"""Kernel-level numerics: every HIP entry point against a plain PyTorch fp32 reference of the
+same op (CPU), in f32 (tight) and bf16 (storage-rounding) tolerances.  Runs on the GPU box."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cfpnet_amd import hip, ops  # noqa: E402
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2.5e-2, 2.5e-2)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def q(x, dtype):
+    """Quantise a reference input the way the device tensor is stored."""
+    return x.to(dtype).float()
+
+
+def to_act(x2d: torch.Tensor, dtype, ld=None, c0=0) -> ops.Act:
+    rows, C = x2d.shape
+    ld = ld or C
+    buf = torch.zeros(rows, ld, dtype=dtype, device=DEV)
+    buf[:, c0:c0 + C] = x2d.to(dtype).to(DEV)
+    return ops.Act(buf, c0, C)
+
+
+def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def from_nhwc(t2d, B, H, W):
+    return t2d.float().cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def close(got, ref, dtype, what=""):
+    rt, at = tol(dtype)
+    err = (got - ref).abs()
+    bound = at * ref.abs().max().clamp(min=1e-3) + rt * ref.abs()
+    assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e} ref max {float(ref.abs().max()):.3e}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pads(t,l,b,r)
+    (2, 9, 11, 8, 40, 3, 2, (0, 0, 1, 1)),        # stem-like, SAME asymmetric (odd sizes)
+    (1, 12, 16, 40, 16, 3, 1, (1, 1, 1, 1)),      # Cout 16 tile
+    (2, 10, 14, 16, 64, 3, 2, (0, 0, 1, 1)),      # edge-residual expand, even input
+    (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)),    # up1 first conv, K = 3528
+    (2, 8, 8, 136, 816, 1, 1, (0, 0, 0, 0)),      # pointwise, Cout tail (816 = 6*128 + 48)
+    (1, 30, 40, 128, 128, 6, 6, (0, 0, 0, 0)),    # GSA sr conv: kernel = stride = 6
+    (1, 13, 17, 32, 32, 3, 1, (1, 1, 1, 1)),      # Cout 32 tile, ragged M
+    (1, 1, 300, 256, 256, 1, 1, (0, 0, 0, 0)),    # Linear (rows = 300)
+    (1, 1, 70, 8, 32, 1, 1, (0, 0, 0, 0)),        # K = 8 (ToF first layer)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, dtype):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x = q(rnd(B, Cin, H, W, seed=1), dtype)
+    w = q(rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    scale = rnd(Cout, seed=3).abs() + 0.5
+    shift = rnd(Cout, seed=4)
+    Ho = (H + pt + pb - k) // s + 1
+    Wo = (W + pl + pr - k) // s + 1
+    res = q(rnd(B, Cout, Ho, Wo, seed=5), dtype)
+    ref = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s)
+    ref = F.silu(ref * scale[None, :, None, None] + shift[None, :, None, None]) + res
+    xa = to_act(nhwc(x), dtype, ld=Cin + 16, c0=8)
+    wa = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV)
+    ra = to_act(nhwc(res), dtype)
+    out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True).slice(0, Cout)
+    out = ops.Act(out.buf, 16, Cout)
+    ops.conv2d(xa, wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_SILU, ra)
+    torch.cuda.synchronize()
+    close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"conv {case}")
+    # the slice neighbours must be untouched
+    assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_RELU, hip.ACT_LRELU, hip.ACT_GELU, hip.ACT_SIGMOID])
+def test_conv_activations_no_scale(act, dtype):
+    x = q(rnd(1, 64, 6, 10, seed=7), dtype)
+    w = q(rnd(96, 64, 1, 1, seed=8, scale=0.2), dtype)
+    ref = F.conv2d(x, w)
+    ref = {hip.ACT_NONE: lambda t: t, hip.ACT_RELU: F.relu, hip.ACT_LRELU: lambda t: F.leaky_relu(t, 0.01),
+           hip.ACT_GELU: F.gelu, hip.ACT_SIGMOID: torch.sigmoid}[act](ref)
+    out = ops.new_act(60, 96, dtype, DEV)
+    ops.conv2d(to_act(nhwc(x), dtype), w.reshape(96, 64).to(dtype).to(DEV), None, None, out, 1, 6, 10, 1, 1, 1, 0, 0, 6, 10, act)
+    close(from_nhwc(out.torch(), 1, 6, 10), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (1, 15, 20, 1392, 1, (1, 1, 1, 1)),
+                                  (2, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 5, 3, 8, 1, (1, 1, 1, 1))])
+def test_dwconv3x3(case, dtype):
+    B, H, W, Cc, s, (pt, pl, pb, pr) = case
+    x = q(rnd(B, Cc, H, W, seed=1), dtype)
+    w = q(rnd(Cc, 1, 3, 3, seed=2, scale=0.4), dtype)
+    scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
+    Ho, Wo = (H + pt + pb - 3) // s + 1, (W + pl + pr - 3) // s + 1
+    ref = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s, 0, 1, Cc)
+    ref = F.silu(ref * scale[None, :, None, None] + shift[None, :, None, None])
+    wa = w.reshape(Cc, 9).t().contiguous().to(dtype).to(DEV)       # [9][C]
+    out = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+    ops.dwconv3x3(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"dw3x3 {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(1, 30, 40, 128, 7), (2, 20, 37, 64, 15), (1, 40, 50, 32, 31), (1, 9, 9, 8, 31)])
+def test_dwconv_large(case, dtype):
+    B, H, W, Cc, k = case
+    x = q(rnd(B, Cc, H, W, seed=1), dtype)
+    w = rnd(Cc, 1, k, k, seed=2, scale=1.0 / k)
+    scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
+    ref = F.relu(F.conv2d(x, w, None, 1, (k - 1) // 2, 1, Cc) * scale[None, :, None, None] + shift[None, :, None, None])
+    wa = w.reshape(Cc, k * k).t().contiguous().to(DEV)             # [k*k][C] f32
+    out = ops.new_act(B * H * W, Cc, dtype, DEV)
+    ops.dwconv_large(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, hip.ACT_RELU)
+    close(from_nhwc(out.torch(), B, H, W), ref, dtype, f"dwlarge {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 300, 1392, 7), (1, 1200, 128, 16), (3, 77, 672, 1), (1, 5000, 128, 64)])
+def test_channel_sum_and_se(case, dtype):
+    B, HW, Cc, ns = case
+    x = q(rnd(B, HW, Cc, seed=1), dtype)
+    part = torch.zeros(B, ns, Cc, device=DEV)
+    ops.channel_sum(to_act(x.reshape(B * HW, Cc), dtype), part, B, HW, ns)
+    ref = x.sum(1)
+    assert torch.allclose(part.sum(1).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(HW))
+    R = 34
+    wr, br, we, be = rnd(R, Cc, seed=2, scale=0.05), rnd(R, seed=3), rnd(Cc, R, seed=4, scale=0.2), rnd(Cc, seed=5)
+    gate = torch.empty(B, Cc, device=DEV)
+    ops.se_gate(part, ns, 1.0 / HW, wr.to(DEV), br.to(DEV), we.to(DEV), be.to(DEV), gate, B, Cc, R)
+    gref = torch.sigmoid(F.silu((ref / HW) @ wr.t() + br) @ we.t() + be)
+    assert torch.allclose(gate.cpu(), gref, rtol=1e-4, atol=1e-5)
+    xa = to_act(x.reshape(B * HW, Cc), dtype)
+    ops.scale_channels(xa, gate, B, HW)
+    close(xa.torch().float().cpu().reshape(B, HW, Cc), x * gref[:, None, :], dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cc", [32, 64, 128])
+@pytest.mark.parametrize("rows", [1, 257, 4800])
+def test_layernorm(rows, Cc, dtype):
+    x = q(rnd(rows, Cc, seed=1, scale=3.0) + 0.7, dtype)
+    g, b = rnd(Cc, seed=2).abs() + 0.5, rnd(Cc, seed=3)
+    res = q(rnd(rows, Cc, seed=4), dtype)
+    out = ops.new_act(rows, Cc, dtype, DEV, ld=2 * Cc, zero=True)
+    out = ops.Act(out.buf, Cc, Cc)
+    ops.layernorm(to_act(x, dtype), g.to(DEV), b.to(DEV), 1e-5, out, rows, to_act(res, dtype))
+    close(out.torch().float().cpu(), F.layer_norm(x, (Cc,), g, b, 1e-5) + res, dtype)
+    ops.layernorm(to_act(x, dtype), g.to(DEV), b.to(DEV), 1e-6, out, rows, None)
+    close(out.torch().float().cpu(), F.layer_norm(x, (Cc,), g, b, 1e-6), dtype)
+
+
+def lin_attn_ref(qh, kh, vh, S, eps=1e-6):
+    """[N,L,h,d], [N,S',h,d] -> attention.py:31-49 with an explicit v_length S."""
+    Q, K = F.elu(qh) + 1, F.elu(kh) + 1
+    KV = torch.einsum("nshd,nshv->nhdv", K, vh / S)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + eps)
+    return torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("heads,d", [(4, 32), (4, 16), (4, 8), (8, 16), (8, 8), (8, 4)])
+def test_attention_zone_mode(heads, d, dtype):
+    """hist2image: each zone's queries (p1 x p2 pixels) attend to that zone's 16 ToF samples."""
+    B, zn, p1, p2, Dm = 2, 3, 2, 5, heads * d
+    Z = zn * zn
+    qx = q(rnd(B, zn * p1, zn * p2, Dm, seed=1), dtype)
+    kx, vx = q(rnd(B * Z, 16, Dm, seed=2), dtype), q(rnd(B * Z, 16, Dm, seed=3), dtype)
+    kv = torch.empty(B * Z * heads * d * d, device=DEV)
+    ks = torch.empty(B * Z * heads * d, device=DEV)
+    n = ops.attn_kv_ws_floats(B * Z, 1, 16, 1, 16, heads, d)
+    ws = torch.empty(max(n, 1), device=DEV)
+    ops.attn_kv_reduce(to_act(kx.reshape(-1, Dm), dtype), to_act(vx.reshape(-1, Dm), dtype), kv, ks, ws, B * Z, 1, 16, 1, 16,
+                       (0, 1, 0, 16), False, 16.0, heads, d)
+    out = ops.new_act(B * zn * p1 * zn * p2, Dm, dtype, DEV)
+    ops.attn_apply(to_act(qx.reshape(-1, Dm), dtype), kv, ks, out, B, zn * p1, zn * p2, p1, p2, (0, 0, 0, 0), 16.0, heads, d)
+    qz = qx.reshape(B, zn, p1, zn, p2, Dm).permute(0, 1, 3, 2, 4, 5).reshape(B * Z, p1 * p2, heads, d)
+    ref = lin_attn_ref(qz, kx.reshape(B * Z, 16, heads, d), vx.reshape(B * Z, 16, heads, d), 16)
+    ref = ref.reshape(B, zn, zn, p1, p2, Dm).permute(0, 1, 3, 2, 4, 5).reshape(B, zn * p1, zn * p2, Dm)
+    close(out.torch().float().cpu().reshape(B, zn * p1, zn * p2, Dm), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("H,W,ws,heads,d", [(30, 40, 6, 8, 16), (13, 20, 9, 8, 8), (24, 31, 12, 8, 4)])
+def test_attention_window_mode_with_padding(H, W, ws, heads, d, dtype):
+    """LSA: zero-padded windows; padded tokens count with K = 1, V = 0 (transformer.py:101-107)."""
+    B, Dm = 2, heads * d
+    x = q(rnd(B, H, W, 3 * Dm, seed=1), dtype)
+    xa = to_act(x.reshape(-1, 3 * Dm), dtype)
+    G = B * math.ceil(H / ws) * math.ceil(W / ws)
+    kv, ks = torch.empty(G * heads * d * d, device=DEV), torch.empty(G * heads * d, device=DEV)
+    ws_buf = torch.empty(max(ops.attn_kv_ws_floats(B, H, W, ws, ws, heads, d), 1), device=DEV)
+    ops.attn_kv_reduce(xa.slice(Dm, Dm), xa.slice(2 * Dm, Dm), kv, ks, ws_buf, B, H, W, ws, ws, (0, H, 0, W), True,
+                       float(ws * ws), heads, d)
+    out = ops.new_act(B * H * W, Dm, dtype, DEV)
+    ops.attn_apply(xa.slice(0, Dm), kv, ks, out, B, H, W, ws, ws, (0, 0, 0, 0), float(ws * ws), heads, d)
+    pb, pr = (ws - H % ws) % ws, (ws - W % ws) % ws
+    xp = F.pad(x, (0, 0, 0, pr, 0, pb))
+    Hp, Wp = H + pb, W + pr
+    nh, nw = Hp // ws, Wp // ws
+    win = xp.reshape(B, nh, ws, nw, ws, 3 * Dm).permute(0, 1, 3, 2, 4, 5).reshape(B * nh * nw, ws * ws, 3, heads, d)
+    ref = lin_attn_ref(win[:, :, 0], win[:, :, 1], win[:, :, 2], ws * ws)
+    ref = ref.reshape(B, nh, nw, ws, ws, Dm).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, Dm)[:, :H, :W]
+    close(out.torch().float().cpu().reshape(B, H, W, Dm), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("heads,d,H,W", [(4, 8, 120, 160), (4, 32, 30, 40)])
+def test_attention_inside_outside_and_global(heads, d, H, W, dtype):
+    """DAPM: keys = inside rectangle (split over many waves), queries = outside tokens only."""
+    B, Dm = 2, heads * d
+    y0, y1, x0, x1 = H // 10, H - H // 12, W // 7, W - W // 9
+    x = q(rnd(B, H, W, 3 * Dm, seed=1), dtype)
+    xa = to_act(x.reshape(-1, 3 * Dm), dtype)
+    S = (y1 - y0) * (x1 - x0)
+    kv, ks = torch.empty(B * heads * d * d, device=DEV), torch.empty(B * heads * d, device=DEV)
+    ws_buf = torch.empty(max(ops.attn_kv_ws_floats(B, H, W, H, W, heads, d), 1), device=DEV)
+    ops.attn_kv_reduce(xa.slice(Dm, Dm), xa.slice(2 * Dm, Dm), kv, ks, ws_buf, B, H, W, H, W, (y0, y1, x0, x1), False, float(S), heads, d)
+    out = ops.new_act(B * H * W, Dm, dtype, DEV)
+    ops.attn_apply(xa.slice(0, Dm), kv, ks, out, B, H, W, H, W, (y0, y1, x0, x1), float(S), heads, d)
+    ins = x[:, y0:y1, x0:x1].reshape(B, S, 3, heads, d)
+    ref = lin_attn_ref(x.reshape(B, H * W, 3, heads, d)[:, :, 0], ins[:, :, 1], ins[:, :, 2], S).reshape(B, H, W, Dm).clone()
+    ref[:, y0:y1, x0:x1] = 0
+    close(out.torch().float().cpu().reshape(B, H, W, Dm), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resize_matches_interpolate(dtype):
+    B, Cc = 2, 64
+    x = q(rnd(B, Cc, 15, 20, seed=1), dtype)
+    dst = ops.new_act(B * 30 * 40, Cc, dtype, DEV, ld=Cc + 40, zero=True)
+    ops.resize_bilinear(to_act(nhwc(x), dtype), 15, 20, (0, 0, 15, 20), dst, 30, 40, (0, 0, 30, 40), B)
+    close(from_nhwc(dst.torch(), B, 30, 40), F.interpolate(x, size=[30, 40], mode="bilinear", align_corners=True), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_zone_crop_resize_and_masked_scatter(dtype):
+    """fusion.py:136-157: crop (with overhang) -> 28->32 bilinear -> ... -> zero invalid zones ->
+    32->28 bilinear -> add onto the in-image part of the rectangle."""
+    B, Cc, H, W = 2, 32, 30, 40
+    sy, sx, tz, zn, p = -3, 6, 28, 8, 4
+    x = q(rnd(B, Cc, H, W, seed=1), dtype)
+    grid = ops.new_act(B * 32 * 32, Cc, dtype, DEV)
+    ops.resize_bilinear(to_act(nhwc(x), dtype), H, W, (sy, sx, tz, tz), grid, 32, 32, (0, 0, 32, 32), B)
+    padded = F.pad(x, (0, 0, 3, 3))
+    crop = padded[:, :, sy + 3:sy + 3 + tz, sx:sx + tz]
+    ref_grid = F.interpolate(crop, size=[32, 32], mode="bilinear", align_corners=True)
+    close(from_nhwc(grid.torch(), B, 32, 32), ref_grid, dtype, "crop+resize")
+    valid = (torch.rand(B, zn * zn, generator=torch.Generator().manual_seed(3)) > 0.3)
+    zf = q(rnd(B, Cc, 32, 32, seed=5), dtype)
+    tok = to_act(nhwc(x), dtype)
+    ops.resize_bilinear(to_act(nhwc(zf), dtype), 32, 32, (0, 0, 32, 32), tok, H, W, (sy, sx, tz, tz), B,
+                        zone_valid=valid.to(torch.uint8).to(DEV), zn=zn, p1=p, p2=p, accumulate=True)
+    m = valid.reshape(B, 1, zn, 1, zn, 1).expand(B, 1, zn, p, zn, p).reshape(B, 1, 32, 32).float()
+    back = F.interpolate(zf * m, size=[tz, tz], mode="bilinear", align_corners=True)
+    ref = x.clone()
+    ref[:, :, 0:sy + tz, sx:sx + tz] += back[:, :, -sy:, :]
+    close(from_nhwc(tok.torch(), B, H, W), ref, dtype, "masked scatter-add")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rowtable_copy_and_layout(dtype):
+    B, H, W, Cc, Hm, Wm = 2, 26, 34, 128, 30, 40
+    x = q(rnd(B * H * W, Cc, seed=1), dtype)
+    table = rnd(Hm * Wm, Cc, seed=2)
+    out = ops.new_act(B * H * W, Cc, dtype, DEV, ld=2 * Cc)
+    ops.add_rowtable(to_act(x, dtype), table.to(DEV), out, B * H * W, H, W, Wm, 3, 5)
+    ref = x.reshape(B, H, W, Cc) + table.reshape(Hm, Wm, Cc)[3:3 + H, 5:5 + W]
+    close(out.torch().float().cpu().reshape(B, H, W, Cc), ref, dtype)
+    cp = ops.new_act(B * H * W, Cc, dtype, DEV)
+    ops.copy_rows(out, cp, B * H * W)
+    assert torch.equal(cp.torch(), out.torch())
+    rgb = rnd(2, 3, 10, 12, seed=4)
+    o8 = ops.new_act(2 * 120, 8, dtype, DEV)
+    ops.rgb_to_nhwc8(rgb.to(DEV), o8, 2, 10, 12)
+    got = o8.torch().float().cpu().reshape(2, 10, 12, 8)
+    assert torch.equal(got[..., :3], rgb.to(dtype).float().permute(0, 2, 3, 1)) and float(got[..., 3:].abs().max()) == 0
+    s = rnd(77, seed=6)
+    o8 = ops.new_act(77, 8, dtype, DEV)
+    ops.scalar_to_rows8(s.to(DEV), o8, 77)
+    got = o8.torch().float().cpu()
+    assert torch.equal(got[:, 0], s.to(dtype).float()) and float(got[:, 1:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("norm", [0, 1, 2])
+def test_bin_regressor(norm):
+    B, Cc, hid, nb, HW, ns = 3, 128, 256, 256, 1000, 5
+    part = rnd(B, ns, Cc, seed=1, scale=30.0)
+    w1x1 = rnd(Cc, Cc, seed=2, scale=0.1)
+    w0, b0 = rnd(hid, Cc, seed=3, scale=0.1), rnd(hid, seed=4, scale=0.1)
+    w1, b1 = rnd(hid, hid, seed=5, scale=0.08), rnd(hid, seed=6, scale=0.1)
+    w2, b2 = rnd(nb, hid, seed=7, scale=0.08), rnd(nb, seed=8, scale=0.1)
+    edges, centers = torch.empty(B, nb + 1, device=DEV), torch.empty(B, nb, device=DEV)
+    d = lambda t: t.to(DEV)
+    ops.bin_regressor(d(part), ns, 1.0 / HW, d(w1x1), d(w0), d(b0), d(w1), d(b1), d(w2), d(b2), 1e-3, 10.0, norm, edges, centers,
+                      B, Cc, hid, nb)
+    y = (part.sum(1) / HW) @ w1x1.t()
+    y = F.leaky_relu(y @ w0.t() + b0, 0.01)
+    y = F.leaky_relu(y @ w1.t() + b1, 0.01)
+    y = y @ w2.t() + b2
+    if norm == 0:
+        y = torch.relu(y) + 0.1
+        y = y / y.sum(1, keepdim=True)
+    elif norm == 1:
+        y = torch.softmax(y, 1)
+    else:
+        y = torch.sigmoid(y)
+        y = y / y.sum(1, keepdim=True)
+    e = torch.cumsum(F.pad((10.0 - 1e-3) * y, (1, 0), value=1e-3), 1)
+    assert torch.allclose(edges.cpu(), e, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(centers.cpu(), 0.5 * (e[:, :-1] + e[:, 1:]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("HW", [64, 1000, 76800 // 16])
+def test_bin_softmax(HW, dtype):
+    B, nb = 2, 256
+    logits = q(rnd(B * HW, nb, seed=1, scale=3.0), dtype)
+    centers = torch.sort(torch.rand(B, nb, generator=torch.Generator().manual_seed(2)) * 10, dim=1)[0]
+    prob = torch.zeros(B, nb, HW, dtype=dtype, device=DEV)
+    pred = torch.empty(B, HW, device=DEV)
+    ops.bin_softmax(to_act(logits, dtype), centers.to(DEV), prob, pred, B, HW, nb)
+    p = torch.softmax(logits.reshape(B, HW, nb), dim=2)
+    close(prob.float().cpu(), p.permute(0, 2, 1), dtype, "prob")
+    assert torch.allclose(pred.cpu(), (p * centers[:, None, :]).sum(2), rtol=1e-4, atol=1e-4)
+    pred2 = torch.empty(B, HW, device=DEV)
+    ops.bin_softmax(to_act(logits, dtype), centers.to(DEV), None, pred2, B, HW, nb)
+    assert torch.equal(pred, pred2)
