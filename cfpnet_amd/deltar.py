@@ -1,0 +1,154 @@
+"""`Deltar`: the drop-in model object (boundary of SURVEY.md §8b).
+
+Mirrors what the reference's callers use (`/root/reference/src/models/deltar.py:8-82`,
+`src/utils/utils.py:7-11`, `train.py:78-80`, `src/utils/model_io.py:5-55`):
+
+  * `make_model(args)` -> `Deltar(n_bins, min_val, max_val, norm)`
+  * `forward(input_data)` with `input_data = {'rgb', 'additional': {hist_data, rect_data, mask,
+    patch_info}}` returning `(bin_edges, pred)` in training mode and
+    `(bin_edges, pred, prob, None)` in eval mode
+  * `state_dict()` / `load_state_dict(strict)` with the reference's key names and shapes,
+    including the 48 dead tensors, so the authors' checkpoints load unchanged
+  * `get_1x_lr_params()` / `get_10x_lr_params()` parameter groups
+
+It is a parameter container: no submodule has arithmetic of its own.  `forward` hands the
+parameters to `cfpnet_amd.engine.Engine`, which runs the hand-written HIP kernels.  There is no
+PyTorch fallback: without a GPU and the built extension `forward` raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import spec, weights
+from .config import args as _global_args
+
+
+def _flag(ns, name, default):
+    try:
+        return getattr(ns, name)
+    except AttributeError:
+        return default
+
+
+class _Store(nn.Module):
+    """Registers parameters/buffers under dotted reference key names by building the matching
+    tree of (empty) nn.Module containers."""
+
+    def _put(self, dotted: str, tensor: torch.Tensor, is_buffer: bool):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Store())
+            mod = mod._modules[p]
+        if is_buffer:
+            mod.register_buffer(parts[-1], tensor)
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class Deltar(_Store):
+    def __init__(self, n_bins: int = 100, min_val: float = 0.1, max_val: float = 10, norm: str = "linear", *,
+                 args=None, dtype=torch.bfloat16, stem_act: bool = False, init: str = "deterministic"):
+        super().__init__()
+        a = args if args is not None else _global_args
+        self.num_classes = n_bins
+        self.min_val, self.max_val, self.norm = min_val, max_val, norm
+        # model-affecting flags are snapshotted at construction (the reference reads the global
+        # `args` at construction AND at forward: fusion.py:16,25,134,154; deltar.py:69,77)
+        self.layer_names: List[str] = list(_flag(a, "attention_layer", spec.BASELINE_LAYERS))
+        self.zone_sample_num: int = int(_flag(a, "zone_sample_num", 16))
+        self.change_embedding: bool = bool(_flag(a, "change_embedding", False))
+        self.no_skip_inside: bool = bool(_flag(a, "no_skip_inside", False))
+        self.hist_encoder_10x: bool = bool(_flag(a, "hist_encoder_10x", False))
+        for ln in self.layer_names:
+            if ln not in ("hist2image", "image", "combine1"):
+                raise NotImplementedError(ln)      # fusion.py:37
+        self.compute_dtype = dtype
+        self.stem_act = stem_act
+        self._manifest = spec.model_manifest(self.layer_names, n_bins, self.zone_sample_num)
+        for key, shape, kind in self._manifest:
+            if init == "deterministic":
+                t = torch.from_numpy(weights.make_tensor(key, shape, kind).copy())
+            else:
+                t = torch.zeros(shape, dtype=torch.int64 if kind == "bn_count" else torch.float32)
+            self._put(key, t, is_buffer=kind in ("bn_mean", "bn_var", "bn_count"))
+        self._engine = None
+        self._engine_version = -1
+        self._version_counter = 0
+
+    # -- reference API ------------------------------------------------------------------
+    def _get_name(self):
+        return "Deltar"
+
+    def _group(self, prefixes) -> Iterator[nn.Parameter]:
+        for name, p in self.named_parameters():
+            if name.split(".")[0] in prefixes:
+                yield p
+
+    def get_1x_lr_params(self):   # lr / 10 (deltar.py:68-74)
+        return self._group(("img_encoder",) if self.hist_encoder_10x else ("img_encoder", "hist_encoder"))
+
+    def get_10x_lr_params(self):  # lr (deltar.py:76-82)
+        g = ("decoder", "depth_head", "conv_out") + (("hist_encoder",) if self.hist_encoder_10x else ())
+        return self._group(g)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self._version_counter += 1
+        return r
+
+    def invalidate(self):
+        """Call after mutating parameters in place so the packed device copies are rebuilt."""
+        self._version_counter += 1
+
+    # -- execution ----------------------------------------------------------------------
+    def engine(self, device=None):
+        from .engine import Engine
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            dev = torch.device("cuda:0")
+        if self._engine is None or self._engine_version != self._version_counter or self._engine.device != dev:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            self._engine = Engine(sd, layer_names=self.layer_names, n_bins=self.num_classes, min_val=self.min_val,
+                                  max_val=self.max_val, norm=self.norm, change_embedding=self.change_embedding,
+                                  no_skip_inside=self.no_skip_inside, stem_act=self.stem_act, dtype=self.compute_dtype,
+                                  device=dev, zone_sample_num=self.zone_sample_num)
+            self._engine_version = self._version_counter
+        return self._engine
+
+    @staticmethod
+    def draw_pos_offsets(H: int, W: int) -> Dict[str, tuple]:
+        """Window into the learned positional tables.  When the feature map is smaller than the
+        table (416x544 crops) the reference draws the offset with `torch.randint` on the CPU
+        generator, y then x, coarsest scale first (fusion.py:87-91); same draws here."""
+        out = {}
+        for name, s in (("cross_atten3", 16), ("cross_atten2", 8), ("cross_atten1", 4)):
+            Hm, Wm = spec.FUSION[name][1]
+            h, w = H // s, W // s
+            oy = int(torch.randint(0, Hm - h + 1, [1])) if h < Hm else 0
+            ox = int(torch.randint(0, Wm - w + 1, [1])) if w < Wm else 0
+            out[name] = (oy, ox)
+        return out
+
+    def forward(self, input_data: Dict, **kwargs):
+        if self.training:
+            raise NotImplementedError(
+                "cfpnet_amd: the training step (backward kernels, batch-statistics BatchNorm) is not built yet; "
+                "call model.eval() -- see DESIGN.md 'Out of scope this round'")
+        eng = self.engine(input_data["rgb"].device if input_data["rgb"].is_cuda else None)
+        pos_offsets = kwargs.get("pos_offsets")
+        if pos_offsets is None:
+            pos_offsets = self.draw_pos_offsets(input_data["rgb"].shape[-2], input_data["rgb"].shape[-1])
+        edges, pred, prob = eng.forward(input_data, return_prob=kwargs.get("return_prob", True), pos_offsets=pos_offsets)
+        return edges, pred, prob, None
+
+
+def make_model(args):
+    """`src/utils/utils.py:7-11`."""
+    if args.model_name == "deltar":
+        return Deltar(n_bins=args.n_bins, min_val=args.min_depth, max_val=args.max_depth, norm=args.norm, args=args)
+    raise NotImplementedError(args.model_name)
