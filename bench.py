@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth maps / second at 480x640, bf16, HIP kernels only.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one eval-mode `Deltar.forward` (RGB encoder, ToF histogram encoder, decoder with the
+cross-zone fusion blocks, adaptive-bin head, `prob` output included -- exactly what the
+reference returns, `/root/reference/src/models/deltar.py:34-67`) over one batch of `--batch`
+synthetic 480x640 images + 8x8 ToF zones that is already resident in HBM (BASELINE.json
+configs[1]).  Inference does not shard: with N > 1 every rank runs an independent replica on its
+own batch (no data-path collective) and `value` is the sum over ranks = N*batch*K / max-rank-time.
+
+The JSON line also carries
+  roofline      the dominant kernel family by GPU time (timed with HIP events around every launch
+                of an instrumented pass on the same stream), algorithmic FLOPs / bytes vs peak
+  dw3x3         the encoder's depthwise 3x3 kernels against the HBM roofline (north_star target)
+  cpu_baseline  the CPU oracle (a PyTorch-CPU restatement of the reference, `oracle/`) timed on
+                this box's host cores on a bounded sample (B=1 forwards); also yields abs_rel
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+CONV_VARIANTS = {0: "conv_igemm<bf16,256x16>", 1: "conv_igemm<bf16,256x32>", 2: "conv_igemm<bf16,128x64>",
+                 3: "conv_igemm<bf16,128x128>"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the HIP graph")
+    ap.add_argument("--no-prob", action="store_true", help="skip the [B,256,H/2,W/2] prob output (not the reference contract)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-times", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def kernel_times(engine, inputs, return_prob, reps=3):
+    """Instrumented eager passes: HIP events (on the launch stream) around every C-ABI call."""
+    from cfpnet_amd import hip
+    recs = []
+    real_call = hip.call
+    stem_w = engine.P["stem.w"].data_ptr()
+    hist_w = engine.P["hist_encoder.hist_extractor1.pointnet_encoder.l1.w"].data_ptr()
+
+    def timed_call(name, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_call(name, *a)
+        e1.record()
+        fam, flops, byts = name, 0.0, 0.0
+        if name == "cfp_conv2d_nhwc":
+            B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo = a[9:21]
+            M = B * Ho * Wo
+            cin_true = 3 if a[2] == stem_w else (1 if a[2] == hist_w else Cin)
+            flops = 2.0 * M * Cout * KH * KW * cin_true
+            byts = 2.0 * (M * Cout + B * H * W * Cin + Cout * KH * KW * Cin)
+            fam = CONV_VARIANTS[hip.load().cfp_conv2d_variant(M, Cout)]
+        elif name == "cfp_dwconv3x3_nhwc":
+            B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16]
+            flops = 2.0 * 9 * B * Ho * Wo * C
+            byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)
+        elif name == "cfp_dwconv_large_nhwc":
+            B, H, W, C, k = a[7:12]
+            flops = 2.0 * k * k * B * H * W * C
+            byts = 2.0 * 2 * B * H * W * C
+        recs.append((fam, e0, e1, flops, byts))
+    hip.call = timed_call
+    try:
+        agg = {}
+        for _ in range(reps):
+            recs.clear()
+            engine.forward(inputs, return_prob=return_prob)
+            torch.cuda.synchronize()
+            for fam, e0, e1, flops, byts in recs:
+                d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
+                d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += flops; d[3] += byts
+    finally:
+        hip.call = real_call
+    return {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps) for k, v in agg.items()}
+
+
+def cpu_baseline(budget_s, layers, sd):
+    from cfpnet_amd import synthetic
+    from oracle import cfpnet_oracle as O
+    inp = synthetic.make_inputs(1, 480, 640, 8, 56, seed=synthetic.SEED)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    out = O.forward(sd, inp, layer_names=layers)      # warm-up (also the abs_rel reference)
+    first = time.perf_counter() - t0
+    times = []
+    while sum(times) + first < budget_s and len(times) < 20:
+        t0 = time.perf_counter()
+        O.forward(sd, inp, layer_names=layers)
+        times.append(time.perf_counter() - t0)
+    if not times:
+        times = [first]
+    times.sort()
+    med = times[len(times) // 2]
+    return inp, out, dict(value=1.0 / med, unit="maps/s", cores=torch.get_num_threads(), kind="port",
+                          sample=f"{len(times)} x B=1 480x640 full forward of the CPU oracle (PyTorch CPU fp32), median {med * 1e3:.0f} ms")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.engine import Engine
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    engine = Engine(sd, layer_names=layers, dtype=torch.bfloat16, device=dev)
+    inputs = synthetic.to_device(synthetic.make_inputs(a.batch, a.height, a.width, 8, 56, seed=synthetic.SEED + rank), dev)
+    return_prob = not a.no_prob
+
+    if a.eager:
+        step = lambda: engine.forward(inputs, return_prob=return_prob)
+    else:
+        engine.capture(inputs, return_prob=return_prob)
+        step = lambda: engine.replay()
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        maps = world * a.batch * a.steps
+        line = {
+            "metric": "depth maps/sec @ 480x640 bf16 (whole job; per_gpu = value / n_gpus)",
+            "value": maps / elapsed, "unit": "maps/s", "per_gpu": maps / elapsed / world,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward incl. prob output"
+                                   if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward, prob output skipped",
+                       "layers": "hist2image combine1 image x2 (CFPNet)", "launch": "eager" if a.eager else "hipGraph replay",
+                       "parallelism": "replicas only" if world > 1 else "single GPU"},
+        }
+        if not a.no_kernel_times:
+            kt = kernel_times(engine, inputs, return_prob)
+            total_ms = sum(v["ms"] for v in kt.values())
+            convs = {k: v for k, v in kt.items() if k.startswith("conv_igemm")}
+            dom = max(convs, key=lambda k: convs[k]["ms"])
+            d = convs[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": d["launches"],
+                                "avg_launch_us": d["ms"] * 1e3 / d["launches"], "share_of_gpu_time": d["ms"] / total_ms}
+            if "cfp_dwconv3x3_nhwc" in kt:
+                w = kt["cfp_dwconv3x3_nhwc"]
+                gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
+                line["dw3x3"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                 "launches_per_step": w["launches"], "avg_launch_us": w["ms"] * 1e3 / w["launches"]}
+            line["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
+            line["kernel_ms_total"] = total_ms
+        if world == 1 and not a.no_cpu_baseline:
+            import numpy as np
+            inp1, (e0, p0, pr0), cb = cpu_baseline(a.cpu_seconds, layers, sd)
+            line["cpu_baseline"] = cb
+            _, p1, _ = engine.forward(synthetic.to_device(inp1, dev), return_prob=False)
+            p1 = p1.float().cpu().numpy()
+            line["abs_rel"] = float(np.mean(np.abs(p0.numpy() - p1) / p0.numpy()))
+            line["rel_l1"] = float(np.abs(p0.numpy() - p1).sum() / np.abs(p0.numpy()).sum())
+        print(json.dumps(line))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,6 +18,8 @@
 // bf16 results go through LDS so global stores are full 16-byte vectors along the channel axis.
 #include "common.h"
 
+extern "C" int cfp_conv2d_variant(int M, int Cout);
+
 namespace {
 
 struct ConvP {
@@ -283,13 +285,12 @@ template <typename T>
 void dispatch(const ConvP& p, hipStream_t s) {
   // Tile choice: widest N tile that the layer fills; fall back to a smaller M tile when the
   // 128x128 grid would leave most of the 256 CUs idle.
-  if (p.Cout <= 16) return launch<T, 256, 16, 4, 1>(p, s);
-  if (p.Cout <= 32) return launch<T, 256, 32, 4, 1>(p, s);
-  if (p.Cout <= 64) return launch<T, 128, 64, 2, 2>(p, s);
-  long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.Cout, 128);
-  bool waste = (p.Cout % 128) != 0 && (p.Cout % 128) <= 64;   // e.g. Cout = 136, 160, 448
-  if (t128 < 192 || waste) return launch<T, 128, 64, 2, 2>(p, s);
-  return launch<T, 128, 128, 2, 2>(p, s);
+  switch (cfp_conv2d_variant(p.M, p.Cout)) {
+    case 0: return launch<T, 256, 16, 4, 1>(p, s);
+    case 1: return launch<T, 256, 32, 4, 1>(p, s);
+    case 2: return launch<T, 128, 64, 2, 2>(p, s);
+    default: return launch<T, 128, 128, 2, 2>(p, s);
+  }
 }
 
 }  // namespace
@@ -324,4 +325,15 @@ extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) dispatch<bf16_t>(p, s); else dispatch<float>(p, s);
   return cfp_check_launch("cfp_conv2d_nhwc");
+}
+
+// Which tile configuration cfp_conv2d_nhwc picks for a problem (for per-kernel accounting in
+// bench.py): 0 = 256x16, 1 = 256x32, 2 = 128x64, 3 = 128x128.
+extern "C" int cfp_conv2d_variant(int M, int Cout) {
+  if (Cout <= 16) return 0;
+  if (Cout <= 32) return 1;
+  if (Cout <= 64) return 2;
+  long long t128 = (long long)cdiv(M, 128) * cdiv(Cout, 128);
+  bool waste = (Cout % 128) != 0 && (Cout % 128) <= 64;
+  return (t128 < 192 || waste) ? 2 : 3;
 }

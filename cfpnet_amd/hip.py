@@ -23,6 +23,7 @@ SIGNATURES = {
     "cfp_version": (_i, []),
     "cfp_last_error": (C.c_char_p, []),
     "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p]),
+    "cfp_conv2d_variant": (_i, [_i, _i]),
     "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),

@@ -51,6 +51,10 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                     int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
 
+/* Tile configuration cfp_conv2d_nhwc uses for (M = B*Ho*Wo, Cout): 0 = 256x16, 1 = 256x32,
+ * 2 = 128x64, 3 = 128x128 output tile per workgroup (per-kernel accounting in bench.py). */
+int cfp_conv2d_variant(int M, int Cout);
+
 /* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused
  * BatchNorm scale/shift + activation.  w packed [9][C].  HBM-bandwidth-bound.
  * Replaces timm InvertedResidual.conv_dw + bn2 + SiLU (encoder.py:66-69, 24 convs). */

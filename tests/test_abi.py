@@ -1,0 +1,99 @@
+"""The C-ABI shared library builds, loads and exports every symbol include/cfpnet_hip.h declares
+(no kernel is launched: this runs without a GPU), and argument validation reports errors through
+return codes + cfp_last_error() instead of faulting."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cfpnet_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return hip.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cfpnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from cfpnet_amd import hip
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cfpnet_hip.h but not exported"
+    assert set(names) == set(hip.SIGNATURES), set(names) ^ set(hip.SIGNATURES)
+    assert lib.cfp_version() >= 100
+
+
+def test_validation_errors_are_reported_not_faulted(lib):
+    from cfpnet_amd import hip
+    # null pointers / bad dtype / bad shapes must come back as negative codes with a message
+    rc = lib.cfp_conv2d_nhwc(0, 8, 0, 0, 0, 0, 0, 0, 8, 1, 4, 4, 8, 8, 3, 3, 1, 1, 1, 4, 4, 0, hip.BF16, 0)
+    assert rc == -1 and "null" in hip.last_error()
+    rc = lib.cfp_layernorm(16, 24, 16, 16, 1e-5, 0, 0, 16, 24, 4, 24, hip.BF16, 0)    # 24/8 = 3 lanes: not a power of two
+    assert rc == -2 and "power of two" in hip.last_error()
+    rc = lib.cfp_attn_kv_reduce(16, 32, 16, 32, 16, 16, 0, 1, 1, 16, 1, 16, 0, 1, 0, 16, 0, 16.0, 4, 5, hip.F32, 0)
+    assert rc == -2 and "head dim" in hip.last_error()
+    rc = lib.cfp_dwconv_large_nhwc(16, 32, 16, 16, 16, 16, 32, 1, 8, 8, 32, 8, 0, hip.F32, 0)   # even kernel
+    assert rc == -2
+    with pytest.raises(RuntimeError, match="cfp_bin_softmax failed"):
+        hip.call("cfp_bin_softmax", 16, 256, 16, 0, 16, 1, 64, 100, hip.F32, 0)
+    assert lib.cfp_attn_kv_ws_floats(0, 1, 1, 1, 1, 1, 8) == 0
+    assert lib.cfp_conv2d_variant(614400, 128) == 3 and lib.cfp_conv2d_variant(100, 16) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Engine refuses to run without a GPU (and never imports the oracle)."""
+    import torch
+    import cfpnet_amd.engine as E
+    src = open(E.__file__).read() + open(os.path.join(ROOT, "cfpnet_amd", "deltar.py")).read() + \
+        open(os.path.join(ROOT, "cfpnet_amd", "ops.py")).read()
+    assert "oracle" not in src.replace("CPU oracle", "")
+    if not torch.cuda.is_available():
+        from cfpnet_amd import spec, weights
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            E.Engine(weights.make_torch_state_dict(spec.model_manifest()), layer_names=spec.COMBINE1_LAYERS)
+
+
+def test_deltar_container_on_cpu():
+    """State-dict contract and parameter groups need no GPU."""
+    import torch
+    from cfpnet_amd import config, spec
+    from cfpnet_amd.deltar import make_model
+    args = config.parse_args(["@" + os.path.join(ROOT, "configs", "cfpnet_combine1.txt")])
+    m = make_model(args)
+    sd = m.state_dict()
+    man = spec.model_manifest(spec.COMBINE1_LAYERS)
+    assert list(sd.keys()) == [k for k, _, _ in man] or set(sd) == {k for k, _, _ in man}
+    for k, shape, _ in man:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    # checkpoint round trip incl. the DataParallel 'module.' prefix (model_io.py:47-52)
+    from cfpnet_amd.model_io import load_checkpoint, save_checkpoint
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, "w", "ck.pt")
+        wrapped = torch.nn.DataParallel(m) if False else None
+        torch.save({"model": {"module." + k: v for k, v in sd.items()}, "epoch": 3}, os.path.join(d, "ck.pt"))
+        m2 = make_model(args)
+        with torch.no_grad():
+            for p in m2.parameters():
+                p.zero_()
+        m2, _, ep = load_checkpoint(os.path.join(d, "ck.pt"), m2)
+        assert ep == 3 and all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), sd.values()))
+        save_checkpoint(m, torch.optim.AdamW(m.parameters()), 1, f)
+        assert os.path.exists(f)
+    n1 = sum(p.numel() for p in m.get_1x_lr_params())
+    n10 = sum(p.numel() for p in m.get_10x_lr_params())
+    assert n1 == 12_461_982 and n1 + n10 == spec.param_count(man)     # hist_encoder_10x: hist params at full lr
+    with pytest.raises(NotImplementedError):
+        args.attention_layer = ["hist2image", "bogus"]
+        make_model(args)
