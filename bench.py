@@ -69,7 +69,7 @@ def kernel_times(engine, inputs, return_prob, reps=3):
         e1.record()
         fam, flops, byts = name, 0.0, 0.0
         if name == "cfp_conv2d_nhwc":
-            B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo = a[9:21]
+            B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo = a[9:21]   # noqa
             M = B * Ho * Wo
             cin_true = 3 if a[2] == stem_w else (1 if a[2] == hist_w else Cin)
             flops = 2.0 * M * Cout * KH * KW * cin_true
@@ -103,7 +103,13 @@ def cpu_baseline(budget_s, layers, sd):
     from cfpnet_amd import synthetic
     from oracle import cfpnet_oracle as O
     inp = synthetic.make_inputs(1, 480, 640, 8, 56, seed=synthetic.SEED)
-    cores = os.cpu_count() or 1
+    # threads = cores this process may actually run on (cgroup/affinity), capped at 32: oneDNN
+    # convolutions of this size stop scaling (and oversubscription is catastrophic) beyond that
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
     out = O.forward(sd, inp, layer_names=layers)      # warm-up (also the abs_rel reference)

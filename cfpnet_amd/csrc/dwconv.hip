@@ -6,9 +6,7 @@
 //          a run of full 16-byte-per-lane accesses along the channel axis.  Row re-use (3x) is
 //          served by L2; column re-use by registers.
 // dwlarge: LKPM's 7x7 / 15x15 / 31x31 depthwise convs (C = 128 / 64 / 32).  Up to 480 FLOP/byte
-//          -> vector-FMA bound.  A 16x16-pixel x 8-channel tile plus halo is staged in LDS as
-//          f32; each thread produces an 8-pixel vertical strip of one channel with a sliding
-//          register window (8 FMAs per LDS operand read).
+//          -> vector-FMA bound; design notes at the kernel.
 #include "common.h"
 
 namespace {
@@ -90,20 +88,113 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
 }
 
 // ---- large kernel ------------------------------------------------------------------------
-constexpr int LT = 16;   // output tile edge
-constexpr int LC = 8;    // channels per workgroup
+// Workgroup = 512 threads = 8 waves; wave w owns channel c0 + w of a 32-row x 32-column output
+// tile, lane = (column, 16-row strip).  The input tile + halo sits in LDS planar per channel
+// ([8][32+K-1][32+K-1] f32) so the 64 lanes of a wave read 2 x 32 consecutive floats:
+// conflict-free ds_read_b32.  The channel is wave-uniform, so the K*K weights come through the
+// scalar cache (s_load) and cost no LDS or VALU slot: the inner loop is 16 v_fma per LDS read.
+// The vertical sliding window lives in a 32-register ring addressed with compile-time indices (K
+// is a template parameter, the ky loop is fully unrolled): no register moves, and each row is
+// fetched LPRE steps before its first use so the LDS latency hides behind ~128 FMAs.
+constexpr int LTH = 32, LTW = 32, LC = 8, LSTRIP = 16, LPRE = 8;
 
-template <typename T>
-__global__ __launch_bounds__(256) void dwlarge_kernel(const T* __restrict__ in, int in_ld,
+template <typename T, int K>
+__global__ __launch_bounds__(512) void dwlarge_kernel(const T* __restrict__ in, int in_ld,
                                                       const float* __restrict__ w, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, T* __restrict__ out,
-                                                      int out_ld, int B, int H, int W, int C, int k, int act) {
+                                                      int out_ld, int B, int H, int W, int C, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int HALO = (K - 1) / 2;
+  constexpr int TPH = LTH + K - 1, TPW = LTW + K - 1;
+  constexpr int VE = Vec<T>::N;
+  constexpr int VPP = LC / VE;
+  float* sIn = lds;                         // [LC][TPH][TPW]
+
+  const int tiles_x = (W + LTW - 1) / LTW, tiles_y = (H + LTH - 1) / LTH;
+  const int cgs = C / LC;
+  int bid = blockIdx.x;
+  const int cg = bid % cgs; bid /= cgs;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int c0 = cg * LC;
+  const int y0 = ty * LTH - HALO, x0 = tx * LTW - HALO;
+  const int tid = threadIdx.x;
+
+  for (int i = tid; i < TPH * TPW * VPP; i += 512) {
+    const int v = i % VPP, pix = i / VPP;
+    const int py = pix / TPW, px = pix % TPW;
+    const int y = y0 + py, x = x0 + px;
+    float vals[VE];
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      Vec<T>::load(in + ((long long)(b * H + y) * W + x) * in_ld + c0 + v * VE, vals);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) vals[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) sIn[(v * VE + e) * (TPH * TPW) + pix] = vals[e];
+  }
+  __syncthreads();
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int col = lane & 31, strip = lane >> 5;
+  const float* __restrict__ wc = w + (long long)(c0 + wave) * (K * K);   // [kx][ky], wave-uniform
+  const float* base = sIn + wave * (TPH * TPW) + (strip * LSTRIP) * TPW + col;
+  constexpr int NROW = LSTRIP + K - 1;     // input rows a strip touches
+  float acc[LSTRIP];
+#pragma unroll
+  for (int i = 0; i < LSTRIP; ++i) acc[i] = 0.f;
+
+  for (int kx = 0; kx < K; ++kx) {
+    const float* colp = base + kx;
+    float win[32];
+#pragma unroll
+    for (int i = 0; i < LSTRIP - 1 + LPRE; ++i)
+      if (i < NROW) win[i & 31] = colp[i * TPW];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      constexpr int AHEAD = LSTRIP - 1 + LPRE;
+      if (ky + AHEAD < NROW) win[(ky + AHEAD) & 31] = colp[(ky + AHEAD) * TPW];
+      const float wv = wc[kx * K + ky];
+#pragma unroll
+      for (int i = 0; i < LSTRIP; ++i) acc[i] = fmaf(win[(ky + i) & 31], wv, acc[i]);
+    }
+  }
+  const float sc = scale[c0 + wave], sh = shift[c0 + wave];
+  __syncthreads();                          // everyone is done reading sIn: reuse it as [pixel][8]
+  float* sOut = lds;
+#pragma unroll
+  for (int i = 0; i < LSTRIP; ++i) sOut[((strip * LSTRIP + i) * LTW + col) * LC + wave] = apply_act(acc[i] * sc + sh, act);
+  __syncthreads();
+  for (int pix = tid; pix < LTH * LTW; pix += 512) {
+    const int py = pix / LTW, px = pix % LTW;
+    const int y = ty * LTH + py, x = tx * LTW + px;
+    if (y < H && x < W) {
+      float v[LC];
+      Vec<float>::load(sOut + pix * LC, v);
+      Vec<float>::load(sOut + pix * LC + 4, v + 4);
+      T* dp = out + ((long long)(b * H + y) * W + x) * out_ld + c0;
+#pragma unroll
+      for (int q = 0; q < VPP; ++q) Vec<T>::store(dp + q * VE, v + q * VE);
+    }
+  }
+}
+
+// generic odd k (3..31): 16x16 tile, weights staged in LDS
+constexpr int LT = 16;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwlarge_generic_kernel(const T* __restrict__ in, int in_ld,
+                                                              const float* __restrict__ w, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, T* __restrict__ out,
+                                                              int out_ld, int B, int H, int W, int C, int k, int act) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int halo = (k - 1) / 2;
-  const int TP = LT + k - 1;            // staged tile edge
+  const int TP = LT + k - 1;
   float* sIn = lds;                     // [TP][TP][LC]
-  float* sW = lds + TP * TP * LC;       // [k*k][LC]
-
+  float* sW = lds + TP * TP * LC;       // [ky*k+kx][LC]
   const int tiles_x = (W + LT - 1) / LT, tiles_y = (H + LT - 1) / LT;
   const int cgs = C / LC;
   int bid = blockIdx.x;
@@ -114,11 +205,12 @@ __global__ __launch_bounds__(256) void dwlarge_kernel(const T* __restrict__ in, 
   const int c0 = cg * LC;
   const int y0 = ty * LT - halo, x0 = tx * LT - halo;
   const int tid = threadIdx.x;
-
-  // stage weights [k*k][8] and the input tile (zero outside the image)
-  for (int i = tid; i < k * k * LC; i += 256) sW[i] = w[(i / LC) * C + c0 + (i % LC)];
+  for (int i = tid; i < k * k * LC; i += 256) {
+    const int c = i % LC, t = i / LC, ky = t / k, kx = t % k;
+    sW[i] = w[(long long)(c0 + c) * k * k + kx * k + ky];
+  }
   constexpr int VE = Vec<T>::N;
-  constexpr int VPP = LC / VE;          // 16-byte vectors per pixel (1 for bf16, 2 for f32)
+  constexpr int VPP = LC / VE;
   for (int i = tid; i < TP * TP * VPP; i += 256) {
     int v = i % VPP, pix = i / VPP;
     int py = pix / TP, px = pix % TP;
@@ -134,15 +226,12 @@ __global__ __launch_bounds__(256) void dwlarge_kernel(const T* __restrict__ in, 
     for (int e = 0; e < VE; ++e) sIn[pix * LC + v * VE + e] = vals[e];
   }
   __syncthreads();
-
-  // thread -> (channel, column, 8-row strip)
   const int c = tid & 7;
   const int col = (tid >> 3) & 15;
   const int r0 = (tid >> 7) * 8;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-
   for (int kx = 0; kx < k; ++kx) {
     const float* colp = sIn + ((r0 * TP) + col + kx) * LC + c;
     float win[8];
@@ -161,11 +250,41 @@ __global__ __launch_bounds__(256) void dwlarge_kernel(const T* __restrict__ in, 
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     int y = ty * LT + r0 + i, x = tx * LT + col;
-    if (y < H && x < W) {
-      float v = apply_act(acc[i] * sc + sh, act);
-      out[((long long)(b * H + y) * W + x) * out_ld + c0 + c] = from_f32<T>(v);
-    }
+    if (y < H && x < W) out[((long long)(b * H + y) * W + x) * out_ld + c0 + c] = from_f32<T>(apply_act(acc[i] * sc + sh, act));
   }
+}
+
+template <typename T, int K>
+hipError_t launch_dwlarge(const void* in, int in_ld, const float* w, const float* scale, const float* shift, void* out,
+                          int out_ld, int B, int H, int W, int C, int act, hipStream_t s) {
+  constexpr int TPH = LTH + K - 1, TPW = LTW + K - 1;
+  size_t lds = (size_t)LC * TPH * TPW * sizeof(float);
+  if (lds < (size_t)LTH * LTW * LC * sizeof(float)) lds = (size_t)LTH * LTW * LC * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)dwlarge_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  long long blocks = (long long)B * cdiv(H, LTH) * cdiv(W, LTW) * (C / LC);
+  hipLaunchKernelGGL((dwlarge_kernel<T, K>), dim3((unsigned)blocks), dim3(512), lds, s, (const T*)in, in_ld, w, scale, shift,
+                     (T*)out, out_ld, B, H, W, C, act);
+  return hipSuccess;
+}
+
+template <typename T>
+hipError_t launch_dwlarge_any(const void* in, int in_ld, const float* w, const float* scale, const float* shift, void* out,
+                              int out_ld, int B, int H, int W, int C, int k, int act, hipStream_t s) {
+  switch (k) {
+    case 7: return launch_dwlarge<T, 7>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, act, s);
+    case 15: return launch_dwlarge<T, 15>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, act, s);
+    case 31: return launch_dwlarge<T, 31>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, act, s);
+    default: break;
+  }
+  const int TP = LT + k - 1;
+  size_t lds = (size_t)(TP * TP * LC + k * k * LC) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)dwlarge_generic_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  long long blocks = (long long)B * cdiv(H, LT) * cdiv(W, LT) * (C / LC);
+  hipLaunchKernelGGL(dwlarge_generic_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, s, (const T*)in, in_ld, w, scale, shift,
+                     (T*)out, out_ld, B, H, W, C, k, act);
+  return hipSuccess;
 }
 
 }  // namespace
@@ -205,23 +324,11 @@ extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, 
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && out_ld % ve == 0 && in_ld >= C &&
                   out_ld >= C, CFP_ESHAPE, "cfp_dwconv_large_nhwc: bad shape");
   CFP_REQUIRE(aligned16(in) && aligned16(out), CFP_EINVAL, "cfp_dwconv_large_nhwc: pointers must be 16-byte aligned");
+  CFP_REQUIRE((long long)B * cdiv(H, 16) * cdiv(W, 16) * (C / 8) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_nhwc: grid too large");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int TP = LT + k - 1;
-  size_t lds = (size_t)(TP * TP * LC + k * k * LC) * sizeof(float);
-  long long blocks = (long long)B * cdiv(H, LT) * cdiv(W, LT) * (C / LC);
-  CFP_REQUIRE(blocks < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_nhwc: grid too large");
-  hipError_t e;
-  if (dtype == CFP_BF16) {
-    e = hipFuncSetAttribute((const void*)dwlarge_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL(dwlarge_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)in, in_ld, w,
-                         scale, shift, (bf16_t*)out, out_ld, B, H, W, C, k, act);
-  } else {
-    e = hipFuncSetAttribute((const void*)dwlarge_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      hipLaunchKernelGGL(dwlarge_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)in, in_ld, w,
-                         scale, shift, (float*)out, out_ld, B, H, W, C, k, act);
-  }
+  hipError_t e = dtype == CFP_BF16
+      ? launch_dwlarge_any<bf16_t>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, k, act, s)
+      : launch_dwlarge_any<float>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, k, act, s);
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
   return cfp_check_launch("cfp_dwconv_large_nhwc");
 }

@@ -1,8 +1,29 @@
 // Adaptive-bins head: bin-width regressor (tiny, one workgroup per image) and the per-pixel
 // 256-way softmax + expectation over bin centres.
-#include "common.h"
+#include "igemm_core.h"
 
 namespace {
+
+// dense layer for one image: out[o] = act(bias[o] + sum_c in[c] * wt[c][o]).  Weights are stored
+// TRANSPOSED ([n_in][n_out]): thread o walks c with unit-stride-across-threads (coalesced) loads that
+// do not depend on each other, so the compiler keeps many in flight; `in` is broadcast from LDS.
+__device__ __forceinline__ void fc_layer(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                                         float* __restrict__ outv, int n_in, int n_out, bool lrelu) {
+  for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < n_in; c += 4) {
+      s0 = fmaf(in[c], wt[(long long)c * n_out + o], s0);
+      s1 = fmaf(in[c + 1], wt[(long long)(c + 1) * n_out + o], s1);
+      s2 = fmaf(in[c + 2], wt[(long long)(c + 2) * n_out + o], s2);
+      s3 = fmaf(in[c + 3], wt[(long long)(c + 3) * n_out + o], s3);
+    }
+    for (; c < n_in; ++c) s0 = fmaf(in[c], wt[(long long)c * n_out + o], s0);
+    float s = (s0 + s1) + (s2 + s3) + (bias ? bias[o] : 0.f);
+    outv[o] = (lrelu && s < 0.f) ? 0.01f * s : s;
+  }
+  __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void bin_regressor_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
                                                             const float* __restrict__ w1x1, const float* __restrict__ w0,
@@ -11,9 +32,7 @@ __global__ __launch_bounds__(256) void bin_regressor_kernel(const float* __restr
                                                             const float* __restrict__ b2, float min_val, float max_val,
                                                             int norm, float* __restrict__ edges, float* __restrict__ centers,
                                                             int C, int hidden, int nbins) {
-  extern __shared__ float sm[];
-  float* a = sm;                 // [max(C, hidden, nbins)]
-  float* t = sm + 512;           // second buffer
+  __shared__ float a[512], t[512];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
@@ -21,31 +40,10 @@ __global__ __launch_bounds__(256) void bin_regressor_kernel(const float* __restr
     a[c] = s * inv_hw;
   }
   __syncthreads();
-  // conv1x1 without bias commutes with the spatial mean (decoder.py:24-25)
-  for (int o = tid; o < C; o += 256) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(a[c], w1x1[(long long)o * C + c], s);
-    t[o] = s;
-  }
-  __syncthreads();
-  for (int o = tid; o < hidden; o += 256) {
-    float s = b0[o];
-    for (int c = 0; c < C; ++c) s = fmaf(t[c], w0[(long long)o * C + c], s);
-    a[o] = s > 0.f ? s : 0.01f * s;
-  }
-  __syncthreads();
-  for (int o = tid; o < hidden; o += 256) {
-    float s = b1[o];
-    for (int c = 0; c < hidden; ++c) s = fmaf(a[c], w1[(long long)o * hidden + c], s);
-    t[o] = s > 0.f ? s : 0.01f * s;
-  }
-  __syncthreads();
-  for (int o = tid; o < nbins; o += 256) {
-    float s = b2[o];
-    for (int c = 0; c < hidden; ++c) s = fmaf(t[c], w2[(long long)o * hidden + c], s);
-    a[o] = s;
-  }
-  __syncthreads();
+  fc_layer(a, w1x1, nullptr, t, C, C, false);   // conv1x1 without bias commutes with the spatial mean
+  fc_layer(t, w0, b0, a, C, hidden, true);
+  fc_layer(a, w1, b1, t, hidden, hidden, true);
+  fc_layer(t, w2, b2, a, hidden, nbins, false);
   if (tid == 0) {
     // sequential on purpose: torch.cumsum / the L1 normalisation run in bin order on the host too
     float total = 0.f;
@@ -142,7 +140,7 @@ extern "C" int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw,
   CFP_REQUIRE(partial && w1x1 && w0 && b0 && w1 && b1 && w2 && b2 && edges && centers, CFP_EINVAL, "cfp_bin_regressor: null pointer");
   CFP_REQUIRE(B > 0 && nsplit > 0 && C > 0 && C <= 512 && hidden > 0 && hidden <= 512 && nbins > 0 && nbins <= 512 &&
                   norm >= 0 && norm <= 2, CFP_ESHAPE, "cfp_bin_regressor: bad shape (C, hidden, nbins <= 512)");
-  hipLaunchKernelGGL(bin_regressor_kernel, dim3(B), dim3(256), 1024 * sizeof(float), reinterpret_cast<hipStream_t>(stream), partial,
+  hipLaunchKernelGGL(bin_regressor_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial,
                      nsplit, inv_hw, w1x1, w0, b0, w1, b1, w2, b2, min_val, max_val, norm, edges, centers, C, hidden, nbins);
   return cfp_check_launch("cfp_bin_regressor");
 }
@@ -170,8 +168,99 @@ extern "C" int cfp_bin_softmax(const void* logits, int ld, const float* centers,
   return cfp_check_launch("cfp_bin_softmax");
 }
 
+// ---- fused bin head ----------------------------------------------------------------------
+// logits = x @ w^T + bias (1x1 conv, Cin -> 256) on the matrix cores; the 128 x 256 logit tile never
+// leaves the registers: row softmax + expectation with 16-lane shuffle butterflies on the MFMA
+// accumulator layout, probabilities transposed through LDS so the NCHW write is 16-byte vectors
+// along the pixel axis.
+namespace {
+constexpr int HBM_ = 128, HBN_ = 256, HPITCH = HBM_ + 8;
+
+__global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const float* __restrict__ bias,
+                                                             const float* __restrict__ centers, bf16_t* __restrict__ prob,
+                                                             float* __restrict__ pred, int HW) {
+  constexpr int TM = 2, TN = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * HBM_;
+  f32x4 acc[TM][TN];
+  igemm_mainloop<bf16_t, HBM_, HBN_, 4, 1>(p, m0, 0, 0, (p.K + 31) / 32, smem, acc);
+  __syncthreads();
+  bf16_t* sP = reinterpret_cast<bf16_t*>(smem);      // [256][HPITCH]
+  float bs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bs[j] = bias[j * 16 + fr];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row0 = wave * 32 + i * 16 + fq * 4;           // this lane's 4 rows: row0 .. row0+3
+    const int mrow = m0 + row0;
+    const int bidx = min(mrow, p.M - 1) / HW;               // rows of one lane never straddle images when HW % 4 == 0
+    float cen[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cen[j] = centers[(long long)bidx * HBN_ + j * 16 + fr];
+    float pr[4][TN];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { pr[r][j] = acc[i][j][r] + bs[j]; mx = fmaxf(mx, pr[r][j]); }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { pr[r][j] = __expf(pr[r][j] - mx); s += pr[r][j]; }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+      const float inv = 1.f / s;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { pr[r][j] *= inv; dot = fmaf(pr[r][j], cen[j], dot); }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) dot += __shfl_xor(dot, o, 64);
+      if (fr == 0 && mrow + r < p.M) pred[mrow + r] = dot;
+    }
+    if (prob) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        uint32_t lo = (uint32_t)f2bf(pr[0][j]) | ((uint32_t)f2bf(pr[1][j]) << 16);
+        uint32_t hi = (uint32_t)f2bf(pr[2][j]) | ((uint32_t)f2bf(pr[3][j]) << 16);
+        uint2 v = {lo, hi};
+        *reinterpret_cast<uint2*>(sP + (j * 16 + fr) * HPITCH + row0) = v;
+      }
+    }
+  }
+  if (!prob) return;
+  __syncthreads();
+  constexpr int CH = HBM_ / 8;
+  for (int q = tid; q < HBN_ * CH; q += 256) {
+    const int n = q / CH, ch = q % CH;
+    const int m = m0 + ch * 8;
+    if (m >= p.M) continue;
+    const int b = m / HW, hw = m % HW;                 // HW % 8 == 0: a chunk stays inside one image
+    *reinterpret_cast<u32x4*>(prob + ((long long)b * HBN_ + n) * HW + hw) = *reinterpret_cast<const u32x4*>(sP + n * HPITCH + ch * 8);
+  }
+}
+}  // namespace
+
 extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
                                   void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream) {
-  cfp_set_error("cfp_bin_head_fused: not built in this version");
-  return CFP_EINVAL;
+  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_bin_head_fused: bf16 only (use cfp_conv2d_nhwc + cfp_bin_softmax for f32)");
+  CFP_REQUIRE(x && w && bias && centers && pred, CFP_EINVAL, "cfp_bin_head_fused: null pointer");
+  CFP_REQUIRE(B > 0 && HW > 0 && HW % 8 == 0 && Cin > 0 && Cin % 8 == 0 && x_ld % 8 == 0 && x_ld >= Cin &&
+                  (long long)B * HW < (1ll << 31), CFP_ESHAPE, "cfp_bin_head_fused: bad shape (HW and Cin must be multiples of 8)");
+  CFP_REQUIRE(aligned16(x) && aligned16(w) && aligned16(prob), CFP_EINVAL, "cfp_bin_head_fused: pointers must be 16-byte aligned");
+  ConvP p;
+  p.in = x; p.w = w; p.out = nullptr; p.res = nullptr; p.scale = nullptr; p.shift = nullptr;
+  p.in_ld = x_ld; p.out_ld = 0; p.res_ld = 0;
+  p.B = 1; p.H = 1; p.W = B * HW; p.Cin = Cin; p.Ho = 1; p.Wo = B * HW; p.Cout = HBN_;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
+  size_t lds = (size_t)HBN_ * HPITCH * sizeof(bf16_t);
+  size_t ops_lds = 2 * (HBM_ + HBN_) * 64;
+  if (lds < ops_lds) lds = ops_lds;
+  hipError_t e = hipFuncSetAttribute((const void*)bin_head_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { cfp_set_error(std::string("cfp_bin_head_fused: ") + hipGetErrorString(e)); return CFP_EHIP; }
+  hipLaunchKernelGGL(bin_head_fused_kernel, dim3(cdiv(p.M, HBM_)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p, bias,
+                     centers, (bf16_t*)prob, pred, HW);
+  return cfp_check_launch("cfp_bin_head_fused");
 }

@@ -1,0 +1,186 @@
+// Shared implicit-GEMM main loop (see conv_igemm.hip for the design notes).
+#pragma once
+#include "common.h"
+
+struct ConvP {
+  const void* in;
+  const void* w;
+  void* out;
+  const void* res;
+  const float* scale;
+  const float* shift;
+  int in_ld, out_ld, res_ld;
+  int B, H, W, Cin, Ho, Wo, Cout;
+  int KH, KW, stride, pad_t, pad_l;
+  int M, K;
+  int act;
+  int pointwise;  // KH == KW == 1, stride 1, no padding: A rows are plain pixel rows
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) {
+  // physical 16-byte chunk of (row, logical chunk); g = [0,3,2,1][(row >> 2) & 3]
+  int q = (row >> 2) & 3;
+  int g = (4 - q) & 3;
+  return chunk ^ g;
+}
+
+// Accumulates C[m0.., n0..] over K-steps [ks_begin, ks_end) into acc (16x16 MFMA tiles).
+// smem: 2 * (BM + BN) * 64 bytes.  All 256 threads of the workgroup must call it.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void igemm_mainloop(const ConvP& p, int m0, int n0, int ks_begin, int ks_end,
+                                               unsigned char* smem, f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
+  constexpr int VE = Vec<T>::N;           // elements per 16-byte chunk
+  constexpr int BK = 4 * VE;              // 64-byte rows
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int A_ROWS = BM / 64;         // rows of A per thread per K-step
+  constexpr int B_ROWS = (BN + 63) / 64;  // rows of W per thread per K-step
+  constexpr bool kBf16 = sizeof(T) == 2;
+  auto sA = [&](int st) -> unsigned char* { return smem + st * ((BM + BN) * 64); };
+  auto sB = [&](int st) -> unsigned char* { return smem + st * ((BM + BN) * 64) + BM * 64; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(p.w);
+
+  // ---- per-thread row bookkeeping for the A tile --------------------------------------
+  const int ld_row = tid >> 2;  // 0..63
+  const int ld_chunk = tid & 3;
+  long long a_base[A_ROWS];     // element offset of (b, hi0, wi0) -- may be "virtual" (negative hi0)
+  int a_hi0[A_ROWS], a_wi0[A_ROWS];
+  bool a_ok[A_ROWS];
+#pragma unroll
+  for (int i = 0; i < A_ROWS; ++i) {
+    int m = m0 + ld_row + 64 * i;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    if (p.pointwise) {
+      a_base[i] = (long long)mm * p.in_ld;
+      a_hi0[i] = 0;
+      a_wi0[i] = 0;
+    } else {
+      int wo = mm % p.Wo;
+      int t = mm / p.Wo;
+      int ho = t % p.Ho;
+      int b = t / p.Ho;
+      a_hi0[i] = ho * p.stride - p.pad_t;
+      a_wi0[i] = wo * p.stride - p.pad_l;
+      a_base[i] = (long long)b * p.H * p.W * p.in_ld;
+    }
+  }
+  bool b_ok[B_ROWS];
+  long long b_base[B_ROWS];
+#pragma unroll
+  for (int i = 0; i < B_ROWS; ++i) {
+    int r = ld_row + 64 * i;
+    int n = n0 + r;
+    b_ok[i] = (r < BN) && (n < p.Cout);
+    b_base[i] = (long long)(b_ok[i] ? n : 0) * p.K;
+  }
+
+  u32x4 ra[A_ROWS], rb[B_ROWS];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  auto load_tiles = [&](int k0) {
+    int k = k0 + ld_chunk * VE;
+    bool kok = k < p.K;
+    int kh = 0, kw = 0, cc = k;
+    if (!p.pointwise) {
+      int tap = k / p.Cin;
+      cc = k - tap * p.Cin;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+      bool ok = a_ok[i] && kok;
+      long long off = a_base[i] + cc;
+      if (!p.pointwise) {
+        ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        off += ((long long)hi * p.W + wi) * p.in_ld;
+      }
+      ra[i] = ok ? *reinterpret_cast<const u32x4*>(in + off) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      rb[i] = (b_ok[i] && kok) ? *reinterpret_cast<const u32x4*>(wt + b_base[i] + k) : zero4;
+    }
+  };
+  auto store_tiles = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      int r = ld_row + 64 * i;
+      *reinterpret_cast<u32x4*>(sA(st) + r * 64 + swz(r, ld_chunk) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      int r = ld_row + 64 * i;
+      if (r < BN) *reinterpret_cast<u32x4*>(sB(st) + r * 64 + swz(r, ld_chunk) * 16) = rb[i];
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(ks_begin * BK);
+  store_tiles(0);
+  __syncthreads();
+
+  const int fr = lane & 15;   // fragment row within a 16-row block
+  const int fq = lane >> 4;   // k-chunk (bf16) / k index (f32)
+
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int st = (ks - ks_begin) & 1;
+    if (ks + 1 < ks_end) load_tiles((ks + 1) * BK);
+
+    const unsigned char* cA = sA(st) + (wm * (BM / WM)) * 64;
+    const unsigned char* cB = sB(st) + (wn * (BN / WN)) * 64;
+    if constexpr (kBf16) {
+      s16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int r = i * 16 + fr;   // wave row offsets are multiples of 16, so (r>>2)&3 is unchanged by them
+        af[i] = *reinterpret_cast<const s16x8*>(cA + r * 64 + swz(r, fq) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int r = j * 16 + fr;
+        bfr[j] = *reinterpret_cast<const s16x8*>(cB + r * 64 + swz(r, fq) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {   // four 16x16x4 steps cover BK = 16
+        float af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          int r = i * 16 + fr;
+          af[i] = *reinterpret_cast<const float*>(cA + r * 64 + swz(r, kk) * 16 + fq * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          int r = j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const float*>(cB + r * 64 + swz(r, kk) * 16 + fq * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ks + 1 < ks_end) store_tiles(st ^ 1);
+    __syncthreads();
+  }
+}

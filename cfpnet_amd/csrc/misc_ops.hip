@@ -52,15 +52,17 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
   (void)lanes_r;
 }
 
-// ---- SE gate: one workgroup per batch element --------------------------------------------
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
-                                                      const float* __restrict__ wr, const float* __restrict__ br,
-                                                      const float* __restrict__ we, const float* __restrict__ be,
-                                                      float* __restrict__ gate, int C, int R) {
-  extern __shared__ float sm[];   // mean[C] then hidden[R]
-  float* mean = sm;
-  float* hid = sm + C;
-  const int b = blockIdx.x;
+// ---- SE block --------------------------------------------------------------------------
+// se_hidden: mean (from the partial sums) -> FC(C->R) + bias -> SiLU.  One wave per hidden unit;
+// lanes walk the channels, so weight rows are read as coalesced 256-byte runs and the dot product
+// ends in a wavefront shuffle reduction.
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
+                                                        const float* __restrict__ wr, const float* __restrict__ br,
+                                                        float* __restrict__ hidden, int C, int R) {
+  // grid (ceil(R/4), B): every wave of a workgroup produces one hidden unit, so the 4 x ceil(R/4) x B
+  // dot products run in parallel instead of one after the other (they are latency-, not bandwidth-bound)
+  extern __shared__ float mean[];   // [C]
+  const int b = blockIdx.y;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
     for (int j = 0; j < nsplit; ++j) s += partial[((long long)b * nsplit + j) * C + c];
@@ -68,17 +70,57 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int r = wave; r < R; r += 4) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(mean[c], wr[(long long)r * C + c], s);
-    s = wave_sum(s);
-    if (lane == 0) hid[r] = apply_act(s + br[r], CFP_ACT_SILU);
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float* wrow = wr + (long long)r * C;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = lane;
+  for (; c + 192 < C; c += 256) {     // 4 independent loads in flight per lane
+    s0 = fmaf(mean[c], wrow[c], s0);
+    s1 = fmaf(mean[c + 64], wrow[c + 64], s1);
+    s2 = fmaf(mean[c + 128], wrow[c + 128], s2);
+    s3 = fmaf(mean[c + 192], wrow[c + 192], s3);
   }
+  for (; c < C; c += 64) s0 = fmaf(mean[c], wrow[c], s0);
+  const float s = wave_sum((s0 + s1) + (s2 + s3));
+  if (lane == 0) hidden[(long long)b * R + r] = apply_act(s + br[r], CFP_ACT_SILU);
+}
+
+// se_scale: x[b, hw, c] *= sigmoid(hidden[b] . we_t[:, c] + be[c]).  A thread keeps one 16-byte
+// channel vector, computes its gate once (R x VE FMAs, expand weights stored [R][C] so the
+// reads are coalesced) and then walks rows.
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(T* __restrict__ x, int ld, const float* __restrict__ hidden,
+                                                       const float* __restrict__ we_t, const float* __restrict__ be,
+                                                       int HW, int C, int R, int row_lanes) {
+  constexpr int VE = Vec<T>::N;
+  extern __shared__ float hid[];    // [R]
+  const int b = blockIdx.y;
+  for (int r = threadIdx.x; r < R; r += 256) hid[r] = hidden[(long long)b * R + r];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = be[c];
-    for (int r = 0; r < R; ++r) s = fmaf(hid[r], we[(long long)c * R + r], s);
-    gate[(long long)b * C + c] = 1.f / (1.f + __expf(-s));
+  const int CV = C / VE;
+  const int items = CV * row_lanes;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int cv = it % CV, rl = it / CV;
+    float g[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] = be[cv * VE + e];
+    for (int r = 0; r < R; ++r) {
+      const float h = hid[r];
+      const float* wp = we_t + (long long)r * C + cv * VE;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = fmaf(h, wp[e], g[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] = 1.f / (1.f + __expf(-g[e]));
+    for (int row = rl; row < HW; row += row_lanes) {
+      T* p = x + ((long long)b * HW + row) * ld + cv * VE;
+      float v[VE];
+      Vec<T>::load(p, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] *= g[e];
+      Vec<T>::store(p, v);
+    }
   }
 }
 
@@ -291,14 +333,35 @@ extern "C" int cfp_channel_sum(const void* in, int in_ld, float* partial, int B,
   return cfp_check_launch("cfp_channel_sum");
 }
 
-extern "C" int cfp_se_gate(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
-                           const float* w_expand, const float* b_expand, float* gate, int B, int C, int R,
-                           cfp_stream_t stream) {
-  CFP_REQUIRE(partial && w_reduce && b_reduce && w_expand && b_expand && gate, CFP_EINVAL, "cfp_se_gate: null pointer");
-  CFP_REQUIRE(B > 0 && C > 0 && R > 0 && nsplit > 0 && (size_t)(C + R) * 4 <= 64 * 1024, CFP_ESHAPE, "cfp_se_gate: bad shape");
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + R) * sizeof(float), reinterpret_cast<hipStream_t>(stream),
-                     partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand, b_expand, gate, C, R);
-  return cfp_check_launch("cfp_se_gate");
+extern "C" int cfp_se_hidden(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                             float* hidden, int B, int C, int R, cfp_stream_t stream) {
+  CFP_REQUIRE(partial && w_reduce && b_reduce && hidden, CFP_EINVAL, "cfp_se_hidden: null pointer");
+  CFP_REQUIRE(B > 0 && C > 0 && R > 0 && nsplit > 0 && (size_t)C * 4 <= 64 * 1024, CFP_ESHAPE, "cfp_se_hidden: bad shape");
+  hipLaunchKernelGGL(se_hidden_kernel, dim3(cdiv(R, 4), B), dim3(256), (size_t)C * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                     partial, nsplit, inv_hw, w_reduce, b_reduce, hidden, C, R);
+  return cfp_check_launch("cfp_se_hidden");
+}
+
+extern "C" int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand, int B, int HW,
+                            int C, int R, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_se_scale");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(x && hidden && w_expand_t && b_expand && aligned16(x), CFP_EINVAL, "cfp_se_scale: bad pointer");
+  CFP_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0 && C % 8 == 0 && R > 0 && R <= 4096 && ld % ve == 0 && ld >= C, CFP_ESHAPE,
+              "cfp_se_scale: bad shape");
+  const int cv = C / ve;
+  int row_lanes = (256 * 256 / B) / cv;          // ~one wave of the chip per image batch
+  if (row_lanes > HW) row_lanes = HW;
+  if (row_lanes < 1) row_lanes = 1;
+  const int blocks = cdiv((long long)cv * row_lanes, 256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (bf16_t*)x, ld, hidden,
+                       w_expand_t, b_expand, HW, C, R, row_lanes);
+  else
+    hipLaunchKernelGGL(se_scale_kernel<float>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (float*)x, ld, hidden,
+                       w_expand_t, b_expand, HW, C, R, row_lanes);
+  return cfp_check_launch("cfp_se_scale");
 }
 
 extern "C" int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream) {

@@ -52,6 +52,8 @@ class Engine:
         self.P: Dict[str, torch.Tensor] = {}
         self._plans: Dict[tuple, dict] = {}
         self._graph = None
+        self._splitk_ws: Optional[torch.Tensor] = None
+        self._capturing = False
         self.load_state_dict(state_dict)
 
     # ------------------------------------------------------------------------------ packing
@@ -125,7 +127,7 @@ class Engine:
                 self.P[q + ".dw.s"], self.P[q + ".dw.t"] = self._fold_bn(sd, q + ".bn2", None, wd.shape[0], EPS)
                 self.P[q + ".se.wr"] = self._dev(sd[q + ".se.conv_reduce.weight"].reshape(b.se_rd, b.mid))
                 self.P[q + ".se.br"] = self._dev(sd[q + ".se.conv_reduce.bias"])
-                self.P[q + ".se.we"] = self._dev(sd[q + ".se.conv_expand.weight"].reshape(b.mid, b.se_rd))
+                self.P[q + ".se.we_t"] = self._dev(sd[q + ".se.conv_expand.weight"].reshape(b.mid, b.se_rd).t())
                 self.P[q + ".se.be"] = self._dev(sd[q + ".se.conv_expand.bias"])
                 self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn3", eps=EPS)
         for ex in (1, 2, 3):
@@ -161,7 +163,7 @@ class Engine:
                     k = l + ".large_kernel_path"
                     wd = sd[k + ".dwconv2.weight"].float()
                     kk = wd.shape[-1]
-                    self.P[k + ".dw.w"] = self._dev(wd.reshape(wd.shape[0], kk * kk).t())     # f32 [k*k][C]
+                    self.P[k + ".dw.w"] = self._dev(wd[:, 0].transpose(1, 2).reshape(wd.shape[0], kk * kk))   # f32 [C][kx][ky]
                     self.P[k + ".dw.s"], self.P[k + ".dw.t"] = self._fold_bn(sd, k + ".bn1", sd[k + ".dwconv2.bias"], wd.shape[0], _BN_EPS)
                     self.P[k + ".norm.g"], self.P[k + ".norm.b"] = self._dev(sd[k + ".norm.weight"]), self._dev(sd[k + ".norm.bias"])
                     self._conv(sd, k + ".pw1", k + ".pwconv1.weight", k + ".pwconv1.bias")
@@ -170,9 +172,9 @@ class Engine:
                     raise NotImplementedError(ln)
         h = "depth_head"
         self._conv(sd, h + ".conv3x3", h + ".conv3x3.weight", h + ".conv3x3.bias")
-        self.P[h + ".w1x1"] = self._dev(sd[h + ".conv1x1.weight"].reshape(128, 128))
+        self.P[h + ".w1x1"] = self._dev(sd[h + ".conv1x1.weight"].reshape(128, 128).t())      # [in][out]
         for i in (0, 2, 4):
-            self.P[f"{h}.r{i}.w"], self.P[f"{h}.r{i}.b"] = self._dev(sd[f"{h}.regressor.{i}.weight"]), self._dev(sd[f"{h}.regressor.{i}.bias"])
+            self.P[f"{h}.r{i}.w"], self.P[f"{h}.r{i}.b"] = self._dev(sd[f"{h}.regressor.{i}.weight"].t()), self._dev(sd[f"{h}.regressor.{i}.bias"])
         self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias")
 
     # ------------------------------------------------------------------------------ buffers
@@ -201,11 +203,23 @@ class Engine:
             (pt, pb), (pl, pr) = pads
             Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
         ops.conv2d(x, self.P[name + ".w"], self.P[name + ".s"], self.P[name + ".t"], out, B, H, W, k, k, stride, pt, pl,
-                   Ho, Wo, act, residual)
+                   Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, k * k * x.C))
         return Ho, Wo
 
     def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None):
-        ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual)
+        ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual,
+                   self._ws(rows, out.C, x.C))
+
+    def _ws(self, M: int, Cout: int, K: int) -> Optional[torch.Tensor]:
+        """Split-K scratch shared by all layers (kernels on one stream run in order)."""
+        need = ops.conv2d_ws_bytes(M, Cout, K, ops.DT[self.dtype])
+        if need == 0:
+            return None
+        if self._splitk_ws is None or self._splitk_ws.numel() * 4 < need:
+            if self._capturing:
+                raise RuntimeError("split-K workspace must be sized by a warm-up forward before graph capture")
+            self._splitk_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return self._splitk_ws
 
     def _encoder(self, plan, rgb: torch.Tensor, B, H, W, taps):
         """encoder.py:71-79 over timm tf_efficientnetv2_b3 blocks; returns the five tap Acts."""
@@ -238,13 +252,12 @@ class Engine:
                 mid2 = self._act(plan, f"enc{bi}.dw", B * ho * wo, b.mid)
                 ops.dwconv3x3(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, B, h, w, b.stride,
                               pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
-                ns = max(1, min(64, (ho * wo) // 64))
+                ns = max(1, min(16, (ho * wo) // 64))
                 part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
-                gate = self._f32(plan, f"enc{bi}.gate", B * b.mid)
+                hid = self._f32(plan, f"enc{bi}.hid", B * b.se_rd)
                 ops.channel_sum(mid2, part, B, ho * wo, ns)
-                ops.se_gate(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], self.P[q + ".se.we"],
-                            self.P[q + ".se.be"], gate, B, b.mid, b.se_rd)
-                ops.scale_channels(mid2, gate, B, ho * wo)
+                ops.se_hidden(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], hid, B, b.mid, b.se_rd)
+                ops.se_scale(mid2, hid, self.P[q + ".se.we_t"], self.P[q + ".se.be"], B, ho * wo, b.se_rd)
                 self._cv(q + ".pwl", mid2, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
             x, h, w = out, ho, wo
             if bi in spec.ENC_TAPS:
@@ -346,7 +359,7 @@ class Engine:
                 hk, wk = gsa_keys(H, W, ws)
                 kraw = self._act(plan, f"{name}.gsa.kraw", B * hk * wk, D)
                 ops.conv2d(tok[cur].slice(0, D), self.P[l + ".gsa.sr.w"], self.P[l + ".gsa.sr.s"], self.P[l + ".gsa.sr.t"], kraw,
-                           B, H, W, ws, ws, ws, 0, 0, hk, wk)
+                           B, H, W, ws, ws, ws, 0, 0, hk, wk, ws=self._ws(B * hk * wk, D, ws * ws * D))
                 keys = self._act(plan, f"{name}.gsa.keys", B * hk * wk, D)
                 ops.layernorm(kraw, self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5, keys, B * hk * wk)
                 S = hk * wk
@@ -412,8 +425,12 @@ class Engine:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self.forward(static, return_prob=return_prob, pos_offsets=pos_offsets)
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g):
+                out = self.forward(static, return_prob=return_prob, pos_offsets=pos_offsets)
+        finally:
+            self._capturing = False
         self._graph = (g, static, out)
         return out
 
@@ -519,11 +536,15 @@ class Engine:
         ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
                           self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
                           edges, centers, B, 128, 256, self.n_bins)
-        logits = self._act(plan, "logits", Mh, self.n_bins)
-        self._lin("conv_out.w", ram, logits, Mh, hip.ACT_NONE, None, "conv_out")
         pred = torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
         prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
-        ops.bin_softmax(logits, centers, prob, pred, B, HWh, self.n_bins)
+        if self.dtype == torch.bfloat16 and self.n_bins == 256 and HWh % 8 == 0:
+            # 1x1 conv + softmax + expectation in one kernel: the logits never reach HBM
+            ops.bin_head_fused(ram, self.P["conv_out.w"], self.P["conv_out.t"], centers, prob, pred, B, HWh)
+        else:
+            logits = self._act(plan, "logits", Mh, self.n_bins)
+            self._lin("conv_out.w", ram, logits, Mh, hip.ACT_NONE, None, "conv_out")
+            ops.bin_softmax(logits, centers, prob, pred, B, HWh, self.n_bins)
         if taps is not None:
             taps["unet_out"] = self._nchw(unet, B, hs[0], wsz[0])
             taps["ram"] = self._nchw(ram, B, hs[0], wsz[0])

@@ -22,12 +22,14 @@ _p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "cfp_version": (_i, []),
     "cfp_last_error": (C.c_char_p, []),
-    "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p]),
+    "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
+    "cfp_conv2d_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "cfp_conv2d_variant": (_i, [_i, _i]),
     "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
-    "cfp_se_gate": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "cfp_se_hidden": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _p]),
+    "cfp_se_scale": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_scale_channels": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_layernorm": (_i, [_p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_attn_kv_ws_floats": (_sz, [_i] * 7),

@@ -56,17 +56,23 @@ def _s():
     return hip.current_stream()
 
 
+def conv2d_ws_bytes(M: int, Cout: int, K: int, dt: int) -> int:
+    return int(hip.load().cfp_conv2d_ws_bytes(M, Cout, K, dt))
+
+
 def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo,
-           act=hip.ACT_NONE, residual: Optional[Act] = None):
+           act=hip.ACT_NONE, residual: Optional[Act] = None, ws: Optional[torch.Tensor] = None):
     assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
     assert w.dtype == x.buf.dtype and w.shape == (out.C, KH * KW * x.C), (w.shape, out.C, KH, KW, x.C)
     hip.call("cfp_conv2d_nhwc", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
-             B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+             B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
+             hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 
-def linear(x: Act, w: torch.Tensor, scale, shift, out: Act, rows: int, act=hip.ACT_NONE, residual: Optional[Act] = None):
-    conv2d(x, w, scale, shift, out, 1, 1, rows, 1, 1, 1, 0, 0, 1, rows, act, residual)
+def linear(x: Act, w: torch.Tensor, scale, shift, out: Act, rows: int, act=hip.ACT_NONE, residual: Optional[Act] = None,
+           ws: Optional[torch.Tensor] = None):
+    conv2d(x, w, scale, shift, out, 1, 1, rows, 1, 1, 1, 0, 0, 1, rows, act, residual, ws)
 
 
 def dwconv3x3(x: Act, w, scale, shift, out: Act, B, H, W, stride, pad_t, pad_l, Ho, Wo, act):
@@ -84,9 +90,14 @@ def channel_sum(x: Act, partial: torch.Tensor, B, HW, nsplit):
     hip.call("cfp_channel_sum", x.ptr, x.ld, partial.data_ptr(), B, HW, x.C, nsplit, x.dt, _s())
 
 
-def se_gate(partial, nsplit, inv_hw, wr, br, we, be, gate, B, C, R):
-    hip.call("cfp_se_gate", partial.data_ptr(), nsplit, float(inv_hw), wr.data_ptr(), br.data_ptr(), we.data_ptr(),
-             be.data_ptr(), gate.data_ptr(), B, C, R, _s())
+def se_hidden(partial, nsplit, inv_hw, wr, br, hidden, B, C, R):
+    hip.call("cfp_se_hidden", partial.data_ptr(), nsplit, float(inv_hw), wr.data_ptr(), br.data_ptr(), hidden.data_ptr(),
+             B, C, R, _s())
+
+
+def se_scale(x: Act, hidden, we_t, be, B, HW, R):
+    assert we_t.shape == (R, x.C)
+    hip.call("cfp_se_scale", x.ptr, x.ld, hidden.data_ptr(), we_t.data_ptr(), be.data_ptr(), B, HW, x.C, R, x.dt, _s())
 
 
 def scale_channels(x: Act, gate, B, HW):

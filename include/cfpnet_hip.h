@@ -49,7 +49,13 @@ const char* cfp_last_error(void);
 int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                     const void* residual, int res_ld, void* out, int out_ld,
                     int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                    int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
+                    int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
+                    void* ws, size_t ws_bytes, cfp_stream_t stream);
+
+/* Scratch cfp_conv2d_nhwc wants for (M = B*Ho*Wo, Cout, K = KH*KW*Cin): non-zero only for layers it
+ * runs split-K (few output tiles, long K: the GSA sr convs, the 1/32-scale pointwise convs).  With
+ * ws == NULL or too small the layer runs un-split (same result up to f32 re-association). */
+size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype);
 
 /* Tile configuration cfp_conv2d_nhwc uses for (M = B*Ho*Wo, Cout): 0 = 256x16, 1 = 256x32,
  * 2 = 128x64, 3 = 128x128 output tile per workgroup (per-kernel accounting in bench.py). */
@@ -62,9 +68,10 @@ int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* sc
                        void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                        int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
 
-/* Large-kernel depthwise convolution (k = 7 / 15 / 31, stride 1, "same"), fused bias + BatchNorm +
- * ReLU.  w packed [k*k][C] as f32.  Vector-FMA-bound.  Replaces Block14.dwconv2 + bn1 + relu
- * (convnext.py:30,45-47). */
+/* Large-kernel depthwise convolution (odd k <= 31; 7 / 15 / 31 have dedicated kernels), stride 1,
+ * "same" padding, fused bias + BatchNorm + ReLU.  w packed [C][kx][ky] as f32 (per-channel
+ * contiguous, column-major taps: the kernel slides vertically and fetches weights through the
+ * scalar cache).  Vector-FMA-bound.  Replaces Block14.dwconv2 + bn1 + relu (convnext.py:30,45-47). */
 int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float* scale, const float* shift,
                           void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                           cfp_stream_t stream);
@@ -75,10 +82,15 @@ int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float
 int cfp_channel_sum(const void* in, int in_ld, float* partial, int B, int HW, int C, int nsplit, int dtype,
                     cfp_stream_t stream);
 
-/* Squeeze-excite gate: mean -> FC(C->R)+bias -> SiLU -> FC(R->C)+bias -> sigmoid, f32 weights.
- * gate[b][c] f32.  Replaces timm SqueezeExcite (inside encoder.py:66-69 blocks). */
-int cfp_se_gate(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
-                const float* w_expand, const float* b_expand, float* gate, int B, int C, int R, cfp_stream_t stream);
+/* Squeeze-excite, first half: mean -> FC(C->R) + bias -> SiLU; hidden[b][r] f32.  w_reduce [R][C] f32.
+ * Replaces timm SqueezeExcite.conv_reduce + act (inside the encoder.py:66-69 blocks). */
+int cfp_se_hidden(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                  float* hidden, int B, int C, int R, cfp_stream_t stream);
+
+/* Squeeze-excite, second half, in place: x[b,hw,c] *= sigmoid(hidden[b] . w_expand_t[:, c] + b_expand[c]).
+ * w_expand_t is the expand weight TRANSPOSED to [R][C] f32.  Replaces conv_expand + sigmoid gate + multiply. */
+int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand,
+                 int B, int HW, int C, int R, int dtype, cfp_stream_t stream);
 
 /* x[b, hw, c] *= gate[b, c] in place. */
 int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream);
@@ -140,11 +152,12 @@ int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_str
 
 /* Bin-width regressor + bin edges/centres, one workgroup per batch element, all f32:
  *   mean -> conv1x1 (no bias) -> Linear/LeakyReLU x2 -> Linear -> norm -> widths -> cumsum
+ * Every weight matrix is passed TRANSPOSED, [n_in][n_out] (coalesced across output threads).
  * norm: 0 linear (relu + 0.1, L1-normalise), 1 softmax, 2 sigmoid (L1-normalise).
  * edges [B][nbins+1], centers [B][nbins].  Replaces decoder.py:23-36 + deltar.py:53-59. */
-int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw, const float* w1x1,
-                      const float* w0, const float* b0, const float* w1, const float* b1,
-                      const float* w2, const float* b2, float min_val, float max_val, int norm,
+int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw, const float* w1x1_t,
+                      const float* w0_t, const float* b0, const float* w1_t, const float* b1,
+                      const float* w2_t, const float* b2, float min_val, float max_val, int norm,
                       float* edges, float* centers, int B, int C, int hidden, int nbins, cfp_stream_t stream);
 
 /* Per-pixel softmax over nbins logits + expectation over bin centres:

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_validation_errors_are_reported_not_faulted(lib):
     from cfpnet_amd import hip
     # null pointers / bad dtype / bad shapes must come back as negative codes with a message
-    rc = lib.cfp_conv2d_nhwc(0, 8, 0, 0, 0, 0, 0, 0, 8, 1, 4, 4, 8, 8, 3, 3, 1, 1, 1, 4, 4, 0, hip.BF16, 0)
+    rc = lib.cfp_conv2d_nhwc(0, 8, 0, 0, 0, 0, 0, 0, 8, 1, 4, 4, 8, 8, 3, 3, 1, 1, 1, 4, 4, 0, hip.BF16, 0, 0, 0)
     assert rc == -1 and "null" in hip.last_error()
     rc = lib.cfp_layernorm(16, 24, 16, 16, 1e-5, 0, 0, 16, 24, 4, 24, hip.BF16, 0)    # 24/8 = 3 lanes: not a power of two
     assert rc == -2 and "power of two" in hip.last_error()
@@ -49,6 +49,7 @@ def test_validation_errors_are_reported_not_faulted(lib):
         hip.call("cfp_bin_softmax", 16, 256, 16, 0, 16, 1, 64, 100, hip.F32, 0)
     assert lib.cfp_attn_kv_ws_floats(0, 1, 1, 1, 1, 1, 8) == 0
     assert lib.cfp_conv2d_variant(614400, 128) == 3 and lib.cfp_conv2d_variant(100, 16) == 0
+    assert lib.cfp_conv2d_ws_bytes(614400, 128, 1152, hip.BF16) == 0 and lib.cfp_conv2d_ws_bytes(240, 128, 4608, hip.BF16) > 0
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -64,6 +64,8 @@ CONV_CASES = [
     (1, 13, 17, 32, 32, 3, 1, (1, 1, 1, 1)),      # Cout 32 tile, ragged M
     (1, 1, 300, 256, 256, 1, 1, (0, 0, 0, 0)),    # Linear (rows = 300)
     (1, 1, 70, 8, 32, 1, 1, (0, 0, 0, 0)),        # K = 8 (ToF first layer)
+    (2, 60, 80, 64, 64, 9, 9, (0, 0, 0, 0)),      # GSA sr conv at 1/8: M = 96, K = 5184 -> split-K
+    (2, 15, 20, 1392, 232, 1, 1, (0, 0, 0, 0)),   # 1/32-scale project conv: M = 600, K = 1392 -> split-K
 ]
 
 
@@ -85,9 +87,15 @@ def test_conv2d(case, dtype):
     ra = to_act(nhwc(res), dtype)
     out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True).slice(0, Cout)
     out = ops.Act(out.buf, 16, Cout)
-    ops.conv2d(xa, wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_SILU, ra)
+    nws = ops.conv2d_ws_bytes(B * Ho * Wo, Cout, k * k * Cin, ops.DT[dtype])
+    ws = torch.empty(max(nws // 4, 1), device=DEV) if nws else None
+    ops.conv2d(xa, wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_SILU, ra, ws)
     torch.cuda.synchronize()
-    close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"conv {case}")
+    close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"conv {case} (splitk ws {nws})")
+    if nws:   # the un-split kernel must agree
+        out.buf.zero_()
+        ops.conv2d(xa, wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_SILU, ra, None)
+        close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"conv {case} (no ws)")
     # the slice neighbours must be untouched
     assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
 
@@ -123,14 +131,15 @@ def test_dwconv3x3(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [(1, 30, 40, 128, 7), (2, 20, 37, 64, 15), (1, 40, 50, 32, 31), (1, 9, 9, 8, 31)])
+@pytest.mark.parametrize("case", [(1, 30, 40, 128, 7), (2, 20, 37, 64, 15), (1, 40, 50, 32, 31), (1, 9, 9, 8, 31), (1, 21, 19, 16, 5),
+                                  (2, 17, 33, 8, 13)])
 def test_dwconv_large(case, dtype):
     B, H, W, Cc, k = case
     x = q(rnd(B, Cc, H, W, seed=1), dtype)
     w = rnd(Cc, 1, k, k, seed=2, scale=1.0 / k)
     scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
     ref = F.relu(F.conv2d(x, w, None, 1, (k - 1) // 2, 1, Cc) * scale[None, :, None, None] + shift[None, :, None, None])
-    wa = w.reshape(Cc, k * k).t().contiguous().to(DEV)             # [k*k][C] f32
+    wa = w[:, 0].transpose(1, 2).reshape(Cc, k * k).contiguous().to(DEV)   # [C][kx][ky] f32
     out = ops.new_act(B * H * W, Cc, dtype, DEV)
     ops.dwconv_large(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, B, H, W, k, hip.ACT_RELU)
     close(from_nhwc(out.torch(), B, H, W), ref, dtype, f"dwlarge {case}")
@@ -147,13 +156,17 @@ def test_channel_sum_and_se(case, dtype):
     assert torch.allclose(part.sum(1).cpu(), ref, rtol=1e-4, atol=1e-3 * math.sqrt(HW))
     R = 34
     wr, br, we, be = rnd(R, Cc, seed=2, scale=0.05), rnd(R, seed=3), rnd(Cc, R, seed=4, scale=0.2), rnd(Cc, seed=5)
-    gate = torch.empty(B, Cc, device=DEV)
-    ops.se_gate(part, ns, 1.0 / HW, wr.to(DEV), br.to(DEV), we.to(DEV), be.to(DEV), gate, B, Cc, R)
-    gref = torch.sigmoid(F.silu((ref / HW) @ wr.t() + br) @ we.t() + be)
-    assert torch.allclose(gate.cpu(), gref, rtol=1e-4, atol=1e-5)
+    hid = torch.empty(B, R, device=DEV)
+    ops.se_hidden(part, ns, 1.0 / HW, wr.to(DEV), br.to(DEV), hid, B, Cc, R)
+    href = F.silu((ref / HW) @ wr.t() + br)
+    assert torch.allclose(hid.cpu(), href, rtol=1e-4, atol=1e-5)
+    gref = torch.sigmoid(href @ we.t() + be)
     xa = to_act(x.reshape(B * HW, Cc), dtype)
-    ops.scale_channels(xa, gate, B, HW)
+    ops.se_scale(xa, hid, we.t().contiguous().to(DEV), be.to(DEV), B, HW, R)
     close(xa.torch().float().cpu().reshape(B, HW, Cc), x * gref[:, None, :], dtype)
+    xb = to_act(x.reshape(B * HW, Cc), dtype)
+    ops.scale_channels(xb, gref.to(DEV), B, HW)
+    close(xb.torch().float().cpu().reshape(B, HW, Cc), x * gref[:, None, :], dtype)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -313,7 +326,8 @@ def test_bin_regressor(norm):
     w2, b2 = rnd(nb, hid, seed=7, scale=0.08), rnd(nb, seed=8, scale=0.1)
     edges, centers = torch.empty(B, nb + 1, device=DEV), torch.empty(B, nb, device=DEV)
     d = lambda t: t.to(DEV)
-    ops.bin_regressor(d(part), ns, 1.0 / HW, d(w1x1), d(w0), d(b0), d(w1), d(b1), d(w2), d(b2), 1e-3, 10.0, norm, edges, centers,
+    dt = lambda t: t.t().contiguous().to(DEV)       # weights go in transposed: [n_in][n_out]
+    ops.bin_regressor(d(part), ns, 1.0 / HW, dt(w1x1), dt(w0), d(b0), dt(w1), d(b1), dt(w2), d(b2), 1e-3, 10.0, norm, edges, centers,
                       B, Cc, hid, nb)
     y = (part.sum(1) / HW) @ w1x1.t()
     y = F.leaky_relu(y @ w0.t() + b0, 0.01)
@@ -346,4 +360,23 @@ def test_bin_softmax(HW, dtype):
     assert torch.allclose(pred.cpu(), (p * centers[:, None, :]).sum(2), rtol=1e-4, atol=1e-4)
     pred2 = torch.empty(B, HW, device=DEV)
     ops.bin_softmax(to_act(logits, dtype), centers.to(DEV), None, pred2, B, HW, nb)
+    assert torch.equal(pred, pred2)
+
+
+@pytest.mark.parametrize("HW", [128 * 3, 1000, 4808])
+def test_bin_head_fused(HW):
+    """conv_out (1x1, 128 -> 256) + softmax + expectation in one kernel vs the unfused torch chain."""
+    B, Cin, nb = 2, 128, 256
+    x = q(rnd(B * HW, Cin, seed=1), torch.bfloat16)
+    w = q(rnd(nb, Cin, seed=2, scale=0.25), torch.bfloat16)
+    bias = rnd(nb, seed=3)
+    centers = torch.sort(torch.rand(B, nb, generator=torch.Generator().manual_seed(2)) * 10, dim=1)[0]
+    prob = torch.zeros(B, nb, HW, dtype=torch.bfloat16, device=DEV)
+    pred = torch.empty(B, HW, device=DEV)
+    ops.bin_head_fused(to_act(x, torch.bfloat16), w.to(torch.bfloat16).to(DEV), bias.to(DEV), centers.to(DEV), prob, pred, B, HW)
+    p = torch.softmax((x @ w.t() + bias).reshape(B, HW, nb), dim=2)
+    close(prob.float().cpu(), p.permute(0, 2, 1), torch.bfloat16, "prob")
+    assert torch.allclose(pred.cpu(), (p * centers[:, None, :]).sum(2), rtol=2e-3, atol=2e-3)
+    pred2 = torch.empty(B, HW, device=DEV)
+    ops.bin_head_fused(to_act(x, torch.bfloat16), w.to(torch.bfloat16).to(DEV), bias.to(DEV), centers.to(DEV), None, pred2, B, HW)
     assert torch.equal(pred, pred2)
