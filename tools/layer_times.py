@@ -7,7 +7,7 @@ from cfpnet_amd import hip, spec, synthetic, weights
 from cfpnet_amd.engine import Engine
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--top", type=int, default=60)
-ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--group", action="store_true")
 a = ap.parse_args()
 layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
@@ -53,6 +53,15 @@ for i, (name, args, ms) in acc.items():
     elif name == "cfp_resize_bilinear":
         desc = f"{args[2]}x{args[3]} -> {args[14]}x{args[15]} C={args[22]}"
     rows.append((ms, i, name, desc, fl))
+if a.group:
+    g = {}
+    for ms, i, name, desc, fl in rows:
+        d = g.setdefault((name, desc), [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl
+    tot = sum(r[0] for r in rows)
+    print(f"launches {len(rows)} total {tot:.3f} ms")
+    for (name, desc), (n, ms, fl) in sorted(g.items(), key=lambda kv: -kv[1][1])[: a.top]:
+        print(f"{ms*1e3:9.1f} us  x{n:3d} ({ms/n*1e3:7.1f} each) {name:24s} {desc:52s} {fl/ms/1e9 if fl else 0:8.1f} TF/s")
+    sys.exit(0)
 tot = sum(r[0] for r in rows)
 print(f"launches {len(rows)} total {tot:.3f} ms")
 for ms, i, name, desc, fl in sorted(rows, reverse=True)[: a.top]:
