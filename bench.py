@@ -34,8 +34,6 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
-CONV_VARIANTS = {0: "conv_igemm<bf16,256x16>", 1: "conv_igemm<bf16,256x32>", 2: "conv_igemm<bf16,128x64>",
-                 3: "conv_igemm<bf16,128x128>"}
 
 
 def parse():
@@ -56,7 +54,7 @@ def parse():
 
 def kernel_times(engine, inputs, return_prob, reps=3):
     """Instrumented eager passes: HIP events (on the launch stream) around every C-ABI call."""
-    from cfpnet_amd import hip
+    from cfpnet_amd import hip, ops
     recs = []
     real_call = hip.call
     stem_w = engine.P["stem.w"].data_ptr()
@@ -68,13 +66,15 @@ def kernel_times(engine, inputs, return_prob, reps=3):
         real_call(name, *a)
         e1.record()
         fam, flops, byts = name, 0.0, 0.0
-        if name == "cfp_conv2d_nhwc":
+        if name in ("cfp_conv2d_nhwc", "cfp_conv2d_nhwc_ex"):
             B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo = a[9:21]   # noqa
             M = B * Ho * Wo
             cin_true = 3 if a[2] == stem_w else (1 if a[2] == hist_w else Cin)
             flops = 2.0 * M * Cout * KH * KW * cin_true
             byts = 2.0 * (M * Cout + B * H * W * Cin + Cout * KH * KW * Cin)
-            fam = CONV_VARIANTS[hip.load().cfp_conv2d_variant(M, Cout)]
+            piw = a[26] if name.endswith("_ex") else 0
+            v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, a[22], Ho * Wo if piw else 0, B)
+            fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
         elif name == "cfp_dwconv3x3_nhwc":
             B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16]
             flops = 2.0 * 9 * B * Ho * Wo * C
@@ -187,7 +187,7 @@ def main():
         if not a.no_kernel_times:
             kt = kernel_times(engine, inputs, return_prob)
             total_ms = sum(v["ms"] for v in kt.values())
-            convs = {k: v for k, v in kt.items() if k.startswith("conv_igemm")}
+            convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2"))}
             dom = max(convs, key=lambda k: convs[k]["ms"])
             d = convs[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -67,6 +67,28 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   }
 }
 
+// Activation with the kind as a compile-time constant, and a dispatcher that hoists the (wave-uniform)
+// runtime switch out of per-element loops: `with_act(act, [&](auto A) { ... act_c<A.value>(x) ... })`.
+template <int ACT> __device__ __forceinline__ float act_c(float x) {
+  if constexpr (ACT == CFP_ACT_RELU) return x > 0.f ? x : 0.f;
+  else if constexpr (ACT == CFP_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
+  else if constexpr (ACT == CFP_ACT_SILU) return x / (1.f + __expf(-x));
+  else if constexpr (ACT == CFP_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  else if constexpr (ACT == CFP_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+  else return x;
+}
+template <int V> struct IntC { static constexpr int value = V; };
+template <typename F> __device__ __forceinline__ void with_act(int act, F&& f) {
+  switch (act) {
+    case CFP_ACT_RELU: f(IntC<CFP_ACT_RELU>{}); break;
+    case CFP_ACT_LRELU: f(IntC<CFP_ACT_LRELU>{}); break;
+    case CFP_ACT_SILU: f(IntC<CFP_ACT_SILU>{}); break;
+    case CFP_ACT_GELU: f(IntC<CFP_ACT_GELU>{}); break;
+    case CFP_ACT_SIGMOID: f(IntC<CFP_ACT_SIGMOID>{}); break;
+    default: f(IntC<CFP_ACT_NONE>{}); break;
+  }
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }  // elu(x)+1
 
 __device__ __forceinline__ float wave_sum(float v) {

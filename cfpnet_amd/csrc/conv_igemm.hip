@@ -67,17 +67,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     constexpr int CP = (BM * (BN + 8) * 2 <= 2 * (BM + BN) * 64) ? BN + 8 : BN;
     static_assert(BM * CP * 2 <= 2 * (BM + BN) * 64, "C tile must fit in the operand LDS");
     bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+    with_act(p.act, [&](auto A) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = wm * (BM / WM) + i * 16 + fq * 4 + r;
-          int col = wn * (BN / WN) + j * 16 + fr;
-          float v = apply_act(acc[i][j][r] * sc[j] + sh[j], p.act);
-          sC[row * CP + col] = f2bf(v);
-        }
+          for (int r = 0; r < 4; ++r) {
+            int row = wm * (BM / WM) + i * 16 + fq * 4 + r;
+            int col = wn * (BN / WN) + j * 16 + fr;
+            sC[row * CP + col] = f2bf(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+          }
+    });
     __syncthreads();
     constexpr int CH = BN / 8;   // 16-byte chunks per tile row
     for (int q = tid; q < BM * CH; q += 256) {
@@ -96,6 +97,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(out) + (long long)m * p.out_ld + n) = v;
     }
   } else {
+    with_act(p.act, [&](auto A) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]);
+    });
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           int m = m0 + wm * (BM / WM) + i * 16 + fq * 4 + r;
           int n = n0 + wn * (BN / WN) + j * 16 + fr;
           if (m < p.M && n < p.Cout) {
-            float v = apply_act(acc[i][j][r] * sc[j] + sh[j], p.act);
+            float v = acc[i][j][r];
             if (res) v += to_f32<T>(res[(long long)m * p.res_ld + n]);
             out[(long long)m * p.out_ld + n] = from_f32<T>(v);
           }
@@ -173,11 +182,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         v[e] += x[0]; v[e + 1] += x[1]; v[e + 2] += x[2]; v[e + 3] += x[3];
       }
     }
+    with_act(p.act, [&](auto A) {
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      float sc = p.scale ? p.scale[n + e] : 1.f, sh = p.shift ? p.shift[n + e] : 0.f;
-      v[e] = apply_act(v[e] * sc + sh, p.act);
-    }
+      for (int e = 0; e < VE; ++e) {
+        float sc = p.scale ? p.scale[n + e] : 1.f, sh = p.shift ? p.shift[n + e] : 0.f;
+        v[e] = act_c<decltype(A)::value>(v[e] * sc + sh);
+      }
+    });
     if (res) {
       float r[VE];
       Vec<T>::load(res + m * p.res_ld + n, r);
@@ -230,8 +241,20 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 
 }  // namespace
 
-// Which tile configuration cfp_conv2d_nhwc picks for a problem (for per-kernel accounting in
-// bench.py): 0 = 256x16, 1 = 256x32, 2 = 128x64, 3 = 128x128.
+// ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
+// (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
+static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+extern "C" int cfp_debug_set(int key, int value) {
+  switch (key) {
+    case 0: g_force_variant = value; return CFP_OK;
+    case 1: g_force_splits = value; return CFP_OK;
+    case 2: g_use_v1 = value; return CFP_OK;
+    default: cfp_set_error("cfp_debug_set: unknown key"); return CFP_EINVAL;
+  }
+}
+
+// Which tile configuration the first-generation (f32) kernel picks: 0 = 256x16, 1 = 256x32,
+// 2 = 128x64, 3 = 128x128.
 extern "C" int cfp_conv2d_variant(int M, int Cout) {
   if (Cout <= 16) return 0;
   if (Cout <= 32) return 1;
@@ -241,16 +264,80 @@ extern "C" int cfp_conv2d_variant(int M, int Cout) {
   return (t128 < 192 || waste) ? 2 : 3;
 }
 
+namespace {
+
+// Plan for a bf16 problem: kernel generation, tile variant, K-splits.  The rules are fitted on the
+// per-shape sweep of tools/conv_bench.py over this network's 80 distinct conv/linear problems at
+// batch 8 (profiles/r1_conv_sweep.json; every variant x 1..16 splits, back-to-back launches):
+//   * what decides is workgroups resident per CU, not prefetch depth: the 64x64 tile with 3 stages
+//     (48 KB LDS, 3 workgroups/CU) is the best or within 10 % of it for most problems;
+//   * 128x128 pays only for the largest problems (>= 10^7 outputs with K >= 512, or a long K),
+//     and then with 2 stages (2 workgroups/CU) rather than 3;
+//   * short-K, many-row problems (K <= 576 at >= 10^5 rows, K <= 64 at >= 3*10^4 rows) are
+//     bandwidth- and launch-bound: the first-generation kernel (K-step 32, 12-24 KB LDS, up to 6
+//     workgroups/CU) wins or ties there;
+//   * few-row / long-K problems (GSA sr convs) want 8 K-splits.
+struct Plan2 { int variant, splits; bool gen1; };
+
+Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split) {
+  Plan2 pl{4, 1, false};
+  const int nv = igemm2_num_variants();
+  if (rpb <= 0 && ((M >= 100000 && K <= 576) || (M >= 30000 && K <= 64))) pl.gen1 = true;
+  if (N <= 16) pl.variant = 10;
+  else if (N <= 32) pl.variant = M >= 400000 ? 7 : 9;
+  else if ((M * N >= 614400ll * 128 && K >= 512) || (M * N >= 38400ll * 128 && K >= 2048)) pl.variant = 1;
+  else if ((N >= 256 && K >= 2048) || N >= 1024) pl.variant = 12;
+  if (allow_split && M <= 1100 && K >= 2048) { pl.variant = 4; pl.splits = 8; }
+  if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }
+  if (g_force_splits >= 1) pl.splits = g_force_splits;
+  return pl;
+}
+
+int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cout channels
+  switch (Cout) {
+    case 128: return M <= 20000 ? 12 : 1;
+    case 64: return 2;
+    case 32: return 8;
+    case 16: return 11;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int dtype, int rows_per_batch, int B, int* variant, int* splits) {
+  if (dtype == CFP_BF16 && !g_use_v1) {
+    Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0);
+    if (pl.gen1) {
+      if (variant) *variant = cfp_conv2d_variant(M, Cout);
+      if (splits) *splits = pick_splits(M, Cout, K, dtype);
+    } else {
+      if (variant) *variant = 100 + pl.variant;
+      if (splits) *splits = pl.splits;
+    }
+  } else {
+    if (variant) *variant = cfp_conv2d_variant(M, Cout);
+    if (splits) *splits = pick_splits(M, Cout, K, dtype);
+  }
+  return CFP_OK;
+}
+
 extern "C" size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype) {
   if (M <= 0 || Cout <= 0 || K <= 0) return 0;
-  int s = pick_splits(M, Cout, K, dtype);
+  int v, s;
+  cfp_conv2d_plan(M, Cout, K, dtype, 0, 1, &v, &s);
   return s <= 1 ? 0 : (size_t)s * M * Cout * sizeof(float);
 }
 
-extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
-                               const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
-                               int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+extern "C" int cfp_layernorm(const void* in, int in_ld, const float* gamma, const float* beta, float eps,
+                             const void* residual, int res_ld, void* out, int out_ld, int rows, int C, int dtype,
+                             cfp_stream_t stream);
+
+extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                                  const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
+                                  int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                                  int dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   CFP_REQUIRE(in && w && out, CFP_EINVAL, "cfp_conv2d_nhwc: null pointer");
   CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_conv2d_nhwc: bad dtype");
   const int ve = vec_elems(dtype);
@@ -267,6 +354,8 @@ extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const f
               "cfp_conv2d_nhwc: output size inconsistent with input size");
   CFP_REQUIRE((long long)B * Ho * Wo < (1ll << 31) && (long long)KH * KW * Cin < (1ll << 31), CFP_ESHAPE,
               "cfp_conv2d_nhwc: problem too large");
+  CFP_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), CFP_EINVAL, "cfp_conv2d_nhwc: ln_gamma / ln_beta must come together");
+  CFP_REQUIRE(!ln_gamma || (aligned16(ln_gamma) && aligned16(ln_beta)), CFP_EINVAL, "cfp_conv2d_nhwc: LayerNorm parameters must be 16-byte aligned");
   ConvP p;
   p.in = in; p.w = w; p.out = out; p.res = residual; p.scale = scale; p.shift = shift;
   p.in_ld = in_ld; p.out_ld = out_ld; p.res_ld = res_ld;
@@ -274,10 +363,62 @@ extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const f
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W) ? 1 : 0;
-  // split-K only if the caller brought a large enough workspace; otherwise the plain kernel
-  int splits = pick_splits(p.M, Cout, p.K, dtype);
-  if (splits > 1 && (!ws || ws_bytes < (size_t)splits * p.M * Cout * sizeof(float))) splits = 1;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == CFP_BF16) dispatch<bf16_t>(p, (float*)ws, splits, s); else dispatch<float>(p, (float*)ws, splits, s);
-  return cfp_check_launch("cfp_conv2d_nhwc");
+
+  const bool gen2 = dtype == CFP_BF16 && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
+                    (long long)H * W * in_ld < (1ll << 30);
+  if (gen2) {
+    const int rpb = per_image_weights ? Ho * Wo : 0;
+    int ln_variant = ln_gamma ? pick_ln_variant(Cout, p.M) : -1;
+    Plan2 pl = plan2(p.M, Cout, p.K, rpb, B, rpb == 0 && ln_variant < 0);
+    if (pl.gen1 && !ln_gamma) goto gen1_path;
+    if (ln_variant >= 0 && g_force_variant < 0) pl.variant = ln_variant;
+    if (ln_variant >= 0) { p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; pl.splits = 1; }
+    if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * p.K; pl.splits = 1; }
+    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) pl.splits = 1;
+    const bool ln_after = ln_gamma && ln_variant < 0;   // Cout has no exact-width tile: LayerNorm as a second kernel
+    if (ln_after) p.res = nullptr;
+    int rc = igemm2_launch(pl.variant, p, (float*)ws, pl.splits, s);
+    CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: gen-2 kernel launch failed");
+    if (pl.splits > 1) {
+      long long total = (long long)p.M * (Cout / 8);
+      int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+      hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
+    }
+    int e = cfp_check_launch("cfp_conv2d_nhwc");
+    if (e != CFP_OK || !ln_after) return e;
+    return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
+  }
+
+gen1_path:
+  // first-generation kernels (f32 parity mode, short-K bf16): per-image weights run image by image,
+  // LayerNorm as a second kernel
+  if (ln_gamma) p.res = nullptr;
+  const int nimg = per_image_weights ? B : 1;
+  const size_t esz = dtype == CFP_BF16 ? 2 : 4;
+  for (int b = 0; b < nimg; ++b) {
+    ConvP q = p;
+    if (per_image_weights) {
+      q.B = 1; q.M = Ho * Wo;
+      q.in = (const char*)in + (size_t)b * H * W * in_ld * esz;
+      q.out = (char*)out + (size_t)b * Ho * Wo * out_ld * esz;
+      if (q.res) q.res = (const char*)q.res + (size_t)b * Ho * Wo * res_ld * esz;
+      q.w = (const char*)w + (size_t)b * Cout * p.K * esz;
+    }
+    int splits = pick_splits(q.M, Cout, q.K, dtype);
+    if (splits > 1 && (!ws || ws_bytes < (size_t)splits * q.M * Cout * sizeof(float))) splits = 1;
+    if (dtype == CFP_BF16) dispatch<bf16_t>(q, (float*)ws, splits, s); else dispatch<float>(q, (float*)ws, splits, s);
+  }
+  int e = cfp_check_launch("cfp_conv2d_nhwc");
+  if (e != CFP_OK || !ln_gamma) return e;
+  return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
+}
+
+extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                               const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                               int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  return cfp_conv2d_nhwc_ex(in, in_ld, w, scale, shift, residual, res_ld, out, out_ld, B, H, W, Cin, Cout, KH, KW, stride,
+                            pad_t, pad_l, Ho, Wo, act, dtype, nullptr, nullptr, 0.f, 0, ws, ws_bytes, stream);
 }

@@ -11,78 +11,128 @@
 
 namespace {
 
-template <typename T, int STRIDE, int PW>
+// Raw 16-byte vector -> VE floats, or zeros when !ok (the select is on the VALUE: the load itself is
+// unconditional from a clamped address, so a thread's 18 input + 9 weight loads are all in flight
+// together instead of one branch + wait per tap).
+template <typename T> __device__ __forceinline__ void unpack_masked(const u32x4& raw, bool ok, float* v);
+template <> __device__ __forceinline__ void unpack_masked<bf16_t>(const u32x4& raw, bool ok, float* v) {
+  const uint32_t m = ok ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t x = raw[i] & m;
+    v[2 * i] = __uint_as_float(x << 16);
+    v[2 * i + 1] = __uint_as_float(x & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void unpack_masked<float>(const u32x4& raw, bool ok, float* v) {
+  const uint32_t m = ok ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(raw[i] & m);
+}
+
+// Depthwise 3x3 (+ optional per-(image, row strip, channel) sums of the stored output for
+// squeeze-excite: the H*W mean timm's SqueezeExcite takes of this tensor then needs no extra pass).
+//
+// HBM-bound (4.3 FLOP/byte), and at batch 8 a launch moves only 13-30 MB, so what matters is that
+// every byte is requested from memory once and that all of a workgroup's requests are in flight
+// together.  Workgroup = one image, one strip of R output rows (full width), CVB channel vectors
+// (16-byte vectors: 8 bf16 / 4 f32):
+//   1. the input strip + halo ((R-1)*S+3 rows x (Wo-1)*S+3 columns, zeros outside the image) goes
+//      global -> LDS in one sweep of 16-byte loads, CVB*16 contiguous bytes per pixel (128/256 B);
+//      read amplification = halo rows only (1.2-1.7x) instead of 9 taps / column reuse (4.5-6x);
+//   2. thread = (channel vector, pixel slot): 9 conflict-free ds_read_b128 per output pixel (a
+//      16-lane read group covers 256 contiguous bytes), weights held in registers, f32 FMAs,
+//      BN scale/shift + activation, one 16-byte store per output pixel;
+//   3. per-channel sums of the stored values are reduced over the pixel slots through LDS in slot
+//      order (deterministic) and written as partial[b][strip][c].
+// grid = (ceil(CV/CVB), B * nstrips).
+template <typename T, int STRIDE, int CVB>
 __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, int in_ld, const T* __restrict__ w,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                    T* __restrict__ out, int out_ld, int B, int H, int W, int C,
-                                                    int pad_t, int pad_l, int Ho, int Wo, int act) {
+                                                    T* __restrict__ out, int out_ld, float* __restrict__ partial, int B, int H,
+                                                    int W, int C, int pad_t, int pad_l, int Ho, int Wo, int act, int R,
+                                                    int nstrips) {
   constexpr int VE = Vec<T>::N;
-  constexpr int IW = (PW - 1) * STRIDE + 3;   // input columns feeding PW outputs
+  constexpr int NSLOT = 256 / CVB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  u32x4* tile = reinterpret_cast<u32x4*>(dsm);          // [rows_in][cols_in][CVB]
   const int CV = C / VE;
-  const int WG = (Wo + PW - 1) / PW;
-  const long long total = (long long)B * Ho * WG * CV;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    int cv = (int)(idx % CV);
-    long long t = idx / CV;
-    int wg = (int)(t % WG);
-    t /= WG;
-    int ho = (int)(t % Ho);
-    int b = (int)(t / Ho);
-    const int c0 = cv * VE;
-    const int wo0 = wg * PW;
-    const int hi0 = ho * STRIDE - pad_t;
-    const int wi0 = wo0 * STRIDE - pad_l;
+  const int strip = blockIdx.y % nstrips, b = blockIdx.y / nstrips;
+  const int cv0 = blockIdx.x * CVB;
+  const int ho_begin = strip * R;
+  const int rows = min(R, Ho - ho_begin);
+  const int rows_in = (rows - 1) * STRIDE + 3, cols_in = (Wo - 1) * STRIDE + 3;
+  const int hi_base = ho_begin * STRIDE - pad_t, wi_base = -pad_l;
+  const int tid = threadIdx.x;
+  const int cvl = tid % CVB, slot = tid / CVB;
+  const bool cv_ok = cv0 + cvl < CV;
+  const int c0 = (cv_ok ? cv0 + cvl : 0) * VE;
 
-    float acc[PW][VE];
+  // ---- 1. input strip + halo -> LDS (every load of the workgroup in flight together) ----------
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int items = rows_in * cols_in * CVB;
+  for (int i = tid; i < items; i += 256) {
+    const int px = i / CVB;                       // cvl == i % CVB because 256 % CVB == 0
+    const int ty = px / cols_in, tx = px - ty * cols_in;
+    const int hi = hi_base + ty, wi = wi_base + tx;
+    const bool ok = cv_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+    const int hic = min(max(hi, 0), H - 1), wic = min(max(wi, 0), W - 1);
+    u32x4 v = *reinterpret_cast<const u32x4*>(in + ((long long)(b * H + hic) * W + wic) * in_ld + c0);
+    tile[i] = ok ? v : zero4;
+  }
+  u32x4 wraw[9];
 #pragma unroll
-    for (int p = 0; p < PW; ++p)
+  for (int t = 0; t < 9; ++t) wraw[t] = *reinterpret_cast<const u32x4*>(w + t * C + c0);
+  float sc[VE], sh[VE];
 #pragma unroll
-      for (int e = 0; e < VE; ++e) acc[p][e] = 0.f;
+  for (int e = 0; e < VE; e += 4) { Vec<float>::load(scale + c0 + e, sc + e); Vec<float>::load(shift + c0 + e, sh + e); }
+  float wv[9][VE];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) unpack_masked<T>(wraw[t], true, wv[t]);
+  __syncthreads();
 
+  // ---- 2. compute from LDS ---------------------------------------------------------------------
+  float csum[VE];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int hi = hi0 + kh;
-      if (hi < 0 || hi >= H) continue;
-      float wv[3][VE];
+  for (int e = 0; e < VE; ++e) csum[e] = 0.f;
+  with_act(act, [&](auto A) {
+    for (int u = slot; u < rows * Wo; u += NSLOT) {
+      const int r = u / Wo, x = u - r * Wo;
+      const u32x4* tp = tile + ((r * STRIDE) * cols_in + x * STRIDE) * CVB + cvl;
+      float acc[VE];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) Vec<T>::load(w + (kh * 3 + kw) * C + c0, wv[kw]);
-      const T* row = in + ((long long)(b * H + hi) * W) * in_ld + c0;
+      for (int e = 0; e < VE; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int x = 0; x < IW; ++x) {
-        const int wi = wi0 + x;
-        float v[VE];
-        if (wi >= 0 && wi < W) {
-          Vec<T>::load(row + (long long)wi * in_ld, v);
-        } else {
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int e = 0; e < VE; ++e) v[e] = 0.f;
+        for (int kw = 0; kw < 3; ++kw) {
+          float v[VE];
+          unpack_masked<T>(tp[(kh * cols_in + kw) * CVB], true, v);
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[e] = fmaf(v[e], wv[kh * 3 + kw][e], acc[e]);
         }
 #pragma unroll
-        for (int p = 0; p < PW; ++p) {
-          const int kw = x - p * STRIDE;   // compile-time after unrolling
-          if (kw >= 0 && kw < 3) {
-#pragma unroll
-            for (int e = 0; e < VE; ++e) acc[p][e] = fmaf(v[e], wv[kw][e], acc[p][e]);
-          }
-        }
+      for (int e = 0; e < VE; ++e) {
+        acc[e] = to_f32<T>(from_f32<T>(act_c<decltype(A)::value>(acc[e] * sc[e] + sh[e])));   // the stored (rounded) value
+        csum[e] += acc[e];
       }
+      if (cv_ok) Vec<T>::store(out + ((long long)(b * Ho + ho_begin + r) * Wo + x) * out_ld + c0, acc);
     }
-    float sc[VE], sh[VE];
-    Vec<float>::load(scale + c0, sc);
-    Vec<float>::load(shift + c0, sh);
-    if constexpr (VE == 8) {
-      Vec<float>::load(scale + c0 + 4, sc + 4);
-      Vec<float>::load(shift + c0 + 4, sh + 4);
-    }
+  });
+  if (partial == nullptr) return;   // uniform
+
+  // ---- 3. channel sums over the pixel slots ---------------------------------------------------
+  __syncthreads();                  // everyone is done reading the tile: reuse it
+  float* red = reinterpret_cast<float*>(dsm);   // [NSLOT][CVB*VE]
 #pragma unroll
-    for (int p = 0; p < PW; ++p) {
-      const int wo = wo0 + p;
-      if (wo >= Wo) break;
-      float o[VE];
-#pragma unroll
-      for (int e = 0; e < VE; ++e) o[e] = apply_act(acc[p][e] * sc[e] + sh[e], act);
-      Vec<T>::store(out + ((long long)(b * Ho + ho) * Wo + wo) * out_ld + c0, o);
+  for (int e = 0; e < VE; ++e) red[slot * (CVB * VE) + cvl * VE + e] = csum[e];
+  __syncthreads();
+  if (tid < CVB * VE) {
+    const int c = cv0 * VE + tid;
+    if (c < C) {
+      float s = 0.f;
+      for (int j = 0; j < NSLOT; ++j) s += red[j * (CVB * VE) + tid];
+      partial[((long long)b * nstrips + strip) * C + c] = s;
     }
   }
 }
@@ -289,29 +339,93 @@ hipError_t launch_dwlarge_any(const void* in, int in_ld, const float* w, const f
 
 }  // namespace
 
+namespace {
+// Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
+// Among the configurations whose input strip fits 64 KB of LDS, take the one with the lowest
+// (halo read amplification) x (penalty for leaving CUs idle).
+struct DwPlan { int cvb, R, nstrips; size_t lds; };
+inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
+  DwPlan best{8, 1, Ho, 0};
+  double bc = 1e30;
+  const int CV = C / ve;
+  const int cols_in = (Wo - 1) * stride + 3;
+  const int cvbs[2] = {16, 8};
+  for (int k = 0; k < 2; ++k) {
+    const int cvb = cvbs[k];
+    for (int R = 1; R <= Ho; ++R) {
+      const int rows_in = (R - 1) * stride + 3;
+      size_t lds = (size_t)rows_in * cols_in * cvb * 16;
+      const size_t red = (size_t)(256 / cvb) * cvb * ve * sizeof(float);
+      if (lds < red) lds = red;
+      if (lds > 64 * 1024) break;
+      const long long blocks = (long long)cdiv(CV, cvb) * B * cdiv(Ho, R);
+      const double halo = (double)rows_in / (R * stride);
+      const double fill = blocks >= 512 ? 1.0 : 512.0 / (double)blocks;
+      const double pad = (double)(cdiv(CV, cvb) * cvb) / CV;
+      const double c = halo * fill * pad;
+      if (c < bc) { bc = c; best = DwPlan{cvb, R, cdiv(Ho, R), lds}; }
+    }
+  }
+  if (best.lds == 0) {   // a single row does not fit (very wide map): still correct, LDS request will fail loudly
+    best.lds = (size_t)3 * cols_in * best.cvb * 16;
+  }
+  return best;
+}
+
+int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld,
+                 float* partial, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
+                 cfp_stream_t stream, const char* who) {
+  CFP_REQUIRE(in && w && out && scale && shift, CFP_EINVAL, std::string(who) + ": null pointer");
+  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, std::string(who) + ": bad dtype");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(stride == 1 || stride == 2, CFP_ESHAPE, std::string(who) + ": stride must be 1 or 2");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && out_ld % ve == 0 &&
+                  in_ld >= C && out_ld >= C, CFP_ESHAPE, std::string(who) + ": bad shape");
+  CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
+              std::string(who) + ": pointers must be 16-byte aligned");
+  const DwPlan d = dw_plan(B, Ho, Wo, C, stride, ve);
+  CFP_REQUIRE((long long)B * d.nstrips <= 65535, CFP_ESHAPE, std::string(who) + ": grid too large");
+  CFP_REQUIRE(d.lds <= 64 * 1024, CFP_ESHAPE, std::string(who) + ": map too wide for the LDS strip");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(cdiv(C / ve, d.cvb), B * d.nstrips);
+#define DW_LAUNCH(T, S, V)                                                                                                \
+  do {                                                                                                                    \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)dw3x3_kernel<T, S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+      if (e != hipSuccess) { cfp_set_error(std::string(who) + ": " + hipGetErrorString(e)); return CFP_EHIP; }            \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((dw3x3_kernel<T, S, V>), grid, dim3(256), d.lds, s, (const T*)in, in_ld, (const T*)w, scale, shift,  \
+                       (T*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);                  \
+  } while (0)
+#define DW_CVB(T, S) do { if (d.cvb == 16) DW_LAUNCH(T, S, 16); else DW_LAUNCH(T, S, 8); } while (0)
+  if (dtype == CFP_BF16) { if (stride == 1) DW_CVB(bf16_t, 1); else DW_CVB(bf16_t, 2); }
+  else { if (stride == 1) DW_CVB(float, 1); else DW_CVB(float, 2); }
+#undef DW_CVB
+#undef DW_LAUNCH
+  return cfp_check_launch(who);
+}
+}  // namespace
+
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                                   void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                                   int Ho, int Wo, int act, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(in && w && out && scale && shift, CFP_EINVAL, "cfp_dwconv3x3_nhwc: null pointer");
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_dwconv3x3_nhwc: bad dtype");
-  const int ve = vec_elems(dtype);
-  CFP_REQUIRE(stride == 1 || stride == 2, CFP_ESHAPE, "cfp_dwconv3x3_nhwc: stride must be 1 or 2");
-  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && out_ld % ve == 0 &&
-                  in_ld >= C && out_ld >= C, CFP_ESHAPE, "cfp_dwconv3x3_nhwc: bad shape");
-  CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
-              "cfp_dwconv3x3_nhwc: pointers must be 16-byte aligned");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  constexpr int PW = 4;
-  long long total = (long long)B * Ho * cdiv(Wo, PW) * (C / ve);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 256 * 32) blocks = 256 * 32;
-#define DW_LAUNCH(T, S)                                                                                            \
-  hipLaunchKernelGGL((dw3x3_kernel<T, S, PW>), dim3(blocks), dim3(256), 0, s, (const T*)in, in_ld, (const T*)w,    \
-                     scale, shift, (T*)out, out_ld, B, H, W, C, pad_t, pad_l, Ho, Wo, act)
-  if (dtype == CFP_BF16) { if (stride == 1) DW_LAUNCH(bf16_t, 1); else DW_LAUNCH(bf16_t, 2); }
-  else { if (stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
-#undef DW_LAUNCH
-  return cfp_check_launch("cfp_dwconv3x3_nhwc");
+  return dw3x3_launch(in, in_ld, w, scale, shift, out, out_ld, nullptr, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype,
+                      stream, "cfp_dwconv3x3_nhwc");
+}
+
+extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+  return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype)).nstrips;
+}
+
+extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                                      void* out, int out_ld, float* partial, int B, int H, int W, int C, int stride,
+                                      int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(partial, CFP_EINVAL, "cfp_dwconv3x3_sum_nhwc: null pointer");
+  return dw3x3_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype,
+                      stream, "cfp_dwconv3x3_sum_nhwc");
 }
 
 extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float* scale,
@@ -332,3 +446,4 @@ extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, 
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
   return cfp_check_launch("cfp_dwconv_large_nhwc");
 }
+

@@ -5,66 +5,94 @@
 namespace {
 
 // dense layer for one image: out[o] = act(bias[o] + sum_c in[c] * wt[c][o]).  Weights are stored
-// TRANSPOSED ([n_in][n_out]): thread o walks c with unit-stride-across-threads (coalesced) loads that
-// do not depend on each other, so the compiler keeps many in flight; `in` is broadcast from LDS.
+// TRANSPOSED ([n_in][n_out]) so thread o's loads are unit-stride across threads.  The block is
+// 1024 threads: the input range is cut in 4 slices (one per 256-thread group) and every thread
+// issues its loads 16 at a time, so a layer costs a handful of memory round trips instead of n_in / 4.
 __device__ __forceinline__ void fc_layer(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-                                         float* __restrict__ outv, int n_in, int n_out, bool lrelu) {
-  for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+                                         float* __restrict__ outv, float* __restrict__ part, int n_in, int n_out, bool lrelu) {
+  const int g = threadIdx.x >> 8, o0 = threadIdx.x & 255;
+  const int per = (n_in + 3) >> 2;
+  const int c0 = g * per, c1 = min(n_in, c0 + per);
+  for (int o = o0; o < n_out; o += 256) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 3 < n_in; c += 4) {
-      s0 = fmaf(in[c], wt[(long long)c * n_out + o], s0);
-      s1 = fmaf(in[c + 1], wt[(long long)(c + 1) * n_out + o], s1);
-      s2 = fmaf(in[c + 2], wt[(long long)(c + 2) * n_out + o], s2);
-      s3 = fmaf(in[c + 3], wt[(long long)(c + 3) * n_out + o], s3);
+    for (int c = c0; c < c1; c += 16) {
+      float w[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) w[j] = (c + j < c1) ? wt[(long long)(c + j) * n_out + o] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        s0 = fmaf((c + j < c1) ? in[c + j] : 0.f, w[j], s0);
+        s1 = fmaf((c + j + 1 < c1) ? in[c + j + 1] : 0.f, w[j + 1], s1);
+        s2 = fmaf((c + j + 2 < c1) ? in[c + j + 2] : 0.f, w[j + 2], s2);
+        s3 = fmaf((c + j + 3 < c1) ? in[c + j + 3] : 0.f, w[j + 3], s3);
+      }
     }
-    for (; c < n_in; ++c) s0 = fmaf(in[c], wt[(long long)c * n_out + o], s0);
-    float s = (s0 + s1) + (s2 + s3) + (bias ? bias[o] : 0.f);
+    part[g * 512 + o] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+    float s = (part[o] + part[512 + o]) + (part[1024 + o] + part[1536 + o]) + (bias ? bias[o] : 0.f);
     outv[o] = (lrelu && s < 0.f) ? 0.01f * s : s;
   }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void bin_regressor_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
-                                                            const float* __restrict__ w1x1, const float* __restrict__ w0,
-                                                            const float* __restrict__ b0, const float* __restrict__ w1,
-                                                            const float* __restrict__ b1, const float* __restrict__ w2,
-                                                            const float* __restrict__ b2, float min_val, float max_val,
-                                                            int norm, float* __restrict__ edges, float* __restrict__ centers,
-                                                            int C, int hidden, int nbins) {
-  __shared__ float a[512], t[512];
+__global__ __launch_bounds__(1024) void bin_regressor_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
+                                                             const float* __restrict__ w1x1, const float* __restrict__ w0,
+                                                             const float* __restrict__ b0, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, float min_val, float max_val,
+                                                             int norm, float* __restrict__ edges, float* __restrict__ centers,
+                                                             int C, int hidden, int nbins) {
+  __shared__ float a[512], t[512], part[4 * 512];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += partial[((long long)b * nsplit + j) * C + c];
-    a[c] = s * inv_hw;
+  // spatial mean from the per-slice partial sums: slices are summed in order by 4 groups, then combined
+  {
+    const int g = tid >> 8, c0 = tid & 255;
+    const int per = (nsplit + 3) >> 2;
+    for (int c = c0; c < C; c += 256) {
+      float s = 0.f;
+      for (int j = g * per; j < min(nsplit, (g + 1) * per); ++j) s += partial[((long long)b * nsplit + j) * C + c];
+      part[g * 512 + c] = s;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) a[c] = ((part[c] + part[512 + c]) + (part[1024 + c] + part[1536 + c])) * inv_hw;
+    __syncthreads();
   }
-  __syncthreads();
-  fc_layer(a, w1x1, nullptr, t, C, C, false);   // conv1x1 without bias commutes with the spatial mean
-  fc_layer(t, w0, b0, a, C, hidden, true);
-  fc_layer(a, w1, b1, t, hidden, hidden, true);
-  fc_layer(t, w2, b2, a, hidden, nbins, false);
+  fc_layer(a, w1x1, nullptr, t, part, C, C, false);   // conv1x1 without bias commutes with the spatial mean
+  fc_layer(t, w0, b0, a, part, C, hidden, true);
+  fc_layer(a, w1, b1, t, part, hidden, hidden, true);
+  fc_layer(t, w2, b2, a, part, hidden, nbins, false);
+  // normalisation: y_i in parallel, then bin order sums on one lane (torch.cumsum order)
+  if (norm != 1) {
+    for (int i = tid; i < nbins; i += 1024) a[i] = norm == 0 ? fmaxf(a[i], 0.f) + 0.1f : 1.f / (1.f + expf(-a[i]));
+    __syncthreads();
+  }
   if (tid == 0) {
-    // sequential on purpose: torch.cumsum / the L1 normalisation run in bin order on the host too
     float total = 0.f;
     if (norm == 1) {
       float mx = a[0];
       for (int i = 1; i < nbins; ++i) mx = fmaxf(mx, a[i]);
       for (int i = 0; i < nbins; ++i) { a[i] = expf(a[i] - mx); total += a[i]; }
     } else {
-      for (int i = 0; i < nbins; ++i) {
-        float y = norm == 0 ? fmaxf(a[i], 0.f) + 0.1f : 1.f / (1.f + expf(-a[i]));
-        a[i] = y;
-        total += y;
-      }
+      for (int i = 0; i < nbins; ++i) total += a[i];
     }
+    t[0] = total;
+  }
+  __syncthreads();
+  {
+    const float total = t[0];
+    __syncthreads();
+    for (int i = tid; i < nbins; i += 1024) t[i] = (max_val - min_val) * (a[i] / total);
+    __syncthreads();
+  }
+  if (tid == 0) {
     float e = min_val;
     float* eb = edges + (long long)b * (nbins + 1);
     float* cb = centers + (long long)b * nbins;
     eb[0] = e;
     for (int i = 0; i < nbins; ++i) {
-      float wdt = (max_val - min_val) * (a[i] / total);
-      float e2 = e + wdt;
+      float e2 = e + t[i];
       eb[i + 1] = e2;
       cb[i] = 0.5f * (e + e2);
       e = e2;
@@ -140,7 +168,7 @@ extern "C" int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw,
   CFP_REQUIRE(partial && w1x1 && w0 && b0 && w1 && b1 && w2 && b2 && edges && centers, CFP_EINVAL, "cfp_bin_regressor: null pointer");
   CFP_REQUIRE(B > 0 && nsplit > 0 && C > 0 && C <= 512 && hidden > 0 && hidden <= 512 && nbins > 0 && nbins <= 512 &&
                   norm >= 0 && norm <= 2, CFP_ESHAPE, "cfp_bin_regressor: bad shape (C, hidden, nbins <= 512)");
-  hipLaunchKernelGGL(bin_regressor_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial,
+  hipLaunchKernelGGL(bin_regressor_kernel, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), partial,
                      nsplit, inv_hw, w1x1, w0, b0, w1, b1, w2, b2, min_val, max_val, norm, edges, centers, C, hidden, nbins);
   return cfp_check_launch("cfp_bin_regressor");
 }
@@ -255,6 +283,7 @@ extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const 
   p.in_ld = x_ld; p.out_ld = 0; p.res_ld = 0;
   p.B = 1; p.H = 1; p.W = B * HW; p.Cin = Cin; p.Ho = 1; p.Wo = B * HW; p.Cout = HBN_;
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0;
   size_t lds = (size_t)HBN_ * HPITCH * sizeof(bf16_t);
   size_t ops_lds = 2 * (HBM_ + HBN_) * 64;
   if (lds < ops_lds) lds = ops_lds;

@@ -15,7 +15,18 @@ struct ConvP {
   int M, K;
   int act;
   int pointwise;  // KH == KW == 1, stride 1, no padding: A rows are plain pixel rows
+  // --- second-generation (bf16) kernel only; zero / null elsewhere ---
+  const float* ln_gamma;   // fused LayerNorm over the Cout axis after scale/shift/act (needs Cout == tile width)
+  const float* ln_beta;
+  float ln_eps;
+  int rows_per_batch;      // > 0: M-tiles do not straddle images and image b uses weights w + b * w_bstride
+  long long w_bstride;     // elements
 };
+
+// conv_igemm2.hip
+int igemm2_num_variants();
+void igemm2_variant_shape(int v, int* bm, int* bn, int* stages);
+int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
 
 __device__ __forceinline__ int swz(int row, int chunk) {
   // physical 16-byte chunk of (row, logical chunk); g = [0,3,2,1][(row >> 2) & 3]

@@ -60,30 +60,44 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict_
                                                         const float* __restrict__ wr, const float* __restrict__ br,
                                                         float* __restrict__ hidden, int C, int R) {
   // grid (ceil(R/4), B): every wave of a workgroup produces one hidden unit, so the 4 x ceil(R/4) x B
-  // dot products run in parallel instead of one after the other (they are latency-, not bandwidth-bound)
-  extern __shared__ float mean[];   // [C]
+  // dot products run in parallel instead of one after the other (they are latency-, not bandwidth-bound).
+  // All loads are 16-byte and issued in groups of four before the first use.
+  extern __shared__ __attribute__((aligned(16))) float mean[];   // [C]
   const int b = blockIdx.y;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += partial[((long long)b * nsplit + j) * C + c];
-    mean[c] = s * inv_hw;
+  const int C4 = C >> 2;
+  for (int c4 = threadIdx.x; c4 < C4; c4 += 256) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 3 < nsplit; j += 4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j) * C + c4 * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 1) * C + c4 * 4);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 2) * C + c4 * 4);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 3) * C + c4 * 4);
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; j < nsplit; ++j) s += *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(mean + c4 * 4) = s * inv_hw;
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
   if (r >= R) return;
   const float* wrow = wr + (long long)r * C;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int c = lane;
-  for (; c + 192 < C; c += 256) {     // 4 independent loads in flight per lane
-    s0 = fmaf(mean[c], wrow[c], s0);
-    s1 = fmaf(mean[c + 64], wrow[c + 64], s1);
-    s2 = fmaf(mean[c + 128], wrow[c + 128], s2);
-    s3 = fmaf(mean[c + 192], wrow[c + 192], s3);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int c4 = lane;
+  for (; c4 + 192 < C4; c4 += 256) {     // four independent 16-byte loads in flight per lane
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wrow + c4 * 4);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wrow + (c4 + 64) * 4);
+    const f32x4 w2 = *reinterpret_cast<const f32x4*>(wrow + (c4 + 128) * 4);
+    const f32x4 w3 = *reinterpret_cast<const f32x4*>(wrow + (c4 + 192) * 4);
+    acc += w0 * *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+    acc += w1 * *reinterpret_cast<const f32x4*>(mean + (c4 + 64) * 4);
+    acc += w2 * *reinterpret_cast<const f32x4*>(mean + (c4 + 128) * 4);
+    acc += w3 * *reinterpret_cast<const f32x4*>(mean + (c4 + 192) * 4);
   }
-  for (; c < C; c += 64) s0 = fmaf(mean[c], wrow[c], s0);
-  const float s = wave_sum((s0 + s1) + (s2 + s3));
-  if (lane == 0) hidden[(long long)b * R + r] = apply_act(s + br[r], CFP_ACT_SILU);
+  for (; c4 < C4; c4 += 64) acc += *reinterpret_cast<const f32x4*>(wrow + c4 * 4) * *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+  const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  if (lane == 0) hidden[(long long)b * R + r] = act_c<CFP_ACT_SILU>(s + br[r]);
 }
 
 // se_scale: x[b, hw, c] *= sigmoid(hidden[b] . we_t[:, c] + be[c]).  A thread keeps one 16-byte
@@ -120,6 +134,70 @@ __global__ __launch_bounds__(256) void se_scale_kernel(T* __restrict__ x, int ld
 #pragma unroll
       for (int e = 0; e < VE; ++e) v[e] *= g[e];
       Vec<T>::store(p, v);
+    }
+  }
+}
+
+// se_fold: per-image project weights  wout[b][n][c] = w[n][c] * sigmoid(hidden[b] . we_t[:, c] + be[c]).
+// Same thread layout as se_scale (one 16-byte channel vector per thread, gate computed once), but
+// the rows walked are the Cout rows of the project weight instead of the H*W rows of the activation.
+// Loads are issued four rows at a time (the loop bodies carry no dependence through memory).
+template <typename T>
+__global__ __launch_bounds__(256) void se_fold_kernel(const T* __restrict__ w, T* __restrict__ wout, const float* __restrict__ hidden,
+                                                      const float* __restrict__ we_t, const float* __restrict__ be, int Cout, int C,
+                                                      int R, int row_lanes) {
+  constexpr int VE = Vec<T>::N;
+  extern __shared__ float hid[];    // [R]
+  const int b = blockIdx.y;
+  for (int r = threadIdx.x; r < R; r += 256) hid[r] = hidden[(long long)b * R + r];
+  __syncthreads();
+  const int CV = C / VE;
+  const int items = CV * row_lanes;
+  for (int it = blockIdx.x * 256 + threadIdx.x; it < items; it += gridDim.x * 256) {
+    const int cv = it % CV, rl = it / CV;
+    float g[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] = be[cv * VE + e];
+    int r = 0;
+    for (; r + 3 < R; r += 4) {
+      float wp[4][VE];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < VE; e += 4) Vec<float>::load(we_t + (long long)(r + k) * C + cv * VE + e, wp[k] + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float h = hid[r + k];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) g[e] = fmaf(h, wp[k][e], g[e]);
+      }
+    }
+    for (; r < R; ++r) {
+      const float h = hid[r];
+      const float* wp = we_t + (long long)r * C + cv * VE;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = fmaf(h, wp[e], g[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) g[e] = 1.f / (1.f + __expf(-g[e]));
+    int n = rl;
+    for (; n + 3 * row_lanes < Cout; n += 4 * row_lanes) {
+      float v[4][VE];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Vec<T>::load(w + (long long)(n + k * row_lanes) * C + cv * VE, v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[k][e] *= g[e];
+        Vec<T>::store(wout + ((long long)b * Cout + n + k * row_lanes) * C + cv * VE, v[k]);
+      }
+    }
+    for (; n < Cout; n += row_lanes) {
+      float v[VE];
+      Vec<T>::load(w + (long long)n * C + cv * VE, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] *= g[e];
+      Vec<T>::store(wout + ((long long)b * Cout + n) * C + cv * VE, v);
     }
   }
 }
@@ -336,10 +414,33 @@ extern "C" int cfp_channel_sum(const void* in, int in_ld, float* partial, int B,
 extern "C" int cfp_se_hidden(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
                              float* hidden, int B, int C, int R, cfp_stream_t stream) {
   CFP_REQUIRE(partial && w_reduce && b_reduce && hidden, CFP_EINVAL, "cfp_se_hidden: null pointer");
-  CFP_REQUIRE(B > 0 && C > 0 && R > 0 && nsplit > 0 && (size_t)C * 4 <= 64 * 1024, CFP_ESHAPE, "cfp_se_hidden: bad shape");
+  CFP_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && R > 0 && nsplit > 0 && (size_t)C * 4 <= 64 * 1024, CFP_ESHAPE, "cfp_se_hidden: bad shape");
+  CFP_REQUIRE(aligned16(partial) && aligned16(w_reduce), CFP_EINVAL, "cfp_se_hidden: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(se_hidden_kernel, dim3(cdiv(R, 4), B), dim3(256), (size_t)C * sizeof(float), reinterpret_cast<hipStream_t>(stream),
                      partial, nsplit, inv_hw, w_reduce, b_reduce, hidden, C, R);
   return cfp_check_launch("cfp_se_hidden");
+}
+
+extern "C" int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden, const float* w_expand_t, const float* b_expand,
+                           int B, int Cout, int C, int R, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_se_fold");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(w_proj && w_out && hidden && w_expand_t && b_expand && aligned16(w_proj) && aligned16(w_out) && aligned16(w_expand_t),
+              CFP_EINVAL, "cfp_se_fold: bad pointer");
+  CFP_REQUIRE(B > 0 && B <= 65535 && Cout > 0 && C > 0 && C % 8 == 0 && R > 0 && R <= 4096, CFP_ESHAPE, "cfp_se_fold: bad shape");
+  const int cv = C / ve;
+  int row_lanes = (256 * 256 / B) / cv;          // ~one wave of the chip per call
+  if (row_lanes > Cout) row_lanes = Cout;
+  if (row_lanes < 1) row_lanes = 1;
+  const int blocks = cdiv((long long)cv * row_lanes, 256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(se_fold_kernel<bf16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const bf16_t*)w_proj,
+                       (bf16_t*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
+  else
+    hipLaunchKernelGGL(se_fold_kernel<float>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const float*)w_proj,
+                       (float*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
+  return cfp_check_launch("cfp_se_fold");
 }
 
 extern "C" int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand, int B, int HW,

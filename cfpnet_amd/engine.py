@@ -186,6 +186,13 @@ class Engine:
         assert a.rows == rows and a.ld == (ld or C), key
         return Act(a.buf, 0, C)
 
+    def _buf(self, plan, key: str, shape, dtype) -> torch.Tensor:
+        bufs = plan["bufs"]
+        if key not in bufs:
+            bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
+        assert tuple(bufs[key].shape) == tuple(shape), key
+        return bufs[key]
+
     def _f32(self, plan, key: str, n: int) -> torch.Tensor:
         bufs = plan["bufs"]
         if key not in bufs:
@@ -206,9 +213,9 @@ class Engine:
                    Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, k * k * x.C))
         return Ho, Wo
 
-    def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None):
+    def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None, ln=None):
         ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual,
-                   self._ws(rows, out.C, x.C))
+                   None if ln is not None else self._ws(rows, out.C, x.C), ln)
 
     def _ws(self, M: int, Cout: int, K: int) -> Optional[torch.Tensor]:
         """Split-K scratch shared by all layers (kernels on one stream run in order)."""
@@ -250,15 +257,18 @@ class Engine:
                 mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
                 self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
                 mid2 = self._act(plan, f"enc{bi}.dw", B * ho * wo, b.mid)
-                ops.dwconv3x3(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, B, h, w, b.stride,
-                              pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
-                ns = max(1, min(16, (ho * wo) // 64))
+                # depthwise + BN + SiLU, emitting the per-strip channel sums squeeze-excite needs
+                ns = ops.dwconv3x3_strips(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype])
                 part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
+                ops.dwconv3x3_sum(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w, b.stride,
+                                  pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
                 hid = self._f32(plan, f"enc{bi}.hid", B * b.se_rd)
-                ops.channel_sum(mid2, part, B, ho * wo, ns)
                 ops.se_hidden(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], hid, B, b.mid, b.se_rd)
-                ops.se_scale(mid2, hid, self.P[q + ".se.we_t"], self.P[q + ".se.be"], B, ho * wo, b.se_rd)
-                self._cv(q + ".pwl", mid2, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
+                # the SE gate multiplies the project conv's input channels: fold it into per-image weights
+                wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
+                ops.se_fold(self.P[q + ".pwl.w"], wb, hid, self.P[q + ".se.we_t"], self.P[q + ".se.be"], B, b.cout, b.mid, b.se_rd)
+                ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
+                           res, None, per_image_weights=True)
             x, h, w = out, ho, wo
             if bi in spec.ENC_TAPS:
                 tap_acts.append(out)
@@ -305,13 +315,11 @@ class Engine:
         msg = self._act(plan, f"{tag}.msg", rows_q, D)
         ops.attn_apply(qb.slice(0, D), kv, ks, msg, apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"],
                        (0, 0, 0, 0), kvmode["v_length"], heads, d)
-        m2 = self._act(plan, f"{tag}.m2", rows_q, D)
-        self._lin(p + ".merge", msg, m2, rows_q)
-        ops.layernorm(m2, self.P[p + ".norm1.g"], self.P[p + ".norm1.b"], 1e-5, xb.slice(D, D), rows_q)
+        # merge -> norm1 and mlp -> norm2 -> + x: the LayerNorms run in the GEMM epilogues
+        self._lin(p + ".merge", msg, xb.slice(D, D), rows_q, ln=(self.P[p + ".norm1.g"], self.P[p + ".norm1.b"], 1e-5))
         hid = self._act(plan, f"{tag}.hid", rows_q, 2 * D)
         self._lin(p + ".mlp0", xb, hid, rows_q, hip.ACT_RELU)
-        self._lin(p + ".mlp2", hid, m2, rows_q)
-        ops.layernorm(m2, self.P[p + ".norm2.g"], self.P[p + ".norm2.b"], 1e-5, out, rows_q, residual=x)
+        self._lin(p + ".mlp2", hid, out, rows_q, residual=x, ln=(self.P[p + ".norm2.g"], self.P[p + ".norm2.b"], 1e-5))
 
     def _fusion(self, plan, name: str, x: Act, feat1: Act, zone_valid: torch.Tensor, geo: FusionGeometry, B, H, W, out: Act,
                 pos_offset, taps):

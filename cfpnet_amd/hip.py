@@ -23,9 +23,15 @@ SIGNATURES = {
     "cfp_version": (_i, []),
     "cfp_last_error": (C.c_char_p, []),
     "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
+    "cfp_conv2d_nhwc_ex": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _p, _f, _i, _p, _sz, _p]),
     "cfp_conv2d_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "cfp_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p]),
+    "cfp_debug_set": (_i, [_i, _i]),
     "cfp_conv2d_variant": (_i, [_i, _i]),
     "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),
+    "cfp_dwconv3x3_strips": (_i, [_i] * 6),
+    "cfp_dwconv3x3_sum_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p] + [_i] * 11 + [_p]),
+    "cfp_se_fold": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_hidden": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _p]),

@@ -61,23 +61,69 @@ def conv2d_ws_bytes(M: int, Cout: int, K: int, dt: int) -> int:
 
 
 def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo,
-           act=hip.ACT_NONE, residual: Optional[Act] = None, ws: Optional[torch.Tensor] = None):
+           act=hip.ACT_NONE, residual: Optional[Act] = None, ws: Optional[torch.Tensor] = None, ln=None,
+           per_image_weights: bool = False):
+    """`ln = (gamma, beta, eps)` fuses a LayerNorm over the output channels (residual added after it);
+    `per_image_weights`: w is [B, Cout, K] and image b uses w[b]."""
     assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
-    assert w.dtype == x.buf.dtype and w.shape == (out.C, KH * KW * x.C), (w.shape, out.C, KH, KW, x.C)
-    hip.call("cfp_conv2d_nhwc", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
+    wshape = (B, out.C, KH * KW * x.C) if per_image_weights else (out.C, KH * KW * x.C)
+    assert w.dtype == x.buf.dtype and tuple(w.shape) == wshape and w.is_contiguous(), (w.shape, wshape)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    hip.call("cfp_conv2d_nhwc_ex", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
              B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
+             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights),
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 
+# tile shape (BM, BN, LDS stages) of second-generation variant v (conv_igemm2.hip kCfg)
+GEN2_TILES = [(128, 128, 3), (128, 128, 2), (128, 64, 3), (128, 64, 4), (64, 64, 3), (64, 64, 4), (256, 32, 3), (256, 32, 2),
+              (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3)]
+GEN1_TILES = [(256, 16), (256, 32), (128, 64), (128, 128)]
+
+
+def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
+    t = "bf16" if dt == hip.BF16 else "f32"
+    if variant >= 100:
+        bm, bn, st = GEN2_TILES[variant - 100]
+        n = f"igemm2<{t},{bm}x{bn},s{st}>"
+    else:
+        bm, bn = GEN1_TILES[variant]
+        n = f"conv_igemm<{t},{bm}x{bn}>"
+    return n + (f"+splitK" if splits > 1 else "")
+
+
+def conv2d_plan(M: int, Cout: int, K: int, dt: int, rows_per_batch: int = 0, B: int = 1):
+    import ctypes
+    v, s = ctypes.c_int(0), ctypes.c_int(0)
+    hip.load().cfp_conv2d_plan(M, Cout, K, dt, rows_per_batch, B, ctypes.byref(v), ctypes.byref(s))
+    return v.value, s.value
+
+
 def linear(x: Act, w: torch.Tensor, scale, shift, out: Act, rows: int, act=hip.ACT_NONE, residual: Optional[Act] = None,
-           ws: Optional[torch.Tensor] = None):
-    conv2d(x, w, scale, shift, out, 1, 1, rows, 1, 1, 1, 0, 0, 1, rows, act, residual, ws)
+           ws: Optional[torch.Tensor] = None, ln=None):
+    conv2d(x, w, scale, shift, out, 1, 1, rows, 1, 1, 1, 0, 0, 1, rows, act, residual, ws, ln)
 
 
 def dwconv3x3(x: Act, w, scale, shift, out: Act, B, H, W, stride, pad_t, pad_l, Ho, Wo, act):
     hip.call("cfp_dwconv3x3_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
              B, H, W, x.C, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+
+
+def dwconv3x3_strips(B: int, Ho: int, Wo: int, C: int, stride: int, dt: int) -> int:
+    return int(hip.load().cfp_dwconv3x3_strips(B, Ho, Wo, C, stride, dt))
+
+
+def dwconv3x3_sum(x: Act, w, scale, shift, out: Act, partial: torch.Tensor, B, H, W, stride, pad_t, pad_l, Ho, Wo, act):
+    assert partial.dtype == torch.float32 and partial.numel() >= B * dwconv3x3_strips(B, Ho, Wo, x.C, stride, x.dt) * x.C
+    hip.call("cfp_dwconv3x3_sum_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
+             partial.data_ptr(), B, H, W, x.C, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+
+
+def se_fold(w_proj: torch.Tensor, w_out: torch.Tensor, hidden, we_t, be, B, Cout, C, R):
+    assert w_proj.shape == (Cout, C) and w_out.shape == (B, Cout, C) and w_proj.dtype == w_out.dtype and we_t.shape == (R, C)
+    hip.call("cfp_se_fold", w_proj.data_ptr(), w_out.data_ptr(), hidden.data_ptr(), we_t.data_ptr(), be.data_ptr(),
+             B, Cout, C, R, DT[w_proj.dtype], _s())
 
 
 def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):

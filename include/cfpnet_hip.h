@@ -52,14 +52,41 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
                     int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
                     void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* cfp_conv2d_nhwc with two more fusions (same reference ops, fewer launches):
+ *   - ln_gamma/ln_beta != NULL: LayerNorm over the Cout axis (eps = ln_eps) applied after
+ *     scale/shift/act, the residual is added AFTER the LayerNorm:
+ *         out = LN(act(conv * scale + shift)) * gamma + beta + residual
+ *     (transformer.py:63,68-70: merge -> norm1, mlp -> norm2 -> + x).  Fused into the GEMM
+ *     epilogue when a tile spans exactly Cout channels (bf16, Cout in {16,32,64,128}), otherwise
+ *     run as a second kernel on `out` in place.
+ *   - per_image_weights != 0: `w` holds B weight matrices [B][Cout][K]; image b of the batch uses
+ *     matrix b.  Used for the squeeze-excite gate folded into the project conv of the encoder's
+ *     inverted-residual blocks (x * gate[b,:]) @ W^T == x @ (W * gate[b,:])^T, see cfp_se_fold. */
+int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                       const void* residual, int res_ld, void* out, int out_ld,
+                       int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                       int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, int per_image_weights,
+                       void* ws, size_t ws_bytes, cfp_stream_t stream);
+
 /* Scratch cfp_conv2d_nhwc wants for (M = B*Ho*Wo, Cout, K = KH*KW*Cin): non-zero only for layers it
  * runs split-K (few output tiles, long K: the GSA sr convs, the 1/32-scale pointwise convs).  With
  * ws == NULL or too small the layer runs un-split (same result up to f32 re-association). */
 size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype);
 
-/* Tile configuration cfp_conv2d_nhwc uses for (M = B*Ho*Wo, Cout): 0 = 256x16, 1 = 256x32,
- * 2 = 128x64, 3 = 128x128 output tile per workgroup (per-kernel accounting in bench.py). */
+/* Kernel plan cfp_conv2d_nhwc uses for a problem (per-kernel accounting in bench.py and
+ * tools/conv_bench.py).  *variant: 0..3 = first-generation tiles 256x16 / 256x32 / 128x64 /
+ * 128x128 (f32); 100 + v = second-generation (bf16, LDS-DMA staged) variant v.  *splits = K-splits.
+ * rows_per_batch > 0 describes a per_image_weights call (B images of rows_per_batch rows). */
+int cfp_conv2d_plan(int M, int Cout, int K, int dtype, int rows_per_batch, int B, int* variant, int* splits);
+
+/* First-generation tile choice for (M, Cout): 0 = 256x16, 1 = 256x32, 2 = 128x64, 3 = 128x128. */
 int cfp_conv2d_variant(int M, int Cout);
+
+/* Test/benchmark knobs, not for production use (process-global, not thread-safe):
+ * key 0 = force second-generation variant (-1 = automatic), key 1 = force K-splits (-1 = automatic),
+ * key 2 = 1 routes bf16 through the first-generation kernel. */
+int cfp_debug_set(int key, int value);
 
 /* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused
  * BatchNorm scale/shift + activation.  w packed [9][C].  HBM-bandwidth-bound.
@@ -67,6 +94,16 @@ int cfp_conv2d_variant(int M, int Cout);
 int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                        void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                        int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
+
+/* cfp_dwconv3x3_nhwc that ALSO emits sums of the stored output per (image, row strip, channel):
+ *   partial[b][s][c] (f32), s < cfp_dwconv3x3_strips(B, Ho, Wo, C, stride, dtype)
+ * so the H*W mean that timm's SqueezeExcite takes of this tensor (x.mean((2,3))) needs no extra
+ * pass: cfp_se_hidden(partial, nsplit = strips, ...) consumes it directly.  Strip order and the
+ * in-strip reduction order are fixed: the sums are run-to-run deterministic. */
+int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype);
+int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                           void* out, int out_ld, float* partial, int B, int H, int W, int C, int stride,
+                           int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
 
 /* Large-kernel depthwise convolution (odd k <= 31; 7 / 15 / 31 have dedicated kernels), stride 1,
  * "same" padding, fused bias + BatchNorm + ReLU.  w packed [C][kx][ky] as f32 (per-channel
@@ -91,6 +128,15 @@ int cfp_se_hidden(const float* partial, int nsplit, float inv_hw, const float* w
  * w_expand_t is the expand weight TRANSPOSED to [R][C] f32.  Replaces conv_expand + sigmoid gate + multiply. */
 int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand,
                  int B, int HW, int C, int R, int dtype, cfp_stream_t stream);
+
+/* Squeeze-excite gate folded into the following project conv's weights:
+ *   w_out[b][n][c] = w_proj[n][c] * sigmoid(hidden[b] . w_expand_t[:, c] + b_expand[c])
+ * (x * gate[b,:]) @ W^T == x @ (W * gate[b,:])^T, so conv_expand + sigmoid + the gating multiply of
+ * SqueezeExcite and conv_pwl become one per-image-weights GEMM (cfp_conv2d_nhwc_ex) with no pass
+ * over the expanded activation.  hidden from cfp_se_hidden; w_expand_t [R][C] f32; w_proj [Cout][C]
+ * and w_out [B][Cout][C] in `dtype`. */
+int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden, const float* w_expand_t, const float* b_expand,
+                int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
 /* x[b, hw, c] *= gate[b, c] in place. */
 int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream);

@@ -100,6 +100,111 @@ def test_conv2d(case, dtype):
     assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
 
 
+def _conv_ref_and_args(case, dtype, seed=1):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x = q(rnd(B, Cin, H, W, seed=seed), dtype)
+    w = q(rnd(Cout, Cin, k, k, seed=seed + 1, scale=1.0 / math.sqrt(Cin * k * k)), dtype)
+    scale = rnd(Cout, seed=seed + 2).abs() + 0.5
+    shift = rnd(Cout, seed=seed + 3)
+    Ho = (H + pt + pb - k) // s + 1
+    Wo = (W + pl + pr - k) // s + 1
+    res = q(rnd(B, Cout, Ho, Wo, seed=seed + 4), dtype)
+    ref = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s)
+    ref = F.silu(ref * scale[None, :, None, None] + shift[None, :, None, None]) + res
+    xa = to_act(nhwc(x), dtype, ld=Cin + 16, c0=8)
+    wa = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV)
+    ra = to_act(nhwc(res), dtype)
+    return ref, xa, wa, scale.to(DEV), shift.to(DEV), ra, Ho, Wo
+
+
+GEN2_VARIANTS = list(range(13))
+
+
+@pytest.mark.parametrize("variant", GEN2_VARIANTS)
+def test_conv2d_gen2_every_tile_variant(variant):
+    """Every second-generation (LDS-DMA staged) tile configuration on every conv case, forced through
+    the debug knob, un-split and with 4 K-splits."""
+    dtype = torch.bfloat16
+    lib = hip.load()
+    try:
+        lib.cfp_debug_set(0, variant)
+        for case in CONV_CASES:
+            B, H, W, Cin, Cout, k, s, _ = case
+            ref, xa, wa, scale, shift, ra, Ho, Wo = _conv_ref_and_args(case, dtype)
+            for splits in (1, 4):
+                lib.cfp_debug_set(1, splits)
+                out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True)
+                out = ops.Act(out.buf, 16, Cout)
+                ws = torch.empty(splits * B * Ho * Wo * Cout, device=DEV)
+                ops.conv2d(xa, wa, scale, shift, out, B, H, W, k, k, s, case[7][0], case[7][1], Ho, Wo, hip.ACT_SILU, ra, ws)
+                torch.cuda.synchronize()
+                close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"gen2 v{variant} splits {splits} conv {case}")
+                assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+    finally:
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(1, -1)
+
+
+def test_conv2d_gen2_matches_gen1_bitwise_inputs():
+    """Same bf16 inputs through both kernel generations: results agree to bf16 rounding of an f32
+    accumulation in a different order."""
+    dtype = torch.bfloat16
+    lib = hip.load()
+    case = (2, 30, 40, 168, 64, 3, 1, (1, 1, 1, 1))
+    B, H, W, Cin, Cout, k, s, _ = case
+    ref, xa, wa, scale, shift, ra, Ho, Wo = _conv_ref_and_args(case, dtype)
+    outs = []
+    try:
+        for v1 in (0, 1):
+            lib.cfp_debug_set(2, v1)
+            out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV)
+            ops.conv2d(xa, wa, scale, shift, out, B, H, W, k, k, s, 1, 1, Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            outs.append(out.torch().float().cpu())
+    finally:
+        lib.cfp_debug_set(2, 0)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2.0 ** -6 * float(outs[0].abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,Cin,Cout", [(300, 256, 128), (4800, 128, 64), (1000, 64, 32), (77, 64, 16), (50, 32, 256)])
+def test_linear_with_fused_layernorm(rows, Cin, Cout, dtype):
+    """out = LN(x @ W^T) * g + b + residual  (transformer.py:63,68-70).  Cout = 256 has no exact-width
+    tile and exercises the two-kernel fallback."""
+    x = q(rnd(rows, Cin, seed=1), dtype)
+    w = q(rnd(Cout, Cin, seed=2, scale=1.0 / math.sqrt(Cin)), dtype)
+    g, b = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    res = q(rnd(rows, Cout, seed=5), dtype)
+    y = x @ w.t()
+    if dtype == torch.bfloat16:
+        y = q(y, dtype)           # the pre-LayerNorm tile is rounded to the storage type
+    ref = F.layer_norm(y, (Cout,), g, b, 1e-5) + res
+    out = ops.new_act(rows, Cout, dtype, DEV, ld=Cout + 8, zero=True)
+    out = ops.Act(out.buf, 8, Cout)
+    ops.linear(to_act(x, dtype), w.to(dtype).to(DEV), None, None, out, rows, hip.ACT_NONE, to_act(res, dtype), None,
+               ln=(g.to(DEV), b.to(DEV), 1e-5))
+    torch.cuda.synchronize()
+    close(out.torch().float().cpu(), ref, dtype, f"linear+LN {rows}x{Cin}->{Cout}")
+    assert float(out.buf[:, :8].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,Cin,Cout", [(3, 300, 1392, 232), (2, 1200, 816, 136), (2, 70, 64, 24)])
+def test_pointwise_conv_per_image_weights(B, HW, Cin, Cout, dtype):
+    """Image b of the batch multiplies with its own weight matrix (SE gate folded into the project conv)."""
+    x = q(rnd(B, HW, Cin, seed=1), dtype)
+    w = q(rnd(B, Cout, Cin, seed=2, scale=1.0 / math.sqrt(Cin)), dtype)
+    scale, shift = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
+    res = q(rnd(B, HW, Cout, seed=5), dtype)
+    ref = torch.einsum("bmk,bnk->bmn", x, w) * scale + shift + res
+    out = ops.new_act(B * HW, Cout, dtype, DEV)
+    ops.conv2d(to_act(x.reshape(B * HW, Cin), dtype), w.to(dtype).to(DEV).contiguous(), scale.to(DEV), shift.to(DEV), out,
+               B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, to_act(res.reshape(B * HW, Cout), dtype), None,
+               per_image_weights=True)
+    torch.cuda.synchronize()
+    close(out.torch().float().cpu().reshape(B, HW, Cout), ref, dtype, f"per-image weights {B}x{HW}x{Cin}->{Cout}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", [hip.ACT_NONE, hip.ACT_RELU, hip.ACT_LRELU, hip.ACT_GELU, hip.ACT_SIGMOID])
 def test_conv_activations_no_scale(act, dtype):
@@ -128,6 +233,58 @@ def test_dwconv3x3(case, dtype):
     out = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
     ops.dwconv3x3(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
     close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"dw3x3 {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (2, 15, 20, 1392, 1, (1, 1, 1, 1)), (3, 30, 40, 816, 1, (1, 1, 1, 1)),
+                                  (2, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 5, 3, 8, 1, (1, 1, 1, 1))])
+def test_dwconv3x3_with_fused_channel_sums(case, dtype):
+    B, H, W, Cc, s, (pt, pl, pb, pr) = case
+    x = q(rnd(B, Cc, H, W, seed=1), dtype)
+    w = q(rnd(Cc, 1, 3, 3, seed=2, scale=0.4), dtype)
+    scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
+    Ho, Wo = (H + pt + pb - 3) // s + 1, (W + pl + pr - 3) // s + 1
+    ref = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s, 0, 1, Cc)
+    ref = F.silu(ref * scale[None, :, None, None] + shift[None, :, None, None])
+    wa = w.reshape(Cc, 9).t().contiguous().to(dtype).to(DEV)
+    out = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+    ns = ops.dwconv3x3_strips(B, Ho, Wo, Cc, s, ops.DT[dtype])
+    part = torch.full((B, ns, Cc), float("nan"), device=DEV)
+    ops.dwconv3x3_sum(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    torch.cuda.synchronize()
+    got = from_nhwc(out.torch(), B, Ho, Wo)
+    close(got, ref, dtype, f"dw3x3+sum {case}")
+    sums = part.sum(1).cpu()
+    want = got.sum((2, 3))                      # sums are of the STORED tensor
+    assert torch.allclose(sums, want, rtol=1e-4, atol=1e-3 * float(want.abs().max())), float((sums - want).abs().max())
+    part2 = torch.zeros_like(part)
+    ops.dwconv3x3_sum(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, part2, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    torch.cuda.synchronize()
+    assert torch.equal(part, part2)             # deterministic reduction order
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_se_fold_equals_gated_activation(dtype):
+    """(x * gate) @ W^T == x @ (W * gate)^T with the gate computed from the squeezed means."""
+    B, HW, C, R, Cout = 3, 300, 448, 28, 112
+    x = q(rnd(B, HW, C, seed=1), dtype)
+    wr, br = rnd(R, C, seed=2, scale=0.05), rnd(R, seed=3, scale=0.1)
+    we, be = rnd(C, R, seed=4, scale=0.2), rnd(C, seed=5, scale=0.1)
+    wp = q(rnd(Cout, C, seed=6, scale=1.0 / math.sqrt(C)), dtype)
+    mean = x.mean(1)
+    hid = F.silu(mean @ wr.t() + br)
+    gate = torch.sigmoid(hid @ we.t() + be)
+    ref = torch.einsum("bmc,nc->bmn", x * gate[:, None, :], wp)
+    part = x.sum(1).reshape(B, 1, C).contiguous().to(DEV)
+    hidden = torch.empty(B, R, device=DEV)
+    ops.se_hidden(part, 1, 1.0 / HW, wr.to(DEV), br.to(DEV), hidden, B, C, R)
+    wb = torch.empty(B, Cout, C, dtype=dtype, device=DEV)
+    ops.se_fold(wp.to(dtype).to(DEV), wb, hidden, we.t().contiguous().to(DEV), be.to(DEV), B, Cout, C, R)
+    out = ops.new_act(B * HW, Cout, dtype, DEV)
+    ops.conv2d(to_act(x.reshape(B * HW, C), dtype), wb, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None,
+               per_image_weights=True)
+    torch.cuda.synchronize()
+    close(out.torch().float().cpu().reshape(B, HW, Cout), ref, dtype, "se fold")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -3,7 +3,7 @@
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cfpnet_amd import hip, spec, synthetic, weights
+from cfpnet_amd import hip, ops, spec, synthetic, weights
 from cfpnet_amd.engine import Engine
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--top", type=int, default=60)
@@ -30,10 +30,12 @@ for r in range(R):
 rows = []
 for i, (name, args, ms) in acc.items():
     desc, fl = "", 0
-    if name == "cfp_conv2d_nhwc":
+    if name in ("cfp_conv2d_nhwc", "cfp_conv2d_nhwc_ex"):
         B, H, W, Cin, Cout, KH, KW, st, pt, pl, Ho, Wo = args[9:21]
         M = B * Ho * Wo; fl = 2.0 * M * Cout * KH * KW * Cin
-        desc = f"M={M} N={Cout} K={KH*KW*Cin} k{KH} s{st} v{hip.load().cfp_conv2d_variant(M, Cout)}"
+        ex = name.endswith("_ex")
+        v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, args[22], Ho * Wo if (ex and args[26]) else 0, B)
+        desc = f"M={M} N={Cout} K={KH*KW*Cin} k{KH} s{st} v{v}/s{sp}" + (" LN" if ex and args[23] else "") + (" PIW" if ex and args[26] else "")
     elif name == "cfp_dwconv3x3_nhwc":
         B, H, W, C, st = args[7:12]; desc = f"{B}x{H}x{W}x{C} s{st}"
     elif name == "cfp_dwconv_large_nhwc":
