@@ -73,7 +73,7 @@ def kernel_times(engine, inputs, return_prob, reps=3):
             flops = 2.0 * M * Cout * KH * KW * cin_true
             byts = 2.0 * (M * Cout + B * H * W * Cin + Cout * KH * KW * Cin)
             piw = a[26] if name.endswith("_ex") else 0
-            v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, a[22], Ho * Wo if piw else 0, B)
+            v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, a[22], Ho * Wo if piw else 0, B, KH, stride)
             fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
         elif name == "cfp_dwconv3x3_nhwc":
             B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16]
@@ -187,7 +187,7 @@ def main():
         if not a.no_kernel_times:
             kt = kernel_times(engine, inputs, return_prob)
             total_ms = sum(v["ms"] for v in kt.values())
-            convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2"))}
+            convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2", "conv3x3_direct"))}
             dom = max(convs, key=lambda k: convs[k]["ms"])
             d = convs[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

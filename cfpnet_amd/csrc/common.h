@@ -60,9 +60,9 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
     case CFP_ACT_RELU: return x > 0.f ? x : 0.f;
     case CFP_ACT_LRELU: return x > 0.f ? x : 0.01f * x;
-    case CFP_ACT_SILU: return x / (1.f + __expf(-x));
+    case CFP_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));
     case CFP_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-    case CFP_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    case CFP_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-x));
     default: return x;
   }
 }
@@ -72,9 +72,9 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 template <int ACT> __device__ __forceinline__ float act_c(float x) {
   if constexpr (ACT == CFP_ACT_RELU) return x > 0.f ? x : 0.f;
   else if constexpr (ACT == CFP_ACT_LRELU) return x > 0.f ? x : 0.01f * x;
-  else if constexpr (ACT == CFP_ACT_SILU) return x / (1.f + __expf(-x));
+  else if constexpr (ACT == CFP_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));   // v_rcp_f32: 1 ulp, no div sequence
   else if constexpr (ACT == CFP_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-  else if constexpr (ACT == CFP_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+  else if constexpr (ACT == CFP_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
   else return x;
 }
 template <int V> struct IntC { static constexpr int value = V; };

@@ -1,0 +1,238 @@
+// bf16 3x3 stride-1 convolution with an LDS-resident input halo tile ("direct" convolution on the
+// matrix cores).
+//
+// The implicit GEMM of conv_igemm2.hip fetches every input pixel nine times (once per filter tap)
+// from L2 into LDS: for this network's big 3x3 layers that is 0.9-1.4 GB of L2->LDS traffic per
+// launch and it, not the MFMA rate, sets their time (measured: 6-9 TB/s of operand traffic at
+// 25-45 % MFMA utilisation).  Here a workgroup owns a TH x 16 patch of output pixels and stages the
+// (TH+2) x 18 input halo ONCE per 64-channel chunk; the nine taps are nine shifted views of that
+// tile, so the A-operand traffic drops 4-7x and the weights become the larger stream.
+//
+//   * K order: chunk of 64 input channels (outer) -> kernel row kh -> kernel column kw -> 2 x k32.
+//     One pipeline step = (chunk, kh): the weight slab [3 kw][BN][64 ch] for it is DMA'd while the
+//     previous step computes; the halo tile of the NEXT chunk is DMA'd during kh = 0 of this one.
+//   * both operands use `global_load_lds_dwordx4` into 128-byte rows (one row = one halo pixel or
+//     one (kw, cout) weight row) with the chunk XOR swizzle of conv_igemm2.hip, so the 16 lanes of
+//     an MFMA operand read (16 consecutive pixels / 16 consecutive couts) are conflict-free;
+//     out-of-image halo pixels and the channel tail read the zero word.
+//   * MFMA v_mfma_f32_16x16x32_bf16; an M-tile is 16 consecutive output pixels of one row.
+//   * epilogue as in conv_igemm2.hip: scale/shift, activation, residual, 16-byte channel vectors.
+#include "igemm_core.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16b[4] = {0u, 0u, 0u, 0u};
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int TH, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int TW = 16;
+  constexpr int BM = TH * TW;
+  constexpr int TM = TH / WM;              // 16-pixel tile rows per wave
+  constexpr int TN = BN / WN / 16;
+  constexpr int HW_ = TW + 2;              // halo width
+  constexpr int HP = (TH + 2) * HW_;       // halo pixels
+  constexpr int NAG = (HP + 7) / 8;        // 8-pixel DMA groups
+  constexpr int NAH = (NAG + 3) / 4;       // per wave
+  constexpr int A_BYTES = NAH * 4 * 1024;
+  constexpr int NBG = BN * 3 / 8;          // 8-row DMA groups of the [3][BN] weight slab
+  constexpr int NBW = (NBG + 3) / 4;
+  constexpr int B_BYTES = ((NBG + 3) / 4) * 4 * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  auto sA = [&](int buf) -> unsigned char* { return smem + buf * A_BYTES; };
+  auto sB = [&](int buf) -> unsigned char* { return smem + 2 * A_BYTES + buf * B_BYTES; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+
+  // ---- tile coordinates: N-tiles of one pixel patch are adjacent workgroups (they share the halo in L2)
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tile_n = bid % tiles_n; bid /= tiles_n;
+  const int tx_ = bid % tiles_x; bid /= tiles_x;
+  const int ty_ = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int n0 = tile_n * BN, x0 = tx_ * TW, y0 = ty_ * TH;
+
+  const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
+  const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero16b);
+
+  // ---- per-lane DMA bookkeeping ---------------------------------------------------------------
+  int a_off[NAH];       // element offset of the halo pixel inside the image, or -1
+#pragma unroll
+  for (int i = 0; i < NAH; ++i) {
+    const int hp = (i * 4 + wave) * 8 + rsub;
+    const int hy = hp / HW_, hx = hp - hy * HW_;
+    const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+    const bool ok = hp < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    a_off[i] = ok ? (y * p.W + x) * p.in_ld + lc * 8 : -1;
+  }
+  int b_off[NBW];       // element offset of (cout row, kw) in the weight tensor (+ lane's chunk), or -1
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int br = (((j * 4 + wave) % NBG) * 8) + rsub;   // row of the [3][BN] slab
+    const int kw = br / BN, n = n0 + (br - kw * BN);
+    b_off[j] = n < p.Cout ? n * p.K + kw * p.Cin + lc * 8 : -1;
+  }
+  const int nchunks = (p.Cin + 63) >> 6;
+  const int nsteps = nchunks * 3;
+
+  auto issue_a = [&](int chunk, int buf) {
+    const int c0 = chunk * 64;
+    const bool cok = c0 + lc * 8 < p.Cin;
+#pragma unroll
+    for (int i = 0; i < NAH; ++i) glds16((cok && a_off[i] >= 0) ? in + a_off[i] + c0 : zsrc, sA(buf) + (i * 4 + wave) * 1024);
+  };
+  auto issue_b = [&](int step, int buf) {
+    const int chunk = step / 3, kh = step - chunk * 3;
+    const int c0 = chunk * 64;
+    const bool cok = c0 + lc * 8 < p.Cin;
+    const int koff = kh * 3 * p.Cin + c0;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+      glds16((cok && b_off[j] >= 0) ? wt + b_off[j] + koff : zsrc, sB(buf) + ((j * 4 + wave) % NBG) * 1024);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_a(0, 0);
+  issue_b(0, 0);
+  for (int s = 0; s < nsteps; ++s) {
+    const int chunk = s / 3, kh = s - chunk * 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // slab s (+ halo of this chunk) landed; everyone is past step s-1
+    asm volatile("" ::: "memory");
+    if (s + 1 < nsteps) issue_b(s + 1, (s + 1) & 1);
+    if (kh == 0 && chunk + 1 < nchunks) issue_a(chunk + 1, (chunk + 1) & 1);
+
+    const unsigned char* cA = sA(chunk & 1);
+    const unsigned char* cB = sB(s & 1) + (wn * (BN / WN)) * 128;
+    const int nsub = (p.Cin - chunk * 64) > 32 ? 2 : 1;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (sub < nsub) {   // wave-uniform
+          s16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int hp = (wm * TM + i + kh) * HW_ + fr + kw;
+            af[i] = *reinterpret_cast<const s16x8*>(cA + hp * 128 + (((sub * 4 + fq) ^ (hp & 7)) * 16));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int br = kw * BN + j * 16 + fr;     // + wn * (BN / WN) folded into cB (a multiple of 16)
+            bfr[j] = *reinterpret_cast<const s16x8*>(cB + br * 128 + (((sub * 4 + fq) ^ (fr & 7)) * 16));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // operand buffers are free: LDS becomes the C tile
+
+  constexpr int CP = BN + 8;
+  static_assert(BM * CP * 2 <= 2 * A_BYTES + 2 * B_BYTES, "C tile must fit in the operand LDS");
+  bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+  float sc[TN], sh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 16 + fr;
+    const bool ok = n < p.Cout;
+    sc[j] = (ok && p.scale) ? p.scale[n] : 1.f;
+    sh[j] = (ok && p.shift) ? p.shift[n] : 0.f;
+  }
+  with_act(p.act, [&](auto A) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (wm * TM + i) * 16 + fq * 4 + r;
+          const int col = wn * (BN / WN) + j * 16 + fr;
+          sC[row * CP + col] = f2bf(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+        }
+  });
+  __syncthreads();
+  constexpr int CH = BN / 8;
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
+  const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.res);
+  for (int q = tid; q < BM * CH; q += 256) {
+    const int row = q / CH, ch = q % CH;
+    const int y = y0 + row / TW, x = x0 + row % TW;
+    const int n = n0 + ch * 8;
+    if (y >= p.Ho || x >= p.Wo || n >= p.Cout) continue;
+    const long long m = ((long long)b * p.Ho + y) * p.Wo + x;
+    u32x4 v = *reinterpret_cast<const u32x4*>(sC + row * CP + ch * 8);
+    if (res) {
+      float a[8], r8[8];
+      Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v), a);
+      Vec<bf16_t>::load(res + m * p.res_ld + n, r8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += r8[e];
+      Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(&v), a);
+    }
+    *reinterpret_cast<u32x4*>(out + m * p.out_ld + n) = v;
+  }
+}
+
+template <int TH, int BN, int WM, int WN>
+int launch3(const ConvP& p, hipStream_t s) {
+  constexpr int HP = (TH + 2) * 18, NAG = (HP + 7) / 8, NAH = (NAG + 3) / 4, A_BYTES = NAH * 4 * 1024;
+  constexpr int NBG = BN * 3 / 8, B_BYTES = ((NBG + 3) / 4) * 4 * 1024;
+  constexpr size_t lds = 2 * A_BYTES + 2 * B_BYTES;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = conv3x3_direct_kernel<TH, BN, WM, WN>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+  const long long tiles = (long long)p.B * cdiv(p.Ho, TH) * cdiv(p.Wo, 16) * cdiv(p.Cout, BN);
+  if (tiles >= (1ll << 31)) return -1;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p);
+  return 0;
+}
+
+struct Cfg3 { int th, bn; };
+constexpr Cfg3 kCfg3[] = {{8, 128}, {8, 64}, {16, 64}, {16, 32}, {8, 32}, {16, 16}};
+constexpr int kNumCfg3 = sizeof(kCfg3) / sizeof(kCfg3[0]);
+
+}  // namespace
+
+int conv3x3_num_variants() { return kNumCfg3; }
+void conv3x3_variant_shape(int v, int* th, int* bn) { *th = kCfg3[v].th; *bn = kCfg3[v].bn; }
+
+// Requirements (checked by the caller): bf16, KH = KW = 3, stride 1, Ho = H + pads - 2 etc. as in ConvP,
+// Cin % 8 == 0, H * W * in_ld < 2^31, Cout * K < 2^31.
+int conv3x3_launch(int v, const ConvP& p, hipStream_t s) {
+  switch (v) {
+    case 0: return launch3<8, 128, 2, 2>(p, s);
+    case 1: return launch3<8, 64, 2, 2>(p, s);
+    case 2: return launch3<16, 64, 4, 1>(p, s);
+    case 3: return launch3<16, 32, 4, 1>(p, s);
+    case 4: return launch3<8, 32, 4, 1>(p, s);
+    case 5: return launch3<16, 16, 4, 1>(p, s);
+    default: return -3;
+  }
+}

@@ -244,8 +244,10 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic)
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
+    case 3: case 4: cfp_dw_debug_set(key, value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
     case 2: g_use_v1 = value; return CFP_OK;
@@ -268,28 +270,46 @@ namespace {
 
 // Plan for a bf16 problem: kernel generation, tile variant, K-splits.  The rules are fitted on the
 // per-shape sweep of tools/conv_bench.py over this network's 80 distinct conv/linear problems at
-// batch 8 (profiles/r1_conv_sweep.json; every variant x 1..16 splits, back-to-back launches):
-//   * what decides is workgroups resident per CU, not prefetch depth: the 64x64 tile with 3 stages
-//     (48 KB LDS, 3 workgroups/CU) is the best or within 10 % of it for most problems;
-//   * 128x128 pays only for the largest problems (>= 10^7 outputs with K >= 512, or a long K),
-//     and then with 2 stages (2 workgroups/CU) rather than 3;
-//   * short-K, many-row problems (K <= 576 at >= 10^5 rows, K <= 64 at >= 3*10^4 rows) are
-//     bandwidth- and launch-bound: the first-generation kernel (K-step 32, 12-24 KB LDS, up to 6
-//     workgroups/CU) wins or ties there;
+// batch 8 (profiles/r1_conv_sweep.json: every variant x 1..16 splits, timed inside a replayed HIP
+// graph).  What the sweep says:
+//   * what decides is workgroups resident per CU, not prefetch depth: 2-stage 64x64 / 128x64 /
+//     64x128 tiles (32-48 KB LDS, 3-5 workgroups per CU) beat the 3-stage ones almost everywhere;
+//   * 128x128 (2 stages, 2 workgroups/CU) pays only for >= 10^7 outputs with K >= 512 or a long K;
+//   * short-K, many-row problems are bandwidth-bound: the first-generation kernel (K-step 32,
+//     12-24 KB LDS, up to 6 workgroups/CU) wins or ties there;
+//   * the direct 3x3 kernel (LDS halo tile) wins with its smallest tile (8x16 pixels x 32 couts,
+//     2 workgroups/CU) on the Cout <= 32 layers with K >= 576 and on the 1/16-scale DAPM convs;
 //   * few-row / long-K problems (GSA sr convs) want 8 K-splits.
-struct Plan2 { int variant, splits; bool gen1; };
+struct Plan2 { int variant, splits; bool gen1; int direct; };   // direct >= 0: conv3x3_direct variant
 
-Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split) {
-  Plan2 pl{4, 1, false};
+Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool conv3x3s1 = false) {
+  Plan2 pl{4, 1, false, -1};
   const int nv = igemm2_num_variants();
-  if (rpb <= 0 && ((M >= 100000 && K <= 576) || (M >= 30000 && K <= 64))) pl.gen1 = true;
-  if (N <= 16) pl.variant = 10;
-  else if (N <= 32) pl.variant = M >= 400000 ? 7 : 9;
-  else if ((M * N >= 614400ll * 128 && K >= 512) || (M * N >= 38400ll * 128 && K >= 2048)) pl.variant = 1;
-  else if ((N >= 256 && K >= 2048) || N >= 1024) pl.variant = 12;
-  if (allow_split && M <= 1100 && K >= 2048) { pl.variant = 4; pl.splits = 8; }
+  const bool big = M >= 100000, mid = M >= 30000;
+  if (N <= 16) {
+    if (big && K <= 144) pl.gen1 = true; else pl.variant = 16;
+  } else if (N <= 32) {
+    if (conv3x3s1 && K >= 576 && mid) pl.direct = 4;
+    else if ((big && K <= 128) || (mid && K <= 64)) pl.gen1 = true;
+    else pl.variant = mid ? 16 : 9;
+  } else if (N <= 64) {
+    if ((big && K <= 160) || (mid && K <= 64)) pl.gen1 = true;
+    else pl.variant = big ? 14 : mid ? 13 : 4;
+  } else {
+    if ((big && K <= 288) || (mid && K <= 64)) pl.gen1 = true;
+    else if ((M * N >= 614400ll * 128 && K >= 512) || (mid && K >= 2048)) pl.variant = 1;
+    else if (mid) pl.variant = (N % 128 != 0 && N % 128 <= 64) ? 14 : 15;
+    else if ((N >= 256 && K >= 2048) || N >= 1024) pl.variant = 12;
+    else if (conv3x3s1 && N <= 128 && K >= 1152 && M >= 8000) pl.direct = 4;
+    else pl.variant = 4;
+  }
+  if (rpb > 0) { pl.gen1 = false; pl.direct = -1; if (pl.variant != 12) pl.variant = 4; }
+  if (allow_split && M <= 1100 && K >= 2048) { pl.variant = 4; pl.splits = 8; pl.gen1 = false; pl.direct = -1; }
+  if (g_force_variant >= 200 && conv3x3s1 && g_force_variant - 200 < conv3x3_num_variants()) { pl.direct = g_force_variant - 200; pl.gen1 = false; pl.splits = 1; }
+  else if (g_force_variant >= 0) pl.direct = -1;
   if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }
   if (g_force_splits >= 1) pl.splits = g_force_splits;
+  if (pl.direct >= 0) { pl.gen1 = false; pl.splits = 1; }
   return pl;
 }
 
@@ -305,10 +325,14 @@ int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cou
 
 }  // namespace
 
-extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int dtype, int rows_per_batch, int B, int* variant, int* splits) {
+extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
+                               int* splits) {
   if (dtype == CFP_BF16 && !g_use_v1) {
-    Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0);
-    if (pl.gen1) {
+    Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
+    if (pl.direct >= 0) {
+      if (variant) *variant = 200 + pl.direct;
+      if (splits) *splits = 1;
+    } else if (pl.gen1) {
       if (variant) *variant = cfp_conv2d_variant(M, Cout);
       if (splits) *splits = pick_splits(M, Cout, K, dtype);
     } else {
@@ -325,7 +349,7 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int dtype, int rows_per_b
 extern "C" size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype) {
   if (M <= 0 || Cout <= 0 || K <= 0) return 0;
   int v, s;
-  cfp_conv2d_plan(M, Cout, K, dtype, 0, 1, &v, &s);
+  cfp_conv2d_plan(M, Cout, K, 1, 1, dtype, 0, 1, &v, &s);
   return s <= 1 ? 0 : (size_t)s * M * Cout * sizeof(float);
 }
 
@@ -371,7 +395,13 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
   if (gen2) {
     const int rpb = per_image_weights ? Ho * Wo : 0;
     int ln_variant = ln_gamma ? pick_ln_variant(Cout, p.M) : -1;
-    Plan2 pl = plan2(p.M, Cout, p.K, rpb, B, rpb == 0 && ln_variant < 0);
+    const bool c33 = KH == 3 && KW == 3 && stride == 1 && !ln_gamma && rpb == 0 && (long long)Cout * p.K < (1ll << 31);
+    Plan2 pl = plan2(p.M, Cout, p.K, rpb, B, rpb == 0 && ln_variant < 0, c33);
+    if (pl.direct >= 0) {
+      int rc = conv3x3_launch(pl.direct, p, s);
+      CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: direct 3x3 kernel launch failed");
+      return cfp_check_launch("cfp_conv2d_nhwc");
+    }
     if (pl.gen1 && !ln_gamma) goto gen1_path;
     if (ln_variant >= 0 && g_force_variant < 0) pl.variant = ln_variant;
     if (ln_variant >= 0) { p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; pl.splits = 1; }

@@ -312,6 +312,10 @@ constexpr Cfg kCfg[] = {
     {256, 16, 2},   // 10
     {128, 16, 4},   // 11
     {64, 128, 3},   // 12
+    {64, 64, 2},    // 13
+    {128, 64, 2},   // 14
+    {64, 128, 2},   // 15
+    {128, 32, 2},   // 16
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -356,6 +360,10 @@ int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s
     case 10: return launch2<256, 16, 4, 1, 2>(p, slabs, splits, s);
     case 11: return launch2<128, 16, 4, 1, 4>(p, slabs, splits, s);
     case 12: return launch2<64, 128, 2, 2, 3>(p, slabs, splits, s);
+    case 13: return launch2<64, 64, 2, 2, 2>(p, slabs, splits, s);
+    case 14: return launch2<128, 64, 2, 2, 2>(p, slabs, splits, s);
+    case 15: return launch2<64, 128, 2, 2, 2>(p, slabs, splits, s);
+    case 16: return launch2<128, 32, 4, 1, 2>(p, slabs, splits, s);
     default: return -3;
   }
 }

@@ -40,9 +40,10 @@ template <> __device__ __forceinline__ void unpack_masked<float>(const u32x4& ra
 //   1. the input strip + halo ((R-1)*S+3 rows x (Wo-1)*S+3 columns, zeros outside the image) goes
 //      global -> LDS in one sweep of 16-byte loads, CVB*16 contiguous bytes per pixel (128/256 B);
 //      read amplification = halo rows only (1.2-1.7x) instead of 9 taps / column reuse (4.5-6x);
-//   2. thread = (channel vector, pixel slot): 9 conflict-free ds_read_b128 per output pixel (a
-//      16-lane read group covers 256 contiguous bytes), weights held in registers, f32 FMAs,
-//      BN scale/shift + activation, one 16-byte store per output pixel;
+//   2. thread = (channel vector, pixel slot); a unit of work is a run of 4 output pixels of one row:
+//      3 x 6 conflict-free ds_read_b128 (a 16-lane read group covers 256 contiguous bytes) feed 4
+//      outputs, weights held in registers, f32 FMAs, BN scale/shift + activation, one 16-byte
+//      store per output pixel;
 //   3. per-channel sums of the stored values are reduced over the pixel slots through LDS in slot
 //      order (deterministic) and written as partial[b][strip][c].
 // grid = (ceil(CV/CVB), B * nstrips).
@@ -95,28 +96,46 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
   float csum[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) csum[e] = 0.f;
+  constexpr int L = 4;                         // output pixels per unit (a run along the row)
+  constexpr int IW = (L - 1) * STRIDE + 3;     // input columns feeding a run
+  const int runs = (Wo + L - 1) / L;
   with_act(act, [&](auto A) {
-    for (int u = slot; u < rows * Wo; u += NSLOT) {
-      const int r = u / Wo, x = u - r * Wo;
-      const u32x4* tp = tile + ((r * STRIDE) * cols_in + x * STRIDE) * CVB + cvl;
-      float acc[VE];
+    for (int u = slot; u < rows * runs; u += NSLOT) {
+      const int r = u / runs, x0 = (u - r * runs) * L;
+      float acc[L][VE];
 #pragma unroll
-      for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+      for (int p = 0; p < L; ++p)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int e = 0; e < VE; ++e) acc[p][e] = 0.f;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const u32x4* rp = tile + ((r * STRIDE + kh) * cols_in) * CVB + cvl;
+#pragma unroll
+        for (int xx = 0; xx < IW; ++xx) {
+          const int col = min(x0 * STRIDE + xx, cols_in - 1);   // columns past the row end feed masked outputs only
           float v[VE];
-          unpack_masked<T>(tp[(kh * cols_in + kw) * CVB], true, v);
+          unpack_masked<T>(rp[col * CVB], true, v);
 #pragma unroll
-          for (int e = 0; e < VE; ++e) acc[e] = fmaf(v[e], wv[kh * 3 + kw][e], acc[e]);
+          for (int p = 0; p < L; ++p) {
+            const int kw = xx - p * STRIDE;   // compile-time after unrolling
+            if (kw >= 0 && kw < 3) {
+#pragma unroll
+              for (int e = 0; e < VE; ++e) acc[p][e] = fmaf(v[e], wv[kh * 3 + kw][e], acc[p][e]);
+            }
+          }
         }
-#pragma unroll
-      for (int e = 0; e < VE; ++e) {
-        acc[e] = to_f32<T>(from_f32<T>(act_c<decltype(A)::value>(acc[e] * sc[e] + sh[e])));   // the stored (rounded) value
-        csum[e] += acc[e];
       }
-      if (cv_ok) Vec<T>::store(out + ((long long)(b * Ho + ho_begin + r) * Wo + x) * out_ld + c0, acc);
+#pragma unroll
+      for (int p = 0; p < L; ++p) {
+        if (x0 + p < Wo) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) {
+            acc[p][e] = to_f32<T>(from_f32<T>(act_c<decltype(A)::value>(acc[p][e] * sc[e] + sh[e])));   // the stored (rounded) value
+            csum[e] += acc[p][e];
+          }
+          if (cv_ok) Vec<T>::store(out + ((long long)(b * Ho + ho_begin + r) * Wo + x0 + p) * out_ld + c0, acc[p]);
+        }
+      }
     }
   });
   if (partial == nullptr) return;   // uniform
@@ -344,6 +363,7 @@ namespace {
 // Among the configurations whose input strip fits 64 KB of LDS, take the one with the lowest
 // (halo read amplification) x (penalty for leaving CUs idle).
 struct DwPlan { int cvb, R, nstrips; size_t lds; };
+int g_dw_force_cvb = 0, g_dw_force_R = 0;   // cfp_debug_set keys 3 / 4 (tools/dw_bench.py)
 inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
   DwPlan best{8, 1, Ho, 0};
   double bc = 1e30;
@@ -352,7 +372,9 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
   const int cvbs[2] = {16, 8};
   for (int k = 0; k < 2; ++k) {
     const int cvb = cvbs[k];
+    if (g_dw_force_cvb && cvb != g_dw_force_cvb) continue;
     for (int R = 1; R <= Ho; ++R) {
+      if (g_dw_force_R && R != g_dw_force_R) continue;
       const int rows_in = (R - 1) * stride + 3;
       size_t lds = (size_t)rows_in * cols_in * cvb * 16;
       const size_t red = (size_t)(256 / cvb) * cvb * ve * sizeof(float);
@@ -362,7 +384,9 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
       const double halo = (double)rows_in / (R * stride);
       const double fill = blocks >= 512 ? 1.0 : 512.0 / (double)blocks;
       const double pad = (double)(cdiv(CV, cvb) * cvb) / CV;
-      const double c = halo * fill * pad;
+      const int units = R * cdiv(Wo, 4), nslot = 256 / cvb;          // runs of 4 output pixels over the pixel slots
+      const double util = (double)(cdiv(units, nslot) * nslot) / units;
+      const double c = halo * fill * pad * util;
       if (c < bc) { bc = c; best = DwPlan{cvb, R, cdiv(Ho, R), lds}; }
     }
   }
@@ -407,6 +431,8 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   return cfp_check_launch(who);
 }
 }  // namespace
+
+void cfp_dw_debug_set(int key, int value) { if (key == 3) g_dw_force_cvb = value; else g_dw_force_R = value; }
 
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                                   void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,

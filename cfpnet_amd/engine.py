@@ -54,6 +54,9 @@ class Engine:
         self._graph = None
         self._splitk_ws: Optional[torch.Tensor] = None
         self._capturing = False
+        # independent branches (ToF histogram encoder beside the RGB encoder, bin-width regressor beside
+        # the depth head's 3x3 conv) run on a second HIP stream; fork/join are events, also inside a graph
+        self._side = torch.cuda.Stream(device=self.device)
         self.load_state_dict(state_dict)
 
     # ------------------------------------------------------------------------------ packing
@@ -484,16 +487,19 @@ class Engine:
         b4 = self._act(plan, "tap4", B * hs[4] * wsz[4], e[0])
         plan["tap_dst"] = [cat[4].slice(c[3], e[4]), cat[3].slice(c[2], e[3]), cat[2].slice(c[1], e[2]),
                            cat[1].slice(c[0], e[1]), b4]
+        main = torch.cuda.current_stream(dev)
+        hist = add["hist_data"].to(device=dev, dtype=torch.float32).contiguous()
+        zone_valid = add["mask"].to(device=dev).to(torch.uint8).contiguous()
+        Z, N = hist.shape[1], hist.shape[2]
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):          # ToF branch: 10 tiny launches, hidden under the RGB encoder
+            hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
         if img_features is not None:      # test hook: bypass the RGB encoder with given NCHW features
             for f, dst in zip(img_features, plan["tap_dst"]):
                 dst.torch().copy_(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).to(device=dev, dtype=self.dtype))
         else:
             self._encoder(plan, rgb.to(device=dev, dtype=torch.float32).contiguous(), B, H, W, taps)
 
-        hist = add["hist_data"].to(device=dev, dtype=torch.float32).contiguous()
-        Z, N = hist.shape[1], hist.shape[2]
-        hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
-        zone_valid = add["mask"].to(device=dev).to(torch.uint8).contiguous()
         pinfo = add["patch_info"]
 
         def fuse(name, x, feat, hh, ww, out):
@@ -511,6 +517,7 @@ class Engine:
             self._cv(f"decoder.up{i}.b", t1, t2, B, hd, wd, 3, act=hip.ACT_LRELU)
             return t2
 
+        main.wait_stream(self._side)                  # join: the decoder consumes the ToF embeddings
         xd4 = self._act(plan, "xd4", B * hs[4] * wsz[4], c[0])
         self._cv("decoder.conv4", b4, xd4, B, hs[4], wsz[4], 1)
         x = xd4
@@ -534,16 +541,19 @@ class Engine:
         unet = self._act(plan, "unet", Mh, 128)
         self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
         ram = self._act(plan, "ram", Mh, 128)
-        self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
         ns = max(1, min(256, HWh // 256))
         part = self._f32(plan, "head.sum", B * ns * 128)
-        ops.channel_sum(unet, part, B, HWh, ns)
         edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
         centers = self._f32(plan, "head.centers", B * self.n_bins)
         h = "depth_head"
-        ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
-                          self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
-                          edges, centers, B, 128, 256, self.n_bins)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):          # bin-width regressor branch beside the head's 3x3 conv
+            ops.channel_sum(unet, part, B, HWh, ns)
+            ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
+                              self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
+                              edges, centers, B, 128, 256, self.n_bins)
+        self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
+        main.wait_stream(self._side)
         pred = torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
         prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
         if self.dtype == torch.bfloat16 and self.n_bins == 256 and HWh % 8 == 0:

@@ -25,7 +25,7 @@ SIGNATURES = {
     "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
     "cfp_conv2d_nhwc_ex": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _p, _f, _i, _p, _sz, _p]),
     "cfp_conv2d_ws_bytes": (_sz, [_i, _i, _i, _i]),
-    "cfp_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _p, _p]),
+    "cfp_conv2d_plan": (_i, [_i] * 8 + [_p, _p]),
     "cfp_debug_set": (_i, [_i, _i]),
     "cfp_conv2d_variant": (_i, [_i, _i]),
     "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),

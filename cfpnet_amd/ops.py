@@ -78,13 +78,18 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
 
 # tile shape (BM, BN, LDS stages) of second-generation variant v (conv_igemm2.hip kCfg)
 GEN2_TILES = [(128, 128, 3), (128, 128, 2), (128, 64, 3), (128, 64, 4), (64, 64, 3), (64, 64, 4), (256, 32, 3), (256, 32, 2),
-              (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3)]
+              (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3), (64, 64, 2), (128, 64, 2), (64, 128, 2), (128, 32, 2)]
 GEN1_TILES = [(256, 16), (256, 32), (128, 64), (128, 128)]
+# (tile rows, BN) of direct 3x3 variant v (conv3x3_direct.hip kCfg3); pixel tile = rows x 16
+DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
 
 
 def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
     t = "bf16" if dt == hip.BF16 else "f32"
-    if variant >= 100:
+    if variant >= 200:
+        th, bn = DIRECT3_TILES[variant - 200]
+        n = f"conv3x3_direct<{t},{th}x16px,{bn}>"
+    elif variant >= 100:
         bm, bn, st = GEN2_TILES[variant - 100]
         n = f"igemm2<{t},{bm}x{bn},s{st}>"
     else:
@@ -93,10 +98,10 @@ def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
     return n + (f"+splitK" if splits > 1 else "")
 
 
-def conv2d_plan(M: int, Cout: int, K: int, dt: int, rows_per_batch: int = 0, B: int = 1):
+def conv2d_plan(M: int, Cout: int, K: int, dt: int, rows_per_batch: int = 0, B: int = 1, KH: int = 1, stride: int = 1):
     import ctypes
     v, s = ctypes.c_int(0), ctypes.c_int(0)
-    hip.load().cfp_conv2d_plan(M, Cout, K, dt, rows_per_batch, B, ctypes.byref(v), ctypes.byref(s))
+    hip.load().cfp_conv2d_plan(M, Cout, K, KH, stride, dt, rows_per_batch, B, ctypes.byref(v), ctypes.byref(s))
     return v.value, s.value
 
 

@@ -76,16 +76,19 @@ size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype);
 
 /* Kernel plan cfp_conv2d_nhwc uses for a problem (per-kernel accounting in bench.py and
  * tools/conv_bench.py).  *variant: 0..3 = first-generation tiles 256x16 / 256x32 / 128x64 /
- * 128x128 (f32); 100 + v = second-generation (bf16, LDS-DMA staged) variant v.  *splits = K-splits.
+ * 128x128 (f32); 100 + v = second-generation (bf16, LDS-DMA staged) variant v; 200 + v = direct 3x3
+ * (LDS halo tile) variant v.  *splits = K-splits.  KH/stride describe the filter (K = KH*KH*Cin);
  * rows_per_batch > 0 describes a per_image_weights call (B images of rows_per_batch rows). */
-int cfp_conv2d_plan(int M, int Cout, int K, int dtype, int rows_per_batch, int B, int* variant, int* splits);
+int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
+                    int* splits);
 
 /* First-generation tile choice for (M, Cout): 0 = 256x16, 1 = 256x32, 2 = 128x64, 3 = 128x128. */
 int cfp_conv2d_variant(int M, int Cout);
 
 /* Test/benchmark knobs, not for production use (process-global, not thread-safe):
- * key 0 = force second-generation variant (-1 = automatic), key 1 = force K-splits (-1 = automatic),
- * key 2 = 1 routes bf16 through the first-generation kernel. */
+ * key 0 = force second-generation variant v, or 200 + v = direct 3x3 variant v (-1 = automatic), key 1 = force K-splits (-1 = automatic),
+ * key 2 = 1 routes bf16 through the first-generation kernel; keys 3 / 4 = depthwise 3x3 channel vectors per
+ * workgroup (8 / 16) and output rows per strip (0 = automatic). */
 int cfp_debug_set(int key, int value);
 
 /* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused

@@ -117,7 +117,7 @@ def _conv_ref_and_args(case, dtype, seed=1):
     return ref, xa, wa, scale.to(DEV), shift.to(DEV), ra, Ho, Wo
 
 
-GEN2_VARIANTS = list(range(13))
+GEN2_VARIANTS = list(range(17))
 
 
 @pytest.mark.parametrize("variant", GEN2_VARIANTS)
@@ -143,6 +143,38 @@ def test_conv2d_gen2_every_tile_variant(variant):
     finally:
         lib.cfp_debug_set(0, -1)
         lib.cfp_debug_set(1, -1)
+
+
+DIRECT3_CASES = [
+    (1, 12, 16, 40, 16, 3, 1, (1, 1, 1, 1)),      # Cin < 64 (one partly filled channel chunk), Cout 16
+    (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)),    # 7 channel chunks, tail chunk of 8 channels, 2 N-tiles
+    (1, 13, 17, 32, 32, 3, 1, (1, 1, 1, 1)),      # ragged patch edges
+    (2, 40, 50, 80, 32, 3, 1, (1, 1, 1, 1)),      # up4-like: chunk 64 + 16
+    (1, 33, 47, 168, 64, 3, 1, (0, 2, 2, 0)),     # asymmetric padding
+    (2, 16, 32, 128, 128, 3, 1, (1, 1, 1, 1)),    # exact tiles
+]
+
+
+@pytest.mark.parametrize("variant", list(range(6)))
+def test_conv3x3_direct_every_variant(variant):
+    """The LDS-halo direct 3x3 kernel, every tile variant forced through the debug knob."""
+    dtype = torch.bfloat16
+    lib = hip.load()
+    try:
+        lib.cfp_debug_set(0, 200 + variant)
+        for case in DIRECT3_CASES:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, wa, scale, shift, ra, Ho, Wo = _conv_ref_and_args(case, dtype)
+            v, sp = ops.conv2d_plan(B * Ho * Wo, Cout, 9 * Cin, hip.BF16, 0, B, 3, 1)
+            assert v == 200 + variant
+            out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True)
+            out = ops.Act(out.buf, 16, Cout)
+            ops.conv2d(xa, wa, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"direct3x3 v{variant} conv {case}")
+            assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+    finally:
+        lib.cfp_debug_set(0, -1)
 
 
 def test_conv2d_gen2_matches_gen1_bitwise_inputs():

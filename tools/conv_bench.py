@@ -9,6 +9,7 @@ cfp_debug_set.  Prints a table and writes gpurun_out/conv_bench.json.
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cfpnet_amd import hip, spec, synthetic, weights
 from cfpnet_amd.engine import Engine
 
@@ -50,20 +51,15 @@ for name, args in calls:
     uniq.setdefault(key, [name, args, 0])[2] += 1
 
 
+from _gtime import graph_time_us
+
+
 def timeit(name, args, reps):
-    for _ in range(3):
-        real(name, *args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        real(name, *args)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3   # us
+    # the recorded argument list ends with the stream of the recording pass: re-issue on the CURRENT stream
+    return graph_time_us(lambda: real(name, *args[:-1], hip.current_stream()), calls=max(4, reps // 2), replays=4)
 
 
-nvar = 13
+nvar = 17
 rows = []
 tot_auto = tot_v1 = tot_best = 0.0
 for key, (name, args, cnt) in uniq.items():
@@ -86,14 +82,22 @@ for key, (name, args, cnt) in uniq.items():
                 sweep[f"{v}/{sp}"] = t
                 if t < best[0]:
                     best = (t, f"v{v}/s{sp}")
+        if KH == 3 and st == 1:
+            for v in range(6):
+                lib.cfp_debug_set(0, 200 + v)
+                lib.cfp_debug_set(1, 1)
+                t = timeit(name, args, max(5, a.reps // 2))
+                sweep[f"d{v}/1"] = t
+                if t < best[0]:
+                    best = (t, f"d{v}")
         lib.cfp_debug_set(0, -1)
         lib.cfp_debug_set(1, -1)
     import ctypes
     pv, ps = ctypes.c_int(0), ctypes.c_int(0)
-    lib.cfp_conv2d_plan(M, Cout, K, 1, Ho * Wo if piw else 0, B, ctypes.byref(pv), ctypes.byref(ps))
-    ideal = max(fl / 1.5e15, byts / 5e12) * 1e6 + 2.0
+    lib.cfp_conv2d_plan(M, Cout, K, KH, st, 1, Ho * Wo if piw else 0, B, ctypes.byref(pv), ctypes.byref(ps))
+    ideal = max(fl / 1.5e15, byts / 5e12) * 1e6 + 1.5
     rows.append(dict(M=M, N=Cout, K=K, k=KH, stride=st, ln=ln, piw=piw, count=cnt, auto_us=t_auto, v1_us=t_v1, best_us=best[0],
-                     best=best[1], plan=f"v{pv.value - 100}/s{ps.value}", ideal_us=ideal, gflop=fl / 1e9, sweep=sweep))
+                     best=best[1], plan=(f"d{pv.value - 200}" if pv.value >= 200 else f"v{pv.value - 100}/s{ps.value}" if pv.value >= 100 else f"g1.{pv.value}/s{ps.value}"), ideal_us=ideal, gflop=fl / 1e9, sweep=sweep))
     tot_auto += cnt * t_auto; tot_v1 += cnt * t_v1; tot_best += cnt * best[0]
 
 rows.sort(key=lambda r: -r["auto_us"] * r["count"])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the depthwise 3x3 kernel on the encoder's shapes: automatic plan, forced
+(CVB, R) configurations, and a plain row copy of the same tensor as the bandwidth yardstick."""
+import argparse, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfpnet_amd import hip, ops
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--sweep", action="store_true")
+a = ap.parse_args()
+lib = hip.load()
+DEV = "cuda:0"
+B = a.batch
+shapes = [(60, 80, 224, 2), (30, 40, 448, 1), (30, 40, 672, 1), (30, 40, 816, 1), (30, 40, 816, 2), (15, 20, 1392, 1)]
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _gtime import graph_time_us
+
+
+def timeit(fn, reps):
+    return graph_time_us(fn, calls=12, replays=4)
+
+
+for (H, W, C, s) in shapes:
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt = max((Ho - 1) * s + 3 - H, 0) // 2; pl = max((Wo - 1) * s + 3 - W, 0) // 2
+    # rotate over several buffers so that back-to-back launches do not just hit in L2
+    NB = 6
+    xs = [ops.Act(torch.randn(B * H * W, C, device=DEV).to(torch.bfloat16), 0, C) for _ in range(NB)]
+    outs = [ops.new_act(B * Ho * Wo, C, torch.bfloat16, DEV) for _ in range(NB)]
+    w = torch.randn(9, C, device=DEV).to(torch.bfloat16); sc = torch.ones(C, device=DEV); sh = torch.zeros(C, device=DEV)
+    part = torch.empty(B * 64 * C, device=DEV)
+    k = [0]
+    def run():
+        i = k[0] % NB; k[0] += 1
+        ops.dwconv3x3_sum(xs[i], w, sc, sh, outs[i], part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    def cp():
+        i = k[0] % NB; k[0] += 1
+        ops.copy_rows(xs[i], outs[i], B * Ho * Wo)
+    mb = 2.0 * (B * H * W * C + B * Ho * Wo * C) / 1e6
+    t = timeit(run, a.reps); tc = timeit(cp, a.reps)
+    line = f"{B}x{H}x{W}x{C} s{s}: {mb:6.1f} MB  auto {t:6.1f} us = {mb / t:5.2f} TB/s   copy_rows(out-sized) {tc:6.1f} us = {2.0 * 2 * B * Ho * Wo * C / 1e6 / tc:5.2f} TB/s"
+    if a.sweep:
+        best = (t, "auto")
+        for cvb in (8, 16):
+            for R in (1, 2, 3, 4, 5, 6, 8, 10, 15):
+                if R > Ho: continue
+                lib.cfp_debug_set(3, cvb); lib.cfp_debug_set(4, R)
+                try:
+                    tt = timeit(run, max(5, a.reps // 3))
+                except RuntimeError:
+                    continue
+                line += f"\n      cvb{cvb} R{R}: {tt:6.1f}"
+                if tt < best[0]: best = (tt, f"cvb{cvb} R{R}")
+        lib.cfp_debug_set(3, 0); lib.cfp_debug_set(4, 0)
+        line += f"\n   best {best[1]} {best[0]:.1f} us"
+    print(line, flush=True)

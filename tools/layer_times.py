@@ -34,7 +34,7 @@ for i, (name, args, ms) in acc.items():
         B, H, W, Cin, Cout, KH, KW, st, pt, pl, Ho, Wo = args[9:21]
         M = B * Ho * Wo; fl = 2.0 * M * Cout * KH * KW * Cin
         ex = name.endswith("_ex")
-        v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, args[22], Ho * Wo if (ex and args[26]) else 0, B)
+        v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, args[22], Ho * Wo if (ex and args[26]) else 0, B, KH, st)
         desc = f"M={M} N={Cout} K={KH*KW*Cin} k{KH} s{st} v{v}/s{sp}" + (" LN" if ex and args[23] else "") + (" PIW" if ex and args[26] else "")
     elif name == "cfp_dwconv3x3_nhwc":
         B, H, W, C, st = args[7:12]; desc = f"{B}x{H}x{W}x{C} s{st}"
