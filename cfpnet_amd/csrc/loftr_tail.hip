@@ -1,0 +1,282 @@
+// Fused tail of a LoFTR encoder layer (transformer.py:48-71, attention.py:48-49), bf16:
+//
+//   msg = (Q' KV[g]) / (Q' . Ksum[g] + eps) * S          linear-attention apply, per head
+//   y1  = LayerNorm1(msg @ Wm^T)                          merge + norm1
+//   h   = relu([x | y1] @ W0^T)                           mlp.0 (the concat is a split K range)
+//   out = LayerNorm2(h @ W2^T) + x                        mlp.2 + norm2 + residual
+//
+// Unfused this is 4-5 launches per layer (apply, merge+LN, mlp0, mlp2+LN) over tensors of a few MB,
+// 18 layers per forward.  Here a wave owns 16 token rows from the apply to the final store: its
+// msg / y1 / x / h tiles live in a private LDS region (row pitch padded by 16 bytes, so the MFMA
+// A-operand read of 16 rows is conflict-free), and only the weights are shared: each GEMM streams
+// its [N][64] weight slabs global -> LDS with `global_load_lds_dwordx4` (XOR-swizzled 128-byte rows,
+// double buffered, one barrier per 64-wide K step).  Rows never leave their wave, so both
+// LayerNorms are a 16-lane shuffle reduction over the accumulator registers.
+// Rounding points match the unfused path (msg, the GEMM outputs before each LayerNorm and h are
+// rounded to bf16), so the two paths agree to accumulation order.
+#include "common.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16c[4] = {0u, 0u, 0u, 0u};
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct TailP {
+  const bf16_t* q; const float* kv; const float* ksum; const bf16_t* x; bf16_t* out;
+  const bf16_t* wm; const bf16_t* w0; const bf16_t* w2;
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  int q_ld, x_ld, out_ld;
+  int rows, Hq, Wq, qth, qtw, ggy, ggx;
+  float v_length, eps, ln_eps;
+};
+
+// One GEMM of the chain for this wave's 16 rows: acc[j] += A[16 x K] * W[N x K]^T, N = NT * 16.
+// `afrag(k)` returns the lane's A fragment for columns [k, k + 32) of the wave-private operand.
+// All four waves of the workgroup must call it together (they share the weight slabs).
+template <int NT, int BSTAGE, typename AF>
+__device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const bf16_t* __restrict__ W, int K, AF afrag, unsigned char* sB,
+                                          int wave, int lane) {
+  constexpr int N = NT * 16;
+  constexpr int NBG = N / 8;                  // 8-row DMA groups of a weight slab
+  constexpr int NBW = (NBG + 3) / 4;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero16c);
+  const int nk = (K + 63) >> 6;
+  auto issue = [&](int ks, int st) {
+    const int kk = ks * 64 + lc * 8;
+    const bool kok = kk < K;
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      const int g = (j * 4 + wave) % NBG;
+      const int n = g * 8 + rsub;
+      glds16(kok ? W + (long long)n * K + kk : zsrc, sB + st * BSTAGE + g * 1024);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_s_barrier();               // every wave is done with the previous GEMM's slabs
+  asm volatile("" ::: "memory");
+  issue(0, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+    const unsigned char* cB = sB + (ks & 1) * BSTAGE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int k = ks * 64 + sub * 32;
+      if (k < K) {                            // uniform
+        const s16x8 a = afrag(k);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const s16x8 b = *reinterpret_cast<const s16x8*>(cB + (j * 16 + fr) * 128 + (((sub * 4 + fq) ^ (fr & 7)) * 16));
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// LayerNorm over the N = NT*16 columns of each of this lane's 4 rows (row = fq*4 + r, col = j*16 + fr);
+// the values are first rounded to bf16 (the unfused path stores the GEMM output in bf16).
+template <int NT>
+__device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               float eps, int fr) {
+  constexpr float inv_n = 1.f / (float)(NT * 16);
+  float g[NT], bt[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { g[j] = gamma[j * 16 + fr]; bt[j] = beta[j * 16 + fr]; }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { acc[j][r] = bf2f(f2bf(acc[j][r])); s += acc[j][r]; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_n;
+    float qq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { const float dlt = acc[j][r] - mean; qq = fmaf(dlt, dlt, qq); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    const float rstd = rsqrtf(qq * inv_n + eps);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j][r] = (acc[j][r] - mean) * rstd * g[j] + bt[j];
+  }
+}
+
+template <int D, int HEADS>
+__global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
+  constexpr int d = D / HEADS;
+  constexpr int PA = D + 8, PH = 2 * D + 8;               // row pitches (elements): +16 bytes
+  constexpr int WAVE_LDS = (2 * PA + PH) * 16 * 2;         // msg/y1 | x | h tiles of one wave
+  constexpr int BSTAGE = 2 * D * 128;                      // largest weight slab: [2D rows][64 k]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  unsigned char* sB = smem;
+  bf16_t* tMsg = reinterpret_cast<bf16_t*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  bf16_t* tX = tMsg + 16 * PA;
+  bf16_t* tH = tX + 16 * PA;
+  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+
+  // ---- x tile -> LDS (16-byte vectors) -----------------------------------------------------------
+  constexpr int XCH = D / 8;                               // 16-byte chunks per row
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < p.rows) v = *reinterpret_cast<const u32x4*>(p.x + m * p.x_ld + ch * 8);
+    *reinterpret_cast<u32x4*>(tX + r * PA + ch * 8) = v;
+  }
+
+  // ---- linear-attention apply: lane = (row, head slot) --------------------------------------------
+  {
+    const int r = fr;
+    const long long m = row0 + r;
+    const bool ok = m < p.rows;
+    const long long mm = ok ? m : 0;
+    const int xq = (int)(mm % p.Wq);
+    const long long t = mm / p.Wq;
+    const int yq = (int)(t % p.Hq);
+    const int b = (int)(t / p.Hq);
+    const long long g = ((long long)b * p.ggy + yq / p.qth) * p.ggx + xq / p.qtw;
+#pragma unroll
+    for (int hs = 0; hs < HEADS / 4; ++hs) {
+      const int h = fq + 4 * hs;
+      const float* __restrict__ kv = p.kv + (g * HEADS + h) * d * d;
+      const float* __restrict__ ks = p.ksum + (g * HEADS + h) * d;
+      const bf16_t* qp = p.q + mm * p.q_ld + h * d;
+      float qv[d];
+      if constexpr (d >= 8) {
+#pragma unroll
+        for (int c = 0; c < d; c += 8) Vec<bf16_t>::load(qp + c, qv + c);
+      } else {
+#pragma unroll
+        for (int c = 0; c < d; ++c) qv[c] = bf2f(qp[c]);
+      }
+      float o[d];
+#pragma unroll
+      for (int j = 0; j < d; ++j) o[j] = 0.f;
+      float z = 0.f;
+#pragma unroll
+      for (int i = 0; i < d; ++i) {
+        const float qe = elu1(qv[i]);
+        z = fmaf(qe, ks[i], z);
+#pragma unroll
+        for (int j = 0; j < d; j += 4) {
+          const f32x4 kk = *reinterpret_cast<const f32x4*>(kv + i * d + j);
+          o[j] = fmaf(qe, kk[0], o[j]); o[j + 1] = fmaf(qe, kk[1], o[j + 1]);
+          o[j + 2] = fmaf(qe, kk[2], o[j + 2]); o[j + 3] = fmaf(qe, kk[3], o[j + 3]);
+        }
+      }
+      const float zi = 1.f / (z + p.eps);                    // (o * 1/(z+eps)) * S, as attention.py:48-49
+#pragma unroll
+      for (int j = 0; j < d; ++j) tMsg[r * PA + h * d + j] = ok ? f2bf(o[j] * zi * p.v_length) : (bf16_t)0;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- merge + norm1 -------------------------------------------------------------------------------
+  {
+    f32x4 acc[D / 16];
+    tail_gemm<D / 16, BSTAGE>(acc, p.wm, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tMsg + fr * PA + k + fq * 8); }, sB, wave, lane);
+    tail_layernorm<D / 16>(acc, p.g1, p.b1, p.ln_eps, fr);
+#pragma unroll
+    for (int j = 0; j < D / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tMsg[(fq * 4 + r) * PA + j * 16 + fr] = f2bf(acc[j][r]);   // y1 replaces msg
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- mlp.0: [x | y1] (K = 2D) -> 2D, ReLU ---------------------------------------------------------
+  {
+    f32x4 acc[2 * D / 16];
+    tail_gemm<2 * D / 16, BSTAGE>(acc, p.w0, 2 * D, [&](int k) {
+      const bf16_t* src = k < D ? tX + fr * PA + k : tMsg + fr * PA + (k - D);
+      return *reinterpret_cast<const s16x8*>(src + fq * 8);
+    }, sB, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 2 * D / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PH + j * 16 + fr] = f2bf(fmaxf(acc[j][r], 0.f));
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- mlp.2 (K = 2D) -> D, norm2, + x ---------------------------------------------------------------
+  {
+    f32x4 acc[D / 16];
+    tail_gemm<D / 16, BSTAGE>(acc, p.w2, 2 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
+    tail_layernorm<D / 16>(acc, p.g2, p.b2, p.ln_eps, fr);
+#pragma unroll
+    for (int j = 0; j < D / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = fq * 4 + r, col = j * 16 + fr;
+        tMsg[row * PA + col] = f2bf(acc[j][r] + bf2f(tX[row * PA + col]));     // stage the output tile
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    if (m < p.rows) *reinterpret_cast<u32x4*>(p.out + m * p.out_ld + ch * 8) = *reinterpret_cast<const u32x4*>(tMsg + r * PA + ch * 8);
+  }
+}
+
+template <int D, int HEADS>
+int launch_tail(const TailP& p, hipStream_t s) {
+  constexpr size_t lds = 2 * (2 * D * 128) + 4 * ((2 * (D + 8) + 2 * D + 8) * 16 * 2);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = loftr_tail_kernel<D, HEADS>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
+                              void* out, int out_ld, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
+                              const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
+                              int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
+                              int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_loftr_tail: bf16 only (the f32 parity mode uses the unfused kernels)");
+  CFP_REQUIRE(q && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
+              "cfp_loftr_tail: null pointer");
+  CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && v_length > 0.f, CFP_ESHAPE, "cfp_loftr_tail: bad grid");
+  CFP_REQUIRE((D == 32 || D == 64 || D == 128) && (heads == 4 || heads == 8), CFP_ESHAPE,
+              "cfp_loftr_tail: D must be 32/64/128 and heads 4/8");
+  CFP_REQUIRE(q_ld >= D && x_ld >= D && out_ld >= D && q_ld % 8 == 0 && x_ld % 8 == 0 && out_ld % 8 == 0, CFP_ESHAPE,
+              "cfp_loftr_tail: pitches must be >= D and multiples of 8");
+  CFP_REQUIRE(aligned16(q) && aligned16(x) && aligned16(out) && aligned16(w_merge) && aligned16(w_mlp0) && aligned16(w_mlp2) &&
+                  aligned16(kv), CFP_EINVAL, "cfp_loftr_tail: pointers must be 16-byte aligned");
+  CFP_REQUIRE((long long)NB * Hq * Wq < (1ll << 31), CFP_ESHAPE, "cfp_loftr_tail: too many rows");
+  TailP p;
+  p.q = (const bf16_t*)q; p.kv = kv; p.ksum = ksum; p.x = (const bf16_t*)x; p.out = (bf16_t*)out;
+  p.wm = (const bf16_t*)w_merge; p.w0 = (const bf16_t*)w_mlp0; p.w2 = (const bf16_t*)w_mlp2;
+  p.g1 = ln1_g; p.b1 = ln1_b; p.g2 = ln2_g; p.b2 = ln2_b;
+  p.q_ld = q_ld; p.x_ld = x_ld; p.out_ld = out_ld;
+  p.rows = NB * Hq * Wq; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
+  p.v_length = v_length; p.eps = eps; p.ln_eps = ln_eps;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int rc = -2;
+  if (D == 32 && heads == 4) rc = launch_tail<32, 4>(p, s);
+  else if (D == 32 && heads == 8) rc = launch_tail<32, 8>(p, s);
+  else if (D == 64 && heads == 4) rc = launch_tail<64, 4>(p, s);
+  else if (D == 64 && heads == 8) rc = launch_tail<64, 8>(p, s);
+  else if (D == 128 && heads == 4) rc = launch_tail<128, 4>(p, s);
+  else if (D == 128 && heads == 8) rc = launch_tail<128, 8>(p, s);
+  CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_loftr_tail: launch failed");
+  return cfp_check_launch("cfp_loftr_tail");
+}

@@ -315,6 +315,12 @@ class Engine:
         ws = self._f32(plan, f"{tag}.kvws", nws)
         ops.attn_kv_reduce(kA, vA, kv, ks, ws, kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"],
                            kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
+        if self.dtype == torch.bfloat16:
+            # apply + merge + norm1 + mlp + norm2 + residual in one kernel: the intermediates stay in LDS
+            ops.loftr_tail(qb.slice(0, D), kv, ks, x, out, self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
+                           (self.P[p + ".norm1.g"], self.P[p + ".norm1.b"]), (self.P[p + ".norm2.g"], self.P[p + ".norm2.b"]),
+                           apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"], kvmode["v_length"], heads)
+            return
         msg = self._act(plan, f"{tag}.msg", rows_q, D)
         ops.attn_apply(qb.slice(0, D), kv, ks, msg, apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"],
                        (0, 0, 0, 0), kvmode["v_length"], heads, d)

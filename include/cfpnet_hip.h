@@ -172,6 +172,21 @@ int cfp_attn_apply(const void* q, int q_ld, const float* kv, const float* ksum, 
                    int NB, int Hq, int Wq, int qth, int qtw, int ey0, int ey1, int ex0, int ex1,
                    float v_length, float eps, int heads, int d, int dtype, cfp_stream_t stream);
 
+/* Fused tail of a LoFTR encoder layer, one launch (bf16 only; D in {32,64,128}, heads in {4,8}):
+ *   msg = cfp_attn_apply(q, kv, ksum)                                   attention.py:48-49
+ *   y1  = LayerNorm(msg @ w_merge^T; ln1)                               transformer.py:63
+ *   h   = relu([x | y1] @ w_mlp0^T)                                     transformer.py:66-67 (mlp.0 + ReLU)
+ *   out = LayerNorm(h @ w_mlp2^T; ln2) + x                              transformer.py:67-71
+ * q, x, out: [NB*Hq*Wq rows] with pitches q_ld / x_ld / out_ld; the query -> key-group map is that of
+ * cfp_attn_apply (g = (b, y / qth, x / qtw)); no exclusion rectangle.  w_merge [D][D], w_mlp0 [2D][2D],
+ * w_mlp2 [D][2D], all K-contiguous bf16.  Intermediates stay in LDS; rounding points (bf16 after the
+ * apply, before each LayerNorm and after the ReLU) are those of the unfused sequence. */
+int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
+                   void* out, int out_ld, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
+                   const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
+                   int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
+                   int dtype, cfp_stream_t stream);
+
 /* Bilinear resampling (align_corners=True) of a rectangle of an NHWC map into a rectangle of
  * another one.  The source rectangle may overhang the source map (reads 0 there: F.pad in
  * fusion.py:136).  If zone_valid != NULL, source texel (y,x) is multiplied by

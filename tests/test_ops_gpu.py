@@ -447,6 +447,62 @@ def test_attention_inside_outside_and_global(heads, d, H, W, dtype):
     close(out.torch().float().cpu().reshape(B, H, W, Dm), ref, dtype)
 
 
+@pytest.mark.parametrize("D,heads,NB,Hq,Wq,qth,qtw", [(128, 4, 2, 16, 16, 4, 4), (128, 8, 1, 30, 40, 6, 6), (64, 4, 2, 14, 14, 7, 7),
+                                                     (64, 8, 1, 13, 17, 13, 17), (32, 8, 2, 24, 30, 12, 12), (32, 4, 1, 9, 11, 3, 3)])
+def test_loftr_tail_fused_vs_reference(D, heads, NB, Hq, Wq, qth, qtw):
+    """apply -> merge -> norm1 -> mlp -> norm2 -> +x in one kernel vs the same chain in PyTorch (with
+    the storage-type rounding points of the unfused path) and vs the unfused HIP kernels."""
+    dtype = torch.bfloat16
+    d = D // heads
+    rows = NB * Hq * Wq
+    ggy, ggx = -(-Hq // qth), -(-Wq // qtw)
+    G = NB * ggy * ggx
+    S = float(qth * qtw)
+    qf = q(rnd(rows, D, seed=1), dtype)
+    xf = q(rnd(rows, D, seed=2), dtype)
+    kvf = rnd(G, heads, d, d, seed=3, scale=0.3)
+    ksf = rnd(G, heads, d, seed=4).abs() + 0.5
+    wm = q(rnd(D, D, seed=5, scale=1.0 / math.sqrt(D)), dtype)
+    w0 = q(rnd(2 * D, 2 * D, seed=6, scale=1.0 / math.sqrt(2 * D)), dtype)
+    w2 = q(rnd(D, 2 * D, seed=7, scale=1.0 / math.sqrt(2 * D)), dtype)
+    g1, b1, g2, b2 = rnd(D, seed=8).abs() + 0.5, rnd(D, seed=9), rnd(D, seed=10).abs() + 0.5, rnd(D, seed=11)
+    # reference
+    tok = torch.arange(rows)
+    xq, yq, bq = tok % Wq, (tok // Wq) % Hq, tok // (Wq * Hq)
+    gidx = (bq * ggy + yq // qth) * ggx + xq // qtw
+    Q = F.elu(qf).add(1).reshape(rows, heads, d)
+    num = torch.einsum("rhi,rhij->rhj", Q, kvf[gidx])
+    den = torch.einsum("rhi,rhi->rh", Q, ksf[gidx]) + 1e-6
+    msg = q((num / den[..., None] * S).reshape(rows, D), dtype)
+    y1 = q(F.layer_norm(q(msg @ wm.t(), dtype), (D,), g1, b1, 1e-5), dtype)
+    hmid = q(F.relu(torch.cat([xf, y1], 1) @ w0.t()), dtype)
+    ref = F.layer_norm(q(hmid @ w2.t(), dtype), (D,), g2, b2, 1e-5) + xf
+    # fused kernel
+    qa, xa = to_act(qf, dtype, ld=3 * D), to_act(xf, dtype, ld=2 * D)
+    out = ops.new_act(rows, D, dtype, DEV, ld=2 * D, zero=True)
+    out = ops.Act(out.buf, D, D)
+    kvd, ksd = kvf.contiguous().to(DEV), ksf.contiguous().to(DEV)
+    wmd, w0d, w2d = (t.to(dtype).to(DEV) for t in (wm, w0, w2))
+    ln1, ln2 = (g1.to(DEV), b1.to(DEV)), (g2.to(DEV), b2.to(DEV))
+    ops.loftr_tail(qa, kvd, ksd, xa, out, wmd, w0d, w2d, ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
+    torch.cuda.synchronize()
+    got = out.torch().float().cpu()
+    close(got, ref, dtype, f"loftr tail D={D} heads={heads}")
+    assert float(out.buf[:, :D].abs().max()) == 0
+    # unfused HIP chain
+    msg_a = ops.new_act(rows, D, dtype, DEV)
+    ops.attn_apply(qa, kvd, ksd, msg_a, NB, Hq, Wq, qth, qtw, (0, 0, 0, 0), S, heads, d)
+    xb = ops.new_act(rows, 2 * D, dtype, DEV)
+    xb.buf[:, :D] = xf.to(dtype).to(DEV)
+    ops.linear(msg_a, wmd, None, None, xb.slice(D, D), rows, hip.ACT_NONE, None, None, ln=(ln1[0], ln1[1], 1e-5))
+    hid = ops.new_act(rows, 2 * D, dtype, DEV)
+    ops.linear(xb, w0d, None, None, hid, rows, hip.ACT_RELU)
+    out2 = ops.new_act(rows, D, dtype, DEV)
+    ops.linear(hid, w2d, None, None, out2, rows, hip.ACT_NONE, xb.slice(0, D), None, ln=(ln2[0], ln2[1], 1e-5))
+    torch.cuda.synchronize()
+    close(got, out2.torch().float().cpu(), dtype, f"loftr tail vs unfused D={D} heads={heads}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_resize_matches_interpolate(dtype):
     B, Cc = 2, 64
