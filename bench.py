@@ -75,8 +75,9 @@ def kernel_times(engine, inputs, return_prob, reps=3):
             piw = a[26] if name.endswith("_ex") else 0
             v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, a[22], Ho * Wo if piw else 0, B, KH, stride)
             fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
-        elif name == "cfp_dwconv3x3_nhwc":
-            B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16]
+        elif name in ("cfp_dwconv3x3_nhwc", "cfp_dwconv3x3_sum_nhwc"):
+            B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16] if name == "cfp_dwconv3x3_nhwc" else a[8:17]
+            fam = "cfp_dwconv3x3_nhwc"
             flops = 2.0 * 9 * B * Ho * Wo * C
             byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)
         elif name == "cfp_dwconv_large_nhwc":
@@ -97,6 +98,21 @@ def kernel_times(engine, inputs, return_prob, reps=3):
     finally:
         hip.call = real_call
     return {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps) for k, v in agg.items()}
+
+
+def pmc_traffic(kernel_family: str):
+    """HBM bytes per launch of a kernel family from the last committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for 16-byte
+    streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    e = table.get(kernel_family)
+    return None if e is None else e.get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(budget_s, layers, sd):
@@ -127,16 +143,40 @@ def cpu_baseline(budget_s, layers, sd):
                           sample=f"{len(times)} x B=1 480x640 full forward of the CPU oracle (PyTorch CPU fp32), median {med * 1e3:.0f} ms")
 
 
-def main():
-    a = parse()
+def init_dist(backend: str = "nccl"):
+    """One process per GPU (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns
+    (rank, world, local_rank, dist-module-or-None).  `backend="gloo"` is used by the CPU tests."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if world <= 1:
+        return rank, world, local, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local, dist
+
+
+def max_over_ranks(elapsed: float, dist, device="cpu") -> float:
+    """The job's time is the slowest rank's time (contract: barrier both sides, MAX over ranks)."""
+    if dist is None:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(world: int, batch: int, steps: int, elapsed: float):
+    """Replicas only: every rank pushes its own `batch` maps per step through its own GPU, no data-path
+    collective; whole-job throughput = all maps of all ranks / slowest rank's time."""
+    maps = world * batch * steps
+    return maps / elapsed, maps / elapsed / world
+
+
+def main():
+    a = parse()
+    rank, world, local, dist = init_dist("nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -166,17 +206,13 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
 
     if rank == 0:
-        maps = world * a.batch * a.steps
+        value, per_gpu = job_value(world, a.batch, a.steps, elapsed)
         line = {
-            "metric": "depth maps/sec @ 480x640 bf16 (whole job; per_gpu = value / n_gpus)",
-            "value": maps / elapsed, "unit": "maps/s", "per_gpu": maps / elapsed / world,
+            "metric": "depth maps/sec @ 480x640 bf16 (whole job; per_gpu = value / n_gpus); abs_rel vs CPU oracle",
+            "value": value, "unit": "maps/s", "per_gpu": per_gpu,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward incl. prob output"
@@ -192,13 +228,22 @@ def main():
             d = convs[dom]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launches_per_step": d["launches"],
-                                "avg_launch_us": d["ms"] * 1e3 / d["launches"], "share_of_gpu_time": d["ms"] / total_ms}
+                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(dom), "launches_per_step": d["launches"],
+                                "avg_launch_us": d["ms"] * 1e3 / d["launches"], "share_of_gpu_time": d["ms"] / total_ms,
+                                "flop_per_launch": d["flops"] / d["launches"]}
+            big = max(convs, key=lambda k: convs[k]["flops"] / max(convs[k]["launches"], 1))
+            if big != dom:      # the family holding the largest single GEMM (the depth head's 3x3 conv)
+                e = convs[big]
+                ach2 = e["flops"] / (e["ms"] * 1e-3) / 1e12
+                line["roofline_largest_gemm"] = {"kernel": big, "bound": "mfma", "achieved": ach2, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": ach2 / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(big), "launches_per_step": e["launches"],
+                                                 "avg_launch_us": e["ms"] * 1e3 / e["launches"]}
             if "cfp_dwconv3x3_nhwc" in kt:
                 w = kt["cfp_dwconv3x3_nhwc"]
                 gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
                 line["dw3x3"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                 "launches_per_step": w["launches"], "avg_launch_us": w["ms"] * 1e3 / w["launches"]}
+                                 "traffic": pmc_traffic("dw3x3_kernel"), "launches_per_step": w["launches"],
+                                 "avg_launch_us": w["ms"] * 1e3 / w["launches"], "bytes_per_launch": w["bytes"] / w["launches"]}
             line["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
             line["kernel_ms_total"] = total_ms
         if world == 1 and not a.no_cpu_baseline:
