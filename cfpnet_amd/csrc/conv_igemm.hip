@@ -244,10 +244,10 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
-void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic)
+void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic), 5 = 1 forces the VALU kernel
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
-    case 3: case 4: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 3: case 4: case 5: cfp_dw_debug_set(key, value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
     case 2: g_use_v1 = value; return CFP_OK;

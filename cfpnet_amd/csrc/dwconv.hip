@@ -156,6 +156,234 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
   }
 }
 
+// ---- depthwise 3x3 with the tap reduction on the matrix cores (bf16) ---------------------------
+// In-kernel stamps of the VALU kernel above showed what bounds it at batch 8: per workgroup ~5 us
+// waiting for the strip, then a compute phase that is VALU-ISSUE bound (bf16 unpack + 72 FMA +
+// address arithmetic + SiLU: 0.5 VALU instructions per output element), and no overlap between the
+// two because every resident workgroup is in the same phase.  A depthwise conv has no reduction
+// over channels, but
+//     out[c][p] = sum_t w[t][c] * in[p + off_t][c]
+// is the MFMA  D[i][j] += sum_k A[i][k] B[k][j]  with i = channel (16), j = pixel (16),
+// k = (tap slot t' in {0,1}, channel c' in 0..15),  A[i][(t',c')] = w[2P+t'][i] * delta(c', i)
+// (a DIAGONAL weight block per tap, built once per wave in registers) and B[(t',c')][j] =
+// in[pixel j + off_(2P+t')][c'].  Only 1/16 of the MACs are useful, but the matrix pipe is 16x
+// the vector rate, the bf16 operands need no unpacking, the B fragment of a lane is exactly one
+// 16-byte LDS read (8 channels of one tap of one pixel) at a CONSTANT offset from the run's base
+// address, and the VALU is left with the epilogue: 9 taps = 5 MFMAs per (16 channels x 16 pixels).
+//   * LDS tile [rows_in][cols_in] pixels with a pixel pitch of CVB*16 + 16 bytes: 16 consecutive
+//     pixels read conflict-free without a swizzle, so every address is linear in (pixel, tap);
+//   * a wave owns one 16-channel group and walks the strip in raster order, 16 pixels of a row at
+//     a time (row tails narrower than 16 are gathered from 16/tail consecutive rows), four runs per
+//     loop iteration so their LDS-read -> MFMA -> SiLU chains overlap;
+//   * results are written IN PLACE into the tile at the window's top-left input pixel, which no
+//     later run reads (raster order), so there is no second LDS tile and the copy-out is fully
+//     coalesced 16-byte stores;
+//   * channel sums: per-lane over its pixels, then a 16-lane shuffle reduction; no cross-wave step.
+template <int STRIDE, int CVB>
+__global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restrict__ in, int in_ld, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         bf16_t* __restrict__ out, int out_ld, float* __restrict__ partial, int B,
+                                                         int H, int W, int C, int pad_t, int pad_l, int Ho, int Wo, int act, int R,
+                                                         int nstrips) {
+  constexpr int G = CVB / 2;                      // 16-channel groups per workgroup
+  constexpr int GPW = (G + 3) / 4;                // groups per wave
+  constexpr int PP = CVB * 16 + 16;               // pixel pitch in bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
+  const int CV = C / 8;
+  const int strip = blockIdx.y % nstrips, b = blockIdx.y / nstrips;
+  const int cv0 = blockIdx.x * CVB;
+  const int ho_begin = strip * R;
+  const int rows = min(R, Ho - ho_begin);
+  const int rows_in = (rows - 1) * STRIDE + 3, cols_in = (Wo - 1) * STRIDE + 3;
+  const int hi_base = ho_begin * STRIDE - pad_t, wi_base = -pad_l;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;         // B/D column (pixel) and k-chunk / D row block
+  // diagnostic path of the same kernel (tools/dw_bench.py --stamps): act >= 100 writes per-workgroup phase
+  // stamps AFTER the partial-sum area; the stamps feed no output value
+  const bool stamps = act >= 100;
+  if (stamps) act -= 100;
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tr0 = 0;
+  if (stamps) { tk0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+
+  // per-lane constants are requested BEFORE the tile staging so that their latency hides under it
+  short wv5[GPW][5];
+  float sc[GPW][4], sh[GPW][4];
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + 4 * gi;
+    const int cbase = (cv0 + 2 * g) * 8;
+    const bool g_ok = g < G && cbase < C;
+#pragma unroll
+    for (int pr = 0; pr < 5; ++pr) {
+      const int tap = 2 * pr + (q >> 1);
+      const bool on = g_ok && tap < 9 && (j >> 3) == (q & 1);
+      wv5[gi][pr] = on ? (short)w[min(tap, 8) * C + cbase + j] : (short)0;
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      sc[gi][r4] = g_ok ? scale[cbase + 4 * q + r4] : 1.f;
+      sh[gi][r4] = g_ok ? shift[cbase + 4 * q + r4] : 0.f;
+    }
+  }
+
+  // ---- 1. input strip + halo -> LDS ---------------------------------------------------------------
+  {
+    const int cvl = tid % CVB;
+    const bool cv_ok = cv0 + cvl < CV;
+    const int c0 = (cv_ok ? cv0 + cvl : 0) * 8;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int items = rows_in * cols_in * CVB;
+    for (int i = tid; i < items; i += 256) {
+      const int px = i / CVB;
+      const int ty = px / cols_in, tx = px - ty * cols_in;
+      const int hi = hi_base + ty, wi = wi_base + tx;
+      const bool ok = cv_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const int hic = min(max(hi, 0), H - 1), wic = min(max(wi, 0), W - 1);
+      u32x4 v = *reinterpret_cast<const u32x4*>(in + ((long long)(b * H + hic) * W + wic) * in_ld + c0);
+      *reinterpret_cast<u32x4*>(tile + px * PP + cvl * 16) = ok ? v : zero4;
+    }
+  }
+  {
+    const int nmain_ = Wo >> 4, tw_ = Wo & 15;
+    const int RB_ = (tw_ == 0) ? 1 : ((16 % tw_ == 0) ? 16 / tw_ : 1);
+    const int upb_ = RB_ * nmain_ + (tw_ ? 1 : 0);
+    const int nun_ = ((rows + RB_ - 1) / RB_) * upb_;
+    int* ut = reinterpret_cast<int*>(tile + ((rows_in * cols_in * PP + 15) & ~15));
+    for (int e = tid; e < nun_ * 16; e += 256) {
+      const int u = e >> 4, jj = e & 15;
+      const int rb = u / upb_, k = u - rb * upb_;
+      int r, x; bool valid;
+      if (k < RB_ * nmain_) {
+        r = rb * RB_ + k / nmain_;
+        x = (k % nmain_) * 16 + jj;
+        valid = r < rows;
+      } else {
+        const int jr = (RB_ > 1) ? jj / tw_ : 0;
+        r = rb * RB_ + jr;
+        x = (Wo - tw_) + (jj - jr * tw_);
+        valid = r < rows && (jj - jr * tw_) < tw_ && jr < RB_;
+      }
+      ut[e] = valid ? ((r * STRIDE) * cols_in + x * STRIDE) * PP : -1;
+    }
+  }
+  __syncthreads();
+  if (stamps) tk1 = __builtin_amdgcn_s_memtime();
+
+  // ---- 2. runs of 16 output pixels on the matrix cores -------------------------------------------------
+  // unit list of the strip, in an order that keeps the in-place writes safe: for every block of RB rows,
+  // first the full 16-pixel runs of those rows (raster order), then the gathered row tails.
+  const int nmain = Wo >> 4;                      // full runs per row
+  const int tw = Wo & 15;                         // row tail width
+  const int RB = (tw == 0) ? 1 : ((16 % tw == 0) ? 16 / tw : 1);   // rows gathered into one tail run
+  const int upb = RB * nmain + (tw ? 1 : 0);      // units per row block
+  const int nrb = (rows + RB - 1) / RB;
+  const int nunits = nrb * upb;
+  // window base (byte offset of the top-left input pixel) of lane-pixel j of unit u, or -1: a table in LDS,
+  // filled once per workgroup, so the run loop carries no integer divisions
+  int* utab = reinterpret_cast<int*>(tile + ((rows_in * cols_in * PP + 15) & ~15));
+  const int tapstep = PP;                         // one pixel to the right
+#pragma unroll
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave + 4 * gi;                   // wave-uniform
+    const int cbase = (cv0 + 2 * g) * 8;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < G && cbase < C && act != 99) {         // act 99: timing experiment (staging + copy-out only)
+      s16x8 afr[5];                                // diagonal weight fragments: lane (row i = j, chunk q) holds A[i][k = 8q..8q+7]
+      int toff[5];                                 // byte offset of this lane's tap (pair pr, slot q>>1) + its 16-byte vector
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) afr[pr][e] = (e == (j & 7)) ? wv5[gi][pr] : (short)0;
+        const int tc = min(2 * pr + (q >> 1), 8);
+        toff[pr] = ((tc / 3) * cols_in + tc % 3) * tapstep + (2 * g + (q & 1)) * 16;
+      }
+      const int ooff = (2 * g + (q >> 1)) * 16 + (q & 1) * 8;     // where this lane's 4 output channels live in a pixel
+      with_act(act, [&](auto A) {
+        constexpr int UN = 4;      // runs in flight per iteration: the kernel is bound by the LDS -> MFMA -> SiLU latency chain
+        for (int u0 = 0; u0 < nunits; u0 += UN) {
+          int base[UN]; float vf[UN]; f32x4 acc[UN];
+#pragma unroll
+          for (int t = 0; t < UN; ++t) {
+            const int tb = utab[min(u0 + t, nunits - 1) * 16 + j];
+            const bool valid = tb >= 0 && (u0 + t < nunits);
+            vf[t] = valid ? 1.f : 0.f;
+            base[t] = valid ? tb : 0;                  // invalid lanes read pixel 0 (finite data), results dropped
+            acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          s16x8 bfr[UN][5];
+#pragma unroll
+          for (int t = 0; t < UN; ++t)
+#pragma unroll
+            for (int pr = 0; pr < 5; ++pr) bfr[t][pr] = *reinterpret_cast<const s16x8*>(tile + base[t] + toff[pr]);
+#pragma unroll
+          for (int pr = 0; pr < 5; ++pr)
+#pragma unroll
+            for (int t = 0; t < UN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[pr], bfr[t][pr], acc[t], 0, 0, 0);
+          float y[UN][4];
+#pragma unroll
+          for (int t = 0; t < UN; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              y[t][r4] = act_c<decltype(A)::value>(acc[t][r4] * sc[gi][r4] + sh[gi][r4]);
+              csum[r4] = fmaf(y[t][r4], vf[t], csum[r4]);
+            }
+#pragma unroll
+          for (int t = 0; t < UN; ++t) {
+            if (vf[t] != 0.f) {        // D: lane holds channels cbase + 4q .. +3 of pixel j
+              uint2 pk;
+              pk.x = (uint32_t)f2bf(y[t][0]) | ((uint32_t)f2bf(y[t][1]) << 16);
+              pk.y = (uint32_t)f2bf(y[t][2]) | ((uint32_t)f2bf(y[t][3]) << 16);
+              *reinterpret_cast<uint2*>(tile + base[t] + ooff) = pk;
+            }
+          }
+        }
+      });
+      if (partial != nullptr) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) csum[r4] += __shfl_xor(csum[r4], o, 64);
+        }
+        if (j == 0) {
+          float* dst = partial + ((long long)b * nstrips + strip) * C + cbase + 4 * q;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) dst[r4] = csum[r4];
+        }
+      }
+    } else if (partial != nullptr && g < G && cbase < C && j == 0) {
+      float* dst = partial + ((long long)b * nstrips + strip) * C + cbase + 4 * q;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) dst[r4] = 0.f;
+    }
+  }
+  __syncthreads();
+  if (stamps) tk2 = __builtin_amdgcn_s_memtime();
+
+  // ---- 3. coalesced copy-out of the in-place results -------------------------------------------------
+  {
+    const int cvl = tid % CVB;
+    if (cv0 + cvl < CV) {
+      const int c0 = (cv0 + cvl) * 8;
+      const int npix = rows * Wo;
+      for (int i = tid; i < npix * CVB; i += 256) {
+        const int po = i / CVB;
+        const int r = po / Wo, x = po - r * Wo;
+        const int pxo = (r * STRIDE) * cols_in + x * STRIDE;
+        *reinterpret_cast<u32x4*>(out + ((long long)(b * Ho + ho_begin + r) * Wo + x) * out_ld + c0) =
+            *reinterpret_cast<const u32x4*>(tile + pxo * PP + cvl * 16);
+      }
+    }
+  }
+  if (stamps && partial != nullptr && tid == 0) {
+    const unsigned long long tk3 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    float* dbg = partial + (long long)B * nstrips * C + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    dbg[0] = (float)(tk1 - tk0); dbg[1] = (float)(tk2 - tk1); dbg[2] = (float)(tk3 - tk2);
+    dbg[3] = (float)(tr0 & 0xffffff); dbg[4] = (float)(tr1 & 0xffffff); dbg[5] = 1.f;
+  }
+}
+
 // ---- large kernel ------------------------------------------------------------------------
 // Workgroup = 512 threads = 8 waves; wave w owns channel c0 + w of a 32-row x 32-column output
 // tile, lane = (column, 16-row strip).  The input tile + halo sits in LDS planar per channel
@@ -363,8 +591,8 @@ namespace {
 // Among the configurations whose input strip fits 64 KB of LDS, take the one with the lowest
 // (halo read amplification) x (penalty for leaving CUs idle).
 struct DwPlan { int cvb, R, nstrips; size_t lds; };
-int g_dw_force_cvb = 0, g_dw_force_R = 0;   // cfp_debug_set keys 3 / 4 (tools/dw_bench.py)
-inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
+int g_dw_force_cvb = 0, g_dw_force_R = 0, g_dw_valu = 0;   // cfp_debug_set keys 3 / 4 / 5 (tools/dw_bench.py)
+inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out_tile = false) {
   DwPlan best{8, 1, Ho, 0};
   double bc = 1e30;
   const int CV = C / ve;
@@ -376,7 +604,8 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve) {
     for (int R = 1; R <= Ho; ++R) {
       if (g_dw_force_R && R != g_dw_force_R) continue;
       const int rows_in = (R - 1) * stride + 3;
-      size_t lds = (size_t)rows_in * cols_in * cvb * 16;
+      size_t lds = (size_t)rows_in * cols_in * (out_tile ? cvb * 16 + 16 : cvb * 16);   // out_tile: the MFMA kernel's padded pixel pitch
+      if (out_tile) lds += 16 + (size_t)(R * (cdiv(Wo, 16) + 1) + 16) * 64;              // + its unit table
       const size_t red = (size_t)(256 / cvb) * cvb * ve * sizeof(float);
       if (lds < red) lds = red;
       if (lds > 64 * 1024) break;
@@ -407,7 +636,8 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
                   in_ld >= C && out_ld >= C, CFP_ESHAPE, std::string(who) + ": bad shape");
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
               std::string(who) + ": pointers must be 16-byte aligned");
-  const DwPlan d = dw_plan(B, Ho, Wo, C, stride, ve);
+  const bool mfma = dtype == CFP_BF16 && C % 16 == 0 && !g_dw_valu;
+  const DwPlan d = dw_plan(B, Ho, Wo, C, stride, ve, mfma);
   CFP_REQUIRE((long long)B * d.nstrips <= 65535, CFP_ESHAPE, std::string(who) + ": grid too large");
   CFP_REQUIRE(d.lds <= 64 * 1024, CFP_ESHAPE, std::string(who) + ": map too wide for the LDS strip");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -424,15 +654,30 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
                        (T*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);                  \
   } while (0)
 #define DW_CVB(T, S) do { if (d.cvb == 16) DW_LAUNCH(T, S, 16); else DW_LAUNCH(T, S, 8); } while (0)
-  if (dtype == CFP_BF16) { if (stride == 1) DW_CVB(bf16_t, 1); else DW_CVB(bf16_t, 2); }
+#define DWM_LAUNCH(S, V)                                                                                                  \
+  do {                                                                                                                    \
+    static bool attr = false;                                                                                             \
+    if (!attr) {                                                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void*)dw3x3_mfma_kernel<S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+      if (e != hipSuccess) { cfp_set_error(std::string(who) + ": " + hipGetErrorString(e)); return CFP_EHIP; }            \
+      attr = true;                                                                                                        \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((dw3x3_mfma_kernel<S, V>), grid, dim3(256), d.lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)w, scale, \
+                       shift, (bf16_t*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);      \
+  } while (0)
+#define DWM_CVB(S) do { if (d.cvb == 16) DWM_LAUNCH(S, 16); else DWM_LAUNCH(S, 8); } while (0)
+  if (mfma) { if (stride == 1) DWM_CVB(1); else DWM_CVB(2); }
+  else if (dtype == CFP_BF16) { if (stride == 1) DW_CVB(bf16_t, 1); else DW_CVB(bf16_t, 2); }
   else { if (stride == 1) DW_CVB(float, 1); else DW_CVB(float, 2); }
+#undef DWM_CVB
+#undef DWM_LAUNCH
 #undef DW_CVB
 #undef DW_LAUNCH
   return cfp_check_launch(who);
 }
 }  // namespace
 
-void cfp_dw_debug_set(int key, int value) { if (key == 3) g_dw_force_cvb = value; else g_dw_force_R = value; }
+void cfp_dw_debug_set(int key, int value) { if (key == 3) g_dw_force_cvb = value; else if (key == 4) g_dw_force_R = value; else g_dw_valu = value; }
 
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                                   void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
@@ -443,7 +688,7 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
-  return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype)).nstrips;
+  return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype), dtype == CFP_BF16 && C % 16 == 0 && !g_dw_valu).nstrips;
 }
 
 extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,

@@ -287,8 +287,8 @@ def test_dwconv3x3_with_fused_channel_sums(case, dtype):
     got = from_nhwc(out.torch(), B, Ho, Wo)
     close(got, ref, dtype, f"dw3x3+sum {case}")
     sums = part.sum(1).cpu()
-    want = got.sum((2, 3))                      # sums are of the STORED tensor
-    assert torch.allclose(sums, want, rtol=1e-4, atol=1e-3 * float(want.abs().max())), float((sums - want).abs().max())
+    want = ref.sum((2, 3))                      # sums of the activated tensor (taken before the storage rounding)
+    assert torch.allclose(sums, want, rtol=1e-3, atol=3e-3 * float(want.abs().max())), float((sums - want).abs().max())
     part2 = torch.zeros_like(part)
     ops.dwconv3x3_sum(to_act(nhwc(x), dtype), wa, scale.to(DEV), shift.to(DEV), out, part2, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
     torch.cuda.synchronize()

@@ -8,6 +8,8 @@ from cfpnet_amd import hip, ops
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the MFMA kernel (diagnostic build path, act + 100)")
+ap.add_argument("--phases", action="store_true", help="also time the kernel with its compute phase skipped (act=99)")
 a = ap.parse_args()
 lib = hip.load()
 DEV = "cuda:0"
@@ -31,7 +33,7 @@ for (H, W, C, s) in shapes:
     xs = [ops.Act(torch.randn(B * H * W, C, device=DEV).to(torch.bfloat16), 0, C) for _ in range(NB)]
     outs = [ops.new_act(B * Ho * Wo, C, torch.bfloat16, DEV) for _ in range(NB)]
     w = torch.randn(9, C, device=DEV).to(torch.bfloat16); sc = torch.ones(C, device=DEV); sh = torch.zeros(C, device=DEV)
-    part = torch.empty(B * 64 * C, device=DEV)
+    part = torch.zeros(B * 64 * C + 6 * 65536, device=DEV)
     k = [0]
     def run():
         i = k[0] % NB; k[0] += 1
@@ -39,9 +41,28 @@ for (H, W, C, s) in shapes:
     def cp():
         i = k[0] % NB; k[0] += 1
         ops.copy_rows(xs[i], outs[i], B * Ho * Wo)
+    def run_nocompute():
+        i = k[0] % NB; k[0] += 1
+        ops.dwconv3x3_sum(xs[i], w, sc, sh, outs[i], part, B, H, W, s, pt, pl, Ho, Wo, 99)
     mb = 2.0 * (B * H * W * C + B * Ho * Wo * C) / 1e6
     t = timeit(run, a.reps); tc = timeit(cp, a.reps)
     line = f"{B}x{H}x{W}x{C} s{s}: {mb:6.1f} MB  auto {t:6.1f} us = {mb / t:5.2f} TB/s   copy_rows(out-sized) {tc:6.1f} us = {2.0 * 2 * B * Ho * Wo * C / 1e6 / tc:5.2f} TB/s"
+    if a.stamps:
+        ns = ops.dwconv3x3_strips(B, Ho, Wo, C, s, hip.BF16)
+        part.zero_()
+        torch.cuda.synchronize()
+        ops.dwconv3x3_sum(xs[0], w, sc, sh, outs[0], part, B, H, W, s, pt, pl, Ho, Wo, 100 + hip.ACT_SILU)
+        torch.cuda.synchronize()
+        dbg = part[B * ns * C: B * ns * C + 6 * 60000].reshape(-1, 6).cpu()
+        dbg = dbg[dbg[:, 5] == 1.0]
+        t0, t1 = dbg[:, 3], dbg[:, 4]
+        span = float((t1.max() - t0.min())) * 10.0      # 100 MHz ticks -> ns
+        line += (f"\n      stamps: {dbg.shape[0]} workgroups; cycles load {dbg[:,0].median():.0f} compute {dbg[:,1].median():.0f} "
+                 f"copy-out {dbg[:,2].median():.0f} (max {dbg[:,0].max():.0f}/{dbg[:,1].max():.0f}/{dbg[:,2].max():.0f}); "
+                 f"first start -> last end {span / 1e3:.1f} us; start spread {float(t0.max() - t0.min()) * 10 / 1e3:.1f} us; "
+                 f"median wg lifetime {float((t1 - t0).median()) * 10 / 1e3:.1f} us")
+    if a.phases:
+        line += f"   staging+copy-out only {timeit(run_nocompute, a.reps):6.1f} us"
     if a.sweep:
         best = (t, "auto")
         for cvb in (8, 16):
