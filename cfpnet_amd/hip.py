@@ -47,6 +47,12 @@ SIGNATURES = {
     "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_rgb_to_nhwc8": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "cfp_scalar_to_rows8": (_i, [_p, _p, _i, _i, _p]),
+    "cfp_silog_ws_bytes": (_sz, [_i, _i, _i]),
+    "cfp_silog_loss_fwd": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),
+    "cfp_silog_loss_bwd": (_i, [_p, _p, _f, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "cfp_adamw_step": (_i, [_p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _i, _p, _p]),
+    "cfp_grad_clip_ws_bytes": (_sz, []),
+    "cfp_grad_clip_factor": (_i, [_p, C.c_longlong, _f, _p, _sz, _p, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -1,0 +1,210 @@
+"""Training-step pieces that exist so far: the SILog loss
+(forward + backward HIP kernels), the OneCycle schedule, a flat-buffer AdamW and the gradient
+all-reduce plan for data-parallel training.  The backward kernels of the network itself are not
+built yet, so `Deltar.forward` still raises in training mode.
+
+torch is used for device memory, the stream and `torch.distributed` (RCCL) only.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+
+
+class SILogLoss:
+    """`/root/reference/src/loss.py:4-19`: call with (pred [B,1,Hp,Wp] f32, target [B,1,Ht,Wt] f32, mask bool|None,
+    interpolate).  `forward` returns the device scalar; `backward(grad_loss)` returns d loss / d pred."""
+
+    name = "SILog"
+
+    def __init__(self):
+        self._ws: Optional[torch.Tensor] = None
+        self._stats: Optional[torch.Tensor] = None
+        self._shape = None
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor, mask: Optional[torch.Tensor] = None, interpolate: bool = True):
+        assert pred.is_cuda and pred.dtype == torch.float32 and target.dtype == torch.float32
+        B, _, Hp, Wp = pred.shape
+        Bt, _, Ht, Wt = target.shape
+        assert B == Bt
+        pred, target = pred.contiguous(), target.contiguous()
+        m8 = None
+        if mask is not None:
+            m8 = mask.to(device=pred.device).reshape(B, 1, Ht, Wt).to(torch.uint8).contiguous()
+        need = int(hip.load().cfp_silog_ws_bytes(B, Ht, Wt))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=pred.device)
+        self._stats = torch.empty(4, dtype=torch.float32, device=pred.device)
+        hip.call("cfp_silog_loss_fwd", pred.data_ptr(), Hp, Wp, target.data_ptr(), hip.ptr(m8), Ht, Wt, B, int(interpolate),
+                 self._ws.data_ptr(), self._ws.numel(), self._stats.data_ptr(), hip.current_stream())
+        self._shape = (B, Hp, Wp, Ht, Wt, bool(interpolate))
+        return self._stats[0]
+
+    __call__ = forward
+
+    def backward(self, grad_loss: float = 1.0) -> torch.Tensor:
+        B, Hp, Wp, Ht, Wt, interp = self._shape
+        grad = torch.empty(B, 1, Hp, Wp, dtype=torch.float32, device=self._stats.device)
+        hip.call("cfp_silog_loss_bwd", self._ws.data_ptr(), self._stats.data_ptr(), float(grad_loss), Hp, Wp, Ht, Wt, B, int(interp),
+                 grad.data_ptr(), hip.current_stream())
+        return grad
+
+
+class OneCycle:
+    """torch.optim.lr_scheduler.OneCycleLR as train.py:90-94 configures it: cosine annealing, pct_start 0.3,
+    two phases, momentum (AdamW beta1) cycled inversely between base_momentum and max_momentum.  Note the reference
+    passes the scalar `lr` as max_lr, so BOTH parameter groups follow the same schedule (the lr/10 of the encoder
+    group in train.py:79 is overwritten by the scheduler's initial_lr = max_lr / div_factor)."""
+
+    def __init__(self, max_lr: float, total_steps: int, div_factor: float = 25.0, final_div_factor: float = 100.0,
+                 pct_start: float = 0.3, base_momentum: float = 0.85, max_momentum: float = 0.95):
+        assert total_steps > 0
+        self.total_steps = total_steps
+        self.max_lr = max_lr
+        self.initial_lr = max_lr / div_factor
+        self.min_lr = self.initial_lr / final_div_factor
+        self.base_m, self.max_m = base_momentum, max_momentum
+        self.up_end = float(pct_start * total_steps) - 1.0
+        self.down_end = float(total_steps) - 1.0
+
+    @staticmethod
+    def _cos(start: float, end: float, pct: float) -> float:
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    def at(self, step_num: int) -> Tuple[float, float]:
+        """(lr, beta1) in effect for optimizer step number `step_num` (0-based: the values OneCycleLR has set after
+        `step_num` calls of scheduler.step())."""
+        if step_num > self.total_steps:
+            raise ValueError(f"step {step_num} beyond total_steps {self.total_steps}")
+        if step_num <= self.up_end:
+            pct = step_num / self.up_end if self.up_end > 0 else 1.0
+            return self._cos(self.initial_lr, self.max_lr, pct), self._cos(self.max_m, self.base_m, pct)
+        pct = (step_num - self.up_end) / (self.down_end - self.up_end)
+        return self._cos(self.max_lr, self.min_lr, pct), self._cos(self.base_m, self.max_m, pct)
+
+
+@dataclass
+class Segment:
+    name: str
+    start: int
+    numel: int
+    shape: Tuple[int, ...]
+    group: int          # 0 = "1x" group (encoder [+ hist encoder]), 1 = "10x" group, 2 = dead (never gets a gradient)
+
+
+class FlatParams:
+    """All parameters in ONE flat f32 device buffer, ordered [group 0 | group 1 | dead], every tensor start aligned to
+    4 elements, so that (i) AdamW is one 16-byte-vector sweep per group, (ii) the data-parallel gradient all-reduce is
+    a few large RCCL calls over contiguous ranges, and (iii) the 48 tensors the forward never touches
+    (transformer.py:183-194, convnext.py:38) sit in a tail that is neither reduced nor stepped (their .grad is None in
+    the reference, so torch.optim.AdamW skips them too)."""
+
+    def __init__(self, named_shapes: Sequence[Tuple[str, Tuple[int, ...]]], group_of, device="cpu"):
+        self.segments: List[Segment] = []
+        off = 0
+        self.group_range: Dict[int, Tuple[int, int]] = {}
+        for grp in (0, 1, 2):
+            g0 = off
+            for name, shape in named_shapes:
+                if group_of(name) != grp:
+                    continue
+                n = int(math.prod(shape)) if len(shape) else 1
+                self.segments.append(Segment(name, off, n, tuple(shape), grp))
+                off += (n + 3) // 4 * 4
+            self.group_range[grp] = (g0, off)
+        self.total = off
+        self.live = self.group_range[1][1]          # [0, live) gets gradients
+        self.device = torch.device(device)
+        self.param = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self._by_name = {s.name: s for s in self.segments}
+
+    def view(self, name: str, which: str = "param") -> torch.Tensor:
+        s = self._by_name[name]
+        return getattr(self, which)[s.start:s.start + s.numel].view(s.shape)
+
+    def load(self, state_dict: Dict[str, torch.Tensor]):
+        for s in self.segments:
+            self.view(s.name).copy_(state_dict[s.name].to(torch.float32))
+
+    def buckets(self, bucket_elems: int) -> List[Tuple[int, int]]:
+        """Contiguous [start, end) ranges covering the live gradients, walked from the END of the live range to its
+        beginning: the flat order is encoder -> ... -> head, backward produces gradients head first, so the first
+        bucket can be reduced while the encoder's backward is still running."""
+        out, end = [], self.live
+        while end > 0:
+            start = max(0, end - bucket_elems)
+            out.append((start, end))
+            end = start
+        return out
+
+
+def allreduce_gradients(flat: FlatParams, dist, world: int, bucket_elems: int = 8 * 1024 * 1024, async_op: bool = False):
+    """Average the live gradients over the data-parallel ranks: one all-reduce (RCCL over xGMI with the "nccl"
+    backend; gloo in the CPU tests) per bucket of the flat buffer, no per-tensor calls, dead tail excluded.
+    21.4 M live f32 gradients = 86 MB = 3 buckets of 32 MB."""
+    if dist is None or world <= 1:
+        return []
+    handles = []
+    for (a, b) in flat.buckets(bucket_elems):
+        chunk = flat.grad[a:b]
+        h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=async_op)
+        handles.append((h, chunk))
+    if not async_op:
+        for _, chunk in handles:
+            chunk.div_(world)
+    return handles
+
+
+class FlatAdamW:
+    """torch.optim.AdamW(params=[1x group, 10x group], weight_decay=wd) on a FlatParams buffer: per step one
+    `cfp_adamw_step` launch per group (+ optionally the clip-factor kernels), lr / beta1 from OneCycle."""
+
+    def __init__(self, flat: FlatParams, schedule: OneCycle, weight_decay: float = 0.1, beta2: float = 0.999, eps: float = 1e-8,
+                 clip_grad_norm: Optional[float] = None):
+        assert flat.param.is_cuda, "FlatAdamW runs the HIP kernel: parameters must be on the GPU"
+        self.flat, self.sched = flat, schedule
+        self.wd, self.beta2, self.eps, self.clip = weight_decay, beta2, eps, clip_grad_norm
+        self.m = torch.zeros_like(flat.param)
+        self.v = torch.zeros_like(flat.param)
+        self.step_count = 0
+        self._clip_ws = torch.empty(int(hip.load().cfp_grad_clip_ws_bytes()) // 8, dtype=torch.float64, device=flat.param.device)
+        self._clip_out = torch.ones(2, dtype=torch.float32, device=flat.param.device)
+
+    def step(self):
+        lr, beta1 = self.sched.at(self.step_count)
+        self.step_count += 1
+        f = self.flat
+        scale_ptr = 0
+        if self.clip is not None:
+            hip.call("cfp_grad_clip_factor", f.grad.data_ptr(), f.live, float(self.clip), self._clip_ws.data_ptr(),
+                     self._clip_ws.numel() * 8, self._clip_out.data_ptr(), hip.current_stream())
+            scale_ptr = self._clip_out.data_ptr()
+        for grp in (0, 1):
+            a, b = f.group_range[grp]
+            if b <= a:
+                continue
+            es = 4
+            hip.call("cfp_adamw_step", f.param.data_ptr() + a * es, f.grad.data_ptr() + a * es, self.m.data_ptr() + a * es,
+                     self.v.data_ptr() + a * es, b - a, float(lr), float(beta1), float(self.beta2), float(self.eps), float(self.wd),
+                     self.step_count, scale_ptr, hip.current_stream())
+        return lr, beta1
+
+
+def lr_group_of(hist_encoder_10x: bool):
+    """Parameter-group rule of deltar.py:68-82 plus the dead-tensor rule of SURVEY 2.2."""
+    from . import spec
+
+    def group(name: str) -> int:
+        if spec.is_dead_param(name):
+            return 2
+        top = name.split(".")[0]
+        if top == "img_encoder" or (top == "hist_encoder" and not hist_encoder_10x):
+            return 0
+        return 1
+    return group

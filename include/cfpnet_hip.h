@@ -237,6 +237,32 @@ int cfp_bin_softmax(const void* logits, int ld, const float* centers, void* prob
 int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
                        void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream);
 
+/* ---- training step pieces -------------------------------------------------- */
+
+/* SILogLoss.forward (loss.py:9-19), f32: pred [B,1,Hp,Wp] is bilinearly resized (align_corners=True) to the
+ * target size when `interpolate`, g = log p - log t over the pixels with mask != 0 (mask may be NULL = all),
+ * loss = 10 * sqrt(var_unbiased(g) + 0.15 * mean(g)^2).  stats[4] (device, f32) = {loss, mean(g), n, Dg}.
+ * ws (cfp_silog_ws_bytes) keeps g and 1/p for the backward pass.  Reductions are f64 partial sums combined
+ * in a fixed order (deterministic). */
+size_t cfp_silog_ws_bytes(int B, int Ht, int Wt);
+int cfp_silog_loss_fwd(const float* pred, int Hp, int Wp, const float* target, const unsigned char* mask, int Ht, int Wt,
+                       int B, int interpolate, void* ws, size_t ws_bytes, float* stats, cfp_stream_t stream);
+/* d loss / d pred (same ws / stats as the forward call), scaled by grad_loss; a gather, no atomics. */
+int cfp_silog_loss_bwd(const void* ws, const float* stats, float grad_loss, int Hp, int Wp, int Ht, int Wt, int B,
+                       int interpolate, float* grad_pred, cfp_stream_t stream);
+
+/* torch.optim.AdamW step (train.py:82,131) over one contiguous segment of flat f32 buffers: `step` is the
+ * 1-based step count of the group, beta1 may change per step (OneCycleLR cycles it, train.py:90-94).
+ * grad_scale (device, may be NULL) multiplies the gradient first: the clip factor of cfp_grad_clip_factor. */
+int cfp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                   cfp_stream_t stream);
+/* nn.utils.clip_grad_norm_ (train.py:130) without a host sync: out[0] = min(1, max_norm / (||grad||_2 + 1e-6)),
+ * out[1] = ||grad||_2, both on the device. */
+size_t cfp_grad_clip_ws_bytes(void);
+int cfp_grad_clip_factor(const float* grad, long long n, float max_norm, void* ws, size_t ws_bytes, float* out,
+                         cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
