@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the HIP graph")
+    ap.add_argument("--lanes", type=int, default=2, help="sub-batches run concurrently on their own HIP streams inside the graph")
     ap.add_argument("--no-prob", action="store_true", help="skip the [B,256,H/2,W/2] prob output (not the reference contract)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
@@ -189,9 +190,9 @@ def main():
     return_prob = not a.no_prob
 
     if a.eager:
-        step = lambda: engine.forward(inputs, return_prob=return_prob)
+        step = lambda: engine.forward_lanes(inputs, a.lanes, return_prob=return_prob)
     else:
-        engine.capture(inputs, return_prob=return_prob)
+        engine.capture(inputs, return_prob=return_prob, lanes=a.lanes)
         step = lambda: engine.replay()
     for _ in range(a.warmup):
         step()
@@ -217,7 +218,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward incl. prob output"
                                    if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward, prob output skipped",
-                       "layers": "hist2image combine1 image x2 (CFPNet)", "launch": "eager" if a.eager else "hipGraph replay",
+                       "layers": "hist2image combine1 image x2 (CFPNet)", "launch": ("eager" if a.eager else "hipGraph replay") + (f", {a.lanes} concurrent batch lanes" if a.lanes > 1 else ""),
                        "parallelism": "replicas only" if world > 1 else "single GPU"},
         }
         if not a.no_kernel_times:

@@ -106,13 +106,23 @@ __global__ __launch_bounds__(64) void kv_reduce_kernel(KvP p) {
 
 __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restrict__ ws, float* __restrict__ kv,
                                                           float* __restrict__ ksum, int nsplit, int d, long long items) {
-  // one thread per element of [group*head][d*d + d]
+  // one thread per element of [group*head][d*d + d]; the split partials are summed in split order, eight
+  // independent loads in flight at a time (the serial chain of up to 64 dependent loads was the whole kernel)
   const int per = d * d + d;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items * per; i += (long long)gridDim.x * 256) {
     long long gh = i / per;
     int e = (int)(i % per);
+    const float* base = ws + gh * nsplit * per + e;
     float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += ws[(gh * nsplit + j) * per + e];
+    int j = 0;
+    for (; j + 7 < nsplit; j += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = base[(long long)(j + u) * per];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; j < nsplit; ++j) s += base[(long long)j * per];
     if (e < d * d) kv[gh * d * d + e] = s; else ksum[gh * d + (e - d * d)] = s;
   }
 }

@@ -202,6 +202,129 @@ __global__ __launch_bounds__(256) void se_fold_kernel(const T* __restrict__ w, T
   }
 }
 
+// se_gate_fold: the whole squeeze-excite tail of an inverted-residual block in ONE launch, written for latency
+// (every load batch of a phase is issued before its first use; 16 waves share the serial phases):
+//   phase 0  mean[c]   = sum_s partial[b][s][c] / HW                                (all C channels, LDS)
+//   phase 1  hidden[r] = silu(mean . w_reduce[r] + b_reduce[r])       wave w takes r = w, w+16, ...   (LDS)
+//   phase 2  gate[c]   = sigmoid(hidden . w_expand_t[:, c] + b_expand[c])   for the 256 channels of this slab
+//   phase 3  wout[b][n][c] = w[n][c] * gate[c]                         for every project row n, this slab
+// grid (ceil(C/256), B): every workgroup recomputes mean/hidden of its image (R x C MACs: cheaper than a
+// kernel boundary).  Replaces cfp_se_hidden + cfp_se_fold on the bf16/f32 hot path.
+template <typename T>
+__global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
+                                                            const float* __restrict__ wr, const float* __restrict__ br,
+                                                            const float* __restrict__ we_t, const float* __restrict__ be,
+                                                            const T* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R) {
+  constexpr int VE = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* mean = sm;                         // [C]
+  float* hid = sm + C;                      // [R] (padded to 64)
+  float* gpart = hid + ((R + 63) & ~63);    // [4][256]
+  float* gate = gpart + 4 * 256;            // [256]
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C4 = C >> 2;
+  // ---- phase 0
+  for (int c4 = tid; c4 < C4; c4 += 1024) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int j = 0;
+    for (; j + 3 < nsplit; j += 4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j) * C + c4 * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 1) * C + c4 * 4);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 2) * C + c4 * 4);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j + 3) * C + c4 * 4);
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; j < nsplit; ++j) s += *reinterpret_cast<const f32x4*>(partial + ((long long)b * nsplit + j) * C + c4 * 4);
+    *reinterpret_cast<f32x4*>(mean + c4 * 4) = s * inv_hw;
+  }
+  __syncthreads();
+  // ---- phase 1: 16 waves, up to 4 hidden units each, all weight loads of a wave in flight together
+  {
+    constexpr int MAXL = 8;                  // C <= 8 * 256 floats per lane-stride pass; R <= 64 = 16 waves x 4
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += 2) {      // two hidden units per wave at a time (64 VGPRs of weights in flight)
+      f32x4 wv[2][MAXL];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = wave + 16 * (k0 + k);
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+          const int c4 = lane + 64 * l;
+          wv[k][l] = (r < R && c4 < C4) ? *reinterpret_cast<const f32x4*>(wr + (long long)r * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = wave + 16 * (k0 + k);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+          const int c4 = lane + 64 * l;
+          if (c4 < C4) acc += wv[k][l] * *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        }
+        const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (lane == 0 && r < R) hid[r] = act_c<CFP_ACT_SILU>(s + br[r]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: 256 channels x 4 quarter-ranges of r
+  {
+    const int cl = tid & 255, qr = tid >> 8;
+    const int c = slab * 256 + cl;
+    const int rq = (R + 3) >> 2;
+    const int r0 = qr * rq, r1 = min(R, r0 + rq);
+    float s = 0.f;
+    if (c < C) {
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t[u] = (r0 + u < r1) ? we_t[(long long)(r0 + u) * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s = fmaf((r0 + u < r1) ? hid[r0 + u] : 0.f, t[u], s);
+      for (int r = r0 + 16; r < r1; ++r) s = fmaf(hid[r], we_t[(long long)r * C + c], s);
+    }
+    gpart[qr * 256 + cl] = s;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int c = slab * 256 + tid;
+    const float z = (gpart[tid] + gpart[256 + tid]) + (gpart[512 + tid] + gpart[768 + tid]) + (c < C ? be[c] : 0.f);
+    gate[tid] = act_c<CFP_ACT_SIGMOID>(z);
+  }
+  __syncthreads();
+  // ---- phase 3
+  {
+    constexpr int VPS = 256 / VE;           // vectors per slab row
+    const int vl = tid % VPS, rl = tid / VPS, nrl = 1024 / VPS;
+    const int cv = slab * VPS + vl;
+    if (cv * VE < C) {
+      float g[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = gate[vl * VE + e];
+      int n = rl;
+      for (; n + 3 * nrl < Cout; n += 4 * nrl) {
+        float v[4][VE];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Vec<T>::load(w + (long long)(n + k * nrl) * C + cv * VE, v[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[k][e] *= g[e];
+          Vec<T>::store(wout + ((long long)b * Cout + n + k * nrl) * C + cv * VE, v[k]);
+        }
+      }
+      for (; n < Cout; n += nrl) {
+        float v[VE];
+        Vec<T>::load(w + (long long)n * C + cv * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] *= g[e];
+        Vec<T>::store(wout + ((long long)b * Cout + n) * C + cv * VE, v);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int ld, const float* __restrict__ gate,
                                                              int HW, int C, long long total) {
@@ -441,6 +564,27 @@ extern "C" int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden,
     hipLaunchKernelGGL(se_fold_kernel<float>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const float*)w_proj,
                        (float*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
   return cfp_check_launch("cfp_se_fold");
+}
+
+extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                                const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out, int B, int Cout,
+                                int C, int R, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_se_gate_fold");
+  CFP_REQUIRE(partial && w_reduce && b_reduce && w_expand_t && b_expand && w_proj && w_out, CFP_EINVAL, "cfp_se_gate_fold: null pointer");
+  CFP_REQUIRE(aligned16(partial) && aligned16(w_reduce) && aligned16(w_proj) && aligned16(w_out), CFP_EINVAL,
+              "cfp_se_gate_fold: pointers must be 16-byte aligned");
+  CFP_REQUIRE(B > 0 && B <= 65535 && nsplit > 0 && Cout > 0 && C > 0 && C % 8 == 0 && C <= 2048 && R > 0 && R <= 64, CFP_ESHAPE,
+              "cfp_se_gate_fold: need C % 8 == 0, C <= 2048, R <= 64");
+  const size_t lds = (size_t)(C + ((R + 63) & ~63) + 5 * 256) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(cdiv(C, 256), B);
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(se_gate_fold_kernel<bf16_t>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
+                       b_expand, (const bf16_t*)w_proj, (bf16_t*)w_out, Cout, C, R);
+  else
+    hipLaunchKernelGGL(se_gate_fold_kernel<float>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
+                       b_expand, (const float*)w_proj, (float*)w_out, Cout, C, R);
+  return cfp_check_launch("cfp_se_gate_fold");
 }
 
 extern "C" int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand, int B, int HW,

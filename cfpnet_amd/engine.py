@@ -17,6 +17,7 @@ torch is used for device memory and the current stream only.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -57,6 +58,12 @@ class Engine:
         # independent branches (ToF histogram encoder beside the RGB encoder, bin-width regressor beside
         # the depth head's 3x3 conv) run on a second HIP stream; fork/join are events, also inside a graph
         self._side = torch.cuda.Stream(device=self.device)
+        # batch lanes: the batch can be cut into `lanes` sub-batches whose forwards run concurrently on their own
+        # streams inside one graph (see forward_lanes); per-lane scratch, streams and split-K workspaces
+        self._lane = 0
+        self.use_side_stream = os.environ.get("CFP_NO_SIDE_STREAM", "0") != "1"
+        self._lane_streams: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+        self._lane_ws: Dict[int, torch.Tensor] = {}
         self.load_state_dict(state_dict)
 
     # ------------------------------------------------------------------------------ packing
@@ -225,11 +232,12 @@ class Engine:
         need = ops.conv2d_ws_bytes(M, Cout, K, ops.DT[self.dtype])
         if need == 0:
             return None
-        if self._splitk_ws is None or self._splitk_ws.numel() * 4 < need:
+        ws = self._lane_ws.get(self._lane)
+        if ws is None or ws.numel() * 4 < need:
             if self._capturing:
                 raise RuntimeError("split-K workspace must be sized by a warm-up forward before graph capture")
-            self._splitk_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
-        return self._splitk_ws
+            ws = self._lane_ws[self._lane] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return ws
 
     def _encoder(self, plan, rgb: torch.Tensor, B, H, W, taps):
         """encoder.py:71-79 over timm tf_efficientnetv2_b3 blocks; returns the five tap Acts."""
@@ -265,11 +273,11 @@ class Engine:
                 part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
                 ops.dwconv3x3_sum(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w, b.stride,
                                   pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
-                hid = self._f32(plan, f"enc{bi}.hid", B * b.se_rd)
-                ops.se_hidden(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], hid, B, b.mid, b.se_rd)
-                # the SE gate multiplies the project conv's input channels: fold it into per-image weights
+                # SE tail (mean -> FC -> SiLU -> FC -> sigmoid) in one launch; the gate multiplies the project conv's
+                # input channels, so it is folded into per-image project weights instead of a pass over mid2
                 wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
-                ops.se_fold(self.P[q + ".pwl.w"], wb, hid, self.P[q + ".se.we_t"], self.P[q + ".se.be"], B, b.cout, b.mid, b.se_rd)
+                ops.se_gate_fold(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], self.P[q + ".se.we_t"],
+                                 self.P[q + ".se.be"], self.P[q + ".pwl.w"], wb, B, b.cout, b.mid, b.se_rd)
                 ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
                            res, None, per_image_weights=True)
             x, h, w = out, ho, wo
@@ -423,57 +431,146 @@ class Engine:
     def _nchw(self, a: Act, B, H, W) -> torch.Tensor:
         return a.torch().float().cpu().reshape(B, H, W, a.C).permute(0, 3, 1, 2).contiguous()
 
-    # ------------------------------------------------------------------------------ HIP graph
-    def capture(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None):
-        """Record the whole forward for this input shape into one HIP graph.  The launch list is
-        static (all data-dependent geometry is host-side integers), so replaying it costs one
-        graph launch instead of ~450 kernel launches."""
+    # ------------------------------------------------------------------------------ batch lanes
+    @torch.no_grad()
+    def forward_lanes(self, input_data: dict, lanes: int, *, return_prob: bool = True, pos_offsets: Optional[dict] = None):
+        """The same forward with the batch cut into `lanes` contiguous sub-batches that run CONCURRENTLY, each on its own
+        HIP stream with its own scratch buffers, writing into slices of one set of outputs.  At batch 8 a forward is ~280
+        dependent kernels that each leave most of the 256 CUs idle while they wait on their own loads (a batch-1 forward
+        takes 3.1 ms, a batch-8 one 5.2 ms): independent sample groups fill those gaps.  The zone geometry stays the
+        batch-reduced geometry of the WHOLE batch (fusion.py:75-84), so results are those of the unsplit forward."""
+        rgb = input_data["rgb"]
+        B = rgb.shape[0]
+        lanes = max(1, min(lanes, B))
+        if lanes == 1:
+            return self.forward(input_data, return_prob=return_prob, pos_offsets=pos_offsets)
         dev = self.device
         add = input_data["additional"]
+        H, W = rgb.shape[-2:]
+        edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, 1, H // 2, W // 2, dtype=torch.float32, device=dev)
+        prob = torch.empty(B, self.n_bins, H // 2, W // 2, dtype=self.dtype, device=dev) if return_prob else None
+        main = torch.cuda.current_stream(dev)
+        bounds = [B * i // lanes for i in range(lanes + 1)]
+        for i in range(lanes):
+            if i not in self._lane_streams and i > 0:
+                self._lane_streams[i] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        rgb_d = rgb.to(device=dev, dtype=torch.float32).contiguous()
+        hist_d = add["hist_data"].to(device=dev, dtype=torch.float32).contiguous()
+        mask_d = add["mask"].to(device=dev).to(torch.uint8).contiguous()   # converted once: lanes must not allocate while capturing
+        for i in range(lanes):
+            b0, b1 = bounds[i], bounds[i + 1]
+            sub = {"rgb": rgb_d[b0:b1], "additional": {"hist_data": hist_d[b0:b1], "mask": mask_d[b0:b1],
+                                                       "rect_data": add.get("rect_data"), "patch_info": add["patch_info"]}}
+            outs = (edges[b0:b1], pred[b0:b1], prob[b0:b1] if prob is not None else None)
+            if i == 0:
+                self.forward(sub, return_prob=return_prob, pos_offsets=pos_offsets, lane=0, out=outs)
+            else:
+                st = self._lane_streams[i][0]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self.forward(sub, return_prob=return_prob, pos_offsets=pos_offsets, lane=i, out=outs)
+        for i in range(1, lanes):
+            main.wait_stream(self._lane_streams[i][0])
+        self._lane = 0
+        return edges, pred, prob
+
+    # ------------------------------------------------------------------------------ HIP graph
+    def capture(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None, lanes: int = 1):
+        """Record the whole forward for this input shape into HIP graphs.  The launch list is static (all
+        data-dependent geometry is host-side integers), so replaying costs one graph launch instead of ~280 kernel
+        launches.  With `lanes` > 1 every batch lane gets its OWN graph, captured on and replayed from its own stream
+        (one multi-stream capture of several 280-node branches crashes hipStreamEndCapture on ROCm 7.2); the lane
+        graphs run concurrently and write into slices of one set of output tensors."""
+        dev = self.device
+        add = input_data["additional"]
+        B = input_data["rgb"].shape[0]
+        H, W = input_data["rgb"].shape[-2:]
+        lanes = max(1, min(lanes, B))
         static = {"rgb": input_data["rgb"].to(device=dev, dtype=torch.float32).contiguous().clone(),
                   "additional": {"hist_data": add["hist_data"].to(device=dev, dtype=torch.float32).contiguous().clone(),
-                                 "mask": add["mask"].to(device=dev).clone(),
+                                 "mask": add["mask"].to(device=dev).to(torch.uint8).contiguous().clone(),
                                  "rect_data": add.get("rect_data"), "patch_info": add["patch_info"]}}
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):      # warm-up: allocates every buffer of the plan, sets kernel attributes
-                self.forward(static, return_prob=return_prob, pos_offsets=pos_offsets)
-        torch.cuda.current_stream(dev).wait_stream(side)
+        edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, 1, H // 2, W // 2, dtype=torch.float32, device=dev)
+        prob = torch.empty(B, self.n_bins, H // 2, W // 2, dtype=self.dtype, device=dev) if return_prob else None
+        bounds = [B * i // lanes for i in range(lanes + 1)]
+        subs, outs = [], []
+        for i in range(lanes):
+            b0, b1 = bounds[i], bounds[i + 1]
+            sa = static["additional"]
+            subs.append({"rgb": static["rgb"][b0:b1], "additional": {"hist_data": sa["hist_data"][b0:b1], "mask": sa["mask"][b0:b1],
+                                                                     "rect_data": sa["rect_data"], "patch_info": sa["patch_info"]}})
+            outs.append((edges[b0:b1], pred[b0:b1], prob[b0:b1] if prob is not None else None))
+            if i not in self._lane_streams:
+                self._lane_streams[i] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        graphs = []
+        cur = torch.cuda.current_stream(dev)
+        for i in range(lanes):
+            st = self._lane_streams[i][0]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                for _ in range(2):      # warm-up: allocates every buffer of the lane's plan, sets kernel attributes
+                    self.forward(subs[i], return_prob=return_prob, pos_offsets=pos_offsets, lane=i, out=outs[i])
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g, stream=st):
+                    self.forward(subs[i], return_prob=return_prob, pos_offsets=pos_offsets, lane=i, out=outs[i])
+            finally:
+                self._capturing = False
+            graphs.append(g)
         torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        self._capturing = True
-        try:
-            with torch.cuda.graph(g):
-                out = self.forward(static, return_prob=return_prob, pos_offsets=pos_offsets)
-        finally:
-            self._capturing = False
-        self._graph = (g, static, out)
-        return out
+        self._lane = 0
+        self._graph = (graphs, static, (edges, pred, prob))
+        return edges, pred, prob
 
     def replay(self, input_data: Optional[dict] = None):
         """Re-run the captured forward; `input_data` (same shapes) is copied into the static inputs."""
         if self._graph is None:
             raise RuntimeError("Engine.replay() before capture()")
-        g, static, out = self._graph
+        graphs, static, out = self._graph
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
         if input_data is not None:
             static["rgb"].copy_(input_data["rgb"], non_blocking=True)
             static["additional"]["hist_data"].copy_(input_data["additional"]["hist_data"], non_blocking=True)
-            static["additional"]["mask"].copy_(input_data["additional"]["mask"], non_blocking=True)
-        g.replay()
+            static["additional"]["mask"].copy_(input_data["additional"]["mask"].to(torch.uint8), non_blocking=True)
+        if len(graphs) == 1:
+            st = self._lane_streams[0][0]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                graphs[0].replay()
+            cur.wait_stream(st)
+            return out
+        for i, g in enumerate(graphs):
+            st = self._lane_streams[i][0]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                g.replay()
+        for i in range(len(graphs)):
+            cur.wait_stream(self._lane_streams[i][0])
         return out
 
     # ------------------------------------------------------------------------------ forward
     def _plan(self, B, H, W) -> dict:
-        key = (B, H, W)
+        key = (B, H, W, self._lane)
         if key not in self._plans:
             self._plans[key] = {"bufs": {}}
         return self._plans[key]
 
     @torch.no_grad()
     def forward(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None,
-                taps: Optional[dict] = None, img_features: Optional[Sequence[torch.Tensor]] = None):
-        """Eval-mode forward.  Returns (bin_edges [B,n+1] f32, pred [B,1,H/2,W/2] f32, prob [B,n,H/2,W/2] | None)."""
+                taps: Optional[dict] = None, img_features: Optional[Sequence[torch.Tensor]] = None, lane: int = 0,
+                out: Optional[tuple] = None):
+        """Eval-mode forward.  Returns (bin_edges [B,n+1] f32, pred [B,1,H/2,W/2] f32, prob [B,n,H/2,W/2] | None).
+        `lane` selects an independent set of scratch buffers / side stream (forward_lanes); `out` = preallocated
+        (edges, pred, prob) views to write into."""
+        self._lane = lane
+        side = self._lane_streams[lane][1] if lane in self._lane_streams else self._side
+        if not self.use_side_stream:
+            side = torch.cuda.current_stream(self.device)
         rgb = input_data["rgb"]
         add = input_data["additional"]
         B, _, H, W = rgb.shape
@@ -497,8 +594,8 @@ class Engine:
         hist = add["hist_data"].to(device=dev, dtype=torch.float32).contiguous()
         zone_valid = add["mask"].to(device=dev).to(torch.uint8).contiguous()
         Z, N = hist.shape[1], hist.shape[2]
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):          # ToF branch: 10 tiny launches, hidden under the RGB encoder
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                # ToF branch: 10 tiny launches, hidden under the RGB encoder
             hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
         if img_features is not None:      # test hook: bypass the RGB encoder with given NCHW features
             for f, dst in zip(img_features, plan["tap_dst"]):
@@ -523,7 +620,7 @@ class Engine:
             self._cv(f"decoder.up{i}.b", t1, t2, B, hd, wd, 3, act=hip.ACT_LRELU)
             return t2
 
-        main.wait_stream(self._side)                  # join: the decoder consumes the ToF embeddings
+        main.wait_stream(side)                        # join: the decoder consumes the ToF embeddings
         xd4 = self._act(plan, "xd4", B * hs[4] * wsz[4], c[0])
         self._cv("decoder.conv4", b4, xd4, B, hs[4], wsz[4], 1)
         x = xd4
@@ -549,19 +646,22 @@ class Engine:
         ram = self._act(plan, "ram", Mh, 128)
         ns = max(1, min(256, HWh // 256))
         part = self._f32(plan, "head.sum", B * ns * 128)
-        edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
+        edges = out[0] if out is not None else torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
         centers = self._f32(plan, "head.centers", B * self.n_bins)
         h = "depth_head"
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):          # bin-width regressor branch beside the head's 3x3 conv
+        side.wait_stream(main)
+        with torch.cuda.stream(side):                # bin-width regressor branch beside the head's 3x3 conv
             ops.channel_sum(unet, part, B, HWh, ns)
             ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
                               self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
                               edges, centers, B, 128, 256, self.n_bins)
         self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
-        main.wait_stream(self._side)
-        pred = torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
-        prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
+        main.wait_stream(side)
+        pred = out[1] if out is not None else torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
+        if out is not None:
+            prob = out[2] if return_prob else None
+        else:
+            prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
         if self.dtype == torch.bfloat16 and self.n_bins == 256 and HWh % 8 == 0:
             # 1x1 conv + softmax + expectation in one kernel: the logits never reach HBM
             ops.bin_head_fused(ram, self.P["conv_out.w"], self.P["conv_out.t"], centers, prob, pred, B, HWh)

@@ -32,6 +32,7 @@ SIGNATURES = {
     "cfp_dwconv3x3_strips": (_i, [_i] * 6),
     "cfp_dwconv3x3_sum_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p] + [_i] * 11 + [_p]),
     "cfp_se_fold": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_se_gate_fold": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_hidden": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _p]),

@@ -131,6 +131,13 @@ def se_fold(w_proj: torch.Tensor, w_out: torch.Tensor, hidden, we_t, be, B, Cout
              B, Cout, C, R, DT[w_proj.dtype], _s())
 
 
+def se_gate_fold(partial, nsplit, inv_hw, wr, br, we_t, be, w_proj: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R):
+    assert w_proj.shape == (Cout, C) and w_out.shape == (B, Cout, C) and w_proj.dtype == w_out.dtype
+    assert we_t.shape == (R, C) and wr.shape == (R, C) and partial.numel() >= B * nsplit * C
+    hip.call("cfp_se_gate_fold", partial.data_ptr(), nsplit, float(inv_hw), wr.data_ptr(), br.data_ptr(), we_t.data_ptr(), be.data_ptr(),
+             w_proj.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_proj.dtype], _s())
+
+
 def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
     hip.call("cfp_dwconv_large_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
              B, H, W, x.C, k, act, x.dt, _s())

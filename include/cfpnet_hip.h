@@ -141,6 +141,13 @@ int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, 
 int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden, const float* w_expand_t, const float* b_expand,
                 int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
+/* cfp_se_hidden + cfp_se_fold in one launch (mean -> FC -> SiLU -> FC -> sigmoid -> per-image project weights),
+ * structured for latency: this is what the engine calls between the depthwise conv and the project conv of every
+ * inverted-residual block.  Same arguments as the two calls it replaces; C <= 2048, R <= 64. */
+int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
+                     const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out,
+                     int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
+
 /* x[b, hw, c] *= gate[b, c] in place. */
 int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream);
 

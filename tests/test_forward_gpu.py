@@ -126,3 +126,23 @@ def test_deltar_module_boundary():
     ones = [p for p in model.get_1x_lr_params()]
     tens = [p for p in model.get_10x_lr_params()]
     assert len(ones) + len(tens) == len(list(model.parameters()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_batch_lanes_match_single_stream(dtype, tol):
+    """forward_lanes (sub-batches on concurrent streams, whole-batch zone geometry) == forward, eager and captured."""
+    layers, sd, inp = _full_case(4, 256, 320, 3, 64, 21, 0.25)
+    eng = Engine(sd, layer_names=layers, dtype=dtype)
+    dinp = synthetic.to_device(inp, "cuda:0")
+    e0, p0, pr0 = eng.forward(dinp)
+    torch.cuda.synchronize()
+    for lanes in (2, 4):
+        e1, p1, pr1 = eng.forward_lanes(dinp, lanes)
+        torch.cuda.synchronize()
+        assert rel_l1(p1.cpu().numpy(), p0.cpu().numpy()) < tol, lanes
+        assert np.abs(e1.cpu().numpy() - e0.cpu().numpy()).max() < 1e-4 + tol
+        assert rel_l1(pr1.float().cpu().numpy(), pr0.float().cpu().numpy()) < 5 * tol + 1e-4
+    eng.capture(dinp, lanes=2)
+    e2, p2, pr2 = eng.replay()
+    torch.cuda.synchronize()
+    assert rel_l1(p2.cpu().numpy(), p0.cpu().numpy()) < tol

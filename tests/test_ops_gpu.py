@@ -312,8 +312,13 @@ def test_se_fold_equals_gated_activation(dtype):
     ops.se_hidden(part, 1, 1.0 / HW, wr.to(DEV), br.to(DEV), hidden, B, C, R)
     wb = torch.empty(B, Cout, C, dtype=dtype, device=DEV)
     ops.se_fold(wp.to(dtype).to(DEV), wb, hidden, we.t().contiguous().to(DEV), be.to(DEV), B, Cout, C, R)
+    wb2 = torch.empty_like(wb)
+    ops.se_gate_fold(part, 1, 1.0 / HW, wr.to(DEV), br.to(DEV), we.t().contiguous().to(DEV), be.to(DEV), wp.to(dtype).to(DEV), wb2,
+                     B, Cout, C, R)
+    torch.cuda.synchronize()
+    assert float((wb2.float() - wb.float()).abs().max()) <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-5) * float(wb.float().abs().max())
     out = ops.new_act(B * HW, Cout, dtype, DEV)
-    ops.conv2d(to_act(x.reshape(B * HW, C), dtype), wb, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None,
+    ops.conv2d(to_act(x.reshape(B * HW, C), dtype), wb2, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None,
                per_image_weights=True)
     torch.cuda.synchronize()
     close(out.torch().float().cpu().reshape(B, HW, Cout), ref, dtype, "se fold")
