@@ -479,6 +479,157 @@ __global__ __launch_bounds__(512) void dwlarge_kernel(const T* __restrict__ in, 
   }
 }
 
+// ---- large-kernel depthwise on the matrix cores (bf16): banded Toeplitz GEMM per kernel row ------------
+// The VALU kernel above reaches 53 TFLOP/s (a third of the f32 vector peak) and is the single most expensive
+// non-GEMM kernel of the forward.  Per channel, one kernel row ky is a 1-D correlation along x, i.e. a product with a
+// banded Toeplitz matrix:
+//     out[y][x] += sum_x' in[y + ky][x0 - LM + x'] * T_ky[x'][x],     T_ky[x'][x] = w[ky][x' - (LM - HALO) - x]
+// which is the MFMA  D[i][j] += sum_k A[i][k] B[k][j]  with i = output row (16), j = output column (16), k = x'
+// (16 + LM + HALO <= 64 input columns: one or two K = 32 steps).  About half of the MACs are useful (the band), against
+// 1/16 for the diagonal trick of the 3x3 kernel: 31x31 needs 62 MFMAs per 16x16 output tile of one channel.
+//   * workgroup = 8 waves = 8 channels of a 32 x 32 output patch; the input patch + halo is staged ONCE, transposed
+//     NHWC -> per-channel planes of bf16 in LDS (row pitch an odd number of 16-byte slots: the 16-row A-fragment read is
+//     conflict-free, every fragment is one aligned ds_read_b128);
+//   * the B fragments (the Toeplitz bands in MFMA operand layout, [C][k][NH][64 lanes][8] bf16) are precomputed on the
+//     host at weight-packing time; a wave streams its channel's 62 KB once per patch, fully coalesced, prefetched a
+//     few kernel rows ahead, and applies each fragment to its 4 output tiles;
+//   * epilogue: BN scale/shift + activation, results written in place into the wave's own plane, then a coalesced
+//     NHWC copy-out (16 bytes = 8 channels per pixel).
+template <int K>
+__global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restrict__ in, int in_ld, const bf16_t* __restrict__ tb,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           bf16_t* __restrict__ out, int out_ld, int B, int H, int W, int C, int act) {
+  constexpr int HALO = (K - 1) / 2;
+  constexpr int LM = (HALO + 7) / 8 * 8;                  // left margin, 16-byte aligned
+  constexpr int NH = (16 + LM + HALO + 31) / 32;          // K = 32 steps per kernel row
+  constexpr int TH = 32, TW = 32;
+  constexpr int PH = TH + K - 1;                          // plane rows
+  constexpr int PWV = TW + LM + HALO;                     // plane columns holding real data
+  constexpr int PWA = (TW - 16) + NH * 32;                // columns an A fragment may touch (zero weights beyond PWV)
+  constexpr int PW = (PWA > PWV ? PWA : PWV);
+  constexpr int PITCH = ((PW + 7) / 8 * 8) + (((PW + 7) / 8) % 2 == 0 ? 8 : 0);   // elements; an odd number of 16-byte slots
+  constexpr int PLANE = PH * PITCH;                       // elements per channel plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  bf16_t* planes = reinterpret_cast<bf16_t*>(dsm);        // [8][PH][PITCH]
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int cgs = C / 8;
+  int bid = blockIdx.x;
+  const int cg = bid % cgs; bid /= cgs;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int c0 = cg * 8;
+  const int y0 = ty * TH - HALO, x0 = tx * TW - LM;       // image coordinates of plane (0, 0)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+
+  // B fragments of the first kernel rows are requested before the staging so their latency hides under it
+  const bf16_t* __restrict__ tbc = tb + (long long)(c0 + wave) * K * NH * 64 * 8 + lane * 8;
+  constexpr int PF = 4;                                   // kernel rows per prefetch group
+  s16x8 bnext[PF][NH];
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) bnext[u][h] = *reinterpret_cast<const s16x8*>(tbc + (long long)((u < K ? u : K - 1) * NH + h) * 512);
+
+  // ---- staging: NHWC -> 8 bf16 planes, zeros outside the image and in the k-padding columns ----------------
+  for (int i = tid; i < PH * PITCH; i += 512) {
+    const int py = i / PITCH, px = i - py * PITCH;
+    const int y = y0 + py, x = x0 + px;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (px < PWV && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+      v = *reinterpret_cast<const u32x4*>(in + ((long long)(b * H + y) * W + x) * in_ld + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      planes[(2 * e) * PLANE + i] = (bf16_t)(v[e] & 0xffffu);
+      planes[(2 * e + 1) * PLANE + i] = (bf16_t)(v[e] >> 16);
+    }
+  }
+  __syncthreads();
+
+  // ---- banded Toeplitz GEMM: this wave = channel c0 + wave, 2 x 2 output tiles of 16 x 16 -------------------
+  const bf16_t* pl = planes + wave * PLANE;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int abase = j * PITCH + q * 8;                    // lane's row (tile row j = A row i) and k-chunk
+  for (int ky0 = 0; ky0 < K; ky0 += PF) {
+    s16x8 bcur[PF][NH];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) bcur[u][h] = bnext[u][h];
+    if (ky0 + PF < K) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int kyn = min(ky0 + PF + u, K - 1);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bnext[u][h] = *reinterpret_cast<const s16x8*>(tbc + (long long)(kyn * NH + h) * 512);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int ky = ky0 + u;
+      if (ky < K) {                                       // uniform
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          s16x8 afr[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            afr[t] = *reinterpret_cast<const s16x8*>(pl + abase + ((t >> 1) * 16 + ky) * PITCH + (t & 1) * 16 + h * 32);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[t], bcur[u][h], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- epilogue in place: D lane = (column j, rows 4q .. 4q+3) of each tile -----------------------------------
+  const float sc = scale[c0 + wave], sh = shift[c0 + wave];
+  bf16_t* plw = planes + wave * PLANE;
+  with_act(act, [&](auto A) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        plw[((t >> 1) * 16 + 4 * q + r) * PITCH + (t & 1) * 16 + j] = f2bf(act_c<decltype(A)::value>(acc[t][r] * sc + sh));
+  });
+  __syncthreads();
+  // ---- coalesced NHWC copy-out -------------------------------------------------------------------------------
+  for (int i = tid; i < TH * TW; i += 512) {
+    const int py = i / TW, px = i - py * TW;
+    const int y = ty * TH + py, x = tx * TW + px;
+    if (y < H && x < W) {
+      u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = (uint32_t)planes[(2 * e) * PLANE + py * PITCH + px] | ((uint32_t)planes[(2 * e + 1) * PLANE + py * PITCH + px] << 16);
+      *reinterpret_cast<u32x4*>(out + ((long long)(b * H + y) * W + x) * out_ld + c0) = v;
+    }
+  }
+}
+
+template <int K>
+hipError_t launch_dwlarge_mfma(const void* in, int in_ld, const void* tb, const float* scale, const float* shift, void* out, int out_ld,
+                               int B, int H, int W, int C, int act, hipStream_t s) {
+  constexpr int HALO = (K - 1) / 2, LM = (HALO + 7) / 8 * 8, NH = (16 + LM + HALO + 31) / 32;
+  constexpr int PH = 32 + K - 1, PWV = 32 + LM + HALO, PWA = 16 + NH * 32, PW = (PWA > PWV ? PWA : PWV);
+  constexpr int PITCH = ((PW + 7) / 8 * 8) + (((PW + 7) / 8) % 2 == 0 ? 8 : 0);
+  constexpr size_t lds = (size_t)8 * PH * PITCH * 2;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_mfma_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  long long blocks = (long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8);
+  hipLaunchKernelGGL(dwlarge_mfma_kernel<K>, dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)tb, scale,
+                     shift, (bf16_t*)out, out_ld, B, H, W, C, act);
+  return hipSuccess;
+}
+
 // generic odd k (3..31): 16x16 tile, weights staged in LDS
 constexpr int LT = 16;
 
@@ -718,3 +869,27 @@ extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, 
   return cfp_check_launch("cfp_dwconv_large_nhwc");
 }
 
+
+extern "C" size_t cfp_dwconv_large_toeplitz_elems(int C, int k) {
+  if (C <= 0 || (k != 7 && k != 15 && k != 31)) return 0;
+  const int halo = (k - 1) / 2, lm = (halo + 7) / 8 * 8, nh = (16 + lm + halo + 31) / 32;
+  return (size_t)C * k * nh * 64 * 8;
+}
+
+extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void* toeplitz, const float* scale, const float* shift,
+                                          void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
+                                          cfp_stream_t stream) {
+  CFP_REQUIRE(in && toeplitz && out && scale && shift, CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: null pointer");
+  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: bf16 only (f32 uses cfp_dwconv_large_nhwc)");
+  CFP_REQUIRE(k == 7 || k == 15 || k == 31, CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: k must be 7, 15 or 31");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= C && out_ld >= C,
+              CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: bad shape");
+  CFP_REQUIRE(aligned16(in) && aligned16(out) && aligned16(toeplitz), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: pointers must be 16-byte aligned");
+  CFP_REQUIRE((long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: grid too large");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = k == 31 ? launch_dwlarge_mfma<31>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
+               : k == 15 ? launch_dwlarge_mfma<15>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
+                         : launch_dwlarge_mfma<7>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s);
+  if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_mfma_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
+  return cfp_check_launch("cfp_dwconv_large_mfma_nhwc");
+}

@@ -174,6 +174,8 @@ class Engine:
                     wd = sd[k + ".dwconv2.weight"].float()
                     kk = wd.shape[-1]
                     self.P[k + ".dw.w"] = self._dev(wd[:, 0].transpose(1, 2).reshape(wd.shape[0], kk * kk))   # f32 [C][kx][ky]
+                    if self.dtype == torch.bfloat16 and kk in (7, 15, 31):
+                        self.P[k + ".dw.tb"] = ops.toeplitz_bands(wd, torch.bfloat16).to(self.device)     # MFMA B-operand bands
                     self.P[k + ".dw.s"], self.P[k + ".dw.t"] = self._fold_bn(sd, k + ".bn1", sd[k + ".dwconv2.bias"], wd.shape[0], _BN_EPS)
                     self.P[k + ".norm.g"], self.P[k + ".norm.b"] = self._dev(sd[k + ".norm.weight"]), self._dev(sd[k + ".norm.bias"])
                     self._conv(sd, k + ".pw1", k + ".pwconv1.weight", k + ".pwconv1.bias")
@@ -415,7 +417,11 @@ class Engine:
                 k = l + ".large_kernel_path"
                 xin = tok[cur]
                 t1 = self._act(plan, f"{name}.lk.t1", M, D)
-                ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
+                if (k + ".dw.tb") in self.P:
+                    ops.dwconv_large_mfma(xin.slice(0, D), self.P[k + ".dw.tb"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk,
+                                          hip.ACT_RELU)
+                else:
+                    ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
                 t2 = self._act(plan, f"{name}.lk.t2", M, D)
                 ops.layernorm(t1, self.P[k + ".norm.g"], self.P[k + ".norm.b"], 1e-6, t2, M)
                 h4 = self._act(plan, f"{name}.lk.h4", M, 4 * D)

@@ -143,6 +143,31 @@ def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
              B, H, W, x.C, k, act, x.dt, _s())
 
 
+def toeplitz_bands(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[C,1,k,k] or [C,k,k] depthwise weights (ky, kx) -> the banded-Toeplitz B-operand table of cfp_dwconv_large_mfma_nhwc."""
+    w = w.detach().float().cpu()
+    if w.dim() == 4:
+        w = w[:, 0]
+    C, k, _ = w.shape
+    halo = (k - 1) // 2
+    lm = (halo + 7) // 8 * 8
+    nh = (16 + lm + halo + 31) // 32
+    lane = torch.arange(64)
+    h = torch.arange(nh)
+    e = torch.arange(8)
+    kx = 32 * h[:, None, None] + 8 * (lane[None, :, None] // 16) + e[None, None, :] - (lm - halo) - (lane[None, :, None] % 16)   # [nh,64,8]
+    ok = (kx >= 0) & (kx < k)
+    g = w[:, :, kx.clamp(0, k - 1)]                      # [C, k(ky), nh, 64, 8]
+    g = torch.where(ok[None, None], g, torch.zeros(()))
+    assert g.numel() == int(hip.load().cfp_dwconv_large_toeplitz_elems(C, k))
+    return g.contiguous().to(dtype)
+
+
+def dwconv_large_mfma(x: Act, tb: torch.Tensor, scale, shift, out: Act, B, H, W, k, act):
+    hip.call("cfp_dwconv_large_mfma_nhwc", x.ptr, x.ld, tb.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
+             B, H, W, x.C, k, act, x.dt, _s())
+
+
 def channel_sum(x: Act, partial: torch.Tensor, B, HW, nsplit):
     assert partial.dtype == torch.float32 and partial.numel() >= B * nsplit * x.C
     hip.call("cfp_channel_sum", x.ptr, x.ld, partial.data_ptr(), B, HW, x.C, nsplit, x.dt, _s())

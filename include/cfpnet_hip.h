@@ -116,6 +116,16 @@ int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float
                           void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                           cfp_stream_t stream);
 
+/* cfp_dwconv_large_nhwc on the matrix cores (bf16, k in {7, 15, 31}): every kernel row is a banded Toeplitz product,
+ * 62 MFMAs per 16x16 output tile of one channel for k = 31.  `toeplitz` holds the bands in MFMA B-operand layout,
+ *   toeplitz[c][ky][h][lane][e] = w[c][ky][kx],  kx = 32 h + 8 (lane >> 4) + e - (LM - halo) - (lane & 15)   (0 outside [0, k))
+ * with halo = (k-1)/2, LM = halo rounded up to 8, h < NH = ceil((16 + LM + halo) / 32); cfp_dwconv_large_toeplitz_elems
+ * gives its size in elements.  It is built once per weight tensor on the host (cfpnet_amd/engine.py). */
+size_t cfp_dwconv_large_toeplitz_elems(int C, int k);
+int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void* toeplitz, const float* scale, const float* shift,
+                               void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
+                               cfp_stream_t stream);
+
 /* Per-(batch, channel) sums over H*W, split in `nsplit` row slices: partial[b][s][c] (f32).
  * Consumers divide by H*W.  Replaces x.mean((2,3)) in the SE block and `.mean([2,3])` of
  * DepthRegression (decoder.py:24-25; conv1x1 and mean commute). */

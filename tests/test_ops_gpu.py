@@ -267,6 +267,24 @@ def test_dwconv3x3(case, dtype):
     close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"dw3x3 {case}")
 
 
+@pytest.mark.parametrize("case", [(1, 30, 40, 128, 7), (2, 60, 80, 64, 15), (1, 120, 160, 32, 31), (2, 33, 47, 16, 31), (1, 9, 9, 8, 15)])
+def test_dwconv_large_mfma_toeplitz(case):
+    """Large-kernel depthwise as banded Toeplitz GEMMs on the matrix cores (bf16) vs F.conv2d."""
+    dtype = torch.bfloat16
+    B, H, W, Cc, k = case
+    x = q(rnd(B, Cc, H, W, seed=1), dtype)
+    w = q(rnd(Cc, 1, k, k, seed=2, scale=1.0 / k), dtype)         # the band table stores bf16 weights
+    scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
+    ref = F.relu(F.conv2d(x, w, None, 1, (k - 1) // 2, 1, Cc) * scale[None, :, None, None] + shift[None, :, None, None])
+    tb = ops.toeplitz_bands(w, dtype).to(DEV)
+    out = ops.new_act(B * H * W, Cc, dtype, DEV, ld=Cc + 8, zero=True)
+    out = ops.Act(out.buf, 8, Cc)
+    ops.dwconv_large_mfma(to_act(nhwc(x), dtype, ld=Cc + 16, c0=8), tb, scale.to(DEV), shift.to(DEV), out, B, H, W, k, hip.ACT_RELU)
+    torch.cuda.synchronize()
+    close(from_nhwc(out.torch(), B, H, W), ref, dtype, f"dwlarge mfma {case}")
+    assert float(out.buf[:, :8].abs().max()) == 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (2, 15, 20, 1392, 1, (1, 1, 1, 1)), (3, 30, 40, 816, 1, (1, 1, 1, 1)),
                                   (2, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 5, 3, 8, 1, (1, 1, 1, 1))])
