@@ -102,6 +102,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// XCD-aware block index: hardware deals workgroups round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so
+// logically adjacent tiles that re-read the same lines land on 8 different L2s.  This bijective remap gives every XCD a
+// contiguous chunk of the logical order instead (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // ---- host side -------------------------------------------------------------------------
 void cfp_set_error(const std::string& msg);
 int cfp_check_launch(const char* what);

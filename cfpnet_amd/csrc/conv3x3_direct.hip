@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   // ---- tile coordinates: N-tiles of one pixel patch are adjacent workgroups (they share the halo in L2)
   const int tiles_n = (p.Cout + BN - 1) / BN;
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = bid % tiles_n; bid /= tiles_n;
   const int tx_ = bid % tiles_x; bid /= tiles_x;
   const int ty_ = bid % tiles_y;

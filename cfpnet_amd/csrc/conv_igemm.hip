@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x % tiles_n;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lbid / tiles_n;
+  const int tile_n = lbid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   f32x4 acc[TM][TN];

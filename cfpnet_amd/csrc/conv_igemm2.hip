@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
 
   // ---- tile coordinates -------------------------------------------------------------------
   const int tiles_n = (p.Cout + BN - 1) / BN;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);   // an XCD's L2 sees a contiguous run of tiles (shared A rows / halos / weights)
   int sp = 0;
   if constexpr (SPLITK) { sp = bid % splits; bid /= splits; }
   const int tile_n = bid % tiles_n;

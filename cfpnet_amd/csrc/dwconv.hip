@@ -495,14 +495,14 @@ __global__ __launch_bounds__(512) void dwlarge_kernel(const T* __restrict__ in, 
 //     few kernel rows ahead, and applies each fragment to its 4 output tiles;
 //   * epilogue: BN scale/shift + activation, results written in place into the wave's own plane, then a coalesced
 //     NHWC copy-out (16 bytes = 8 channels per pixel).
-template <int K>
+template <int K, int TH, int TW>
 __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restrict__ in, int in_ld, const bf16_t* __restrict__ tb,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            bf16_t* __restrict__ out, int out_ld, int B, int H, int W, int C, int act) {
   constexpr int HALO = (K - 1) / 2;
   constexpr int LM = (HALO + 7) / 8 * 8;                  // left margin, 16-byte aligned
   constexpr int NH = (16 + LM + HALO + 31) / 32;          // K = 32 steps per kernel row
-  constexpr int TH = 32, TW = 32;
+  constexpr int NTX = TW / 16, NT = (TH / 16) * NTX;     // 16 x 16 output tiles per wave
   constexpr int PH = TH + K - 1;                          // plane rows
   constexpr int PWV = TW + LM + HALO;                     // plane columns holding real data
   constexpr int PWA = (TW - 16) + NH * 32;                // columns an A fragment may touch (zero weights beyond PWV)
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
   bf16_t* planes = reinterpret_cast<bf16_t*>(dsm);        // [8][PH][PITCH]
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int cgs = C / 8;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);             // the channel groups of one patch share an XCD's L2
   const int cg = bid % cgs; bid /= cgs;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -549,12 +549,13 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
   }
   __syncthreads();
 
-  // ---- banded Toeplitz GEMM: this wave = channel c0 + wave, 2 x 2 output tiles of 16 x 16 -------------------
+  // ---- banded Toeplitz GEMM: this wave = channel c0 + wave, (TH/16) x (TW/16) output tiles of 16 x 16 -------------------
   const bf16_t* pl = planes + wave * PLANE;
-  f32x4 acc[4];
+  f32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int abase = j * PITCH + q * 8;                    // lane's row (tile row j = A row i) and k-chunk
+#pragma unroll 1
   for (int ky0 = 0; ky0 < K; ky0 += PF) {
     s16x8 bcur[PF][NH];
 #pragma unroll
@@ -575,12 +576,12 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
       if (ky < K) {                                       // uniform
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-          s16x8 afr[4];
+          s16x8 afr[NT];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            afr[t] = *reinterpret_cast<const s16x8*>(pl + abase + ((t >> 1) * 16 + ky) * PITCH + (t & 1) * 16 + h * 32);
+          for (int t = 0; t < NT; ++t)
+            afr[t] = *reinterpret_cast<const s16x8*>(pl + abase + ((t / NTX) * 16 + ky) * PITCH + (t % NTX) * 16 + h * 32);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[t], bcur[u][h], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[t], bcur[u][h], acc[t], 0, 0, 0);
         }
       }
     }
@@ -590,10 +591,10 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
   bf16_t* plw = planes + wave * PLANE;
   with_act(act, [&](auto A) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        plw[((t >> 1) * 16 + 4 * q + r) * PITCH + (t & 1) * 16 + j] = f2bf(act_c<decltype(A)::value>(acc[t][r] * sc + sh));
+        plw[((t / NTX) * 16 + 4 * q + r) * PITCH + (t % NTX) * 16 + j] = f2bf(act_c<decltype(A)::value>(acc[t][r] * sc + sh));
   });
   __syncthreads();
   // ---- coalesced NHWC copy-out -------------------------------------------------------------------------------
@@ -610,22 +611,22 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
   }
 }
 
-template <int K>
+template <int K, int TH, int TW>
 hipError_t launch_dwlarge_mfma(const void* in, int in_ld, const void* tb, const float* scale, const float* shift, void* out, int out_ld,
                                int B, int H, int W, int C, int act, hipStream_t s) {
   constexpr int HALO = (K - 1) / 2, LM = (HALO + 7) / 8 * 8, NH = (16 + LM + HALO + 31) / 32;
-  constexpr int PH = 32 + K - 1, PWV = 32 + LM + HALO, PWA = 16 + NH * 32, PW = (PWA > PWV ? PWA : PWV);
+  constexpr int PH = TH + K - 1, PWV = TW + LM + HALO, PWA = (TW - 16) + NH * 32, PW = (PWA > PWV ? PWA : PWV);
   constexpr int PITCH = ((PW + 7) / 8 * 8) + (((PW + 7) / 8) % 2 == 0 ? 8 : 0);
   constexpr size_t lds = (size_t)8 * PH * PITCH * 2;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_mfma_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_mfma_kernel<K, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  long long blocks = (long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8);
-  hipLaunchKernelGGL(dwlarge_mfma_kernel<K>, dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)tb, scale,
+  long long blocks = (long long)B * cdiv(H, TH) * cdiv(W, TW) * (C / 8);
+  hipLaunchKernelGGL((dwlarge_mfma_kernel<K, TH, TW>), dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)tb, scale,
                      shift, (bf16_t*)out, out_ld, B, H, W, C, act);
   return hipSuccess;
 }
@@ -886,10 +887,11 @@ extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void*
               CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: bad shape");
   CFP_REQUIRE(aligned16(in) && aligned16(out) && aligned16(toeplitz), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: pointers must be 16-byte aligned");
   CFP_REQUIRE((long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: grid too large");
+  (void)0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = k == 31 ? launch_dwlarge_mfma<31>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
-               : k == 15 ? launch_dwlarge_mfma<15>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
-                         : launch_dwlarge_mfma<7>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s);
+  hipError_t e = k == 31 ? launch_dwlarge_mfma<31, 64, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
+               : k == 15 ? launch_dwlarge_mfma<15, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
+                         : launch_dwlarge_mfma<7, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s);
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_mfma_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
   return cfp_check_launch("cfp_dwconv_large_mfma_nhwc");
 }
