@@ -648,3 +648,84 @@ def test_bin_head_fused(HW):
     pred2 = torch.empty(B, HW, device=DEV)
     ops.bin_head_fused(to_act(x, torch.bfloat16), w.to(torch.bfloat16).to(DEV), bias.to(DEV), centers.to(DEV), None, pred2, B, HW)
     assert torch.equal(pred, pred2)
+
+
+# ---- bit-exact checks of the bf16 fast-path kernels ---------------------------------------------------------------
+# Small-integer inputs and weights make every product and every f32 partial sum exact, so the only rounding is the final
+# f32 -> bf16 store (round-to-nearest-even): the kernels must reproduce the integer convolution BIT FOR BIT, whatever their
+# tiling, K order, LDS swizzle or MFMA operand layout.  This is the parity argument for the kernels the f32 mode never runs.
+def _int_tensor(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+def _bits(t):
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+INT_CONV_CASES = [(2, 20, 24, 40, 48, 3, 1, (1, 1, 1, 1)), (1, 17, 33, 168, 64, 3, 1, (1, 1, 1, 1)), (2, 9, 11, 8, 40, 3, 2, (0, 0, 1, 1)),
+                  (1, 1, 700, 136, 816, 1, 1, (0, 0, 0, 0)), (1, 24, 24, 64, 32, 6, 6, (0, 0, 0, 0))]
+
+
+@pytest.mark.parametrize("variant", list(range(17)) + [200 + v for v in range(6)] + ["gen1"])
+def test_conv_fast_paths_bit_exact_on_integers(variant):
+    lib = hip.load()
+    dtype = torch.bfloat16
+    try:
+        if variant == "gen1":
+            lib.cfp_debug_set(2, 1)
+        else:
+            lib.cfp_debug_set(0, int(variant))
+        for case in INT_CONV_CASES:
+            B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+            if isinstance(variant, int) and variant >= 200 and not (k == 3 and s == 1):
+                continue
+            x = _int_tensor((B, Cin, H, W), -3, 3, 1)
+            w = _int_tensor((Cout, Cin, k, k), -2, 2, 2)
+            Ho, Wo = (H + pt + pb - k) // s + 1, (W + pl + pr - k) // s + 1
+            ref = F.conv2d(F.pad(x.double(), (pl, pr, pt, pb)), w.double(), None, s).float()      # exact integers (< 2^24)
+            out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV)
+            wa = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV)
+            ops.conv2d(to_act(nhwc(x), dtype), wa, None, None, out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_NONE, None, None)
+            torch.cuda.synchronize()
+            got = out.torch().cpu().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+            assert torch.equal(got.view(torch.int16), _bits(ref)), f"variant {variant} case {case}"
+    finally:
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(2, 0)
+
+
+@pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (1, 15, 20, 1392, 1, (1, 1, 1, 1)), (2, 30, 40, 816, 1, (1, 1, 1, 1)),
+                                  (1, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 16, 16, 16, 1, (1, 1, 1, 1))])
+def test_dwconv3x3_mfma_bit_exact_on_integers(case):
+    B, H, W, Cc, s, (pt, pl, pb, pr) = case
+    dtype = torch.bfloat16
+    x = _int_tensor((B, Cc, H, W), -7, 7, 3)
+    w = _int_tensor((Cc, 1, 3, 3), -3, 3, 4)
+    Ho, Wo = (H + pt + pb - 3) // s + 1, (W + pl + pr - 3) // s + 1
+    ref = F.conv2d(F.pad(x.double(), (pl, pr, pt, pb)), w.double(), None, s, 0, 1, Cc).float()
+    out = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+    wa = w.reshape(Cc, 9).t().contiguous().to(dtype).to(DEV)
+    ns = ops.dwconv3x3_strips(B, Ho, Wo, Cc, s, ops.DT[dtype])
+    part = torch.empty(B, ns, Cc, device=DEV)
+    ops.dwconv3x3_sum(to_act(nhwc(x), dtype), wa, torch.ones(Cc, device=DEV), torch.zeros(Cc, device=DEV), out, part, B, H, W, s, pt, pl,
+                      Ho, Wo, hip.ACT_NONE)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().reshape(B, Ho, Wo, Cc).permute(0, 3, 1, 2)
+    assert torch.equal(got.view(torch.int16), _bits(ref))
+    assert torch.equal(part.sum(1).cpu(), ref.sum((2, 3)))           # channel sums of small integers are exact too
+
+
+@pytest.mark.parametrize("case", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (1, 64, 32, 8, 31)])
+def test_dwconv_large_toeplitz_bit_exact_on_integers(case):
+    B, H, W, Cc, k = case
+    dtype = torch.bfloat16
+    x = _int_tensor((B, Cc, H, W), -3, 3, 5)
+    w = _int_tensor((Cc, 1, k, k), -1, 1, 6)
+    ref = F.conv2d(x.double(), w.double(), None, 1, (k - 1) // 2, 1, Cc).float()
+    out = ops.new_act(B * H * W, Cc, dtype, DEV)
+    ops.dwconv_large_mfma(to_act(nhwc(x), dtype), ops.toeplitz_bands(w, dtype).to(DEV), torch.ones(Cc, device=DEV), torch.zeros(Cc, device=DEV),
+                          out, B, H, W, k, hip.ACT_NONE)
+    torch.cuda.synchronize()
+    got = out.torch().cpu().reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    assert torch.equal(got.view(torch.int16), _bits(ref))
