@@ -56,6 +56,10 @@ SIGNATURES = {
     "cfp_adamw_step": (_i, [_p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _i, _p, _p]),
     "cfp_grad_clip_ws_bytes": (_sz, []),
     "cfp_grad_clip_factor": (_i, [_p, C.c_longlong, _f, _p, _sz, _p, _p]),
+    "cfp_tof_hist_sim": (_i, [_p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _i, C.c_double, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "cfp_tof_sample_points": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _p, _p]),
+    "cfp_eval_metrics_ws_bytes": (_sz, [_i]),
+    "cfp_eval_metrics": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

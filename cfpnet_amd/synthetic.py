@@ -82,3 +82,42 @@ def to_device(input_data: Dict, device) -> Dict:
             "patch_info": add["patch_info"],
         },
     }
+
+
+def make_depth(height: int, width: int, seed: int = SEED, holes: float = 0.0, quantise_mm: bool = False) -> np.ndarray:
+    """Synthetic ground-truth depth [H, W] f32 for the ToF simulation: a tilted plane plus two boxes and mild noise
+    (so zones see one or two depth clusters), optionally with a fraction of invalid (zero) pixels in blobs."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
+    d = 0.8 + 2.2 * x / width + 0.7 * y / height
+    for _ in range(2):
+        cy, cx = rng.integers(0, height), rng.integers(0, width)
+        hh, ww = rng.integers(40, 160), rng.integers(40, 200)
+        d[max(0, cy - hh):cy + hh, max(0, cx - ww):cx + ww] -= rng.uniform(0.3, 0.9)
+    d += rng.normal(0.0, 0.01, d.shape)
+    d = np.clip(d, 0.05, 9.5)
+    if holes > 0:
+        m = rng.random((height // 16 + 1, width // 16 + 1)) < holes
+        m = np.kron(m, np.ones((16, 16), dtype=bool))[:height, :width]
+        d[m] = 0.0
+    if quantise_mm:          # NYU ground truth: uint16 millimetres / 1000 in float32
+        return (np.round(d * 1000.0).astype(np.float32) / np.float32(1000.0)).astype(np.float32)
+    return d.astype(np.float32)
+
+
+def make_eval_pair(height: int, width: int, pred_h: int, pred_w: int, seed: int, holes: float = 0.0, noise: float = 0.1):
+    """(gt [H,W], pred [pred_h,pred_w]) float32 for the metric tests: the prediction is the ground truth sampled at
+    model resolution times log-normal noise, with a few out-of-range / non-finite pixels the protocols must clamp."""
+    gt = make_depth(height, width, seed=seed, holes=holes)
+    full = make_depth(height, width, seed=seed, holes=0.0)
+    rng = np.random.default_rng(seed + 1000)
+    ys = np.linspace(0, height - 1, pred_h).round().astype(int)
+    xs = np.linspace(0, width - 1, pred_w).round().astype(int)
+    pred = full[np.ix_(ys, xs)] * np.exp(rng.normal(0.0, noise, (pred_h, pred_w)))
+    pred = pred.astype(np.float32)
+    idx = rng.integers(0, pred.size, 24)
+    pred.flat[idx[:8]] = 0.0
+    pred.flat[idx[8:16]] = 37.5
+    pred.flat[idx[16:20]] = np.inf
+    pred.flat[idx[20:]] = -1.0
+    return gt, pred

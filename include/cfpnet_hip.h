@@ -280,6 +280,45 @@ size_t cfp_grad_clip_ws_bytes(void);
 int cfp_grad_clip_factor(const float* grad, long long n, float max_norm, void* ws, size_t ws_bytes, float* out,
                          cfp_stream_t stream);
 
+/* ---- data path either side of the model ------------------------------------------------- */
+
+/* ToF zone-histogram simulation from ground-truth depth, a whole batch per launch.  Replaces the per-sample CPU
+ * functions get_hist_parallel (src/utils/dataloader.py:83-134) and the uniform branch of
+ * sample_point_from_hist_parallel (:65-80) that the data-loader workers call (src/dataloader/nyu.py:154,179).
+ *   depth    [B] images of H x W f32, `img_stride` elements apart (device)
+ *   zone grid: zone_num x zone_num squares of zone_px pixels whose top-left zone starts at (sy0 + off, sx0 + off);
+ *            the reference uses sy0 = int((H - zone_px*zone_num)/2), 64 px zones when training and 56 px otherwise
+ *            (:94-103).  offsets (device, [B] int32, may be NULL) is the per-sample `train_zone_random_offset`
+ *            draw (:98-100), clamped to +-offset_bound; the grid must stay inside the image for that bound.
+ *   histogram: torch.histc(bins, min=0, max=max_distance) in f32 (:104), bin 0 cleared and floor_count (20)
+ *            subtracted (:108-109), strongest run of consecutive non-zero bins kept (:110-116), moments over bin
+ *            centres built from multiples of bin_width (0.04) in f64 (:118,127-130).
+ *   w0, w1   [nsamp] f32 (device): torch.linspace(1,0,nsamp) / torch.linspace(0,1,nsamp) as the HOST evaluates
+ *            them (tensor_linspace, :42-57; ATen's vectorised linspace differs in the last bit between hosts).
+ * Outputs (device): fh [B,Z,2] f64 (mu, sigma); rect [B,Z,4] f32 (sy,sx,ey,ex); mask [B,Z] u8; pts [B,Z,nsamp] f32
+ * (zero where mask is 0); hist_out [B,Z,bins] i32 (may be NULL): the counts that survive cluster selection. */
+int cfp_tof_hist_sim(const float* depth, long long img_stride, int B, int H, int W, int zone_num, int zone_px, int sy0,
+                     int sx0, const int* offsets, int offset_bound, float max_distance, int bins, double bin_width,
+                     int floor_count, const float* w0, const float* w1, int nsamp, double* fh, float* rect,
+                     unsigned char* mask, float* pts, int* hist_out, cfp_stream_t stream);
+/* The sampling step alone (sample_point_from_hist_parallel with --sample_uniform, dataloader.py:65-80), for callers
+ * that keep the reference's two calls: pts[z, t] = f32(w0[t]*(mu-3 sigma) + w1[t]*(mu+3 sigma)) in f64, 0 if !mask[z]. */
+int cfp_tof_sample_points(const double* fh, const unsigned char* mask, const float* w0, const float* w1, long long nzones,
+                          int nsamp, float* pts, cfp_stream_t stream);
+
+/* Depth-evaluation metrics per image without leaving the device: compute_errors (src/utils/metrics.py:4-24 =
+ * evaluate_all.py:15-35) fused with the protocol around it.
+ *   mode 0 = evaluate_all.py:38-41,80-84: pred clipped to [lo, hi] at model resolution, then bilinear
+ *            (align_corners=True) to H x W; valid pixels lo < gt < hi (args.min_depth / args.max_depth).
+ *   mode 1 = train.py:187-199 (validate): bilinear first, then clamp to [lo, hi], nan -> lo; valid pixels
+ *            lo < gt < hi (args.min_depth_eval / args.max_depth_eval).
+ *   pred [B,Hp,Wp] f32, gt [B,H,W] f32 (device); interpolate = 0 requires equal sizes.
+ * out [B,10] f64 (device) = {a1, a2, a3, abs_rel, rmse, log_10, rmse_log, silog, sq_rel, n_valid}; an image with
+ * n_valid = 0 yields NaN metrics (the reference skips it).  Per-pixel terms f32, sums f64 in a fixed order. */
+size_t cfp_eval_metrics_ws_bytes(int B);
+int cfp_eval_metrics(const float* pred, int Hp, int Wp, const float* gt, int H, int W, int B, int interpolate, int mode,
+                     float lo, float hi, void* ws, size_t ws_bytes, double* out, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

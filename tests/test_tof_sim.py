@@ -1,0 +1,187 @@
+"""ToF zone-histogram simulation: oracle vs the reference's goldens (CPU), HIP kernel vs
+oracle and goldens (GPU, through the C ABI).
+
+Bars: histogram counts, cluster choice, mask and rectangles bit-exact; mu/sigma float64 -- the oracle and the kernel
+sum in the same order, so they are compared bit-for-bit, and both against the reference (whose `torch.sum` order is
+unspecified) to 1e-12 relative; float32 samples exact between kernel and oracle, <= 1 ulp against the reference."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from cfpnet_amd import synthetic
+from oracle import tof_oracle as TO
+
+from helpers import GOLDEN
+
+Z = np.load(os.path.join(GOLDEN, "hist_sim.npz"))
+META = json.loads(bytes(Z["meta"]).decode())
+IDS = [m["name"] for m in META]
+
+
+def _depth(m):
+    return synthetic.make_depth(m["H"], m["W"], seed=m["seed"], holes=max(m["holes"], 0.0), quantise_mm=m["holes"] < 0)
+
+
+def _cfg(m, **kw):
+    d = dict(mode=m["mode"], train_zone_num=m["train_zone_num"], train_zone_random_offset=0, simu_max_distance=4.0,
+             zone_sample_num=16, sample_uniform=True)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+# ------------------------------------------------------------------------------------------- CPU: oracle vs reference
+@pytest.mark.parametrize("m", META, ids=IDS)
+def test_oracle_matches_reference_golden(m):
+    n = m["name"]
+    r = TO.get_hist(_depth(m), m["mode"], m["train_zone_num"], weights=(Z[n + ".w0"], Z[n + ".w1"]))
+    assert np.array_equal(r["mask"], Z[n + ".mask"].astype(bool))
+    assert np.array_equal(r["fr"], Z[n + ".fr"])
+    assert _rel(r["fh"], Z[n + ".fh"]) < 1e-12
+    assert np.array_equal(r["pts"], Z[n + ".pts"])
+    assert r["fh"].dtype == np.float64 and m["fh_dtype"] == "torch.float64"
+
+
+def test_golden_cases_cover_invalid_zones_and_edge_hits():
+    assert 0 < int(Z["eval480_sparse.mask"].sum()) < 64          # some zones without a signal
+    d = _depth(META[IDS.index("eval480_mm")])
+    assert np.any(np.isin(np.round(d * 1000).astype(np.int64) % 40, [0]))   # millimetre depths that sit on bin edges
+
+
+def test_oracle_histogram_rule_matches_torch_histc_near_edges():
+    """The bin rule is int((x*bins)/max) in float32, NOT a search over linspace edges: probe +-3 ulp round every edge."""
+    for md, bins in ((4.0, 100), (3.3, 82), (10.0, 250)):
+        e = (np.arange(1, bins, dtype=np.float64) * md / bins).astype(np.float32)
+        vals = [e]
+        for _ in range(3):
+            vals.append(np.nextafter(vals[-1], np.float32(100)))
+        lo = e
+        for _ in range(3):
+            lo = np.nextafter(lo, np.float32(-100))
+            vals.append(lo)
+        v = np.concatenate(vals + [np.array([0.0, md, np.nextafter(np.float32(md), np.float32(100)), -1e-6, np.nan], dtype=np.float32)])
+        want = torch.histc(torch.from_numpy(v[np.isfinite(v)]), bins=bins, min=0, max=md).numpy().astype(np.int64)
+        assert np.array_equal(TO.zone_histogram(v, md, bins), want)
+
+
+def test_oracle_cluster_selection_ties_and_floor():
+    h = np.zeros(100, dtype=np.int64)
+    h[0] = 500                       # invalid-depth bin: cleared
+    h[10:12] = (70, 50)              # run sum (50+30) = 80
+    h[40:44] = (40, 40, 40, 40)      # run sum 4*20 = 80  -> tie, first wins
+    h[70] = 20                       # exactly the floor: vanishes
+    out = TO.strongest_cluster(h)
+    assert out[10] == 50 and out[11] == 30 and out.sum() == 80
+
+
+# ------------------------------------------------------------------------------------------------- GPU: kernel parity
+def _run_kernel(m, depth, weights=None, offsets=None, cfg=None, want_hist=True):
+    from cfpnet_amd import tof
+    cfg = cfg or _cfg(m)
+    sim = tof.TofSimulator(cfg, "cuda:0")
+    if weights is not None:
+        sim.set_weights(*weights)
+    d = torch.from_numpy(np.ascontiguousarray(depth)).cuda()
+    r = sim.simulate(d, offsets=offsets, want_hist=want_hist)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in r.items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", META, ids=IDS)
+def test_kernel_matches_oracle_and_golden(m):
+    n = m["name"]
+    w = (Z[n + ".w0"], Z[n + ".w1"])
+    dep = _depth(m)
+    r = _run_kernel(m, dep[None], weights=w)
+    o = TO.get_hist(dep, m["mode"], m["train_zone_num"], weights=w)
+    assert np.array_equal(r["hist"][0].astype(np.int64), o["hist"])            # integer stage: bit-exact
+    assert np.array_equal(r["mask"][0], o["mask"])
+    assert np.array_equal(r["rect_data"][0], o["fr"])
+    assert np.array_equal(r["fh"][0], o["fh"])                                  # same summation order: bit-exact f64
+    assert np.array_equal(r["hist_data"][0], o["pts"])
+    # and against the reference itself
+    assert np.array_equal(r["mask"][0], Z[n + ".mask"].astype(bool))
+    assert np.array_equal(r["rect_data"][0], Z[n + ".fr"])
+    assert _rel(r["fh"][0], Z[n + ".fh"]) < 1e-12
+    ulp = np.abs(r["hist_data"][0].view(np.int32).astype(np.int64) - Z[n + ".pts"].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
+
+
+@pytest.mark.gpu
+def test_kernel_batch_offsets_and_strided_input():
+    """B=8 at the headline geometry, per-image grid offsets, depth given as [B,1,H,W]: every image equals the oracle
+    run on that image alone."""
+    B, H, W = 8, 480, 640
+    deps = np.stack([synthetic.make_depth(H, W, seed=900 + i, holes=0.1 * (i % 3)) for i in range(B)])
+    offs = np.array([0, 3, -3, 7, -7, 1, 16, -16], dtype=np.int32)
+    m = dict(mode="online_eval", train_zone_num=8)
+    cfg = _cfg(m, train_zone_random_offset=16)
+    r = _run_kernel(m, deps[:, None], offsets=torch.from_numpy(offs).cuda(), cfg=cfg)
+    for i in range(B):
+        o = TO.get_hist(deps[i], "online_eval", 8, offset=int(offs[i]))
+        assert np.array_equal(r["hist"][i].astype(np.int64), o["hist"]), i
+        assert np.array_equal(r["mask"][i], o["mask"]) and np.array_equal(r["rect_data"][i], o["fr"])
+        assert np.array_equal(r["fh"][i], o["fh"]) and np.array_equal(r["hist_data"][i], o["pts"])
+
+
+@pytest.mark.gpu
+def test_kernel_edge_cases():
+    H, W = 480, 640
+    m = dict(mode="online_eval", train_zone_num=8)
+    # no valid depth anywhere / everything beyond the sensor range / NaNs: every zone masked out, samples zero
+    for fill in (0.0, 7.5, np.nan):
+        r = _run_kernel(m, np.full((1, H, W), fill, dtype=np.float32))
+        assert not r["mask"].any() and not r["hist_data"].any() and not r["hist"].any()
+        assert np.array_equal(r["fh"][0, :, 0], np.zeros(64)) and np.allclose(r["fh"][0, :, 1], 1e-9, rtol=0, atol=0)
+    # exactly max distance lands in the last bin; a flat wall gives sigma = 1e-9 exactly like the reference
+    d = np.full((H, W), 4.0, dtype=np.float32)
+    d[:, :320] = 2.0
+    r = _run_kernel(m, d[None])
+    o = TO.get_hist(d, "online_eval", 8)
+    assert np.array_equal(r["hist"][0].astype(np.int64), o["hist"]) and r["hist"][0, 7, 99] == 56 * 56 - 20
+    assert np.array_equal(r["fh"][0], o["fh"]) and np.array_equal(r["hist_data"][0], o["pts"])
+    # random max distance (bins != 100) and a training grid
+    mt = dict(mode="train", train_zone_num=6)
+    dep = synthetic.make_depth(416, 544, seed=77, holes=0.1)
+    from cfpnet_amd import tof
+    sim = tof.TofSimulator(_cfg(mt), "cuda:0")
+    for md in (3.3, 5.5, 10.0):
+        rr = sim.simulate(torch.from_numpy(dep)[None].cuda(), max_distance=md, want_hist=True)
+        oo = TO.get_hist(dep, "train", 6, max_distance=md)
+        assert rr["hist"].shape[-1] == int(md / 0.04)
+        assert np.array_equal(rr["hist"][0].cpu().numpy().astype(np.int64), oo["hist"])
+        assert np.array_equal(rr["fh"][0].cpu().numpy(), oo["fh"]) and np.array_equal(rr["hist_data"][0].cpu().numpy(), oo["pts"])
+
+
+@pytest.mark.gpu
+def test_reference_named_entry_points_and_errors():
+    from cfpnet_amd import tof
+    m = META[IDS.index("train416")]
+    cfg = _cfg(m)
+    dep = torch.from_numpy(_depth(m))[None].cuda()
+    rgb = torch.zeros(3, m["H"], m["W"], device="cuda:0")
+    fh, fr, mask = tof.get_hist_parallel(rgb, dep, cfg)
+    pts = tof.sample_point_from_hist_parallel(fh, mask, cfg)
+    o = TO.get_hist(_depth(m), m["mode"], m["train_zone_num"])
+    assert fh.dtype == torch.float64 and fh.shape == (36, 2) and mask.dtype == torch.bool and fr.shape == (36, 4)
+    assert np.array_equal(fh.cpu().numpy(), o["fh"]) and np.array_equal(pts.cpu().numpy(), o["pts"])
+    # the sampling step alone, with some zones masked out by the caller
+    mk = mask.clone()
+    mk[::3] = False
+    pts2 = tof.sample_point_from_hist_parallel(fh, mk, cfg).cpu().numpy()
+    assert not pts2[::3].any() and np.array_equal(pts2[1::3], o["pts"][1::3])
+    # a grid that cannot fit the image is refused on the host, before any launch
+    with pytest.raises(RuntimeError, match="zone grid leaves the image"):
+        tof.TofSimulator(_cfg(dict(mode="train", train_zone_num=8)), "cuda:0").simulate(dep)      # 8*64 = 512 > 416
+    with pytest.raises(NotImplementedError):
+        tof.TofSimulator(_cfg(m, sample_uniform=False), "cuda:0")
+    with pytest.raises(ValueError):
+        tof.TofSimulator(cfg, "cuda:0").simulate(dep.double())
