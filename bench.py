@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-times", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--dtype", choices=("bf16", "f16"), default="bf16",
+                    help="16-bit storage format of the headline line (BASELINE.json quotes bf16; f16 = IEEE half, same MFMA rate)")
+    ap.add_argument("--no-f16", action="store_true", help="skip the extra fp16 measurement appended to the bf16 line")
     return ap.parse_args()
 
 
@@ -185,7 +188,8 @@ def main():
     from cfpnet_amd.engine import Engine
     layers = spec.COMBINE1_LAYERS
     sd = weights.make_torch_state_dict(spec.model_manifest(layers))
-    engine = Engine(sd, layer_names=layers, dtype=torch.bfloat16, device=dev)
+    TDT = {"bf16": torch.bfloat16, "f16": torch.float16}
+    engine = Engine(sd, layer_names=layers, dtype=TDT[a.dtype], device=dev)
     inputs = synthetic.to_device(synthetic.make_inputs(a.batch, a.height, a.width, 8, 56, seed=synthetic.SEED + rank), dev)
     return_prob = not a.no_prob
 
@@ -212,10 +216,10 @@ def main():
     if rank == 0:
         value, per_gpu = job_value(world, a.batch, a.steps, elapsed)
         line = {
-            "metric": "depth maps/sec @ 480x640 bf16 (whole job; per_gpu = value / n_gpus); abs_rel vs CPU oracle",
+            "metric": f"depth maps/sec @ 480x640 {a.dtype} (whole job; per_gpu = value / n_gpus); abs_rel vs CPU oracle",
             "value": value, "unit": "maps/s", "per_gpu": per_gpu,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward incl. prob output"
                                    if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward, prob output skipped",
                        "layers": "hist2image combine1 image x2 (CFPNet)", "launch": ("eager" if a.eager else "hipGraph replay") + (f", {a.lanes} concurrent batch lanes" if a.lanes > 1 else ""),
@@ -255,6 +259,29 @@ def main():
             p1 = p1.float().cpu().numpy()
             line["abs_rel"] = float(np.mean(np.abs(p0.numpy() - p1) / p0.numpy()))
             line["rel_l1"] = float(np.abs(p0.numpy() - p1).sum() / np.abs(p0.numpy()).sum())
+            if a.dtype == "bf16" and not a.no_f16:
+                # same workload, same protocol, IEEE-half storage: the precision the 1e-3 relative-L1 gate needs
+                del engine
+                torch.cuda.empty_cache()
+                e16 = Engine(sd, layer_names=layers, dtype=torch.float16, device=dev)
+                if a.eager:
+                    step16 = lambda: e16.forward_lanes(inputs, a.lanes, return_prob=return_prob)
+                else:
+                    e16.capture(inputs, return_prob=return_prob, lanes=a.lanes)
+                    step16 = lambda: e16.replay()
+                for _ in range(a.warmup):
+                    step16()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    step16()
+                torch.cuda.synchronize()
+                el16 = time.perf_counter() - t0
+                _, q1, _ = e16.forward(synthetic.to_device(inp1, dev), return_prob=False)
+                q1 = q1.float().cpu().numpy()
+                line["f16"] = {"value": a.batch * a.steps / el16, "unit": "maps/s", "ms_per_step": el16 / a.steps * 1e3, "dtype": "f16",
+                               "abs_rel": float(np.mean(np.abs(p0.numpy() - q1) / p0.numpy())),
+                               "rel_l1": float(np.abs(p0.numpy() - q1).sum() / np.abs(p0.numpy()).sum())}
         print(json.dumps(line))
     if dist:
         dist.barrier()

@@ -198,7 +198,7 @@ extern "C" size_t cfp_attn_kv_ws_floats(int NB, int Hk, int Wk, int th, int tw, 
 extern "C" int cfp_attn_kv_reduce(const void* k, int k_ld, const void* v, int v_ld, float* kv, float* ksum, float* ws,
                                   int NB, int Hk, int Wk, int th, int tw, int cy0, int cy1, int cx0, int cx1,
                                   int count_pad, float v_length, int heads, int d, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_attn_kv_reduce: bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_attn_kv_reduce: bad dtype");
   CFP_REQUIRE(k && v && kv && ksum, CFP_EINVAL, "cfp_attn_kv_reduce: null pointer");
   CFP_REQUIRE(NB > 0 && Hk > 0 && Wk > 0 && th > 0 && tw > 0 && heads > 0 && (d == 4 || d == 8 || d == 16 || d == 32) &&
                   k_ld >= heads * d && v_ld >= heads * d && v_length > 0.f,
@@ -218,7 +218,7 @@ extern "C" int cfp_attn_kv_reduce(const void* k, int k_ld, const void* v, int v_
 #define KV_LAUNCH(T, D) hipLaunchKernelGGL((kv_reduce_kernel<T, D>), grid, dim3(64), 0, s, p)
 #define KV_SWITCH(T) switch (d) { case 4: KV_LAUNCH(T, 4); break; case 8: KV_LAUNCH(T, 8); break; \
                                   case 16: KV_LAUNCH(T, 16); break; default: KV_LAUNCH(T, 32); break; }
-  if (dtype == CFP_BF16) { KV_SWITCH(bf16_t) } else { KV_SWITCH(float) }
+  if (dtype == CFP_BF16) { KV_SWITCH(bf16_t) } else if (dtype == CFP_F16) { KV_SWITCH(f16_t) } else { KV_SWITCH(float) }
 #undef KV_SWITCH
 #undef KV_LAUNCH
   if (p.nsplit > 1) {
@@ -233,7 +233,7 @@ extern "C" int cfp_attn_kv_reduce(const void* k, int k_ld, const void* v, int v_
 extern "C" int cfp_attn_apply(const void* q, int q_ld, const float* kv, const float* ksum, void* out, int out_ld,
                               int NB, int Hq, int Wq, int qth, int qtw, int ey0, int ey1, int ex0, int ex1,
                               float v_length, float eps, int heads, int d, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_attn_apply: bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_attn_apply: bad dtype");
   CFP_REQUIRE(q && kv && ksum && out, CFP_EINVAL, "cfp_attn_apply: null pointer");
   CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && heads > 0 && (d == 4 || d == 8 || d == 16 || d == 32) &&
                   q_ld >= heads * d && out_ld >= heads * d, CFP_ESHAPE, "cfp_attn_apply: bad shape");
@@ -247,7 +247,7 @@ extern "C" int cfp_attn_apply(const void* q, int q_ld, const float* kv, const fl
 #define AP_LAUNCH(T, D) hipLaunchKernelGGL((attn_apply_kernel<T, D>), dim3(blocks), dim3(256), 0, s, p)
 #define AP_SWITCH(T) switch (d) { case 4: AP_LAUNCH(T, 4); break; case 8: AP_LAUNCH(T, 8); break; \
                                   case 16: AP_LAUNCH(T, 16); break; default: AP_LAUNCH(T, 32); break; }
-  if (dtype == CFP_BF16) { AP_SWITCH(bf16_t) } else { AP_SWITCH(float) }
+  if (dtype == CFP_BF16) { AP_SWITCH(bf16_t) } else if (dtype == CFP_F16) { AP_SWITCH(f16_t) } else { AP_SWITCH(float) }
 #undef AP_SWITCH
 #undef AP_LAUNCH
   return cfp_check_launch("cfp_attn_apply");

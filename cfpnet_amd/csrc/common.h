@@ -7,10 +7,13 @@
 #include "../../include/cfpnet_hip.h"
 
 typedef unsigned short bf16_t;  // storage type of a bf16 element
+typedef _Float16 f16_t;         // storage type of an IEEE half element (CFP_F16): 10 mantissa bits, |x| <= 65504
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -18,7 +21,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(unsigned short, h);
 }
 
-// One 16-byte vector of T: 4 x f32 or 8 x bf16.
+__device__ __forceinline__ float h2f(f16_t v) { return (float)v; }
+__device__ __forceinline__ f16_t f2h(float f) {   // round-to-nearest-even, saturating: an overflow stays finite
+  return (f16_t)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);
+}
+
+// One 16-byte vector of T: 4 x f32 or 8 x bf16 / f16.
 template <typename T> struct Vec;
 template <> struct Vec<float> {
   static constexpr int N = 4;
@@ -49,12 +57,48 @@ template <> struct Vec<bf16_t> {
   }
 };
 
+template <> struct Vec<f16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const f16_t* p, float* v) {
+    f16x8 x = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+  }
+  __device__ static __forceinline__ void store(f16_t* p, const float* v) {
+    f16x8 x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = f2h(v[i]);
+    *reinterpret_cast<f16x8*>(p) = x;
+  }
+};
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f2h(v); }
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+
+// Two f32 -> one packed dword of H (low half = first element).
+template <typename H> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) {
+  f16x2 h = {f2h(a), f2h(b)};
+  return __builtin_bit_cast(uint32_t, h);
+}
+// 16-bit storage element <-> raw bits (LDS planes, packed stores)
+template <typename H> __device__ __forceinline__ H from_bits(unsigned short b) { return __builtin_bit_cast(H, b); }
+template <typename H> __device__ __forceinline__ unsigned short to_bits(H v) { return __builtin_bit_cast(unsigned short, v); }
+
+// D = A(16x32) * B(32x16) + C on the matrix core for either 16-bit format (same rate, same lane layout).
+template <typename H> __device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, const f32x4& c) {
+  if constexpr (sizeof(H) == 2 && !__is_same(H, bf16_t))
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   switch (act) {
@@ -124,5 +168,7 @@ int cfp_check_launch(const char* what);
   } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static inline int vec_elems(int dtype) { return dtype == CFP_BF16 ? 8 : 4; }
+static inline bool is16(int dtype) { return dtype == CFP_BF16 || dtype == CFP_F16; }
+static inline bool dtype_ok(int dtype) { return dtype == CFP_F32 || is16(dtype); }
+static inline int vec_elems(int dtype) { return is16(dtype) ? 8 : 4; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -29,7 +29,7 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <int TH, int BN, int WM, int WN>
+template <typename H, int TH, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int TW = 16;
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   const int b = bid / tiles_y;
   const int n0 = tile_n * BN, x0 = tx_ * TW, y0 = ty_ * TH;
 
-  const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
-  const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero16b);
+  const H* __restrict__ in = reinterpret_cast<const H*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
+  const H* __restrict__ wt = reinterpret_cast<const H*>(p.w);
+  const H* zsrc = reinterpret_cast<const H*>(g_zero16b);
 
   // ---- per-lane DMA bookkeeping ---------------------------------------------------------------
   int a_off[NAH];       // element offset of the halo pixel inside the image, or -1
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma16<H>(af[i], bfr[j], acc[i][j]);
         }
       }
     }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
 
   constexpr int CP = BN + 8;
   static_assert(BM * CP * 2 <= 2 * A_BYTES + 2 * B_BYTES, "C tile must fit in the operand LDS");
-  bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+  H* sC = reinterpret_cast<H*>(smem);
   float sc[TN], sh[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
         for (int r = 0; r < 4; ++r) {
           const int row = (wm * TM + i) * 16 + fq * 4 + r;
           const int col = wn * (BN / WN) + j * 16 + fr;
-          sC[row * CP + col] = f2bf(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+          sC[row * CP + col] = from_f32<H>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
         }
   });
   __syncthreads();
   constexpr int CH = BN / 8;
-  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
-  const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.res);
+  H* __restrict__ out = reinterpret_cast<H*>(p.out);
+  const H* __restrict__ res = reinterpret_cast<const H*>(p.res);
   for (int q = tid; q < BM * CH; q += 256) {
     const int row = q / CH, ch = q % CH;
     const int y = y0 + row / TW, x = x0 + row % TW;
@@ -189,23 +189,23 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
     u32x4 v = *reinterpret_cast<const u32x4*>(sC + row * CP + ch * 8);
     if (res) {
       float a[8], r8[8];
-      Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v), a);
-      Vec<bf16_t>::load(res + m * p.res_ld + n, r8);
+      Vec<H>::load(reinterpret_cast<const H*>(&v), a);
+      Vec<H>::load(res + m * p.res_ld + n, r8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) a[e] += r8[e];
-      Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(&v), a);
+      Vec<H>::store(reinterpret_cast<H*>(&v), a);
     }
     *reinterpret_cast<u32x4*>(out + m * p.out_ld + n) = v;
   }
 }
 
-template <int TH, int BN, int WM, int WN>
+template <typename H, int TH, int BN, int WM, int WN>
 int launch3(const ConvP& p, hipStream_t s) {
   constexpr int HP = (TH + 2) * 18, NAG = (HP + 7) / 8, NAH = (NAG + 3) / 4, A_BYTES = NAH * 4 * 1024;
   constexpr int NBG = BN * 3 / 8, B_BYTES = ((NBG + 3) / 4) * 4 * 1024;
   constexpr size_t lds = 2 * A_BYTES + 2 * B_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = conv3x3_direct_kernel<TH, BN, WM, WN>;
+  auto k = conv3x3_direct_kernel<H, TH, BN, WM, WN>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
   const long long tiles = (long long)p.B * cdiv(p.Ho, TH) * cdiv(p.Wo, 16) * cdiv(p.Cout, BN);
@@ -225,14 +225,15 @@ void conv3x3_variant_shape(int v, int* th, int* bn) { *th = kCfg3[v].th; *bn = k
 
 // Requirements (checked by the caller): bf16, KH = KW = 3, stride 1, Ho = H + pads - 2 etc. as in ConvP,
 // Cin % 8 == 0, H * W * in_ld < 2^31, Cout * K < 2^31.
+#define L3(...) (p.f16 ? launch3<f16_t, __VA_ARGS__>(p, s) : launch3<bf16_t, __VA_ARGS__>(p, s))
 int conv3x3_launch(int v, const ConvP& p, hipStream_t s) {
   switch (v) {
-    case 0: return launch3<8, 128, 2, 2>(p, s);
-    case 1: return launch3<8, 64, 2, 2>(p, s);
-    case 2: return launch3<16, 64, 4, 1>(p, s);
-    case 3: return launch3<16, 32, 4, 1>(p, s);
-    case 4: return launch3<8, 32, 4, 1>(p, s);
-    case 5: return launch3<16, 16, 4, 1>(p, s);
+    case 0: return L3(8, 128, 2, 2);
+    case 1: return L3(8, 64, 2, 2);
+    case 2: return L3(16, 64, 4, 1);
+    case 3: return L3(16, 32, 4, 1);
+    case 4: return L3(8, 32, 4, 1);
+    case 5: return L3(16, 16, 4, 1);
     default: return -3;
   }
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     // C-tile pitch (elements): padded by one 16-byte chunk when the operand LDS has room
     constexpr int CP = (BM * (BN + 8) * 2 <= 2 * (BM + BN) * 64) ? BN + 8 : BN;
     static_assert(BM * CP * 2 <= 2 * (BM + BN) * 64, "C tile must fit in the operand LDS");
-    bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+    T* sC = reinterpret_cast<T*>(smem);
     with_act(p.act, [&](auto A) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           for (int r = 0; r < 4; ++r) {
             int row = wm * (BM / WM) + i * 16 + fq * 4 + r;
             int col = wn * (BN / WN) + j * 16 + fr;
-            sC[row * CP + col] = f2bf(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+            sC[row * CP + col] = from_f32<T>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
           }
     });
     __syncthreads();
@@ -89,13 +89,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       u32x4 v = *reinterpret_cast<const u32x4*>(sC + row * CP + ch * 8);
       if (res) {
         float a[8], b[8];
-        Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(&v), a);
-        Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(res) + (long long)m * p.res_ld + n, b);
+        Vec<T>::load(reinterpret_cast<const T*>(&v), a);
+        Vec<T>::load(res + (long long)m * p.res_ld + n, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += b[e];
-        Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(&v), a);
+        Vec<T>::store(reinterpret_cast<T*>(&v), a);
       }
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(out) + (long long)m * p.out_ld + n) = v;
+      *reinterpret_cast<u32x4*>(out + (long long)m * p.out_ld + n) = v;
     }
   } else {
     with_act(p.act, [&](auto A) {
@@ -220,7 +220,7 @@ int tile_count(int variant, int M, int Cout) {
 
 // K-splits for a problem: only when the grid would leave most CUs idle and K is long.
 int pick_splits(int M, int Cout, int K, int dtype) {
-  const int bk = dtype == CFP_BF16 ? 32 : 16;
+  const int bk = is16(dtype) ? 32 : 16;
   const int nk = cdiv(K, bk);
   const int tiles = tile_count(cfp_conv2d_variant(M, Cout), M, Cout);
   if (tiles >= 128 || nk < 16) return 1;
@@ -328,7 +328,7 @@ int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cou
 
 extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                                int* splits) {
-  if (dtype == CFP_BF16 && !g_use_v1) {
+  if (is16(dtype) && !g_use_v1) {
     Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
     if (pl.direct >= 0) {
       if (variant) *variant = 200 + pl.direct;
@@ -364,7 +364,7 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
                                   int dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                   int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   CFP_REQUIRE(in && w && out, CFP_EINVAL, "cfp_conv2d_nhwc: null pointer");
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_conv2d_nhwc: bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_nhwc: bad dtype");
   const int ve = vec_elems(dtype);
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0,
               CFP_ESHAPE, "cfp_conv2d_nhwc: non-positive dimension");
@@ -386,12 +386,12 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
   p.in_ld = in_ld; p.out_ld = out_ld; p.res_ld = res_ld;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act;
+  p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act; p.f16 = dtype == CFP_F16;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W) ? 1 : 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-  const bool gen2 = dtype == CFP_BF16 && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
+  const bool gen2 = is16(dtype) && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
                     (long long)H * W * in_ld < (1ll << 30);
   if (gen2) {
     const int rpb = per_image_weights ? Ho * Wo : 0;
@@ -415,7 +415,8 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
     if (pl.splits > 1) {
       long long total = (long long)p.M * (Cout / 8);
       int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-      hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
+      if (p.f16) hipLaunchKernelGGL(splitk_reduce_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
+      else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
     }
     int e = cfp_check_launch("cfp_conv2d_nhwc");
     if (e != CFP_OK || !ln_after) return e;
@@ -427,7 +428,7 @@ gen1_path:
   // LayerNorm as a second kernel
   if (ln_gamma) p.res = nullptr;
   const int nimg = per_image_weights ? B : 1;
-  const size_t esz = dtype == CFP_BF16 ? 2 : 4;
+  const size_t esz = is16(dtype) ? 2 : 4;
   for (int b = 0; b < nimg; ++b) {
     ConvP q = p;
     if (per_image_weights) {
@@ -439,7 +440,7 @@ gen1_path:
     }
     int splits = pick_splits(q.M, Cout, q.K, dtype);
     if (splits > 1 && (!ws || ws_bytes < (size_t)splits * q.M * Cout * sizeof(float))) splits = 1;
-    if (dtype == CFP_BF16) dispatch<bf16_t>(q, (float*)ws, splits, s); else dispatch<float>(q, (float*)ws, splits, s);
+    if (dtype == CFP_BF16) dispatch<bf16_t>(q, (float*)ws, splits, s); else if (dtype == CFP_F16) dispatch<f16_t>(q, (float*)ws, splits, s); else dispatch<float>(q, (float*)ws, splits, s);
   }
   int e = cfp_check_launch("cfp_conv2d_nhwc");
   if (e != CFP_OK || !ln_gamma) return e;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK>
+template <typename H, int BM, int BN, int WM, int WN, int STAGES, bool SPLITK>
 __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict__ slabs, int splits) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int TM = BM / WM / 16;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   const int tile_n = bid % tiles_n;
   const int tile_m = bid / tiles_n;
   int m0, m_end;
-  const bf16_t* __restrict__ wt = reinterpret_cast<const bf16_t*>(p.w);
+  const H* __restrict__ wt = reinterpret_cast<const H*>(p.w);
   if (p.rows_per_batch > 0) {
     const int tpb = (p.rows_per_batch + BM - 1) / BM;
     const int b = tile_m / tpb;
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
     k0 = sp * per;
     k1 = min(nk_all, k0 + per);
   }
-  const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
+  const H* __restrict__ in = reinterpret_cast<const H*>(p.in);
 
   // ---- per-lane row bookkeeping -----------------------------------------------------------
-  const bf16_t* a_ptr[NA];
+  const H* a_ptr[NA];
   int a_hi0[NA], a_wi0[NA];
   unsigned a_okmask = 0;
 #pragma unroll
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       a_ptr[i] = in + (((long long)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.in_ld;   // virtual when in the halo
     }
   }
-  const bf16_t* b_ptr[NB];
+  const H* b_ptr[NB];
   unsigned b_okmask = 0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
     if (ok) b_okmask |= 1u << j;
     b_ptr[j] = wt + (long long)(ok ? n : 0) * p.K;
   }
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero16);
+  const H* zsrc = reinterpret_cast<const H*>(g_zero16);
   // im2col position (tap row/column, channel offset) of this lane's chunk in the NEXT K-step to be
   // issued; advanced by 64 channels per K-step without divisions (K-steps are issued in order).
   int i_cc = 0, i_kh = 0, i_kw = 0;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<H>(af[i], bfr[j], acc[i][j]);
     }
   }
   wait_vmcnt<0>();
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   } else {
     constexpr int CP = BN + 8;   // C-tile pitch in elements (one 16-byte chunk of padding)
     static_assert(BM * CP * 2 <= STAGES * STAGE_BYTES, "C tile must fit in the operand LDS");
-    bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+    H* sC = reinterpret_cast<H*>(smem);
     float sc[TN], sh[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -244,13 +244,13 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
           for (int r = 0; r < 4; ++r) {
             const int row = a_row0 + i * 16 + fq * 4 + r;
             const int col = b_row0 + j * 16 + fr;
-            sC[row * CP + col] = f2bf(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+            sC[row * CP + col] = from_f32<H>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
           }
     });
     __syncthreads();
     constexpr int CH = BN / 8;   // 16-byte chunks per tile row (a power of two <= 16)
-    bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
-    const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.res);
+    H* __restrict__ out = reinterpret_cast<H*>(p.out);
+    const H* __restrict__ res = reinterpret_cast<const H*>(p.res);
     const bool ln = p.ln_gamma != nullptr;   // host guarantees Cout == BN
     float g[8], bt[8];
     if (ln) {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       const int m = m0 + row, n = n0 + ch * 8;
       const bool live = m < m_end && n < p.Cout;
       float a[8];
-      Vec<bf16_t>::load(sC + row * CP + ch * 8, a);
+      Vec<H>::load(sC + row * CP + ch * 8, a);
       if (ln) {   // all CH lanes of a row are in one wave and take this branch together
         float s = 0.f;
 #pragma unroll
@@ -283,12 +283,12 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       if (!live) continue;
       if (res) {
         float b[8];
-        Vec<bf16_t>::load(res + (long long)m * p.res_ld + n, b);
+        Vec<H>::load(res + (long long)m * p.res_ld + n, b);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += b[e];
       }
       if (ln || res) {
-        Vec<bf16_t>::store(out + (long long)m * p.out_ld + n, a);
+        Vec<H>::store(out + (long long)m * p.out_ld + n, a);
       } else {
         *reinterpret_cast<u32x4*>(out + (long long)m * p.out_ld + n) = *reinterpret_cast<const u32x4*>(sC + row * CP + ch * 8);
       }
@@ -319,19 +319,19 @@ constexpr Cfg kCfg[] = {
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <typename H, int BM, int BN, int WM, int WN, int STAGES>
 int launch2(const ConvP& p, float* slabs, int splits, hipStream_t s) {
   const size_t lds = (size_t)STAGES * (BM + BN) * 128;
   if (lds > 160 * 1024) return -1;
   long long tiles_m = p.rows_per_batch > 0 ? (long long)p.B * cdiv(p.rows_per_batch, BM) : cdiv(p.M, BM);
   long long tiles = tiles_m * cdiv(p.Cout, BN);
   if (splits <= 1) {
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, false>;
+    auto k = igemm2_kernel<H, BM, BN, WM, WN, STAGES, false>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, slabs, 1);
   } else {
-    auto k = igemm2_kernel<BM, BN, WM, WN, STAGES, true>;
+    auto k = igemm2_kernel<H, BM, BN, WM, WN, STAGES, true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, p, slabs, splits);
@@ -345,25 +345,26 @@ int igemm2_num_variants() { return kNumCfg; }
 void igemm2_variant_shape(int v, int* bm, int* bn, int* stages) { *bm = kCfg[v].bm; *bn = kCfg[v].bn; *stages = kCfg[v].stages; }
 
 // Launch variant v.  Returns 0, or a negative value if the variant cannot run this problem.
+#define L2(...) (p.f16 ? launch2<f16_t, __VA_ARGS__>(p, slabs, splits, s) : launch2<bf16_t, __VA_ARGS__>(p, slabs, splits, s))
 int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s) {
   switch (v) {
-    case 0: return launch2<128, 128, 2, 2, 3>(p, slabs, splits, s);
-    case 1: return launch2<128, 128, 2, 2, 2>(p, slabs, splits, s);
-    case 2: return launch2<128, 64, 2, 2, 3>(p, slabs, splits, s);
-    case 3: return launch2<128, 64, 2, 2, 4>(p, slabs, splits, s);
-    case 4: return launch2<64, 64, 2, 2, 3>(p, slabs, splits, s);
-    case 5: return launch2<64, 64, 2, 2, 4>(p, slabs, splits, s);
-    case 6: return launch2<256, 32, 4, 1, 3>(p, slabs, splits, s);
-    case 7: return launch2<256, 32, 4, 1, 2>(p, slabs, splits, s);
-    case 8: return launch2<128, 32, 4, 1, 3>(p, slabs, splits, s);
-    case 9: return launch2<128, 32, 4, 1, 4>(p, slabs, splits, s);
-    case 10: return launch2<256, 16, 4, 1, 2>(p, slabs, splits, s);
-    case 11: return launch2<128, 16, 4, 1, 4>(p, slabs, splits, s);
-    case 12: return launch2<64, 128, 2, 2, 3>(p, slabs, splits, s);
-    case 13: return launch2<64, 64, 2, 2, 2>(p, slabs, splits, s);
-    case 14: return launch2<128, 64, 2, 2, 2>(p, slabs, splits, s);
-    case 15: return launch2<64, 128, 2, 2, 2>(p, slabs, splits, s);
-    case 16: return launch2<128, 32, 4, 1, 2>(p, slabs, splits, s);
+    case 0: return L2(128, 128, 2, 2, 3);
+    case 1: return L2(128, 128, 2, 2, 2);
+    case 2: return L2(128, 64, 2, 2, 3);
+    case 3: return L2(128, 64, 2, 2, 4);
+    case 4: return L2(64, 64, 2, 2, 3);
+    case 5: return L2(64, 64, 2, 2, 4);
+    case 6: return L2(256, 32, 4, 1, 3);
+    case 7: return L2(256, 32, 4, 1, 2);
+    case 8: return L2(128, 32, 4, 1, 3);
+    case 9: return L2(128, 32, 4, 1, 4);
+    case 10: return L2(256, 16, 4, 1, 2);
+    case 11: return L2(128, 16, 4, 1, 4);
+    case 12: return L2(64, 128, 2, 2, 3);
+    case 13: return L2(64, 64, 2, 2, 2);
+    case 14: return L2(128, 64, 2, 2, 2);
+    case 15: return L2(64, 128, 2, 2, 2);
+    case 16: return L2(128, 32, 4, 1, 2);
     default: return -3;
   }
 }

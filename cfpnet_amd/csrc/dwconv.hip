@@ -24,6 +24,15 @@ template <> __device__ __forceinline__ void unpack_masked<bf16_t>(const u32x4& r
     v[2 * i + 1] = __uint_as_float(x & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void unpack_masked<f16_t>(const u32x4& raw, bool ok, float* v) {
+  const uint32_t m = ok ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f16x2 h = __builtin_bit_cast(f16x2, raw[i] & m);
+    v[2 * i] = (float)h[0];
+    v[2 * i + 1] = (float)h[1];
+  }
+}
 template <> __device__ __forceinline__ void unpack_masked<float>(const u32x4& raw, bool ok, float* v) {
   const uint32_t m = ok ? 0xffffffffu : 0u;
 #pragma unroll
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
 //     later run reads (raster order), so there is no second LDS tile and the copy-out is fully
 //     coalesced 16-byte stores;
 //   * channel sums: per-lane over its pixels, then a 16-lane shuffle reduction; no cross-wave step.
-template <int STRIDE, int CVB>
+template <typename HT, int STRIDE, int CVB>
 __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restrict__ in, int in_ld, const bf16_t* __restrict__ w,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          bf16_t* __restrict__ out, int out_ld, float* __restrict__ partial, int B,
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
 #pragma unroll
           for (int pr = 0; pr < 5; ++pr)
 #pragma unroll
-            for (int t = 0; t < UN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[pr], bfr[t][pr], acc[t], 0, 0, 0);
+            for (int t = 0; t < UN; ++t) acc[t] = mfma16<HT>(afr[pr], bfr[t][pr], acc[t]);
           float y[UN][4];
 #pragma unroll
           for (int t = 0; t < UN; ++t)
@@ -333,8 +342,8 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
           for (int t = 0; t < UN; ++t) {
             if (vf[t] != 0.f) {        // D: lane holds channels cbase + 4q .. +3 of pixel j
               uint2 pk;
-              pk.x = (uint32_t)f2bf(y[t][0]) | ((uint32_t)f2bf(y[t][1]) << 16);
-              pk.y = (uint32_t)f2bf(y[t][2]) | ((uint32_t)f2bf(y[t][3]) << 16);
+              pk.x = pack2<HT>(y[t][0], y[t][1]);
+              pk.y = pack2<HT>(y[t][2], y[t][3]);
               *reinterpret_cast<uint2*>(tile + base[t] + ooff) = pk;
             }
           }
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(512) void dwlarge_kernel(const T* __restrict__ in, 
 //     few kernel rows ahead, and applies each fragment to its 4 output tiles;
 //   * epilogue: BN scale/shift + activation, results written in place into the wave's own plane, then a coalesced
 //     NHWC copy-out (16 bytes = 8 channels per pixel).
-template <int K, int TH, int TW>
+template <typename HT, int K, int TH, int TW>
 __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restrict__ in, int in_ld, const bf16_t* __restrict__ tb,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            bf16_t* __restrict__ out, int out_ld, int B, int H, int W, int C, int act) {
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
           for (int t = 0; t < NT; ++t)
             afr[t] = *reinterpret_cast<const s16x8*>(pl + abase + ((t / NTX) * 16 + ky) * PITCH + (t % NTX) * 16 + h * 32);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[t], bcur[u][h], acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = mfma16<HT>(afr[t], bcur[u][h], acc[t]);
         }
       }
     }
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        plw[((t / NTX) * 16 + 4 * q + r) * PITCH + (t % NTX) * 16 + j] = f2bf(act_c<decltype(A)::value>(acc[t][r] * sc + sh));
+        plw[((t / NTX) * 16 + 4 * q + r) * PITCH + (t % NTX) * 16 + j] = to_bits<HT>(from_f32<HT>(act_c<decltype(A)::value>(acc[t][r] * sc + sh)));
   });
   __syncthreads();
   // ---- coalesced NHWC copy-out -------------------------------------------------------------------------------
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(512) void dwlarge_mfma_kernel(const bf16_t* __restr
   }
 }
 
-template <int K, int TH, int TW>
+template <typename HT, int K, int TH, int TW>
 hipError_t launch_dwlarge_mfma(const void* in, int in_ld, const void* tb, const float* scale, const float* shift, void* out, int out_ld,
                                int B, int H, int W, int C, int act, hipStream_t s) {
   constexpr int HALO = (K - 1) / 2, LM = (HALO + 7) / 8 * 8, NH = (16 + LM + HALO + 31) / 32;
@@ -621,12 +630,12 @@ hipError_t launch_dwlarge_mfma(const void* in, int in_ld, const void* tb, const 
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_mfma_kernel<K, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_mfma_kernel<HT, K, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
   long long blocks = (long long)B * cdiv(H, TH) * cdiv(W, TW) * (C / 8);
-  hipLaunchKernelGGL((dwlarge_mfma_kernel<K, TH, TW>), dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)tb, scale,
+  hipLaunchKernelGGL((dwlarge_mfma_kernel<HT, K, TH, TW>), dim3((unsigned)blocks), dim3(512), lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)tb, scale,
                      shift, (bf16_t*)out, out_ld, B, H, W, C, act);
   return hipSuccess;
 }
@@ -781,14 +790,14 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
                  float* partial, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
                  cfp_stream_t stream, const char* who) {
   CFP_REQUIRE(in && w && out && scale && shift, CFP_EINVAL, std::string(who) + ": null pointer");
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, std::string(who) + ": bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, std::string(who) + ": bad dtype");
   const int ve = vec_elems(dtype);
   CFP_REQUIRE(stride == 1 || stride == 2, CFP_ESHAPE, std::string(who) + ": stride must be 1 or 2");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && out_ld % ve == 0 &&
                   in_ld >= C && out_ld >= C, CFP_ESHAPE, std::string(who) + ": bad shape");
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
               std::string(who) + ": pointers must be 16-byte aligned");
-  const bool mfma = dtype == CFP_BF16 && C % 16 == 0 && !g_dw_valu;
+  const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
   const DwPlan d = dw_plan(B, Ho, Wo, C, stride, ve, mfma);
   CFP_REQUIRE((long long)B * d.nstrips <= 65535, CFP_ESHAPE, std::string(who) + ": grid too large");
   CFP_REQUIRE(d.lds <= 64 * 1024, CFP_ESHAPE, std::string(who) + ": map too wide for the LDS strip");
@@ -806,20 +815,22 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
                        (T*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);                  \
   } while (0)
 #define DW_CVB(T, S) do { if (d.cvb == 16) DW_LAUNCH(T, S, 16); else DW_LAUNCH(T, S, 8); } while (0)
-#define DWM_LAUNCH(S, V)                                                                                                  \
+#define DWM_LAUNCH(HH, S, V)                                                                                                  \
   do {                                                                                                                    \
     static bool attr = false;                                                                                             \
     if (!attr) {                                                                                                          \
-      hipError_t e = hipFuncSetAttribute((const void*)dw3x3_mfma_kernel<S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+      hipError_t e = hipFuncSetAttribute((const void*)dw3x3_mfma_kernel<HH, S, V>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
       if (e != hipSuccess) { cfp_set_error(std::string(who) + ": " + hipGetErrorString(e)); return CFP_EHIP; }            \
       attr = true;                                                                                                        \
     }                                                                                                                     \
-    hipLaunchKernelGGL((dw3x3_mfma_kernel<S, V>), grid, dim3(256), d.lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)w, scale, \
+    hipLaunchKernelGGL((dw3x3_mfma_kernel<HH, S, V>), grid, dim3(256), d.lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)w, scale, \
                        shift, (bf16_t*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);      \
   } while (0)
-#define DWM_CVB(S) do { if (d.cvb == 16) DWM_LAUNCH(S, 16); else DWM_LAUNCH(S, 8); } while (0)
-  if (mfma) { if (stride == 1) DWM_CVB(1); else DWM_CVB(2); }
+#define DWM_CVB(HH, S) do { if (d.cvb == 16) DWM_LAUNCH(HH, S, 16); else DWM_LAUNCH(HH, S, 8); } while (0)
+  if (mfma && dtype == CFP_F16) { if (stride == 1) DWM_CVB(f16_t, 1); else DWM_CVB(f16_t, 2); }
+  else if (mfma) { if (stride == 1) DWM_CVB(bf16_t, 1); else DWM_CVB(bf16_t, 2); }
   else if (dtype == CFP_BF16) { if (stride == 1) DW_CVB(bf16_t, 1); else DW_CVB(bf16_t, 2); }
+  else if (dtype == CFP_F16) { if (stride == 1) DW_CVB(f16_t, 1); else DW_CVB(f16_t, 2); }
   else { if (stride == 1) DW_CVB(float, 1); else DW_CVB(float, 2); }
 #undef DWM_CVB
 #undef DWM_LAUNCH
@@ -840,7 +851,7 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
-  return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype), dtype == CFP_BF16 && C % 16 == 0 && !g_dw_valu).nstrips;
+  return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype), is16(dtype) && C % 16 == 0 && !g_dw_valu).nstrips;
 }
 
 extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
@@ -855,7 +866,7 @@ extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, 
                                      const float* shift, void* out, int out_ld, int B, int H, int W, int C, int k,
                                      int act, int dtype, cfp_stream_t stream) {
   CFP_REQUIRE(in && w && out && scale && shift, CFP_EINVAL, "cfp_dwconv_large_nhwc: null pointer");
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_dwconv_large_nhwc: bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_dwconv_large_nhwc: bad dtype");
   const int ve = vec_elems(dtype);
   CFP_REQUIRE(k >= 3 && k <= 31 && (k & 1), CFP_ESHAPE, "cfp_dwconv_large_nhwc: k must be odd, 3..31");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in_ld % ve == 0 && out_ld % ve == 0 && in_ld >= C &&
@@ -865,6 +876,7 @@ extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipError_t e = dtype == CFP_BF16
       ? launch_dwlarge_any<bf16_t>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, k, act, s)
+      : dtype == CFP_F16 ? launch_dwlarge_any<f16_t>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, k, act, s)
       : launch_dwlarge_any<float>(in, in_ld, w, scale, shift, out, out_ld, B, H, W, C, k, act, s);
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
   return cfp_check_launch("cfp_dwconv_large_nhwc");
@@ -881,7 +893,7 @@ extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void*
                                           void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                                           cfp_stream_t stream) {
   CFP_REQUIRE(in && toeplitz && out && scale && shift, CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: null pointer");
-  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: bf16 only (f32 uses cfp_dwconv_large_nhwc)");
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: bf16/f16 only (f32 uses cfp_dwconv_large_nhwc)");
   CFP_REQUIRE(k == 7 || k == 15 || k == 31, CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: k must be 7, 15 or 31");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= C && out_ld >= C,
               CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: bad shape");
@@ -889,9 +901,11 @@ extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void*
   CFP_REQUIRE((long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: grid too large");
   (void)0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = k == 31 ? launch_dwlarge_mfma<31, 64, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
-               : k == 15 ? launch_dwlarge_mfma<15, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s)
-                         : launch_dwlarge_mfma<7, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s);
+#define DWL(HH) (k == 31 ? launch_dwlarge_mfma<HH, 31, 64, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s) \
+               : k == 15 ? launch_dwlarge_mfma<HH, 15, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s) \
+                         : launch_dwlarge_mfma<HH, 7, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s))
+  hipError_t e = dtype == CFP_F16 ? DWL(f16_t) : DWL(bf16_t);
+#undef DWL
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_mfma_nhwc: ") + hipGetErrorString(e)); return CFP_EHIP; }
   return cfp_check_launch("cfp_dwconv_large_mfma_nhwc");
 }

@@ -175,7 +175,7 @@ extern "C" int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw,
 
 extern "C" int cfp_bin_softmax(const void* logits, int ld, const float* centers, void* prob, float* pred, int B, int HW,
                                int nbins, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, "cfp_bin_softmax: bad dtype");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_bin_softmax: bad dtype");
   CFP_REQUIRE(logits && centers && pred, CFP_EINVAL, "cfp_bin_softmax: null pointer");
   CFP_REQUIRE(B > 0 && B <= 65535 && HW > 0 && (nbins == 256 || nbins == 128 || nbins == 64) && ld >= nbins, CFP_ESHAPE,
               "cfp_bin_softmax: nbins must be 64, 128 or 256");
@@ -190,7 +190,7 @@ extern "C" int cfp_bin_softmax(const void* logits, int ld, const float* centers,
                        centers, (T*)prob, pred, HW);                                                               \
   } while (0)
 #define SM_SWITCH(T) switch (nbins) { case 256: SM_LAUNCH(T, 256); break; case 128: SM_LAUNCH(T, 128); break; default: SM_LAUNCH(T, 64); break; }
-  if (dtype == CFP_BF16) { SM_SWITCH(bf16_t); } else { SM_SWITCH(float); }
+  if (dtype == CFP_BF16) { SM_SWITCH(bf16_t); } else if (dtype == CFP_F16) { SM_SWITCH(f16_t); } else { SM_SWITCH(float); }
 #undef SM_SWITCH
 #undef SM_LAUNCH
   return cfp_check_launch("cfp_bin_softmax");
@@ -204,8 +204,9 @@ extern "C" int cfp_bin_softmax(const void* logits, int ld, const float* centers,
 namespace {
 constexpr int HBM_ = 128, HBN_ = 256, HPITCH = HBM_ + 8;
 
+template <typename H>
 __global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const float* __restrict__ bias,
-                                                             const float* __restrict__ centers, bf16_t* __restrict__ prob,
+                                                             const float* __restrict__ centers, H* __restrict__ prob,
                                                              float* __restrict__ pred, int HW) {
   constexpr int TM = 2, TN = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const floa
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * HBM_;
   f32x4 acc[TM][TN];
-  igemm_mainloop<bf16_t, HBM_, HBN_, 4, 1>(p, m0, 0, 0, (p.K + 31) / 32, smem, acc);
+  igemm_mainloop<H, HBM_, HBN_, 4, 1>(p, m0, 0, 0, (p.K + 31) / 32, smem, acc);
   __syncthreads();
-  bf16_t* sP = reinterpret_cast<bf16_t*>(smem);      // [256][HPITCH]
+  H* sP = reinterpret_cast<H*>(smem);      // [256][HPITCH]
   float bs[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bs[j] = bias[j * 16 + fr];
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const floa
     if (prob) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        uint32_t lo = (uint32_t)f2bf(pr[0][j]) | ((uint32_t)f2bf(pr[1][j]) << 16);
-        uint32_t hi = (uint32_t)f2bf(pr[2][j]) | ((uint32_t)f2bf(pr[3][j]) << 16);
+        uint32_t lo = pack2<H>(pr[0][j], pr[1][j]);
+        uint32_t hi = pack2<H>(pr[2][j], pr[3][j]);
         uint2 v = {lo, hi};
         *reinterpret_cast<uint2*>(sP + (j * 16 + fr) * HPITCH + row0) = v;
       }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const floa
 
 extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
                                   void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_bin_head_fused: bf16 only (use cfp_conv2d_nhwc + cfp_bin_softmax for f32)");
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_bin_head_fused: bf16/f16 only (use cfp_conv2d_nhwc + cfp_bin_softmax for f32)");
   CFP_REQUIRE(x && w && bias && centers && pred, CFP_EINVAL, "cfp_bin_head_fused: null pointer");
   CFP_REQUIRE(B > 0 && HW > 0 && HW % 8 == 0 && Cin > 0 && Cin % 8 == 0 && x_ld % 8 == 0 && x_ld >= Cin &&
                   (long long)B * HW < (1ll << 31), CFP_ESHAPE, "cfp_bin_head_fused: bad shape (HW and Cin must be multiples of 8)");
@@ -283,13 +284,19 @@ extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const 
   p.in_ld = x_ld; p.out_ld = 0; p.res_ld = 0;
   p.B = 1; p.H = 1; p.W = B * HW; p.Cin = Cin; p.Ho = 1; p.Wo = B * HW; p.Cout = HBN_;
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
-  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.f16 = dtype == CFP_F16;
   size_t lds = (size_t)HBN_ * HPITCH * sizeof(bf16_t);
   size_t ops_lds = 2 * (HBM_ + HBN_) * 64;
   if (lds < ops_lds) lds = ops_lds;
-  hipError_t e = hipFuncSetAttribute((const void*)bin_head_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = dtype == CFP_F16
+      ? hipFuncSetAttribute((const void*)bin_head_fused_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipFuncSetAttribute((const void*)bin_head_fused_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_bin_head_fused: ") + hipGetErrorString(e)); return CFP_EHIP; }
-  hipLaunchKernelGGL(bin_head_fused_kernel, dim3(cdiv(p.M, HBM_)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p, bias,
-                     centers, (bf16_t*)prob, pred, HW);
+  if (dtype == CFP_F16)
+    hipLaunchKernelGGL(bin_head_fused_kernel<f16_t>, dim3(cdiv(p.M, HBM_)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p, bias,
+                       centers, (f16_t*)prob, pred, HW);
+  else
+    hipLaunchKernelGGL(bin_head_fused_kernel<bf16_t>, dim3(cdiv(p.M, HBM_)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p, bias,
+                       centers, (bf16_t*)prob, pred, HW);
   return cfp_check_launch("cfp_bin_head_fused");
 }

@@ -21,6 +21,7 @@ struct ConvP {
   float ln_eps;
   int rows_per_batch;      // > 0: M-tiles do not straddle images and image b uses weights w + b * w_bstride
   long long w_bstride;     // elements
+  int f16;                 // 16-bit storage is IEEE half (CFP_F16) instead of bf16
 };
 
 // conv_igemm2.hip
@@ -174,7 +175,7 @@ __device__ __forceinline__ void igemm_mainloop(const ConvP& p, int m0, int n0, i
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<T>(af[i], bfr[j], acc[i][j]);
     } else {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {   // four 16x16x4 steps cover BK = 16

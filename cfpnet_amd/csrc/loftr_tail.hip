@@ -25,9 +25,9 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-struct TailP {
-  const bf16_t* q; const float* kv; const float* ksum; const bf16_t* x; bf16_t* out;
-  const bf16_t* wm; const bf16_t* w0; const bf16_t* w2;
+template <typename H> struct TailP {
+  const H* q; const float* kv; const float* ksum; const H* x; H* out;
+  const H* wm; const H* w0; const H* w2;
   const float* g1; const float* b1; const float* g2; const float* b2;
   int q_ld, x_ld, out_ld;
   int rows, Hq, Wq, qth, qtw, ggy, ggx;
@@ -37,8 +37,8 @@ struct TailP {
 // One GEMM of the chain for this wave's 16 rows: acc[j] += A[16 x K] * W[N x K]^T, N = NT * 16.
 // `afrag(k)` returns the lane's A fragment for columns [k, k + 32) of the wave-private operand.
 // All four waves of the workgroup must call it together (they share the weight slabs).
-template <int NT, int BSTAGE, typename AF>
-__device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const bf16_t* __restrict__ W, int K, AF afrag, unsigned char* sB,
+template <typename H, int NT, int BSTAGE, typename AF>
+__device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict__ W, int K, AF afrag, unsigned char* sB,
                                           int wave, int lane) {
   constexpr int N = NT * 16;
   constexpr int NBG = N / 8;                  // 8-row DMA groups of a weight slab
@@ -46,7 +46,7 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const bf16_t* __rest
   const int fr = lane & 15, fq = lane >> 4;
   const int rsub = lane >> 3;
   const int lc = (lane & 7) ^ rsub;
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_zero16c);
+  const H* zsrc = reinterpret_cast<const H*>(g_zero16c);
   const int nk = (K + 63) >> 6;
   auto issue = [&](int ks, int st) {
     const int kk = ks * 64 + lc * 8;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const s16x8 b = *reinterpret_cast<const s16x8*>(cB + (j * 16 + fr) * 128 + (((sub * 4 + fq) ^ (fr & 7)) * 16));
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+          acc[j] = mfma16<H>(a, b, acc[j]);
         }
       }
     }
@@ -86,7 +86,7 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const bf16_t* __rest
 
 // LayerNorm over the N = NT*16 columns of each of this lane's 4 rows (row = fq*4 + r, col = j*16 + fr);
 // the values are first rounded to bf16 (the unfused path stores the GEMM output in bf16).
-template <int NT>
+template <typename H, int NT>
 __device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __restrict__ gamma, const float* __restrict__ beta,
                                                float eps, int fr) {
   constexpr float inv_n = 1.f / (float)(NT * 16);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __
   for (int r = 0; r < 4; ++r) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { acc[j][r] = bf2f(f2bf(acc[j][r])); s += acc[j][r]; }
+    for (int j = 0; j < NT; ++j) { acc[j][r] = to_f32<H>(from_f32<H>(acc[j][r])); s += acc[j][r]; }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const float mean = s * inv_n;
@@ -112,8 +112,8 @@ __device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __
   }
 }
 
-template <int D, int HEADS>
-__global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
+template <typename H, int D, int HEADS>
+__global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   constexpr int d = D / HEADS;
   constexpr int PA = D + 8, PH = 2 * D + 8;               // row pitches (elements): +16 bytes
   constexpr int WAVE_LDS = (2 * PA + PH) * 16 * 2;         // msg/y1 | x | h tiles of one wave
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   unsigned char* sB = smem;
-  bf16_t* tMsg = reinterpret_cast<bf16_t*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
-  bf16_t* tX = tMsg + 16 * PA;
-  bf16_t* tH = tX + 16 * PA;
+  H* tMsg = reinterpret_cast<H*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  H* tX = tMsg + 16 * PA;
+  H* tH = tX + 16 * PA;
   const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
 
   // ---- x tile -> LDS (16-byte vectors) -----------------------------------------------------------
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
       const int h = fq + 4 * hs;
       const float* __restrict__ kv = p.kv + (g * HEADS + h) * d * d;
       const float* __restrict__ ks = p.ksum + (g * HEADS + h) * d;
-      const bf16_t* qp = p.q + mm * p.q_ld + h * d;
+      const H* qp = p.q + mm * p.q_ld + h * d;
       float qv[d];
       if constexpr (d >= 8) {
 #pragma unroll
-        for (int c = 0; c < d; c += 8) Vec<bf16_t>::load(qp + c, qv + c);
+        for (int c = 0; c < d; c += 8) Vec<H>::load(qp + c, qv + c);
       } else {
 #pragma unroll
-        for (int c = 0; c < d; ++c) qv[c] = bf2f(qp[c]);
+        for (int c = 0; c < d; ++c) qv[c] = to_f32<H>(qp[c]);
       }
       float o[d];
 #pragma unroll
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
       }
       const float zi = 1.f / (z + p.eps);                    // (o * 1/(z+eps)) * S, as attention.py:48-49
 #pragma unroll
-      for (int j = 0; j < d; ++j) tMsg[r * PA + h * d + j] = ok ? f2bf(o[j] * zi * p.v_length) : (bf16_t)0;
+      for (int j = 0; j < d; ++j) tMsg[r * PA + h * d + j] = ok ? from_f32<H>(o[j] * zi * p.v_length) : from_bits<H>(0);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -189,40 +189,40 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
   // ---- merge + norm1 -------------------------------------------------------------------------------
   {
     f32x4 acc[D / 16];
-    tail_gemm<D / 16, BSTAGE>(acc, p.wm, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tMsg + fr * PA + k + fq * 8); }, sB, wave, lane);
-    tail_layernorm<D / 16>(acc, p.g1, p.b1, p.ln_eps, fr);
+    tail_gemm<H, D / 16, BSTAGE>(acc, p.wm, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tMsg + fr * PA + k + fq * 8); }, sB, wave, lane);
+    tail_layernorm<H, D / 16>(acc, p.g1, p.b1, p.ln_eps, fr);
 #pragma unroll
     for (int j = 0; j < D / 16; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tMsg[(fq * 4 + r) * PA + j * 16 + fr] = f2bf(acc[j][r]);   // y1 replaces msg
+      for (int r = 0; r < 4; ++r) tMsg[(fq * 4 + r) * PA + j * 16 + fr] = from_f32<H>(acc[j][r]);   // y1 replaces msg
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // ---- mlp.0: [x | y1] (K = 2D) -> 2D, ReLU ---------------------------------------------------------
   {
     f32x4 acc[2 * D / 16];
-    tail_gemm<2 * D / 16, BSTAGE>(acc, p.w0, 2 * D, [&](int k) {
-      const bf16_t* src = k < D ? tX + fr * PA + k : tMsg + fr * PA + (k - D);
+    tail_gemm<H, 2 * D / 16, BSTAGE>(acc, p.w0, 2 * D, [&](int k) {
+      const H* src = k < D ? tX + fr * PA + k : tMsg + fr * PA + (k - D);
       return *reinterpret_cast<const s16x8*>(src + fq * 8);
     }, sB, wave, lane);
 #pragma unroll
     for (int j = 0; j < 2 * D / 16; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PH + j * 16 + fr] = f2bf(fmaxf(acc[j][r], 0.f));
+      for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PH + j * 16 + fr] = from_f32<H>(fmaxf(acc[j][r], 0.f));
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // ---- mlp.2 (K = 2D) -> D, norm2, + x ---------------------------------------------------------------
   {
     f32x4 acc[D / 16];
-    tail_gemm<D / 16, BSTAGE>(acc, p.w2, 2 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
-    tail_layernorm<D / 16>(acc, p.g2, p.b2, p.ln_eps, fr);
+    tail_gemm<H, D / 16, BSTAGE>(acc, p.w2, 2 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
+    tail_layernorm<H, D / 16>(acc, p.g2, p.b2, p.ln_eps, fr);
 #pragma unroll
     for (int j = 0; j < D / 16; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = fq * 4 + r, col = j * 16 + fr;
-        tMsg[row * PA + col] = f2bf(acc[j][r] + bf2f(tX[row * PA + col]));     // stage the output tile
+        tMsg[row * PA + col] = from_f32<H>(acc[j][r] + to_f32<H>(tX[row * PA + col]));     // stage the output tile
       }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP p) {
   }
 }
 
-template <int D, int HEADS>
-int launch_tail(const TailP& p, hipStream_t s) {
+template <typename H, int D, int HEADS>
+int launch_tail(const TailP<H>& p, hipStream_t s) {
   constexpr size_t lds = 2 * (2 * D * 128) + 4 * ((2 * (D + 8) + 2 * D + 8) * 16 * 2);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = loftr_tail_kernel<D, HEADS>;
+  auto k = loftr_tail_kernel<H, D, HEADS>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
@@ -251,7 +251,7 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
                               const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
                               int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
                               int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(dtype == CFP_BF16, CFP_EINVAL, "cfp_loftr_tail: bf16 only (the f32 parity mode uses the unfused kernels)");
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_loftr_tail: bf16/f16 only (the f32 parity mode uses the unfused kernels)");
   CFP_REQUIRE(q && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
               "cfp_loftr_tail: null pointer");
   CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && v_length > 0.f, CFP_ESHAPE, "cfp_loftr_tail: bad grid");
@@ -262,21 +262,25 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
   CFP_REQUIRE(aligned16(q) && aligned16(x) && aligned16(out) && aligned16(w_merge) && aligned16(w_mlp0) && aligned16(w_mlp2) &&
                   aligned16(kv), CFP_EINVAL, "cfp_loftr_tail: pointers must be 16-byte aligned");
   CFP_REQUIRE((long long)NB * Hq * Wq < (1ll << 31), CFP_ESHAPE, "cfp_loftr_tail: too many rows");
-  TailP p;
-  p.q = (const bf16_t*)q; p.kv = kv; p.ksum = ksum; p.x = (const bf16_t*)x; p.out = (bf16_t*)out;
-  p.wm = (const bf16_t*)w_merge; p.w0 = (const bf16_t*)w_mlp0; p.w2 = (const bf16_t*)w_mlp2;
-  p.g1 = ln1_g; p.b1 = ln1_b; p.g2 = ln2_g; p.b2 = ln2_b;
-  p.q_ld = q_ld; p.x_ld = x_ld; p.out_ld = out_ld;
-  p.rows = NB * Hq * Wq; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
-  p.v_length = v_length; p.eps = eps; p.ln_eps = ln_eps;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   int rc = -2;
-  if (D == 32 && heads == 4) rc = launch_tail<32, 4>(p, s);
-  else if (D == 32 && heads == 8) rc = launch_tail<32, 8>(p, s);
-  else if (D == 64 && heads == 4) rc = launch_tail<64, 4>(p, s);
-  else if (D == 64 && heads == 8) rc = launch_tail<64, 8>(p, s);
-  else if (D == 128 && heads == 4) rc = launch_tail<128, 4>(p, s);
-  else if (D == 128 && heads == 8) rc = launch_tail<128, 8>(p, s);
+  auto run = [&](auto tag) {
+    using H = decltype(tag);
+    TailP<H> p;
+    p.q = (const H*)q; p.kv = kv; p.ksum = ksum; p.x = (const H*)x; p.out = (H*)out;
+    p.wm = (const H*)w_merge; p.w0 = (const H*)w_mlp0; p.w2 = (const H*)w_mlp2;
+    p.g1 = ln1_g; p.b1 = ln1_b; p.g2 = ln2_g; p.b2 = ln2_b;
+    p.q_ld = q_ld; p.x_ld = x_ld; p.out_ld = out_ld;
+    p.rows = NB * Hq * Wq; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
+    p.v_length = v_length; p.eps = eps; p.ln_eps = ln_eps;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (D == 32 && heads == 4) rc = launch_tail<H, 32, 4>(p, s);
+    else if (D == 32 && heads == 8) rc = launch_tail<H, 32, 8>(p, s);
+    else if (D == 64 && heads == 4) rc = launch_tail<H, 64, 4>(p, s);
+    else if (D == 64 && heads == 8) rc = launch_tail<H, 64, 8>(p, s);
+    else if (D == 128 && heads == 4) rc = launch_tail<H, 128, 4>(p, s);
+    else if (D == 128 && heads == 8) rc = launch_tail<H, 128, 8>(p, s);
+  };
+  if (dtype == CFP_F16) run(f16_t{}); else run(bf16_t{});
   CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_loftr_tail: launch failed");
   return cfp_check_launch("cfp_loftr_tail");
 }

@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restri
     long long b = i / HW, hw = i % HW;
     const float* p = rgb + b * 3 * HW + hw;
     float v[8] = {p[0], p[HW], p[2 * (long long)HW], 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(out) + i * 8, v);
+    if constexpr (sizeof(T) == 2) Vec<T>::store(out + i * 8, v);
     else { Vec<float>::store(reinterpret_cast<float*>(out) + i * 8, v); Vec<float>::store(reinterpret_cast<float*>(out) + i * 8 + 4, v + 4); }
   }
 }
@@ -503,7 +503,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void scalar_to_rows8_kernel(const float* __restrict__ in, T* __restrict__ out, long long rows) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
     float v[8] = {in[i], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if constexpr (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(out) + i * 8, v);
+    if constexpr (sizeof(T) == 2) Vec<T>::store(out + i * 8, v);
     else { Vec<float>::store(reinterpret_cast<float*>(out) + i * 8, v); Vec<float>::store(reinterpret_cast<float*>(out) + i * 8 + 4, v + 4); }
   }
 }
@@ -517,7 +517,7 @@ inline int ew_blocks(long long total) {
 
 }  // namespace
 
-#define CHECK_DTYPE(name) CFP_REQUIRE(dtype == CFP_F32 || dtype == CFP_BF16, CFP_EINVAL, name ": bad dtype")
+#define CHECK_DTYPE(name) CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, name ": bad dtype")
 
 extern "C" int cfp_channel_sum(const void* in, int in_ld, float* partial, int B, int HW, int C, int nsplit, int dtype,
                                cfp_stream_t stream) {
@@ -529,6 +529,8 @@ extern "C" int cfp_channel_sum(const void* in, int in_ld, float* partial, int B,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, s, (const bf16_t*)in, in_ld, partial, HW, C, nsplit);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(channel_sum_kernel<f16_t>, dim3(nsplit, B), dim3(256), 0, s, (const f16_t*)in, in_ld, partial, HW, C, nsplit);
   else
     hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nsplit, B), dim3(256), 0, s, (const float*)in, in_ld, partial, HW, C, nsplit);
   return cfp_check_launch("cfp_channel_sum");
@@ -560,6 +562,9 @@ extern "C" int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden,
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(se_fold_kernel<bf16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const bf16_t*)w_proj,
                        (bf16_t*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(se_fold_kernel<f16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const f16_t*)w_proj,
+                       (f16_t*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
   else
     hipLaunchKernelGGL(se_fold_kernel<float>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (const float*)w_proj,
                        (float*)w_out, hidden, w_expand_t, b_expand, Cout, C, R, row_lanes);
@@ -581,6 +586,9 @@ extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, 
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(se_gate_fold_kernel<bf16_t>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
                        b_expand, (const bf16_t*)w_proj, (bf16_t*)w_out, Cout, C, R);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(se_gate_fold_kernel<f16_t>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
+                       b_expand, (const f16_t*)w_proj, (f16_t*)w_out, Cout, C, R);
   else
     hipLaunchKernelGGL(se_gate_fold_kernel<float>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
                        b_expand, (const float*)w_proj, (float*)w_out, Cout, C, R);
@@ -603,6 +611,9 @@ extern "C" int cfp_se_scale(void* x, int ld, const float* hidden, const float* w
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(se_scale_kernel<bf16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (bf16_t*)x, ld, hidden,
                        w_expand_t, b_expand, HW, C, R, row_lanes);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(se_scale_kernel<f16_t>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (f16_t*)x, ld, hidden,
+                       w_expand_t, b_expand, HW, C, R, row_lanes);
   else
     hipLaunchKernelGGL(se_scale_kernel<float>, dim3(blocks, B), dim3(256), (size_t)R * sizeof(float), s, (float*)x, ld, hidden,
                        w_expand_t, b_expand, HW, C, R, row_lanes);
@@ -618,6 +629,8 @@ extern "C" int cfp_scale_channels(void* x, int ld, const float* gate, int B, int
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(scale_channels_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (bf16_t*)x, ld, gate, HW, C, total);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(scale_channels_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (f16_t*)x, ld, gate, HW, C, total);
   else
     hipLaunchKernelGGL(scale_channels_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (float*)x, ld, gate, HW, C, total);
   return cfp_check_launch("cfp_scale_channels");
@@ -641,6 +654,9 @@ extern "C" int cfp_layernorm(const void* in, int in_ld, const float* gamma, cons
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)in, in_ld, gamma, beta, eps,
                        (const bf16_t*)residual, res_ld, (bf16_t*)out, out_ld, rows, C);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(layernorm_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16_t*)in, in_ld, gamma, beta, eps,
+                       (const f16_t*)residual, res_ld, (f16_t*)out, out_ld, rows, C);
   else
     hipLaunchKernelGGL(layernorm_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)in, in_ld, gamma, beta, eps,
                        (const float*)residual, res_ld, (float*)out, out_ld, rows, C);
@@ -669,6 +685,7 @@ extern "C" int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, 
   long long total = (long long)B * dh * dw * (C / ve);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(resize_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(resize_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(resize_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
   return cfp_check_launch("cfp_resize_bilinear");
 }
@@ -685,6 +702,9 @@ extern "C" int cfp_add_rowtable(const void* in, int in_ld, const float* table, v
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(add_rowtable_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, table,
                        (bf16_t*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(add_rowtable_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const f16_t*)in, in_ld, table,
+                       (f16_t*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
   else
     hipLaunchKernelGGL(add_rowtable_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, table,
                        (float*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
@@ -701,6 +721,8 @@ extern "C" int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, (bf16_t*)out, out_ld, (long long)rows, C);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(copy_rows_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const f16_t*)in, in_ld, (f16_t*)out, out_ld, (long long)rows, C);
   else
     hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, (long long)rows, C);
   return cfp_check_launch("cfp_copy_rows");
@@ -713,6 +735,7 @@ extern "C" int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W
   long long total = (long long)B * H * W;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(rgb_to_nhwc8_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (bf16_t*)out, H * W, total);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(rgb_to_nhwc8_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (f16_t*)out, H * W, total);
   else hipLaunchKernelGGL(rgb_to_nhwc8_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (float*)out, H * W, total);
   return cfp_check_launch("cfp_rgb_to_nhwc8");
 }
@@ -723,6 +746,7 @@ extern "C" int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dty
   CFP_REQUIRE(rows > 0, CFP_ESHAPE, "cfp_scalar_to_rows8: bad shape");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(scalar_to_rows8_kernel<bf16_t>, dim3(ew_blocks(rows)), dim3(256), 0, s, in, (bf16_t*)out, (long long)rows);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(scalar_to_rows8_kernel<f16_t>, dim3(ew_blocks(rows)), dim3(256), 0, s, in, (f16_t*)out, (long long)rows);
   else hipLaunchKernelGGL(scalar_to_rows8_kernel<float>, dim3(ew_blocks(rows)), dim3(256), 0, s, in, (float*)out, (long long)rows);
   return cfp_check_launch("cfp_scalar_to_rows8");
 }

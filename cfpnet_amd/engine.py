@@ -4,7 +4,7 @@ The reference's forward (`/root/reference/src/models/deltar.py:34-67`) is ~1000 
 ops.  Here the same computation is a static launch list over NHWC buffers:
 
   * parameters are packed once (BatchNorm folded into per-channel scale/shift, conv weights
-    re-laid [Cout][kh][kw][Cin], q/k/v projections concatenated, storage dtype bf16 or f32);
+    re-laid [Cout][kh][kw][Cin], q/k/v projections concatenated, storage dtype bf16, f16 or f32);
   * every `rearrange 'b (h w) c <-> b c h w'` of the reference disappears (tokens ARE NHWC);
   * every `torch.cat` disappears: producers write into channel slices of the consumer's buffer;
   * the zone crop / per-zone regrouping / boolean-mask scatter of `fusion.py:103-157` and the
@@ -42,14 +42,15 @@ class Engine:
         hip.load()   # fail loudly if the HIP extension is missing
         if not torch.cuda.is_available():
             raise RuntimeError("cfpnet_amd.Engine needs a GPU: the product path has no CPU fallback")
-        assert dtype in (torch.bfloat16, torch.float32)
+        assert dtype in (torch.bfloat16, torch.float16, torch.float32)
         self.layer_names = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, float(min_val), float(max_val)
         self.norm = {"linear": 0, "softmax": 1, "sigmoid": 2}[norm]
         self.change_embedding, self.no_skip_inside, self.stem_act = change_embedding, no_skip_inside, stem_act
         self.dtype, self.device = dtype, torch.device(device)
         self.zone_sample_num = zone_sample_num
-        self.ve = 8 if dtype == torch.bfloat16 else 4
+        self.half = dtype in (torch.bfloat16, torch.float16)     # 16-bit storage: the MFMA fast paths
+        self.ve = 8 if self.half else 4
         self.P: Dict[str, torch.Tensor] = {}
         self._plans: Dict[tuple, dict] = {}
         self._graph = None
@@ -174,8 +175,8 @@ class Engine:
                     wd = sd[k + ".dwconv2.weight"].float()
                     kk = wd.shape[-1]
                     self.P[k + ".dw.w"] = self._dev(wd[:, 0].transpose(1, 2).reshape(wd.shape[0], kk * kk))   # f32 [C][kx][ky]
-                    if self.dtype == torch.bfloat16 and kk in (7, 15, 31):
-                        self.P[k + ".dw.tb"] = ops.toeplitz_bands(wd, torch.bfloat16).to(self.device)     # MFMA B-operand bands
+                    if self.half and kk in (7, 15, 31):
+                        self.P[k + ".dw.tb"] = ops.toeplitz_bands(wd, self.dtype).to(self.device)     # MFMA B-operand bands
                     self.P[k + ".dw.s"], self.P[k + ".dw.t"] = self._fold_bn(sd, k + ".bn1", sd[k + ".dwconv2.bias"], wd.shape[0], _BN_EPS)
                     self.P[k + ".norm.g"], self.P[k + ".norm.b"] = self._dev(sd[k + ".norm.weight"]), self._dev(sd[k + ".norm.bias"])
                     self._conv(sd, k + ".pw1", k + ".pwconv1.weight", k + ".pwconv1.bias")
@@ -325,7 +326,7 @@ class Engine:
         ws = self._f32(plan, f"{tag}.kvws", nws)
         ops.attn_kv_reduce(kA, vA, kv, ks, ws, kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"],
                            kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
-        if self.dtype == torch.bfloat16:
+        if self.half:
             # apply + merge + norm1 + mlp + norm2 + residual in one kernel: the intermediates stay in LDS
             ops.loftr_tail(qb.slice(0, D), kv, ks, x, out, self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
                            (self.P[p + ".norm1.g"], self.P[p + ".norm1.b"]), (self.P[p + ".norm2.g"], self.P[p + ".norm2.b"]),
@@ -668,7 +669,7 @@ class Engine:
             prob = out[2] if return_prob else None
         else:
             prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
-        if self.dtype == torch.bfloat16 and self.n_bins == 256 and HWh % 8 == 0:
+        if self.half and self.n_bins == 256 and HWh % 8 == 0:
             # 1x1 conv + softmax + expectation in one kernel: the logits never reach HBM
             ops.bin_head_fused(ram, self.P["conv_out.w"], self.P["conv_out.t"], centers, prob, pred, B, HWh)
         else:

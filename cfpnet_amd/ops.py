@@ -13,12 +13,12 @@ import torch
 
 from . import hip
 
-DT = {torch.float32: hip.F32, torch.bfloat16: hip.BF16}
+DT = {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}
 
 
 @dataclass
 class Act:
-    buf: torch.Tensor      # [rows, ld], contiguous, float32 or bfloat16, on the GPU
+    buf: torch.Tensor      # [rows, ld], contiguous, float32 / bfloat16 / float16, on the GPU
     c0: int
     C: int
 
@@ -85,7 +85,7 @@ DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
 
 
 def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
-    t = "bf16" if dt == hip.BF16 else "f32"
+    t = {hip.BF16: "bf16", hip.F16: "f16"}.get(dt, "f32")
     if variant >= 200:
         th, bn = DIRECT3_TILES[variant - 200]
         n = f"conv3x3_direct<{t},{th}x16px,{bn}>"

@@ -13,7 +13,7 @@
  *     `*_ld` in ELEMENTS, so producers can write straight into a channel slice of a wider
  *     (concatenation) buffer; channel counts, pitches and slice offsets are multiples of
  *     8 elements (bf16) / 4 elements (f32) so that every access is a 16-byte vector
- *   - dtype: CFP_F32 or CFP_BF16 storage; all arithmetic accumulates in f32
+ *   - dtype: CFP_F32, CFP_BF16 or CFP_F16 (IEEE half, saturating stores) storage; all arithmetic accumulates in f32
  *   - all calls are asynchronous on `stream` (a hipStream_t), stateless and re-entrant
  *   - return 0 on success, a negative CFP_E* code otherwise; `cfp_last_error()` gives the
  *     message (thread-local).  No C++ exception crosses this boundary.
@@ -31,7 +31,7 @@ extern "C" {
 typedef void* cfp_stream_t; /* hipStream_t */
 
 enum { CFP_OK = 0, CFP_EINVAL = -1, CFP_ESHAPE = -2, CFP_EHIP = -3 };
-enum { CFP_F32 = 0, CFP_BF16 = 1 };
+enum { CFP_F32 = 0, CFP_BF16 = 1, CFP_F16 = 2 };
 enum { CFP_ACT_NONE = 0, CFP_ACT_RELU = 1, CFP_ACT_LRELU = 2, CFP_ACT_SILU = 3, CFP_ACT_GELU = 4, CFP_ACT_SIGMOID = 5 };
 
 int cfp_version(void);

@@ -15,6 +15,7 @@ from oracle import cfpnet_oracle as O  # noqa: E402
 
 TOL_F32 = 1e-3      # north_star: "within 1e-3 relative L1 on the predicted depth map"
 TOL_BF16 = 5e-2     # bf16 storage end to end (reported, loose bound)
+TOL_F16 = 2.5e-3    # fp16 storage end to end: measured ~1e-3 (the gate itself), bound with margin for other inputs
 
 
 def make_engine(meta, sd, dtype):
@@ -70,17 +71,20 @@ def test_full_model_vs_oracle_f32(B, H, W, zn, zpx, drop):
     assert p1.shape == (B, 1, H // 2, W // 2) and pr1.shape == (B, 256, H // 2, W // 2)
 
 
-def test_full_model_bf16_error_is_bounded():
+@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, TOL_BF16), (torch.float16, TOL_F16)])
+def test_full_model_16bit_error_is_bounded(dtype, bound):
+    """16-bit storage (f32 accumulation): the error is storage rounding accumulated over ~90 layers.  fp16 (10 mantissa
+    bits) sits at the north-star gate of 1e-3 relative L1; bf16 (7 bits) is 8x coarser."""
     layers, sd, inp = _full_case(2, 480, 640, 8, 56, 21, 0.2)
     e0, p0, pr0 = O.forward(sd, inp, layer_names=layers)
-    eng = Engine(sd, layer_names=layers, dtype=torch.bfloat16)
+    eng = Engine(sd, layer_names=layers, dtype=dtype)
     e1, p1, pr1 = eng.forward(inp)
     torch.cuda.synchronize()
     r = rel_l1(p1.cpu().numpy(), p0.numpy())
     abs_rel = float(np.mean(np.abs(p0.numpy() - p1.cpu().numpy()) / p0.numpy()))
-    print(f"bf16 full model: pred relL1 {r:.3e}, abs_rel {abs_rel:.3e}")
-    assert r < TOL_BF16
-    assert pr1.dtype == torch.bfloat16 and abs(float(pr1.float().sum(1).mean()) - 1.0) < 2e-2
+    print(f"{dtype} full model: pred relL1 {r:.3e}, abs_rel {abs_rel:.3e}")
+    assert r < bound
+    assert pr1.dtype == dtype and abs(float(pr1.float().sum(1).mean()) - 1.0) < 2e-2
     # no prob requested -> identical pred
     e2, p2, pr2 = eng.forward(inp, return_prob=False)
     assert pr2 is None and torch.equal(p1, p2)
@@ -128,7 +132,7 @@ def test_deltar_module_boundary():
     assert len(ones) + len(tens) == len(list(model.parameters()))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
 def test_batch_lanes_match_single_stream(dtype, tol):
     """forward_lanes (sub-batches on concurrent streams, whole-batch zone geometry) == forward, eager and captured."""
     layers, sd, inp = _full_case(4, 256, 320, 3, 64, 21, 0.25)

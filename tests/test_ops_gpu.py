@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 from cfpnet_amd import hip, ops  # noqa: E402
 
 DEV = "cuda:0"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+HALF = [torch.bfloat16, torch.float16]      # 16-bit storage: the MFMA fast paths
 
 
 def tol(dtype):
-    return (2e-5, 2e-5) if dtype == torch.float32 else (2.5e-2, 2.5e-2)
+    return {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2.5e-2, 2.5e-2), torch.float16: (4e-3, 4e-3)}[dtype]
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -120,11 +121,11 @@ def _conv_ref_and_args(case, dtype, seed=1):
 GEN2_VARIANTS = list(range(17))
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", GEN2_VARIANTS)
-def test_conv2d_gen2_every_tile_variant(variant):
+def test_conv2d_gen2_every_tile_variant(variant, dtype):
     """Every second-generation (LDS-DMA staged) tile configuration on every conv case, forced through
     the debug knob, un-split and with 4 K-splits."""
-    dtype = torch.bfloat16
     lib = hip.load()
     try:
         lib.cfp_debug_set(0, variant)
@@ -155,10 +156,10 @@ DIRECT3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", list(range(6)))
-def test_conv3x3_direct_every_variant(variant):
+def test_conv3x3_direct_every_variant(variant, dtype):
     """The LDS-halo direct 3x3 kernel, every tile variant forced through the debug knob."""
-    dtype = torch.bfloat16
     lib = hip.load()
     try:
         lib.cfp_debug_set(0, 200 + variant)
@@ -177,10 +178,10 @@ def test_conv3x3_direct_every_variant(variant):
         lib.cfp_debug_set(0, -1)
 
 
-def test_conv2d_gen2_matches_gen1_bitwise_inputs():
+@pytest.mark.parametrize("dtype", HALF)
+def test_conv2d_gen2_matches_gen1_bitwise_inputs(dtype):
     """Same bf16 inputs through both kernel generations: results agree to bf16 rounding of an f32
     accumulation in a different order."""
-    dtype = torch.bfloat16
     lib = hip.load()
     case = (2, 30, 40, 168, 64, 3, 1, (1, 1, 1, 1))
     B, H, W, Cin, Cout, k, s, _ = case
@@ -208,7 +209,7 @@ def test_linear_with_fused_layernorm(rows, Cin, Cout, dtype):
     g, b = rnd(Cout, seed=3).abs() + 0.5, rnd(Cout, seed=4)
     res = q(rnd(rows, Cout, seed=5), dtype)
     y = x @ w.t()
-    if dtype == torch.bfloat16:
+    if dtype in HALF:
         y = q(y, dtype)           # the pre-LayerNorm tile is rounded to the storage type
     ref = F.layer_norm(y, (Cout,), g, b, 1e-5) + res
     out = ops.new_act(rows, Cout, dtype, DEV, ld=Cout + 8, zero=True)
@@ -267,10 +268,10 @@ def test_dwconv3x3(case, dtype):
     close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"dw3x3 {case}")
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(1, 30, 40, 128, 7), (2, 60, 80, 64, 15), (1, 120, 160, 32, 31), (2, 33, 47, 16, 31), (1, 9, 9, 8, 15)])
-def test_dwconv_large_mfma_toeplitz(case):
+def test_dwconv_large_mfma_toeplitz(case, dtype):
     """Large-kernel depthwise as banded Toeplitz GEMMs on the matrix cores (bf16) vs F.conv2d."""
-    dtype = torch.bfloat16
     B, H, W, Cc, k = case
     x = q(rnd(B, Cc, H, W, seed=1), dtype)
     w = q(rnd(Cc, 1, k, k, seed=2, scale=1.0 / k), dtype)         # the band table stores bf16 weights
@@ -334,7 +335,7 @@ def test_se_fold_equals_gated_activation(dtype):
     ops.se_gate_fold(part, 1, 1.0 / HW, wr.to(DEV), br.to(DEV), we.t().contiguous().to(DEV), be.to(DEV), wp.to(dtype).to(DEV), wb2,
                      B, Cout, C, R)
     torch.cuda.synchronize()
-    assert float((wb2.float() - wb.float()).abs().max()) <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-5) * float(wb.float().abs().max())
+    assert float((wb2.float() - wb.float()).abs().max()) <= {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}.get(dtype, 1e-5) * float(wb.float().abs().max())
     out = ops.new_act(B * HW, Cout, dtype, DEV)
     ops.conv2d(to_act(x.reshape(B * HW, C), dtype), wb2, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None,
                per_image_weights=True)
@@ -470,12 +471,12 @@ def test_attention_inside_outside_and_global(heads, d, H, W, dtype):
     close(out.torch().float().cpu().reshape(B, H, W, Dm), ref, dtype)
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("D,heads,NB,Hq,Wq,qth,qtw", [(128, 4, 2, 16, 16, 4, 4), (128, 8, 1, 30, 40, 6, 6), (64, 4, 2, 14, 14, 7, 7),
                                                      (64, 8, 1, 13, 17, 13, 17), (32, 8, 2, 24, 30, 12, 12), (32, 4, 1, 9, 11, 3, 3)])
-def test_loftr_tail_fused_vs_reference(D, heads, NB, Hq, Wq, qth, qtw):
+def test_loftr_tail_fused_vs_reference(D, heads, NB, Hq, Wq, qth, qtw, dtype):
     """apply -> merge -> norm1 -> mlp -> norm2 -> +x in one kernel vs the same chain in PyTorch (with
     the storage-type rounding points of the unfused path) and vs the unfused HIP kernels."""
-    dtype = torch.bfloat16
     d = D // heads
     rows = NB * Hq * Wq
     ggy, ggx = -(-Hq // qth), -(-Wq // qtw)
@@ -631,22 +632,23 @@ def test_bin_softmax(HW, dtype):
     assert torch.equal(pred, pred2)
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("HW", [128 * 3, 1000, 4808])
-def test_bin_head_fused(HW):
+def test_bin_head_fused(HW, dtype):
     """conv_out (1x1, 128 -> 256) + softmax + expectation in one kernel vs the unfused torch chain."""
     B, Cin, nb = 2, 128, 256
-    x = q(rnd(B * HW, Cin, seed=1), torch.bfloat16)
-    w = q(rnd(nb, Cin, seed=2, scale=0.25), torch.bfloat16)
+    x = q(rnd(B * HW, Cin, seed=1), dtype)
+    w = q(rnd(nb, Cin, seed=2, scale=0.25), dtype)
     bias = rnd(nb, seed=3)
     centers = torch.sort(torch.rand(B, nb, generator=torch.Generator().manual_seed(2)) * 10, dim=1)[0]
-    prob = torch.zeros(B, nb, HW, dtype=torch.bfloat16, device=DEV)
+    prob = torch.zeros(B, nb, HW, dtype=dtype, device=DEV)
     pred = torch.empty(B, HW, device=DEV)
-    ops.bin_head_fused(to_act(x, torch.bfloat16), w.to(torch.bfloat16).to(DEV), bias.to(DEV), centers.to(DEV), prob, pred, B, HW)
+    ops.bin_head_fused(to_act(x, dtype), w.to(dtype).to(DEV), bias.to(DEV), centers.to(DEV), prob, pred, B, HW)
     p = torch.softmax((x @ w.t() + bias).reshape(B, HW, nb), dim=2)
-    close(prob.float().cpu(), p.permute(0, 2, 1), torch.bfloat16, "prob")
+    close(prob.float().cpu(), p.permute(0, 2, 1), dtype, "prob")
     assert torch.allclose(pred.cpu(), (p * centers[:, None, :]).sum(2), rtol=2e-3, atol=2e-3)
     pred2 = torch.empty(B, HW, device=DEV)
-    ops.bin_head_fused(to_act(x, torch.bfloat16), w.to(torch.bfloat16).to(DEV), bias.to(DEV), centers.to(DEV), None, pred2, B, HW)
+    ops.bin_head_fused(to_act(x, dtype), w.to(dtype).to(DEV), bias.to(DEV), centers.to(DEV), None, pred2, B, HW)
     assert torch.equal(pred, pred2)
 
 
@@ -659,18 +661,18 @@ def _int_tensor(shape, lo, hi, seed):
     return torch.randint(lo, hi + 1, shape, generator=g).float()
 
 
-def _bits(t):
-    return t.to(torch.bfloat16).view(torch.int16)
+def _bits(t, dtype):
+    return t.to(dtype).view(torch.int16)
 
 
 INT_CONV_CASES = [(2, 20, 24, 40, 48, 3, 1, (1, 1, 1, 1)), (1, 17, 33, 168, 64, 3, 1, (1, 1, 1, 1)), (2, 9, 11, 8, 40, 3, 2, (0, 0, 1, 1)),
                   (1, 1, 700, 136, 816, 1, 1, (0, 0, 0, 0)), (1, 24, 24, 64, 32, 6, 6, (0, 0, 0, 0))]
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", list(range(17)) + [200 + v for v in range(6)] + ["gen1"])
-def test_conv_fast_paths_bit_exact_on_integers(variant):
+def test_conv_fast_paths_bit_exact_on_integers(variant, dtype):
     lib = hip.load()
-    dtype = torch.bfloat16
     try:
         if variant == "gen1":
             lib.cfp_debug_set(2, 1)
@@ -689,17 +691,17 @@ def test_conv_fast_paths_bit_exact_on_integers(variant):
             ops.conv2d(to_act(nhwc(x), dtype), wa, None, None, out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_NONE, None, None)
             torch.cuda.synchronize()
             got = out.torch().cpu().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
-            assert torch.equal(got.view(torch.int16), _bits(ref)), f"variant {variant} case {case}"
+            assert torch.equal(got.view(torch.int16), _bits(ref, dtype)), f"variant {variant} case {case}"
     finally:
         lib.cfp_debug_set(0, -1)
         lib.cfp_debug_set(2, 0)
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (1, 15, 20, 1392, 1, (1, 1, 1, 1)), (2, 30, 40, 816, 1, (1, 1, 1, 1)),
                                   (1, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 16, 16, 16, 1, (1, 1, 1, 1))])
-def test_dwconv3x3_mfma_bit_exact_on_integers(case):
+def test_dwconv3x3_mfma_bit_exact_on_integers(case, dtype):
     B, H, W, Cc, s, (pt, pl, pb, pr) = case
-    dtype = torch.bfloat16
     x = _int_tensor((B, Cc, H, W), -7, 7, 3)
     w = _int_tensor((Cc, 1, 3, 3), -3, 3, 4)
     Ho, Wo = (H + pt + pb - 3) // s + 1, (W + pl + pr - 3) // s + 1
@@ -712,14 +714,14 @@ def test_dwconv3x3_mfma_bit_exact_on_integers(case):
                       Ho, Wo, hip.ACT_NONE)
     torch.cuda.synchronize()
     got = out.torch().cpu().reshape(B, Ho, Wo, Cc).permute(0, 3, 1, 2)
-    assert torch.equal(got.view(torch.int16), _bits(ref))
+    assert torch.equal(got.view(torch.int16), _bits(ref, dtype))
     assert torch.equal(part.sum(1).cpu(), ref.sum((2, 3)))           # channel sums of small integers are exact too
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (1, 64, 32, 8, 31)])
-def test_dwconv_large_toeplitz_bit_exact_on_integers(case):
+def test_dwconv_large_toeplitz_bit_exact_on_integers(case, dtype):
     B, H, W, Cc, k = case
-    dtype = torch.bfloat16
     x = _int_tensor((B, Cc, H, W), -3, 3, 5)
     w = _int_tensor((Cc, 1, k, k), -1, 1, 6)
     ref = F.conv2d(x.double(), w.double(), None, 1, (k - 1) // 2, 1, Cc).float()
@@ -728,4 +730,4 @@ def test_dwconv_large_toeplitz_bit_exact_on_integers(case):
                           out, B, H, W, k, hip.ACT_NONE)
     torch.cuda.synchronize()
     got = out.torch().cpu().reshape(B, H, W, Cc).permute(0, 3, 1, 2)
-    assert torch.equal(got.view(torch.int16), _bits(ref))
+    assert torch.equal(got.view(torch.int16), _bits(ref, dtype))
