@@ -150,3 +150,36 @@ def test_batch_lanes_match_single_stream(dtype, tol):
     e2, p2, pr2 = eng.replay()
     torch.cuda.synchronize()
     assert rel_l1(p2.cpu().numpy(), p0.cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-6)])
+def test_batches_in_flight_match_forward(dtype, tol):
+    """capture(inflight=n): n whole batches in flight on concurrently scheduled streams.  Every result equals the plain
+    forward of the input that was fed to that slot (different inputs per step, slots reused twice)."""
+    layers, sd, _ = _full_case(2, 256, 320, 3, 64, 21, 0.0)
+    eng = Engine(sd, layer_names=layers, dtype=dtype)
+    inps = [synthetic.to_device(synthetic.make_inputs(2, 256, 320, 3, 64, seed=40 + i, drop_hist=0.2 * (i % 2)), "cuda:0") for i in range(7)]
+    want = []
+    for x in inps:
+        e, p, pr = eng.forward(x)
+        want.append((e.clone(), p.clone(), pr.clone()))
+    torch.cuda.synchronize()
+    eng.capture(inps[0], inflight=3)
+    assert 1 <= len(eng._slots) <= 3
+    got = []
+    for x in inps:
+        (e, p, pr), ev = eng.replay_async(x)
+        got.append((e, p, pr, ev))
+        if len(got) >= len(eng._slots):            # consume the oldest before its slot is reused
+            e0, p0, pr0, ev0 = got[len(got) - len(eng._slots)]
+            ev0.synchronize()
+            got[len(got) - len(eng._slots)] = (e0.clone(), p0.clone(), pr0.clone(), None)
+    torch.cuda.synchronize()
+    for i, (w, g) in enumerate(zip(want, got)):
+        assert rel_l1(g[1].cpu().numpy(), w[1].cpu().numpy()) <= tol, i
+        assert torch.equal(g[0], w[0]) or rel_l1(g[0].cpu().numpy(), w[0].cpu().numpy()) <= tol
+        assert rel_l1(g[2].float().cpu().numpy(), w[2].float().cpu().numpy()) <= 10 * tol + 1e-7
+    # the blocking call still works in this mode
+    e, p, pr = eng.replay(inps[3])
+    torch.cuda.synchronize()
+    assert rel_l1(p.cpu().numpy(), want[3][1].cpu().numpy()) <= tol

@@ -9,12 +9,13 @@ mapped to the family names bench.py prints."""
 import csv, json, re, sys, collections
 
 def family(name):
-    m = re.search(r"igemm2_kernel<(\d+), (\d+), \d+, \d+, (\d+), (true|false)>", name)
-    if m: return f"igemm2<bf16,{m.group(1)}x{m.group(2)},s{m.group(3)}>"
-    m = re.search(r"conv_igemm(?:_splitk)?_kernel<unsigned short, (\d+), (\d+)", name)
-    if m: return f"conv_igemm<bf16,{m.group(1)}x{m.group(2)}>"
-    m = re.search(r"conv3x3_direct_kernel<(\d+), (\d+)", name)
-    if m: return f"conv3x3_direct<bf16,{m.group(1)}x16px,{m.group(2)}>"
+    dt = lambda t: "f16" if "Float16" in t else "bf16"
+    m = re.search(r"igemm2_kernel<(unsigned short|_Float16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)>", name)
+    if m: return f"igemm2<{dt(m.group(1))},{m.group(2)}x{m.group(3)},s{m.group(4)}>"
+    m = re.search(r"conv_igemm(?:_splitk)?_kernel<(unsigned short|_Float16), (\d+), (\d+)", name)
+    if m: return f"conv_igemm<{dt(m.group(1))},{m.group(2)}x{m.group(3)}>"
+    m = re.search(r"conv3x3_direct_kernel<(unsigned short|_Float16), (\d+), (\d+)", name)
+    if m: return f"conv3x3_direct<{dt(m.group(1))},{m.group(2)}x16px,{m.group(3)}>"
     m = re.search(r"(?:\(anonymous namespace\)::)?([A-Za-z0-9_]+_kernel)", name)
     return m.group(1) if m else name[:60]
 
