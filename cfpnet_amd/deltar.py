@@ -147,8 +147,10 @@ class Deltar(_Store):
         return edges, pred, prob, None
 
 
-def make_model(args):
-    """`src/utils/utils.py:7-11`."""
+def make_model(args, dtype=None):
+    """`src/utils/utils.py:7-11`.  `dtype` (not in the reference) picks the engine's storage format: torch.bfloat16
+    (default), torch.float16 or torch.float32."""
     if args.model_name == "deltar":
-        return Deltar(n_bins=args.n_bins, min_val=args.min_depth, max_val=args.max_depth, norm=args.norm, args=args)
+        kw = {} if dtype is None else {"dtype": dtype}
+        return Deltar(n_bins=args.n_bins, min_val=args.min_depth, max_val=args.max_depth, norm=args.norm, args=args, **kw)
     raise NotImplementedError(args.model_name)
