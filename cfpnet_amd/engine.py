@@ -669,7 +669,7 @@ class Engine:
         return slot["out"], slot["event"]
 
     def capture_best(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None,
-                     candidates: Sequence = (("lanes", 1), ("lanes", 2), ("inflight", 2), ("inflight", 3), ("inflight", 4)),
+                     candidates: Sequence = (("lanes", 1), ("inflight", 2), ("inflight", 3), ("inflight", 4)),
                      reps: int = 16, allow_inflight: bool = True):
         """capture() with the concurrency mode chosen by measurement: `lanes` sub-batches of one batch side by side, or
         `inflight` whole batches in flight (throughput mode, results through `replay_async`).  How well graphs overlap
