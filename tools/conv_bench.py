@@ -18,6 +18,8 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--out", default="gpurun_out/conv_bench.json")
+ap.add_argument("--inflight", type=int, default=1, help="time every candidate with this many copies running side by side on "
+                "probed-concurrent streams (throughput mode) instead of alone")
 a = ap.parse_args()
 
 layers = spec.COMBINE1_LAYERS
@@ -51,12 +53,17 @@ for name, args in calls:
     uniq.setdefault(key, [name, args, 0])[2] += 1
 
 
-from _gtime import graph_time_us
+from _gtime import graph_time_us, graph_time_us_concurrent
+from cfpnet_amd.engine import concurrent_streams
+STREAMS = concurrent_streams("cuda:0", want=a.inflight) if a.inflight > 1 else None
 
 
 def timeit(name, args, reps):
     # the recorded argument list ends with the stream of the recording pass: re-issue on the CURRENT stream
-    return graph_time_us(lambda: real(name, *args[:-1], hip.current_stream()), calls=max(4, reps // 2), replays=4)
+    fn = lambda: real(name, *args[:-1], hip.current_stream())
+    if STREAMS:
+        return graph_time_us_concurrent(fn, STREAMS, calls=max(4, reps // 2), replays=3)
+    return graph_time_us(fn, calls=max(4, reps // 2), replays=4)
 
 
 nvar = 17
