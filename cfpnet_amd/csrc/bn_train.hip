@@ -1,0 +1,260 @@
+// Training-mode BatchNorm (batch statistics) + activation, forward and backward, on NHWC rows.
+//
+//   reference: every nn.BatchNorm2d / nn.BatchNorm1d of the model in model.train() (train.py:119-131): timm's
+//   BatchNormAct2d in the encoder (encoder.py:57-69), decoder.py:45-50, transformer.py:240-244, convnext.py:30,
+//   encoder.py:10-12 -- followed by SiLU / LeakyReLU / ReLU / nothing.
+//
+//   forward   mean_c, var_c (biased) over the B*H*W rows;  y = act((x - mean) * rsqrt(var + eps) * gamma + beta)
+//             running_mean/var updated with `momentum` (running_var from the UNBIASED variance, like torch)
+//   backward  dz = dy * act'(z);  dbeta = sum dz;  dgamma = sum dz * xhat;
+//             dx = gamma * invstd * (dz - dbeta / n - xhat * dgamma / n)
+//
+// Three passes over the activation forward (sum, centred sum of squares, apply) and two backward (reduce, apply): all
+// HBM-bound column reductions / elementwise sweeps over 16-byte vectors.  Reductions are per-split partials in f32
+// combined in a fixed order (run-to-run deterministic); the variance is the two-pass form (no E[x^2] - E[x]^2
+// cancellation).
+#include "common.h"
+
+namespace {
+
+constexpr int RC_COLS = 32;     // 16-byte vector columns per workgroup
+constexpr int RC_LANES = 8;     // row lanes per workgroup
+
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case CFP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case CFP_ACT_LRELU: return z > 0.f ? 1.f : 0.01f;
+    case CFP_ACT_SILU: { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
+    case CFP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+    case CFP_ACT_SIGMOID: { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
+// MODE 0: s1 = sum x                         (aux unused)
+// MODE 1: s1 = sum (x - mean)^2              (aux0 = mean)
+// MODE 2: s1 = sum dz, s2 = sum dz * xhat    (aux0 = mean, aux1 = invstd, aux2 = scale, aux3 = shift; dz = dy * act'(x*scale+shift))
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, int ld, const T* __restrict__ dy, int dy_ld, long long rows,
+                                                        int C, const float* __restrict__ aux0, const float* __restrict__ aux1,
+                                                        const float* __restrict__ aux2, const float* __restrict__ aux3, int act,
+                                                        float* __restrict__ partial, long long rows_per_split) {
+  constexpr int VE = Vec<T>::N;
+  constexpr int NS = MODE == 2 ? 2 : 1;
+  __shared__ float red[RC_LANES][RC_COLS * 8 * 2];
+  const int tid = threadIdx.x;
+  const int cl = tid & (RC_COLS - 1), rl = tid / RC_COLS;
+  const int c0 = (blockIdx.x * RC_COLS + cl) * VE;
+  const bool c_ok = c0 < C;
+  const int cc = c_ok ? c0 : 0;
+  const long long r0 = (long long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+  float a0[VE], a1[VE], a2[VE], a3[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    a0[e] = (MODE >= 1) ? aux0[cc + e] : 0.f;
+    a1[e] = (MODE == 2) ? aux1[cc + e] : 0.f;
+    a2[e] = (MODE == 2) ? aux2[cc + e] : 0.f;
+    a3[e] = (MODE == 2) ? aux3[cc + e] : 0.f;
+  }
+  float s1[VE], s2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  constexpr int U = 4;
+  for (long long r = r0 + rl; r < r1; r += RC_LANES * U) {
+    float v[U][VE], g[U][VE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = min(r + (long long)u * RC_LANES, r1 - 1);
+      Vec<T>::load(x + rr * ld + cc, v[u]);
+      if (MODE == 2) Vec<T>::load(dy + rr * dy_ld + cc, g[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r + (long long)u * RC_LANES >= r1) continue;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        if (MODE == 0) s1[e] += v[u][e];
+        else if (MODE == 1) { const float d = v[u][e] - a0[e]; s1[e] = fmaf(d, d, s1[e]); }
+        else {
+          const float dz = g[u][e] * act_grad(v[u][e] * a2[e] + a3[e], act);
+          s1[e] += dz;
+          s2[e] = fmaf(dz, (v[u][e] - a0[e]) * a1[e], s2[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { red[rl][(cl * 8 + e) * 2] = s1[e]; red[rl][(cl * 8 + e) * 2 + 1] = s2[e]; }
+  __syncthreads();
+  // fixed-order combination of the 8 row lanes
+  for (int i = tid; i < RC_COLS * VE * NS; i += 256) {
+    const int which = i / (RC_COLS * VE), k = i - which * (RC_COLS * VE);
+    const int c_l = k / VE, e = k - c_l * VE;
+    const int c = (blockIdx.x * RC_COLS + c_l) * VE + e;
+    if (c >= C) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < RC_LANES; ++l) s += red[l][(c_l * 8 + e) * 2 + which];
+    partial[((long long)blockIdx.y * NS + which) * C + c] = s;
+  }
+}
+
+// MODE 0 -> mean; MODE 1 -> var (biased) ; MODE 2 -> dbeta (which 0), dgamma (which 1)
+__global__ __launch_bounds__(256) void colfinal_kernel(const float* __restrict__ partial, int nsplit, int ns, int C, float inv_n,
+                                                       float* __restrict__ out0, float* __restrict__ out1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * ns) return;
+  const int which = i / C, c = i - which * C;
+  float s = 0.f;
+  for (int j = 0; j < nsplit; ++j) s += partial[((long long)j * ns + which) * C + c];
+  (which == 0 ? out0 : out1)[c] = s * inv_n;
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, float eps, float momentum, float unbias, float* __restrict__ running_mean,
+                               float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                               float* __restrict__ invstd, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * is;
+  scale[c] = sc;
+  shift[c] = b - mean[c] * sc;
+  invstd[c] = is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var[c] * unbias;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, int ld, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int act, T* __restrict__ out, int out_ld,
+                                                              long long rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  with_act(act, [&](auto A) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+      const long long r = i / CV;
+      const int c = (int)(i - r * CV) * VE;
+      float v[VE];
+      Vec<T>::load(x + r * ld + c, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = act_c<decltype(A)::value>(v[e] * scale[c + e] + shift[c + e]);
+      Vec<T>::store(out + r * out_ld + c, v);
+    }
+  });
+}
+
+// dx = gamma*invstd * (dz - dbeta/n - xhat * dgamma/n),  dz = dy * act'(x*scale+shift)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, int ld, const T* __restrict__ dy, int dy_ld,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_n,
+                                                           int act, T* __restrict__ dx, int dx_ld, long long rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float v[VE], g[VE];
+    Vec<T>::load(x + r * ld + c, v);
+    Vec<T>::load(dy + r * dy_ld + c, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      const float dz = g[e] * act_grad(v[e] * scale[c + e] + shift[c + e], act);
+      const float xh = (v[e] - mean[c + e]) * invstd[c + e];
+      v[e] = scale[c + e] * (dz - dbeta[c + e] * inv_n - xh * dgamma[c + e] * inv_n);      // scale = gamma * invstd
+    }
+    Vec<T>::store(dx + r * dx_ld + c, v);
+  }
+}
+
+inline int red_splits(long long rows, int C, int ve) {
+  const int colblk = cdiv(C, RC_COLS * ve);
+  long long ns = 1024 / colblk;
+  const long long mx = (rows + 63) / 64;
+  if (ns > mx) ns = mx;
+  if (ns > 4096) ns = 4096;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+inline int ew_grid(long long total) { long long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+template <int MODE>
+int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long rows, int C, const float* a0, const float* a1,
+                  const float* a2, const float* a3, int act, int dtype, float* partial, float* out0, float* out1, float inv_n,
+                  hipStream_t s) {
+  const int ve = vec_elems(dtype);
+  const int ns = red_splits(rows, C, ve);
+  const long long rps = (rows + ns - 1) / ns;
+  const int nsplit = (int)((rows + rps - 1) / rps);
+  const dim3 grid(cdiv(C, RC_COLS * ve), nsplit);
+#define RL(T) hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, ld, (const T*)dy, dy_ld, rows, C, a0, a1, a2, a3, \
+                                 act, partial, rps)
+  if (dtype == CFP_BF16) RL(bf16_t); else if (dtype == CFP_F16) RL(f16_t); else RL(float);
+#undef RL
+  const int nsum = MODE == 2 ? 2 : 1;
+  hipLaunchKernelGGL(colfinal_kernel, dim3(cdiv(C * nsum, 256)), dim3(256), 0, s, partial, nsplit, nsum, C, inv_n, out0, out1);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t cfp_bn_ws_bytes(int C) { return C > 0 ? (size_t)4096 * 2 * C * sizeof(float) : 0; }
+
+#define BN_COMMON(name)                                                                                                      \
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, name ": bad dtype");                                                              \
+  const int ve = vec_elems(dtype);                                                                                           \
+  CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && ld % ve == 0 && ld >= C, CFP_ESHAPE, name ": bad shape");                  \
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, int dtype, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, float* mean, float* var, float* invstd,
+                                  float* scale, float* shift, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(x && mean && var && invstd && scale && shift && ws && aligned16(x), CFP_EINVAL, "cfp_bn_train_stats: bad pointer");
+  BN_COMMON("cfp_bn_train_stats");
+  CFP_REQUIRE(ws_bytes >= cfp_bn_ws_bytes(C), CFP_EINVAL, "cfp_bn_train_stats: workspace too small");
+  float* partial = reinterpret_cast<float*>(ws);
+  const float inv_n = 1.f / (float)rows;
+  launch_reduce<0>(x, ld, nullptr, 0, rows, C, nullptr, nullptr, nullptr, nullptr, 0, dtype, partial, mean, nullptr, inv_n, s);
+  launch_reduce<1>(x, ld, nullptr, 0, rows, C, mean, nullptr, nullptr, nullptr, 0, dtype, partial, var, nullptr, inv_n, s);
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, mean, var, gamma, beta, eps, momentum, unbias, running_mean,
+                     running_var, scale, shift, invstd, C);
+  return cfp_check_launch("cfp_bn_train_stats");
+}
+
+extern "C" int cfp_scale_shift_act(const void* x, int ld, const float* scale, const float* shift, int act, void* out, int out_ld,
+                                   long long rows, int C, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(x && scale && shift && out && aligned16(x) && aligned16(out), CFP_EINVAL, "cfp_scale_shift_act: bad pointer");
+  BN_COMMON("cfp_scale_shift_act");
+  CFP_REQUIRE(out_ld % ve == 0 && out_ld >= C, CFP_ESHAPE, "cfp_scale_shift_act: bad out_ld");
+  const dim3 grid(ew_grid(rows * (C / ve)));
+#define SL(T) hipLaunchKernelGGL(scale_shift_act_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, scale, shift, act, (T*)out, out_ld, rows, C)
+  if (dtype == CFP_BF16) SL(bf16_t); else if (dtype == CFP_F16) SL(f16_t); else SL(float);
+#undef SL
+  return cfp_check_launch("cfp_scale_shift_act");
+}
+
+extern "C" int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld, long long rows, int C, int dtype, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, int act, float* dgamma, float* dbeta,
+                                void* dx, int dx_ld, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(x && dy && mean && invstd && scale && shift && dgamma && dbeta && dx && ws && aligned16(x) && aligned16(dy) && aligned16(dx),
+              CFP_EINVAL, "cfp_bn_train_bwd: bad pointer");
+  BN_COMMON("cfp_bn_train_bwd");
+  CFP_REQUIRE(dy_ld % ve == 0 && dy_ld >= C && dx_ld % ve == 0 && dx_ld >= C, CFP_ESHAPE, "cfp_bn_train_bwd: bad pitch");
+  CFP_REQUIRE(ws_bytes >= cfp_bn_ws_bytes(C), CFP_EINVAL, "cfp_bn_train_bwd: workspace too small");
+  float* partial = reinterpret_cast<float*>(ws);
+  // dbeta = sum dz, dgamma = sum dz * xhat (unscaled sums: inv_n = 1)
+  launch_reduce<2>(x, ld, dy, dy_ld, rows, C, mean, invstd, scale, shift, act, dtype, partial, dbeta, dgamma, 1.f, s);
+  const dim3 grid(ew_grid(rows * (C / ve)));
+  const float inv_n = 1.f / (float)rows;
+#define BL(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, (const T*)dy, dy_ld, mean, invstd, scale, shift, \
+                                 dbeta, dgamma, inv_n, act, (T*)dx, dx_ld, rows, C)
+  if (dtype == CFP_BF16) BL(bf16_t); else if (dtype == CFP_F16) BL(f16_t); else BL(float);
+#undef BL
+  return cfp_check_launch("cfp_bn_train_bwd");
+}

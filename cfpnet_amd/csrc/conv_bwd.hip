@@ -1,0 +1,230 @@
+// Backward of the dense convolution / linear layer: weight gradient, and the weight re-layout the data gradient needs.
+//
+//   reference: autograd of nn.Conv2d / nn.Linear / nn.Conv1d(k=1) in the training step (train.py:119-131).
+//
+// Weight gradient    dW[co][kh][kw][ci] = sum over output pixels m = (b, ho, wo) of
+//                    dY[m][co] * X[b, ho*s - pad_t + kh, wo*s - pad_l + kw, ci]
+// is a GEMM whose REDUCTION axis is the pixel axis (up to 6e5 rows at 1/2 scale) and whose output is small
+// (Cout x KH*KW*Cin), so it is split over pixel chunks: grid = output tiles x chunks, every workgroup reduces its chunk
+// into a 64 x 64 tile on the matrix cores and writes it to its slab; a second kernel adds the slabs in a fixed order
+// (bit-reproducible, no atomics).  Both operands have the reduction index as their ROW index in memory (NHWC), i.e. the
+// MFMA wants them transposed; with v_mfma_f32_16x16x4_f32 an operand is one scalar per lane, so the transposition is
+// just which LDS word a lane reads.  16-bit activations / gradients are widened to f32 while staging: products of
+// bf16/fp16 values are exact in f32 and the accumulation is f32 either way (the 16-bit matrix-core form with
+// ds_read_b64_tr_b16 operand reads is the speed step, not a different result).
+//
+// Data gradient      dX = conv(dilate(dY, stride), flip(W)^T): `cfp_conv2d_weight_flip` produces
+//                    Wt[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci], after which dX is a plain cfp_conv2d_nhwc call
+//                    (stride 1, padding K-1-pad, input dilation = the forward stride).
+#include "common.h"
+
+namespace {
+
+constexpr int WB = 64;          // output tile: 64 (Cout) x 64 (K')
+constexpr int WM = 32;          // pixel rows per staging step
+constexpr int WP = WB + 16;     // LDS row pitch in floats: 80 = 16 mod 32 -> the two k rows of a 32-lane half hit disjoint banks
+
+struct WgP {
+  const void* x; const void* dy; float* slabs;
+  int x_ld, dy_ld;
+  int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+  int M, K, rows_per_split, nsplit;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
+  constexpr int VE = Vec<T>::N;
+  constexpr int VPR = WB / VE;                 // vectors per tile row
+  constexpr int NV = WM * VPR / 256;           // vectors per thread and operand per step (2 for f32, 1 for 16-bit)
+  __shared__ float sD[WM * WP];                // dY tile  [m][co]
+  __shared__ float sX[WM * WP];                // im2col tile [m][k']
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_k = (p.K + WB - 1) / WB;
+  const int tile_co = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_co * tiles_k;
+  const int co0 = tile_co * WB, k0 = tile_k * WB;
+  const int m_begin = blockIdx.y * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(p.dy);
+
+  // this thread's staging slots: row r (0..31), vector v of the row
+  int s_row[NV], s_col[NV];
+  int x_kh[NV], x_kw[NV], x_ci[NV];
+  bool k_ok[NV], co_ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    s_row[i] = q / VPR;
+    s_col[i] = (q - s_row[i] * VPR) * VE;
+    const int kk = k0 + s_col[i];
+    k_ok[i] = kk < p.K;
+    const int tap = kk / p.Cin;                 // (kh, kw); Cin % VE == 0 keeps a vector inside one tap
+    x_ci[i] = kk - tap * p.Cin;
+    x_kh[i] = tap / p.KW;
+    x_kw[i] = tap - x_kh[i] * p.KW;
+    co_ok[i] = co0 + s_col[i] < p.Cout;
+  }
+  const int HoWo = p.Ho * p.Wo;
+
+  float rD[NV][VE], rX[NV][VE];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m0 + s_row[i];
+      const bool m_ok = m < m_end;
+      const int mm = m_ok ? m : m_begin;
+      const int b = mm / HoWo, r = mm - b * HoWo;
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
+      const bool in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
+      // unconditional loads from clamped addresses, the value is selected afterwards (no branch per load)
+      Vec<T>::load(X + ((long long)(b * p.H + hic) * p.W + wic) * p.x_ld + (k_ok[i] ? x_ci[i] : 0), rX[i]);
+      Vec<T>::load(DY + (long long)mm * p.dy_ld + (co_ok[i] ? co0 + s_col[i] : 0), rD[i]);
+      const bool d_ok = m_ok && co_ok[i];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { rX[i][e] = in_ok ? rX[i][e] : 0.f; rD[i][e] = d_ok ? rD[i][e] : 0.f; }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int e = 0; e < VE; e += 4) {
+        *reinterpret_cast<f32x4*>(&sX[s_row[i] * WP + s_col[i] + e]) = f32x4{rX[i][e], rX[i][e + 1], rX[i][e + 2], rX[i][e + 3]};
+        *reinterpret_cast<f32x4*>(&sD[s_row[i] * WP + s_col[i] + e]) = f32x4{rD[i][e], rD[i][e + 1], rD[i][e + 2], rD[i][e + 3]};
+      }
+    }
+  };
+
+  // wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the tile: 2 x 2 accumulators of 16 x 16
+  const int qa = (wave >> 1) * 32, qb = (wave & 1) * 32;
+  const int fr = lane & 15, fk = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WM) {
+    __syncthreads();                           // the previous step's fragment reads are done
+    stash();
+    __syncthreads();
+    if (m0 + WM < m_end) fetch(m0 + WM);       // next step's loads fly while this step is on the matrix cores
+#pragma unroll
+    for (int ks = 0; ks < WM / 4; ++ks) {
+      const int row = ks * 4 + fk;
+      float a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = sD[row * WP + qa + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = sX[row * WP + qb + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // accumulator layout: column (k') = lane & 15, row (co) = 4 * (lane >> 4) + r
+  float* __restrict__ slab = p.slabs + (long long)blockIdx.y * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + qa + i * 16 + fk * 4 + r, kk = k0 + qb + j * 16 + fr;
+        if (co < p.Cout && kk < p.K) slab[(long long)co * p.K + kk] = acc[i][j][r];
+      }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
+                                                           float beta) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += slabs[(long long)j * n + i];
+    dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wt, int Cout, int KH, int KW, int Cin) {
+  const long long n = (long long)Cout * KH * KW * Cin;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    // i indexes the OUTPUT [ci][kh'][kw'][co] so that the writes are coalesced
+    const int co = (int)(i % Cout);
+    long long t = i / Cout;
+    const int kw2 = (int)(t % KW); t /= KW;
+    const int kh2 = (int)(t % KH);
+    const int ci = (int)(t / KH);
+    wt[i] = w[(((long long)co * KH + (KH - 1 - kh2)) * KW + (KW - 1 - kw2)) * Cin + ci];
+  }
+}
+
+inline int wgrad_nsplit(int Cout, int K, int M) {
+  const long long tiles = (long long)cdiv(Cout, WB) * cdiv(K, WB);
+  long long ns = (2048 + tiles - 1) / tiles;                 // ~8 workgroups per CU in total
+  const long long max_ns = cdiv(M, 4 * WM);                  // at least 128 rows per chunk
+  if (ns > max_ns) ns = max_ns;
+  if (ns > 1024) ns = 1024;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+}  // namespace
+
+extern "C" size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M) {
+  if (Cout <= 0 || K <= 0 || M <= 0) return 0;
+  return (size_t)wgrad_nsplit(Cout, K, M) * Cout * K * sizeof(float);
+}
+
+extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int Cin, int Cout,
+                                int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws,
+                                size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(x && dy && dw && ws, CFP_EINVAL, "cfp_conv2d_wgrad: null pointer");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_wgrad: bad dtype");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0, CFP_ESHAPE,
+              "cfp_conv2d_wgrad: non-positive dimension");
+  CFP_REQUIRE(Cin % ve == 0 && Cout % ve == 0 && x_ld % ve == 0 && dy_ld % ve == 0 && x_ld >= Cin && dy_ld >= Cout, CFP_ESHAPE,
+              "cfp_conv2d_wgrad: channel counts / pitches must be multiples of the 16-byte vector");
+  CFP_REQUIRE(aligned16(x) && aligned16(dy), CFP_EINVAL, "cfp_conv2d_wgrad: pointers must be 16-byte aligned");
+  const long long M = (long long)B * Ho * Wo, K = (long long)KH * KW * Cin;
+  CFP_REQUIRE(M < (1ll << 31) && K < (1ll << 31) && (long long)Cout * K < (1ll << 31), CFP_ESHAPE, "cfp_conv2d_wgrad: problem too large");
+  CFP_REQUIRE(ws_bytes >= cfp_conv2d_wgrad_ws_bytes(Cout, (int)K, (int)M), CFP_EINVAL, "cfp_conv2d_wgrad: workspace too small");
+  CFP_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 3) == 0, CFP_EINVAL, "cfp_conv2d_wgrad: workspace must be 4-byte aligned");
+  WgP p;
+  p.x = x; p.dy = dy; p.slabs = reinterpret_cast<float*>(ws); p.x_ld = x_ld; p.dy_ld = dy_ld;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K;
+  p.nsplit = wgrad_nsplit(Cout, (int)K, (int)M);
+  p.rows_per_split = cdiv(cdiv(M, p.nsplit), WM) * WM;
+  p.nsplit = cdiv(M, p.rows_per_split);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(cdiv(Cout, WB) * cdiv(K, WB), p.nsplit);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16_t>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
+  const long long n = (long long)Cout * K;
+  int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+  return cfp_check_launch("cfp_conv2d_wgrad");
+}
+
+extern "C" int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(w && wt && w != wt, CFP_EINVAL, "cfp_conv2d_weight_flip: bad pointer");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_weight_flip: bad dtype");
+  CFP_REQUIRE(Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && (long long)Cout * KH * KW * Cin < (1ll << 31), CFP_ESHAPE,
+              "cfp_conv2d_weight_flip: bad shape");
+  const long long n = (long long)Cout * KH * KW * Cin;
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_F32)
+    hipLaunchKernelGGL(weight_flip_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)w, (float*)wt, Cout, KH, KW, Cin);
+  else
+    hipLaunchKernelGGL(weight_flip_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, (const unsigned short*)w, (unsigned short*)wt,
+                       Cout, KH, KW, Cin);
+  return cfp_check_launch("cfp_conv2d_weight_flip");
+}

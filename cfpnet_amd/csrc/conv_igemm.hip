@@ -358,11 +358,11 @@ extern "C" int cfp_layernorm(const void* in, int in_ld, const float* gamma, cons
                              const void* residual, int res_ld, void* out, int out_ld, int rows, int C, int dtype,
                              cfp_stream_t stream);
 
-extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+static int conv2d_impl(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                                   const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
                                   int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                                   int dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream, int dil) {
   CFP_REQUIRE(in && w && out, CFP_EINVAL, "cfp_conv2d_nhwc: null pointer");
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_nhwc: bad dtype");
   const int ve = vec_elems(dtype);
@@ -375,7 +375,10 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
   CFP_REQUIRE(!residual || (res_ld % ve == 0 && res_ld >= Cout), CFP_ESHAPE, "cfp_conv2d_nhwc: bad res_ld");
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(residual) && aligned16(ws), CFP_EINVAL,
               "cfp_conv2d_nhwc: pointers must be 16-byte aligned");
-  CFP_REQUIRE((Ho - 1) * stride - pad_t + KH - 1 < H + KH && (Wo - 1) * stride - pad_l + KW - 1 < W + KW, CFP_ESHAPE,
+  CFP_REQUIRE(dil >= 1 && (dil == 1 || (stride == 1 && !per_image_weights && !ln_gamma)), CFP_EINVAL, "cfp_conv2d_nhwc: bad input dilation");
+  const long long Hd = (long long)(H - 1) * dil + 1, Wd = (long long)(W - 1) * dil + 1;      // zero-stuffed input size
+  // (a data gradient may extend past the stuffed input: forward pixels the strided window never reached get a zero gradient)
+  CFP_REQUIRE(dil > 1 || ((Ho - 1) * stride - pad_t + KH - 1 < Hd + KH && (Wo - 1) * stride - pad_l + KW - 1 < Wd + KW), CFP_ESHAPE,
               "cfp_conv2d_nhwc: output size inconsistent with input size");
   CFP_REQUIRE((long long)B * Ho * Wo < (1ll << 31) && (long long)KH * KW * Cin < (1ll << 31), CFP_ESHAPE,
               "cfp_conv2d_nhwc: problem too large");
@@ -386,12 +389,12 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
   p.in_ld = in_ld; p.out_ld = out_ld; p.res_ld = res_ld;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act; p.f16 = dtype == CFP_F16;
-  p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W) ? 1 : 0;
+  p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = dil;
+  p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && dil == 1) ? 1 : 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
-  const bool gen2 = is16(dtype) && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
+  const bool gen2 = dil == 1 && is16(dtype) && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
                     (long long)H * W * in_ld < (1ll << 30);
   if (gen2) {
     const int rpb = per_image_weights ? Ho * Wo : 0;
@@ -445,6 +448,26 @@ gen1_path:
   int e = cfp_check_launch("cfp_conv2d_nhwc");
   if (e != CFP_OK || !ln_gamma) return e;
   return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
+}
+
+extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
+                                  const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
+                                  int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
+                                  int dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  return conv2d_impl(in, in_ld, w, scale, shift, residual, res_ld, out, out_ld, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
+                     act, dtype, ln_gamma, ln_beta, ln_eps, per_image_weights, ws, ws_bytes, stream, 1);
+}
+
+// Data gradient of a convolution: dX [B,H,W,Cin] from dY [B,Ho,Wo,Cout] and the flipped weights of cfp_conv2d_weight_flip
+// ([Cin][KH][KW][Cout]).  dX = conv_stride1(zero-stuff(dY, stride), Wt) with padding K-1-pad, accumulate into dX when
+// `accumulate` (the skip connections' gradient) by passing dX as the residual.
+extern "C" int cfp_conv2d_dgrad(const void* dy, int dy_ld, const void* wt, void* dx, int dx_ld, int B, int H, int W, int Cin, int Cout,
+                                int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, int dtype, void* ws,
+                                size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(pad_t >= 0 && pad_l >= 0 && pad_t < KH && pad_l < KW, CFP_ESHAPE, "cfp_conv2d_dgrad: padding must be smaller than the kernel");
+  return conv2d_impl(dy, dy_ld, wt, nullptr, nullptr, accumulate ? dx : nullptr, dx_ld, dx, dx_ld, B, Ho, Wo, Cout, Cin, KH, KW, 1,
+                     KH - 1 - pad_t, KW - 1 - pad_l, H, W, CFP_ACT_NONE, dtype, nullptr, nullptr, 0.f, 0, ws, ws_bytes, stream, stride);
 }
 
 extern "C" int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,

@@ -22,6 +22,8 @@ struct ConvP {
   int rows_per_batch;      // > 0: M-tiles do not straddle images and image b uses weights w + b * w_bstride
   long long w_bstride;     // elements
   int f16;                 // 16-bit storage is IEEE half (CFP_F16) instead of bf16
+  int dil;                 // input dilation (gen-1 kernels only): the input is read as if `dil - 1` zeros sat between its pixels --
+                           // the data gradient of a stride-`dil` convolution; H / W stay the REAL input size
 };
 
 // conv_igemm2.hip
@@ -118,6 +120,10 @@ __device__ __forceinline__ void igemm_mainloop(const ConvP& p, int m0, int n0, i
       bool ok = a_ok[i] && kok;
       long long off = a_base[i] + cc;
       if (!p.pointwise) {
+        if (p.dil > 1) {        // uniform: (hi, wi) are coordinates of the zero-stuffed input
+          ok = ok && hi >= 0 && wi >= 0 && hi % p.dil == 0 && wi % p.dil == 0;
+          hi /= p.dil; wi /= p.dil;
+        }
         ok = ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
         off += ((long long)hi * p.W + wi) * p.in_ld;
       }

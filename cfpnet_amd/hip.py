@@ -60,6 +60,14 @@ SIGNATURES = {
     "cfp_tof_sample_points": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _p, _p]),
     "cfp_eval_metrics_ws_bytes": (_sz, [_i]),
     "cfp_eval_metrics": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p, _p]),
+    "cfp_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
+    "cfp_conv2d_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 12 + [_f, _i, _p, _sz, _p]),
+    "cfp_conv2d_weight_flip": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_conv2d_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
+    "cfp_bn_ws_bytes": (_sz, [_i]),
+    "cfp_bn_train_stats": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _f, _f] + [_p] * 7 + [_p, _sz, _p]),
+    "cfp_scale_shift_act": (_i, [_p, _i, _p, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
+    "cfp_bn_train_bwd": (_i, [_p, _i, _p, _i, C.c_longlong, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

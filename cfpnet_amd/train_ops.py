@@ -208,3 +208,77 @@ def lr_group_of(hist_encoder_10x: bool):
             return 0
         return 1
     return group
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Backward building blocks of the conv / BatchNorm layers (csrc/conv_bwd.hip, csrc/bn_train.hip).  Thin wrappers over
+# the C ABI on NHWC row tensors [rows, C]; the training engine that chains them is not built yet.
+# ------------------------------------------------------------------------------------------------------------------
+def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, dw: Optional[torch.Tensor] = None,
+                 beta: float = 0.0) -> torch.Tensor:
+    """x2d [B*H*W, Cin], dy2d [B*Ho*Wo, Cout] (same dtype: f32 / bf16 / f16) -> dw [Cout, KH*KW*Cin] f32 (= beta*dw + grad)."""
+    from . import hip, ops
+    Cin, Cout = x2d.shape[1], dy2d.shape[1]
+    K, M = KH * KW * Cin, B * Ho * Wo
+    if dw is None:
+        dw = torch.empty(Cout, K, dtype=torch.float32, device=x2d.device)
+        beta = 0.0
+    nbytes = hip.load().cfp_conv2d_wgrad_ws_bytes(Cout, K, M)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_conv2d_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, Cin, Cout, KH, KW,
+             stride, pad_t, pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
+    return dw
+
+
+def conv2d_weight_flip(w2d: torch.Tensor, Cout, KH, KW, Cin) -> torch.Tensor:
+    """w [Cout, KH*KW*Cin] -> wt [Cin, KH*KW*Cout] with both kernel axes reversed."""
+    from . import hip, ops
+    wt = torch.empty(Cin, KH * KW * Cout, dtype=w2d.dtype, device=w2d.device)
+    hip.call("cfp_conv2d_weight_flip", w2d.data_ptr(), wt.data_ptr(), Cout, KH, KW, Cin, ops.DT[w2d.dtype], hip.current_stream())
+    return wt
+
+
+def conv2d_dgrad(dy2d: torch.Tensor, wt: torch.Tensor, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, Ho, Wo, dx: Optional[torch.Tensor] = None,
+                 accumulate: bool = False) -> torch.Tensor:
+    from . import hip, ops
+    Cout = dy2d.shape[1]
+    if dx is None:
+        dx = torch.empty(B * H * W, Cin, dtype=dy2d.dtype, device=dy2d.device)
+        accumulate = False
+    hip.call("cfp_conv2d_dgrad", dy2d.data_ptr(), dy2d.stride(0), wt.data_ptr(), dx.data_ptr(), dx.stride(0), B, H, W, Cin, Cout, KH, KW,
+             stride, pad_t, pad_l, Ho, Wo, int(accumulate), ops.DT[dy2d.dtype], None, 0, hip.current_stream())
+    return dx
+
+
+class BatchNormTrain:
+    """act(BatchNorm(x)) with batch statistics on [rows, C] NHWC rows: forward keeps what backward needs."""
+
+    def __init__(self, C: int, device, eps: float = 1e-5, momentum: float = 0.1):
+        from . import hip
+        self.C, self.eps, self.momentum = C, eps, momentum
+        f = lambda: torch.empty(C, dtype=torch.float32, device=device)
+        self.mean, self.var, self.invstd, self.scale, self.shift = f(), f(), f(), f(), f()
+        self.nbytes = hip.load().cfp_bn_ws_bytes(C)
+        self.ws = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
+
+    def forward(self, x2d, gamma, beta, running_mean, running_var, act: int):
+        from . import hip, ops
+        rows = x2d.shape[0]
+        hip.call("cfp_bn_train_stats", x2d.data_ptr(), x2d.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.ptr(gamma), hip.ptr(beta), self.eps,
+                 self.momentum, hip.ptr(running_mean), hip.ptr(running_var), self.mean.data_ptr(), self.var.data_ptr(), self.invstd.data_ptr(),
+                 self.scale.data_ptr(), self.shift.data_ptr(), self.ws.data_ptr(), self.nbytes, hip.current_stream())
+        y = torch.empty_like(x2d)
+        hip.call("cfp_scale_shift_act", x2d.data_ptr(), x2d.stride(0), self.scale.data_ptr(), self.shift.data_ptr(), act, y.data_ptr(),
+                 y.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.current_stream())
+        return y
+
+    def backward(self, x2d, dy2d, act: int):
+        from . import hip, ops
+        rows = x2d.shape[0]
+        dgamma = torch.empty(self.C, dtype=torch.float32, device=x2d.device)
+        dbeta = torch.empty_like(dgamma)
+        dx = torch.empty_like(x2d)
+        hip.call("cfp_bn_train_bwd", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), rows, self.C, ops.DT[x2d.dtype],
+                 self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), act, dgamma.data_ptr(),
+                 dbeta.data_ptr(), dx.data_ptr(), dx.stride(0), self.ws.data_ptr(), self.nbytes, hip.current_stream())
+        return dx, dgamma, dbeta

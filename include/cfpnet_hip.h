@@ -319,6 +319,41 @@ size_t cfp_eval_metrics_ws_bytes(int B);
 int cfp_eval_metrics(const float* pred, int Hp, int Wp, const float* gt, int H, int W, int B, int interpolate, int mode,
                      float lo, float hi, void* ws, size_t ws_bytes, double* out, cfp_stream_t stream);
 
+/* ---- training-step kernels: backward of the dense convolution, batch-statistics BatchNorm --------------------------
+ * (building blocks of the training row of SURVEY.md section 8; the training engine that strings them together is not
+ * built yet) */
+
+/* Weight gradient of nn.Conv2d / nn.Linear (autograd of the layers cfp_conv2d_nhwc replaces; train.py:125):
+ * dw[Cout][KH*KW*Cin] (f32) = beta * dw + sum over output pixels of dy[m][co] * x[window(m)][ci].  x [B,H,W,Cin] and
+ * dy [B,Ho,Wo,Cout] in `dtype` (16-bit inputs are widened to f32 on the way to the matrix cores; accumulation f32).
+ * Split over pixel chunks into f32 slabs (ws) that a second kernel adds in a fixed order: bit-reproducible. */
+size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M);
+int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws,
+                     size_t ws_bytes, cfp_stream_t stream);
+/* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: the weights the data gradient convolves with. */
+int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream);
+/* Data gradient: dx [B,H,W,Cin] (+= when accumulate) from dy [B,Ho,Wo,Cout] and the flipped weights, for the forward
+ * geometry (KH,KW,stride,pad_t,pad_l): a stride-1 convolution over dy with `stride - 1` zeros stuffed between its pixels. */
+int cfp_conv2d_dgrad(const void* dy, int dy_ld, const void* wt, void* dx, int dx_ld, int B, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, int dtype, void* ws,
+                     size_t ws_bytes, cfp_stream_t stream);
+
+/* Training-mode BatchNorm over `rows` NHWC rows (nn.BatchNorm2d/1d in model.train()): batch mean / biased variance
+ * (two-pass), running statistics updated with `momentum` (running_var from the unbiased variance), and the folded
+ * per-channel scale = gamma*invstd, shift = beta - mean*scale that cfp_scale_shift_act applies with the activation. */
+size_t cfp_bn_ws_bytes(int C);
+int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, int dtype, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* mean, float* var, float* invstd,
+                       float* scale, float* shift, void* ws, size_t ws_bytes, cfp_stream_t stream);
+/* out = act(x * scale[c] + shift[c]) (BatchNorm apply + SiLU / LeakyReLU / ReLU / GELU / sigmoid / none). */
+int cfp_scale_shift_act(const void* x, int ld, const float* scale, const float* shift, int act, void* out, int out_ld,
+                        long long rows, int C, int dtype, cfp_stream_t stream);
+/* Backward of act(BatchNorm(x)) in training mode: dgamma, dbeta (f32) and dx from the pre-BN input x and dy. */
+int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld, long long rows, int C, int dtype, const float* mean,
+                     const float* invstd, const float* scale, const float* shift, int act, float* dgamma, float* dbeta,
+                     void* dx, int dx_ld, void* ws, size_t ws_bytes, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

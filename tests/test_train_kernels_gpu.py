@@ -1,0 +1,122 @@
+"""Backward building blocks of the training step (conv weight / data gradient, training-mode BatchNorm) against PyTorch
+CPU autograd of the same layer -- the reference's training step is plain autograd over nn.Conv2d / nn.BatchNorm2d
+(train.py:119-131).  f32: relative to the gradient's max 2e-5 (reduction order differs); 16-bit: inputs are quantised the
+same way on both sides, products are exact in f32, so the same bound applies to the weight gradient; outputs stored in
+16 bits carry their storage rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cfpnet_amd import hip, ops, train_ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+OUT_TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3}
+
+CASES = [  # B, H, W, Cin, Cout, k, stride, pads (t, l, b, r)
+    (2, 12, 16, 16, 24, 3, 1, (1, 1, 1, 1)),
+    (2, 9, 11, 8, 40, 3, 2, (0, 0, 1, 1)),        # stem-like: TF SAME on odd sizes
+    (1, 10, 14, 16, 64, 3, 2, (0, 0, 1, 1)),
+    (3, 8, 8, 136, 816, 1, 1, (0, 0, 0, 0)),      # pointwise, ragged Cout tile
+    (1, 30, 40, 32, 32, 6, 6, (0, 0, 0, 0)),      # GSA sr conv: kernel = stride
+    (2, 33, 47, 8, 16, 3, 1, (1, 1, 1, 1)),       # many rows, tiny channels
+    (1, 1, 300, 64, 128, 1, 1, (0, 0, 0, 0)),     # Linear
+]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(t):
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def _ref(case, dtype):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x = rnd(B, Cin, H, W, seed=1).to(dtype).float().requires_grad_(True)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)).to(dtype).float().requires_grad_(True)
+    y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s)
+    dy = rnd(*y.shape, seed=3).to(dtype).float()
+    y.backward(dy)
+    return x.detach(), w.detach(), dy, x.grad, w.grad, y.shape[2], y.shape[3]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_conv_weight_gradient(case, dtype):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x, w, dy, dx_ref, dw_ref, Ho, Wo = _ref(case, dtype)
+    dw = train_ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), B, H, W, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    err = float((got - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 2e-5, (case, dtype, err)
+    # accumulate form: dw <- 0.5 * dw + grad, and bit-reproducible
+    dw2 = train_ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), B, H, W, k, k, s, pt, pl, Ho, Wo, dw=dw.clone(), beta=0.5)
+    dw3 = train_ops.conv2d_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), B, H, W, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    assert torch.equal(dw3, dw)
+    assert float((dw2 - 1.5 * dw).abs().max()) <= 1e-6 * float(dw.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_conv_data_gradient(case, dtype):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x, w, dy, dx_ref, dw_ref, Ho, Wo = _ref(case, dtype)
+    w2d = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV)
+    wt = train_ops.conv2d_weight_flip(w2d, Cout, k, k, Cin)
+    want_wt = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, k * k * Cout).to(dtype)
+    assert torch.equal(wt.cpu(), want_wt)
+    dyd = nhwc(dy).to(dtype).to(DEV)
+    dx = train_ops.conv2d_dgrad(dyd, wt, B, H, W, Cin, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    got = dx.float().cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    scale = float(dx_ref.abs().max())
+    assert float((got - dx_ref).abs().max()) <= OUT_TOL[dtype] * scale, (case, dtype)
+    # accumulate into an existing gradient (skip connections)
+    base = rnd(B * H * W, Cin, seed=9).to(dtype).to(DEV)
+    acc = train_ops.conv2d_dgrad(dyd, wt, B, H, W, Cin, k, k, s, pt, pl, Ho, Wo, dx=base.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    assert float((acc.float() - (base.float() + dx.float())).abs().max()) <= 2 * OUT_TOL[dtype] * (scale + 4.0)
+
+
+ACTS = [hip.ACT_NONE, hip.ACT_RELU, hip.ACT_LRELU, hip.ACT_SILU, hip.ACT_GELU, hip.ACT_SIGMOID]
+TORCH_ACT = {hip.ACT_NONE: lambda t: t, hip.ACT_RELU: F.relu, hip.ACT_LRELU: lambda t: F.leaky_relu(t, 0.01), hip.ACT_SILU: F.silu,
+             hip.ACT_GELU: F.gelu, hip.ACT_SIGMOID: torch.sigmoid}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("rows,C", [(2 * 30 * 40, 136), (5000, 8), (77, 1392), (3 * 60 * 80, 64)])
+def test_batchnorm_training_forward_backward(rows, C, act, dtype):
+    eps, mom = 1e-3, 0.1
+    x = (rnd(rows, C, seed=1) * 1.7 + 0.3).to(dtype).float().requires_grad_(True)
+    gamma = (rnd(C, seed=2).abs() + 0.5).requires_grad_(True)
+    beta = rnd(C, seed=3).requires_grad_(True)
+    rm, rv = rnd(C, seed=4), rnd(C, seed=5).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = TORCH_ACT[act](F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, mom, eps))
+    dy = rnd(rows, C, seed=6).to(dtype).float()
+    y.backward(dy)
+
+    bn = train_ops.BatchNormTrain(C, DEV, eps=eps, momentum=mom)
+    xd, rmd, rvd = x.detach().to(dtype).to(DEV), rm.to(DEV), rv.to(DEV)
+    yd = bn.forward(xd, gamma.detach().to(DEV), beta.detach().to(DEV), rmd, rvd, act)
+    dx, dgamma, dbeta = bn.backward(xd, dy.to(dtype).to(DEV), act)
+    torch.cuda.synchronize()
+    tol = OUT_TOL[dtype]
+    assert float((bn.mean.cpu() - x.detach().mean(0)).abs().max()) < 1e-5
+    assert float((bn.var.cpu() - x.detach().var(0, unbiased=False)).abs().max()) < 2e-5 * float(x.detach().var(0).max())
+    assert torch.allclose(rmd.cpu(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    assert float((yd.float().cpu() - y.detach()).abs().max()) <= tol * float(y.detach().abs().max()) + 1e-6
+    gs = float(x.grad.abs().max())
+    assert float((dx.float().cpu() - x.grad).abs().max()) <= tol * gs + 2e-5 * gs
+    assert float((dgamma.cpu() - gamma.grad).abs().max()) <= 3e-5 * float(gamma.grad.abs().max()) + 1e-5
+    assert float((dbeta.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
