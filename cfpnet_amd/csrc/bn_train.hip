@@ -34,13 +34,14 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 // MODE 0: s1 = sum x                         (aux unused)
 // MODE 1: s1 = sum (x - mean)^2              (aux0 = mean)
 // MODE 2: s1 = sum dz, s2 = sum dz * xhat    (aux0 = mean, aux1 = invstd, aux2 = scale, aux3 = shift; dz = dy * act'(x*scale+shift))
+// MODE 3: s1 = sum dy, s2 = sum dy * xhat    (LayerNorm: aux0 = per-ROW [rows][2] (mean, rstd))
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, int ld, const T* __restrict__ dy, int dy_ld, long long rows,
                                                         int C, const float* __restrict__ aux0, const float* __restrict__ aux1,
                                                         const float* __restrict__ aux2, const float* __restrict__ aux3, int act,
                                                         float* __restrict__ partial, long long rows_per_split) {
   constexpr int VE = Vec<T>::N;
-  constexpr int NS = MODE == 2 ? 2 : 1;
+  constexpr int NS = MODE >= 2 ? 2 : 1;
   __shared__ float red[RC_LANES][RC_COLS * 8 * 2];
   const int tid = threadIdx.x;
   const int cl = tid & (RC_COLS - 1), rl = tid / RC_COLS;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
   float a0[VE], a1[VE], a2[VE], a3[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) {
-    a0[e] = (MODE >= 1) ? aux0[cc + e] : 0.f;
+    a0[e] = (MODE == 1 || MODE == 2) ? aux0[cc + e] : 0.f;
     a1[e] = (MODE == 2) ? aux1[cc + e] : 0.f;
     a2[e] = (MODE == 2) ? aux2[cc + e] : 0.f;
     a3[e] = (MODE == 2) ? aux3[cc + e] : 0.f;
@@ -61,12 +62,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
   for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   constexpr int U = 4;
   for (long long r = r0 + rl; r < r1; r += RC_LANES * U) {
-    float v[U][VE], g[U][VE];
+    float v[U][VE], g[U][VE], rmean[U], rrstd[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long rr = min(r + (long long)u * RC_LANES, r1 - 1);
       Vec<T>::load(x + rr * ld + cc, v[u]);
-      if (MODE == 2) Vec<T>::load(dy + rr * dy_ld + cc, g[u]);
+      if (MODE >= 2) Vec<T>::load(dy + rr * dy_ld + cc, g[u]);
+      if (MODE == 3) { rmean[u] = aux0[rr * 2]; rrstd[u] = aux0[rr * 2 + 1]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -75,10 +77,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
       for (int e = 0; e < VE; ++e) {
         if (MODE == 0) s1[e] += v[u][e];
         else if (MODE == 1) { const float d = v[u][e] - a0[e]; s1[e] = fmaf(d, d, s1[e]); }
-        else {
+        else if (MODE == 2) {
           const float dz = g[u][e] * act_grad(v[u][e] * a2[e] + a3[e], act);
           s1[e] += dz;
           s2[e] = fmaf(dz, (v[u][e] - a0[e]) * a1[e], s2[e]);
+        } else {
+          s1[e] += g[u][e];
+          s2[e] = fmaf(g[u][e], (v[u][e] - rmean[u]) * rrstd[u], s2[e]);
         }
       }
     }
@@ -172,6 +177,82 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// LayerNorm backward, data part: one row per LPR lanes (LPR = C / VE, a power of two <= 64), like the forward kernel.
+//   xhat = (x - mean) * rstd;  g = dy * gamma;  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat));  stats[row] = (mean, rstd)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, int ld, const T* __restrict__ dy, int dy_ld,
+                                                            const float* __restrict__ gamma, float eps, T* __restrict__ dx, int dx_ld,
+                                                            float* __restrict__ stats, long long rows, int C, int accumulate) {
+  constexpr int VE = Vec<T>::N;
+  const int LPR = C / VE;
+  const int rows_per_block = 256 / LPR;
+  const int lr = threadIdx.x % LPR, rb = threadIdx.x / LPR;
+  float gm[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) gm[e] = gamma[lr * VE + e];
+  const float inv_c = 1.f / (float)C;
+  for (long long row0 = (long long)blockIdx.x * rows_per_block; row0 < rows; row0 += (long long)gridDim.x * rows_per_block) {
+    const long long row = row0 + rb;
+    const bool ok = row < rows;
+    const long long rr = ok ? row : rows - 1;
+    float v[VE], g[VE];
+    Vec<T>::load(x + rr * ld + lr * VE, v);
+    Vec<T>::load(dy + rr * dy_ld + lr * VE, g);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s += v[e];
+    for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) { const float d = v[e] - mean; q = fmaf(d, d, q); }
+    for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+      v[e] = (v[e] - mean) * rstd;          // xhat
+      g[e] *= gm[e];
+      sg += g[e];
+      sgx = fmaf(g[e], v[e], sgx);
+    }
+    for (int o = LPR >> 1; o > 0; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+    sg *= inv_c; sgx *= inv_c;
+    if (ok) {
+      float o_[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) o_[e] = rstd * (g[e] - sg - v[e] * sgx);
+      if (accumulate) {
+        float a_[VE];
+        Vec<T>::load(dx + row * dx_ld + lr * VE, a_);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o_[e] += a_[e];
+      }
+      Vec<T>::store(dx + row * dx_ld + lr * VE, o_);
+      if (lr == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    }
+  }
+}
+
+// dz = dy * act'(z)  (z = the pre-activation the forward kernel saw)
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, int ld, const T* __restrict__ dy, int dy_ld, int act,
+                                                      T* __restrict__ dz, int dz_ld, long long rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float v[VE], g[VE];
+    Vec<T>::load(z + r * ld + c, v);
+    Vec<T>::load(dy + r * dy_ld + c, g);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = g[e] * act_grad(v[e], act);
+    Vec<T>::store(dz + r * dz_ld + c, v);
+  }
+}
+
 inline int red_splits(long long rows, int C, int ve) {
   const int colblk = cdiv(C, RC_COLS * ve);
   long long ns = 1024 / colblk;
@@ -196,7 +277,7 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
                                  act, partial, rps)
   if (dtype == CFP_BF16) RL(bf16_t); else if (dtype == CFP_F16) RL(f16_t); else RL(float);
 #undef RL
-  const int nsum = MODE == 2 ? 2 : 1;
+  const int nsum = MODE >= 2 ? 2 : 1;
   hipLaunchKernelGGL(colfinal_kernel, dim3(cdiv(C * nsum, 256)), dim3(256), 0, s, partial, nsplit, nsum, C, inv_n, out0, out1);
   return 0;
 }
@@ -257,4 +338,52 @@ extern "C" int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld
   if (dtype == CFP_BF16) BL(bf16_t); else if (dtype == CFP_F16) BL(f16_t); else BL(float);
 #undef BL
   return cfp_check_launch("cfp_bn_train_bwd");
+}
+
+/* Column sum over rows: the bias gradient of a conv / linear layer (sum over pixels of dy). */
+extern "C" int cfp_colsum(const void* x, int ld, long long rows, int C, int dtype, float* out, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(x && out && ws && aligned16(x), CFP_EINVAL, "cfp_colsum: bad pointer");
+  BN_COMMON("cfp_colsum");
+  CFP_REQUIRE(ws_bytes >= cfp_bn_ws_bytes(C), CFP_EINVAL, "cfp_colsum: workspace too small");
+  launch_reduce<0>(x, ld, nullptr, 0, rows, C, nullptr, nullptr, nullptr, nullptr, 0, dtype, reinterpret_cast<float*>(ws), out, nullptr, 1.f, s);
+  return cfp_check_launch("cfp_colsum");
+}
+
+extern "C" int cfp_act_bwd(const void* z, int ld, const void* dy, int dy_ld, int act, void* dz, int dz_ld, long long rows, int C, int dtype,
+                           cfp_stream_t stream) {
+  CFP_REQUIRE(z && dy && dz && aligned16(z) && aligned16(dy) && aligned16(dz), CFP_EINVAL, "cfp_act_bwd: bad pointer");
+  BN_COMMON("cfp_act_bwd");
+  CFP_REQUIRE(dy_ld % ve == 0 && dy_ld >= C && dz_ld % ve == 0 && dz_ld >= C, CFP_ESHAPE, "cfp_act_bwd: bad pitch");
+  const dim3 grid(ew_grid(rows * (C / ve)));
+#define AL(T) hipLaunchKernelGGL(act_bwd_kernel<T>, grid, dim3(256), 0, s, (const T*)z, ld, (const T*)dy, dy_ld, act, (T*)dz, dz_ld, rows, C)
+  if (dtype == CFP_BF16) AL(bf16_t); else if (dtype == CFP_F16) AL(f16_t); else AL(float);
+#undef AL
+  return cfp_check_launch("cfp_act_bwd");
+}
+
+extern "C" size_t cfp_layernorm_bwd_ws_bytes(long long rows, int C) {
+  return (rows > 0 && C > 0) ? cfp_bn_ws_bytes(C) + (size_t)rows * 2 * sizeof(float) : 0;
+}
+
+/* Backward of nn.LayerNorm over the channel axis: dx (+= when accumulate), dgamma, dbeta. */
+extern "C" int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                                 int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
+                                 cfp_stream_t stream) {
+  CFP_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && ws && aligned16(x) && aligned16(dy) && aligned16(dx), CFP_EINVAL,
+              "cfp_layernorm_bwd: bad pointer");
+  BN_COMMON("cfp_layernorm_bwd");
+  const int lpr = C / ve;
+  CFP_REQUIRE(lpr <= 64 && (lpr & (lpr - 1)) == 0, CFP_ESHAPE, "cfp_layernorm_bwd: C / vector width must be a power of two <= 64");
+  CFP_REQUIRE(dy_ld % ve == 0 && dy_ld >= C && dx_ld % ve == 0 && dx_ld >= C, CFP_ESHAPE, "cfp_layernorm_bwd: bad pitch");
+  CFP_REQUIRE(ws_bytes >= cfp_layernorm_bwd_ws_bytes(rows, C), CFP_EINVAL, "cfp_layernorm_bwd: workspace too small");
+  float* partial = reinterpret_cast<float*>(ws);
+  float* stats = partial + cfp_bn_ws_bytes(C) / sizeof(float);
+  long long blocks = (rows + (256 / lpr) - 1) / (256 / lpr);
+  if (blocks > 4096) blocks = 4096;
+#define LL(T) hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, (const T*)x, ld, (const T*)dy, dy_ld, gamma, eps, \
+                                 (T*)dx, dx_ld, stats, rows, C, accumulate)
+  if (dtype == CFP_BF16) LL(bf16_t); else if (dtype == CFP_F16) LL(f16_t); else LL(float);
+#undef LL
+  launch_reduce<3>(x, ld, dy, dy_ld, rows, C, stats, nullptr, nullptr, nullptr, 0, dtype, partial, dbeta, dgamma, 1.f, s);
+  return cfp_check_launch("cfp_layernorm_bwd");
 }

@@ -68,6 +68,10 @@ SIGNATURES = {
     "cfp_bn_train_stats": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _f, _f] + [_p] * 7 + [_p, _sz, _p]),
     "cfp_scale_shift_act": (_i, [_p, _i, _p, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_bn_train_bwd": (_i, [_p, _i, _p, _i, C.c_longlong, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
+    "cfp_colsum": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _sz, _p]),
+    "cfp_act_bwd": (_i, [_p, _i, _p, _i, _i, _p, _i, C.c_longlong, _i, _i, _p]),
+    "cfp_layernorm_bwd_ws_bytes": (_sz, [C.c_longlong, _i]),
+    "cfp_layernorm_bwd": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _i, _p, _p, C.c_longlong, _i, _i, _p, _sz, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -282,3 +282,40 @@ class BatchNormTrain:
                  self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), act, dgamma.data_ptr(),
                  dbeta.data_ptr(), dx.data_ptr(), dx.stride(0), self.ws.data_ptr(), self.nbytes, hip.current_stream())
         return dx, dgamma, dbeta
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    """Sum over rows per channel (f32): the bias gradient."""
+    from . import hip, ops
+    C = x2d.shape[1]
+    nbytes = hip.load().cfp_bn_ws_bytes(C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_colsum", x2d.data_ptr(), x2d.stride(0), x2d.shape[0], C, ops.DT[x2d.dtype], out.data_ptr(), ws.data_ptr(), nbytes,
+             hip.current_stream())
+    return out
+
+
+def act_bwd(z2d: torch.Tensor, dy2d: torch.Tensor, act: int) -> torch.Tensor:
+    from . import hip, ops
+    dz = torch.empty_like(z2d)
+    hip.call("cfp_act_bwd", z2d.data_ptr(), z2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), act, dz.data_ptr(), dz.stride(0), z2d.shape[0],
+             z2d.shape[1], ops.DT[z2d.dtype], hip.current_stream())
+    return dz
+
+
+def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, eps: float, dx: Optional[torch.Tensor] = None,
+                  accumulate: bool = False):
+    """-> (dx, dgamma, dbeta)"""
+    from . import hip, ops
+    rows, C = x2d.shape
+    if dx is None:
+        dx, accumulate = torch.empty_like(x2d), False
+    nbytes = hip.load().cfp_layernorm_bwd_ws_bytes(rows, C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x2d.device)
+    dbeta = torch.empty_like(dgamma)
+    hip.call("cfp_layernorm_bwd", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), gamma.data_ptr(), eps, dx.data_ptr(),
+             dx.stride(0), int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ops.DT[x2d.dtype], ws.data_ptr(), nbytes,
+             hip.current_stream())
+    return dx, dgamma, dbeta

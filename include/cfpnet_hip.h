@@ -354,6 +354,18 @@ int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld, long long
                      const float* invstd, const float* scale, const float* shift, int act, float* dgamma, float* dbeta,
                      void* dx, int dx_ld, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* out[c] = sum over rows of x[r][c] (f32): the bias gradient of a conv / linear layer.  ws: cfp_bn_ws_bytes(C). */
+int cfp_colsum(const void* x, int ld, long long rows, int C, int dtype, float* out, void* ws, size_t ws_bytes, cfp_stream_t stream);
+/* dz = dy * act'(z): backward of a stand-alone SiLU / ReLU / LeakyReLU / GELU / sigmoid given its input z. */
+int cfp_act_bwd(const void* z, int ld, const void* dy, int dy_ld, int act, void* dz, int dz_ld, long long rows, int C, int dtype,
+                cfp_stream_t stream);
+/* Backward of nn.LayerNorm over the channel axis (transformer.py:38-39, convnext.py:31): dx (+= when accumulate),
+ * dgamma, dbeta (f32) from the layer's input x and dy. */
+size_t cfp_layernorm_bwd_ws_bytes(long long rows, int C);
+int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                      int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
+                      cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,37 @@ def test_batchnorm_training_forward_backward(rows, C, act, dtype):
     assert float((dx.float().cpu() - x.grad).abs().max()) <= tol * gs + 2e-5 * gs
     assert float((dgamma.cpu() - gamma.grad).abs().max()) <= 3e-5 * float(gamma.grad.abs().max()) + 1e-5
     assert float((dbeta.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(4800, 128), (257, 32), (19200, 64), (1, 256)])
+def test_layernorm_backward(rows, C, dtype):
+    x = (rnd(rows, C, seed=1) * 1.3 + 0.2).to(dtype).float().requires_grad_(True)
+    gamma = (rnd(C, seed=2).abs() + 0.5).requires_grad_(True)
+    beta = rnd(C, seed=3).requires_grad_(True)
+    dy = rnd(rows, C, seed=4).to(dtype).float()
+    F.layer_norm(x, (C,), gamma, beta, 1e-5).backward(dy)
+    xd, dyd = x.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV)
+    dx, dg, db = train_ops.layernorm_bwd(xd, dyd, gamma.detach().to(DEV), 1e-5)
+    base = rnd(rows, C, seed=5).to(dtype).to(DEV)
+    dx2, _, _ = train_ops.layernorm_bwd(xd, dyd, gamma.detach().to(DEV), 1e-5, dx=base.clone(), accumulate=True)
+    torch.cuda.synchronize()
+    gs = float(x.grad.abs().max())
+    assert float((dx.float().cpu() - x.grad).abs().max()) <= (OUT_TOL[dtype] + 2e-5) * gs
+    assert float((dx2.float() - (base.float() + dx.float())).abs().max()) <= 2 * OUT_TOL[dtype] * (gs + 4.0) + 1e-5
+    assert float((dg.cpu() - gamma.grad).abs().max()) <= 3e-5 * float(gamma.grad.abs().max()) + 1e-5
+    assert float((db.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ACTS)
+def test_activation_backward_and_bias_gradient(act, dtype):
+    rows, C = 3001, 72
+    z = rnd(rows, C, seed=1, scale=2.0).to(dtype).float().requires_grad_(True)
+    dy = rnd(rows, C, seed=2).to(dtype).float()
+    TORCH_ACT[act](z).backward(dy)
+    dz = train_ops.act_bwd(z.detach().to(dtype).to(DEV), dy.to(dtype).to(DEV), act)
+    bias_grad = train_ops.colsum(dy.to(dtype).to(DEV))
+    torch.cuda.synchronize()
+    assert float((dz.float().cpu() - z.grad).abs().max()) <= (OUT_TOL[dtype] + 1e-5) * float(z.grad.abs().max())
+    assert float((bias_grad.cpu() - dy.sum(0)).abs().max()) <= 2e-5 * float(dy.sum(0).abs().max()) + 1e-4
