@@ -1,0 +1,332 @@
+// Small backward kernels of the training step: gradient accumulation, positional-encoding gradient, squeeze-excite
+// backward pieces, depthwise 3x3 backward.  All HBM-bound sweeps over 16-byte NHWC vectors; reductions are per-split f32
+// partials combined in a fixed order.
+//
+//   reference: autograd of the corresponding forward ops in model.train() (train.py:119-131) --
+//   skip connections / torch.cat (decoder.py:57, transformer.py:66,238), `x + PE` (fusion.py:87-97), timm SqueezeExcite
+//   and the depthwise conv_dw of InvertedResidual (encoder.py:57-69).
+#include "common.h"
+
+namespace {
+
+inline int ew_grid2(long long total) { long long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// out = a * x + b * y   (y may be null: out = a * x)
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ y, int y_ld, float a, float b,
+                                                    T* __restrict__ out, int out_ld, long long rows, int C) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    float v[VE], w[VE];
+    Vec<T>::load(x + r * x_ld + c, v);
+    if (y) {
+      Vec<T>::load(y + r * y_ld + c, w);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = a * v[e] + b * w[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] *= a;
+    }
+    Vec<T>::store(out + r * out_ld + c, v);
+  }
+}
+
+// dtable[(oy + y) * Wt + ox + x][c] (+)= sum_b dx[b][y][x][c]   -- gradient of `x + PE[oy:oy+H, ox:ox+W]` (f32 table)
+template <typename T>
+__global__ __launch_bounds__(256) void rowtable_grad_kernel(const T* __restrict__ dx, int ld, float* __restrict__ dtable, int B, int H, int W,
+                                                            int C, int Wt, int oy, int ox, float beta) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = (long long)H * W * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long px = i / CV;
+    const int c = (int)(i - px * CV) * VE;
+    const int y = (int)(px / W), x = (int)(px - (long long)y * W);
+    float s[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[e] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float v[VE];
+      Vec<T>::load(dx + ((long long)b * H * W + px) * ld + c, v);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s[e] += v[e];
+    }
+    float* d = dtable + ((long long)(oy + y) * Wt + ox + x) * C + c;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) d[e] = beta != 0.f ? beta * d[e] + s[e] : s[e];
+  }
+}
+
+// out[b][c] = sum over the HW rows of image b of x * y  (squeeze-excite: d gate = sum dy * x).  One workgroup per
+// (image, 32 vector columns): 8 row lanes, fixed-order combination.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ y, int y_ld,
+                                                          float* __restrict__ out, int HW, int C) {
+  constexpr int VE = Vec<T>::N;
+  __shared__ float red[8][32 * 8];
+  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
+  const int c0 = (blockIdx.x * 32 + cl) * VE;
+  const int cc = c0 < C ? c0 : 0;
+  const long long base = (long long)blockIdx.y * HW;
+  float s[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) s[e] = 0.f;
+  for (int r = rl; r < HW; r += 8) {
+    float a[VE], b[VE];
+    Vec<T>::load(x + (base + r) * x_ld + cc, a);
+    Vec<T>::load(y + (base + r) * y_ld + cc, b);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[e] = fmaf(a[e], b[e], s[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) red[rl][cl * 8 + e] = s[e];
+  __syncthreads();
+  for (int i = tid; i < 32 * VE; i += 256) {
+    const int c_l = i / VE, e = i - c_l * VE;
+    const int c = (blockIdx.x * 32 + c_l) * VE + e;
+    if (c >= C) continue;
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) t += red[l][c_l * 8 + e];
+    out[(long long)blockIdx.y * C + c] = t;
+  }
+}
+
+// dx = dy * gate[b][c] + add[b][c]      (squeeze-excite backward: gate path + the broadcast gradient of the mean)
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy, int dy_ld, const float* __restrict__ gate,
+                                                        const float* __restrict__ add, T* __restrict__ dx, int dx_ld, int HW, int C,
+                                                        long long rows) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = rows * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    const long long b = r / HW;
+    float v[VE];
+    Vec<T>::load(dy + r * dy_ld + c, v);
+#pragma unroll
+    for (int e = 0; e < VE; ++e) v[e] = v[e] * gate[b * C + c + e] + (add ? add[b * C + c + e] : 0.f);
+    Vec<T>::store(dx + r * dx_ld + c, v);
+  }
+}
+
+// depthwise 3x3 data gradient, any stride: dx[hi][wi][c] = sum_{kh,kw} dy[(hi + pt - kh)/s][(wi + pl - kw)/s][c] * w[kh][kw][c]
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ w, T* __restrict__ dx,
+                                                          int dx_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho,
+                                                          int Wo, int accumulate) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = (long long)B * H * W * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long px = i / CV;
+    const int c = (int)(i - px * CV) * VE;
+    const int wi = (int)(px % W);
+    const long long t = px / W;
+    const int hi = (int)(t % H), b = (int)(t / H);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hn = hi + pad_t - kh;
+      if (hn < 0 || hn % stride != 0 || hn / stride >= Ho) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wn = wi + pad_l - kw;
+        if (wn < 0 || wn % stride != 0 || wn / stride >= Wo) continue;
+        float g[VE], ww[VE];
+        Vec<T>::load(dy + (((long long)b * Ho + hn / stride) * Wo + wn / stride) * dy_ld + c, g);
+        Vec<T>::load(w + (long long)(kh * 3 + kw) * C + c, ww);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = fmaf(g[e], ww[e], acc[e]);
+      }
+    }
+    if (accumulate) {
+      float o[VE];
+      Vec<T>::load(dx + px * dx_ld + c, o);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += o[e];
+    }
+    Vec<T>::store(dx + px * dx_ld + c, acc);
+  }
+}
+
+// depthwise 3x3 weight gradient: partial[split][tap][c] = sum over the split's output pixels of dy * x(window tap)
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+                                                          float* __restrict__ partial, int B, int H, int W, int C, int stride, int pad_t,
+                                                          int pad_l, int Ho, int Wo, long long rows_per_split) {
+  constexpr int VE = Vec<T>::N;
+  __shared__ float red[8][32 * 8];
+  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
+  const int c0 = (blockIdx.x * 32 + cl) * VE;
+  const int cc = c0 < C ? c0 : 0;
+  const long long M = (long long)B * Ho * Wo;
+  const long long r0 = (long long)blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
+  float s[9][VE];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < VE; ++e) s[t][e] = 0.f;
+  for (long long m = r0 + rl; m < r1; m += 8) {
+    const int wo = (int)(m % Wo);
+    const long long tt = m / Wo;
+    const int ho = (int)(tt % Ho), b = (int)(tt / Ho);
+    float g[VE];
+    Vec<T>::load(dy + m * dy_ld + cc, g);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * stride - pad_t + kh;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = wo * stride - pad_l + kw;
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int hic = min(max(hi, 0), H - 1), wic = min(max(wi, 0), W - 1);
+        float v[VE];
+        Vec<T>::load(x + (((long long)b * H + hic) * W + wic) * x_ld + cc, v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[kh * 3 + kw][e] = fmaf(g[e], ok ? v[e] : 0.f, s[kh * 3 + kw][e]);
+      }
+    }
+  }
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[rl][cl * 8 + e] = s[t][e];
+    __syncthreads();
+    for (int i = tid; i < 32 * VE; i += 256) {
+      const int c_l = i / VE, e = i - c_l * VE;
+      const int c = (blockIdx.x * 32 + c_l) * VE + e;
+      if (c >= C) continue;
+      float a = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) a += red[l][c_l * 8 + e];
+      partial[((long long)blockIdx.y * 9 + t) * C + c] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nsplit, long long n, float* __restrict__ out,
+                                                           float beta) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int j = 0; j < nsplit; ++j) s += partial[(long long)j * n + i];
+    out[i] = beta != 0.f ? beta * out[i] + s : s;
+  }
+}
+
+inline int dw_wgrad_splits(long long M, int C, int ve) {
+  const int colblk = cdiv(C, 32 * ve);
+  long long ns = 1024 / colblk;
+  const long long mx = (M + 127) / 128;
+  if (ns > mx) ns = mx;
+  if (ns > 2048) ns = 2048;
+  if (ns < 1) ns = 1;
+  return (int)ns;
+}
+
+}  // namespace
+
+#define TM_COMMON(name)                                                                      \
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, name ": bad dtype");                              \
+  const int ve = vec_elems(dtype);                                                           \
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int cfp_axpby(const void* x, int x_ld, const void* y, int y_ld, float a, float b, void* out, int out_ld, long long rows, int C,
+                         int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(x && out && aligned16(x) && aligned16(y) && aligned16(out), CFP_EINVAL, "cfp_axpby: bad pointer");
+  TM_COMMON("cfp_axpby");
+  CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && out_ld % ve == 0 && x_ld >= C && out_ld >= C && (!y || (y_ld % ve == 0 && y_ld >= C)),
+              CFP_ESHAPE, "cfp_axpby: bad shape");
+  const dim3 grid(ew_grid2(rows * (C / ve)));
+#define L(T) hipLaunchKernelGGL(axpby_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, a, b, (T*)out, out_ld, rows, C)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_axpby");
+}
+
+extern "C" int cfp_rowtable_grad(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
+                                 int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dx && dtable && aligned16(dx), CFP_EINVAL, "cfp_rowtable_grad: bad pointer");
+  TM_COMMON("cfp_rowtable_grad");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0 && ld % ve == 0 && ld >= C && Wt >= ox + W && oy >= 0 && ox >= 0, CFP_ESHAPE,
+              "cfp_rowtable_grad: bad shape");
+  const dim3 grid(ew_grid2((long long)H * W * (C / ve)));
+#define L(T) hipLaunchKernelGGL(rowtable_grad_kernel<T>, grid, dim3(256), 0, s, (const T*)dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_rowtable_grad");
+}
+
+extern "C" int cfp_channel_dot(const void* x, int x_ld, const void* y, int y_ld, float* out, int B, int HW, int C, int dtype,
+                               cfp_stream_t stream) {
+  CFP_REQUIRE(x && y && out && aligned16(x) && aligned16(y), CFP_EINVAL, "cfp_channel_dot: bad pointer");
+  TM_COMMON("cfp_channel_dot");
+  CFP_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && y_ld % ve == 0 && x_ld >= C && y_ld >= C, CFP_ESHAPE,
+              "cfp_channel_dot: bad shape");
+  const dim3 grid(cdiv(C, 32 * ve), B);
+#define L(T) hipLaunchKernelGGL(channel_dot_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, out, HW, C)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_channel_dot");
+}
+
+extern "C" int cfp_bcast_fma(const void* dy, int dy_ld, const float* gate, const float* add, void* dx, int dx_ld, int B, int HW, int C,
+                             int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dy && gate && dx && aligned16(dy) && aligned16(dx), CFP_EINVAL, "cfp_bcast_fma: bad pointer");
+  TM_COMMON("cfp_bcast_fma");
+  CFP_REQUIRE(B > 0 && HW > 0 && C > 0 && C % ve == 0 && dy_ld % ve == 0 && dx_ld % ve == 0 && dy_ld >= C && dx_ld >= C, CFP_ESHAPE,
+              "cfp_bcast_fma: bad shape");
+  const long long rows = (long long)B * HW;
+  const dim3 grid(ew_grid2(rows * (C / ve)));
+#define L(T) hipLaunchKernelGGL(bcast_fma_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, gate, add, (T*)dx, dx_ld, HW, C, rows)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_bcast_fma");
+}
+
+extern "C" int cfp_dwconv3x3_dgrad(const void* dy, int dy_ld, const void* w, void* dx, int dx_ld, int B, int H, int W, int C, int stride,
+                                   int pad_t, int pad_l, int Ho, int Wo, int accumulate, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dy && w && dx && aligned16(dy) && aligned16(w) && aligned16(dx), CFP_EINVAL, "cfp_dwconv3x3_dgrad: bad pointer");
+  TM_COMMON("cfp_dwconv3x3_dgrad");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % ve == 0 && dy_ld % ve == 0 && dx_ld % ve == 0 && dy_ld >= C &&
+                  dx_ld >= C && (stride == 1 || stride == 2), CFP_ESHAPE, "cfp_dwconv3x3_dgrad: bad shape");
+  const dim3 grid(ew_grid2((long long)B * H * W * (C / ve)));
+#define L(T) hipLaunchKernelGGL(dw3x3_dgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, (const T*)w, (T*)dx, dx_ld, B, H, W, C, stride, \
+                                pad_t, pad_l, Ho, Wo, accumulate)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_dwconv3x3_dgrad");
+}
+
+extern "C" size_t cfp_dwconv3x3_wgrad_ws_bytes(int C) { return C > 0 ? (size_t)2048 * 9 * C * sizeof(float) : 0; }
+
+extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                                   int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes,
+                                   cfp_stream_t stream) {
+  CFP_REQUIRE(x && dy && dw && ws && aligned16(x) && aligned16(dy), CFP_EINVAL, "cfp_dwconv3x3_wgrad: bad pointer");
+  TM_COMMON("cfp_dwconv3x3_wgrad");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && dy_ld % ve == 0 && x_ld >= C &&
+                  dy_ld >= C && (stride == 1 || stride == 2), CFP_ESHAPE, "cfp_dwconv3x3_wgrad: bad shape");
+  CFP_REQUIRE(ws_bytes >= cfp_dwconv3x3_wgrad_ws_bytes(C), CFP_EINVAL, "cfp_dwconv3x3_wgrad: workspace too small");
+  const long long M = (long long)B * Ho * Wo;
+  const int ns = dw_wgrad_splits(M, C, ve);
+  const long long rps = (M + ns - 1) / ns;
+  const int nsplit = (int)((M + rps - 1) / rps);
+  float* partial = reinterpret_cast<float*>(ws);
+  const dim3 grid(cdiv(C, 32 * ve), nsplit);
+#define L(T) hipLaunchKernelGGL(dw3x3_wgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B, H, W, C, stride, \
+                                pad_t, pad_l, Ho, Wo, rps)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  const long long n = 9ll * C;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, partial, nsplit, n, dw, beta);
+  return cfp_check_launch("cfp_dwconv3x3_wgrad");
+}

@@ -72,6 +72,13 @@ SIGNATURES = {
     "cfp_act_bwd": (_i, [_p, _i, _p, _i, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_layernorm_bwd_ws_bytes": (_sz, [C.c_longlong, _i]),
     "cfp_layernorm_bwd": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _i, _p, _p, C.c_longlong, _i, _i, _p, _sz, _p]),
+    "cfp_axpby": (_i, [_p, _i, _p, _i, _f, _f, _p, _i, C.c_longlong, _i, _i, _p]),
+    "cfp_rowtable_grad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "cfp_channel_dot": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "cfp_bcast_fma": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_dwconv3x3_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 11 + [_p]),
+    "cfp_dwconv3x3_wgrad_ws_bytes": (_sz, [_i]),
+    "cfp_dwconv3x3_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 9 + [_f, _i, _p, _sz, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

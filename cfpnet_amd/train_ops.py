@@ -319,3 +319,56 @@ def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, ep
              dx.stride(0), int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ops.DT[x2d.dtype], ws.data_ptr(), nbytes,
              hip.current_stream())
     return dx, dgamma, dbeta
+
+
+def axpby(x2d, y2d, a: float, b: float, out=None):
+    from . import hip, ops
+    out = torch.empty_like(x2d) if out is None else out
+    hip.call("cfp_axpby", x2d.data_ptr(), x2d.stride(0), hip.ptr(y2d), y2d.stride(0) if y2d is not None else 0, a, b, out.data_ptr(),
+             out.stride(0), x2d.shape[0], x2d.shape[1], ops.DT[x2d.dtype], hip.current_stream())
+    return out
+
+
+def rowtable_grad(dx2d, dtable, B, H, W, Wt, oy, ox, beta: float = 0.0):
+    from . import hip, ops
+    hip.call("cfp_rowtable_grad", dx2d.data_ptr(), dx2d.stride(0), dtable.data_ptr(), B, H, W, dx2d.shape[1], Wt, oy, ox, beta,
+             ops.DT[dx2d.dtype], hip.current_stream())
+    return dtable
+
+
+def channel_dot(x2d, y2d, B, HW):
+    from . import hip, ops
+    out = torch.empty(B, x2d.shape[1], dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_channel_dot", x2d.data_ptr(), x2d.stride(0), y2d.data_ptr(), y2d.stride(0), out.data_ptr(), B, HW, x2d.shape[1],
+             ops.DT[x2d.dtype], hip.current_stream())
+    return out
+
+
+def bcast_fma(dy2d, gate, add, B, HW, dx=None):
+    from . import hip, ops
+    dx = torch.empty_like(dy2d) if dx is None else dx
+    hip.call("cfp_bcast_fma", dy2d.data_ptr(), dy2d.stride(0), gate.data_ptr(), hip.ptr(add), dx.data_ptr(), dx.stride(0), B, HW,
+             dy2d.shape[1], ops.DT[dy2d.dtype], hip.current_stream())
+    return dx
+
+
+def dwconv3x3_dgrad(dy2d, w9c, B, H, W, stride, pad_t, pad_l, Ho, Wo, dx=None, accumulate=False):
+    from . import hip, ops
+    C = dy2d.shape[1]
+    if dx is None:
+        dx, accumulate = torch.empty(B * H * W, C, dtype=dy2d.dtype, device=dy2d.device), False
+    hip.call("cfp_dwconv3x3_dgrad", dy2d.data_ptr(), dy2d.stride(0), w9c.data_ptr(), dx.data_ptr(), dx.stride(0), B, H, W, C, stride, pad_t,
+             pad_l, Ho, Wo, int(accumulate), ops.DT[dy2d.dtype], hip.current_stream())
+    return dx
+
+
+def dwconv3x3_wgrad(x2d, dy2d, B, H, W, stride, pad_t, pad_l, Ho, Wo, dw=None, beta: float = 0.0):
+    from . import hip, ops
+    C = x2d.shape[1]
+    if dw is None:
+        dw, beta = torch.empty(9, C, dtype=torch.float32, device=x2d.device), 0.0
+    nbytes = hip.load().cfp_dwconv3x3_wgrad_ws_bytes(C)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_dwconv3x3_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, C, stride, pad_t,
+             pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
+    return dw

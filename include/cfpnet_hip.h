@@ -366,6 +366,25 @@ int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_ld, const fl
                       int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
                       cfp_stream_t stream);
 
+/* out = a*x + b*y (y may be NULL): gradient accumulation at skip connections, scaling. */
+int cfp_axpby(const void* x, int x_ld, const void* y, int y_ld, float a, float b, void* out, int out_ld, long long rows, int C,
+              int dtype, cfp_stream_t stream);
+/* Gradient of `x + PE[oy:oy+H, ox:ox+W]` (fusion.py:87-97) w.r.t. the learned table: dtable[...] = beta*dtable + sum_b dx. */
+int cfp_rowtable_grad(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
+                      int dtype, cfp_stream_t stream);
+/* out[b][c] = sum over the HW rows of image b of x*y: gradient of the squeeze-excite gate (sum dy * x). */
+int cfp_channel_dot(const void* x, int x_ld, const void* y, int y_ld, float* out, int B, int HW, int C, int dtype, cfp_stream_t stream);
+/* dx = dy * gate[b][c] + add[b][c] (add may be NULL): squeeze-excite backward w.r.t. the gated activation. */
+int cfp_bcast_fma(const void* dy, int dy_ld, const float* gate, const float* add, void* dx, int dx_ld, int B, int HW, int C, int dtype,
+                  cfp_stream_t stream);
+/* Depthwise 3x3 backward (conv_dw of timm's InvertedResidual): data gradient (+= when accumulate) and weight gradient
+ * dw[9][C] f32 = beta*dw + sum over output pixels of dy * x(tap). */
+int cfp_dwconv3x3_dgrad(const void* dy, int dy_ld, const void* w, void* dx, int dx_ld, int B, int H, int W, int C, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, int accumulate, int dtype, cfp_stream_t stream);
+size_t cfp_dwconv3x3_wgrad_ws_bytes(int C);
+int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

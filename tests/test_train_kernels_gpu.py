@@ -154,3 +154,54 @@ def test_activation_backward_and_bias_gradient(act, dtype):
     torch.cuda.synchronize()
     assert float((dz.float().cpu() - z.grad).abs().max()) <= (OUT_TOL[dtype] + 1e-5) * float(z.grad.abs().max())
     assert float((bias_grad.cpu() - dy.sum(0)).abs().max()) <= 2e-5 * float(dy.sum(0).abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (1, 15, 20, 1392, 1, (1, 1, 1, 1)), (2, 9, 7, 64, 2, (1, 1, 1, 1)),
+                                  (3, 16, 16, 16, 1, (1, 1, 1, 1)), (1, 31, 33, 8, 2, (0, 0, 1, 1))])
+def test_depthwise3x3_backward(case, dtype):
+    B, H, W, C, s, (pt, pl, pb, pr) = case
+    x = rnd(B, C, H, W, seed=1).to(dtype).float().requires_grad_(True)
+    w = rnd(C, 1, 3, 3, seed=2, scale=0.4).to(dtype).float().requires_grad_(True)
+    y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, None, s, 0, 1, C)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(*y.shape, seed=3).to(dtype).float()
+    y.backward(dy)
+    w9c = w.detach().reshape(C, 9).t().contiguous().to(dtype).to(DEV)
+    dyd, xd = nhwc(dy).to(dtype).to(DEV), nhwc(x.detach()).to(dtype).to(DEV)
+    dx = train_ops.dwconv3x3_dgrad(dyd, w9c, B, H, W, s, pt, pl, Ho, Wo)
+    dw = train_ops.dwconv3x3_wgrad(xd, dyd, B, H, W, s, pt, pl, Ho, Wo)
+    dw2 = train_ops.dwconv3x3_wgrad(xd, dyd, B, H, W, s, pt, pl, Ho, Wo, dw=dw.clone(), beta=1.0)
+    torch.cuda.synchronize()
+    got = dx.float().cpu().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    assert float((got - x.grad).abs().max()) <= (OUT_TOL[dtype] + 1e-5) * float(x.grad.abs().max())
+    want_dw = w.grad.reshape(C, 9).t()
+    assert float((dw.cpu() - want_dw).abs().max()) <= 3e-5 * float(want_dw.abs().max())
+    assert float((dw2 - 2 * dw).abs().max()) <= 1e-6 * float(dw.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_squeeze_excite_and_small_backward_pieces(dtype):
+    B, HW, C = 3, 300, 136
+    x = rnd(B * HW, C, seed=1).to(dtype)
+    dy = rnd(B * HW, C, seed=2).to(dtype)
+    gate, add = torch.rand(B, C, generator=torch.Generator().manual_seed(3)), rnd(B, C, seed=4, scale=0.01)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    dot = train_ops.channel_dot(xd, dyd, B, HW)
+    dx = train_ops.bcast_fma(dyd, gate.to(DEV), add.to(DEV), B, HW)
+    z = train_ops.axpby(xd, dyd, 0.5, -2.0)
+    z1 = train_ops.axpby(xd, None, 3.0, 0.0)
+    H, W, Wt = 15, 20, 40
+    tab = torch.zeros(30 * Wt, C, device=DEV)
+    train_ops.rowtable_grad(dyd, tab, B, H, W, Wt, 3, 7)
+    torch.cuda.synchronize()
+    xf, dyf = x.float(), dy.float()
+    want = (xf * dyf).reshape(B, HW, C).sum(1)
+    assert float((dot.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    want_dx = dyf.reshape(B, HW, C) * gate[:, None] + add[:, None]
+    assert float((dx.float().cpu().reshape(B, HW, C) - want_dx).abs().max()) <= OUT_TOL[dtype] * float(want_dx.abs().max()) + 1e-6
+    assert float((z.float().cpu() - (0.5 * xf - 2.0 * dyf)).abs().max()) <= OUT_TOL[dtype] * 10 + 1e-6
+    assert float((z1.float().cpu() - 3.0 * xf).abs().max()) <= OUT_TOL[dtype] * 12 + 1e-6
+    want_tab = torch.zeros(30, Wt, C)
+    want_tab[3:3 + H, 7:7 + W] = dyf.reshape(B, H, W, C).sum(0)
+    assert float((tab.cpu().reshape(30, Wt, C) - want_tab).abs().max()) <= 1e-5
