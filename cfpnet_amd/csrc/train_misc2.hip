@@ -1,0 +1,271 @@
+// Backward kernels, part 2: row gather by index map (crop / regroup / window partition / inside-outside partition and
+// their adjoints), bilinear resize backward, the bin head (softmax + expectation over adaptive bin centres) forward and
+// backward, and the bin-width -> centre chain.
+//
+//   reference: autograd of fusion.py:132-157 (crop, F.interpolate, rearrange, masked scatter), transformer.py:101-116,
+//   215-234 (window partition, mask partition), decoder.py:56 (upsampling), deltar.py:51-61 (softmax, bin centres,
+//   expectation) in model.train().
+#include "common.h"
+
+namespace {
+
+inline int ew_grid3(long long total) { long long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// out[i] = idx[i] >= 0 ? x[idx[i]] : 0   (+ out[i] when accumulate).  Every structural rearrangement of the model is an
+// injective partial map of token rows, so the adjoint of a gather with map m is the gather with m's inverse map.
+template <typename T>
+__global__ __launch_bounds__(256) void index_rows_kernel(const T* __restrict__ x, int x_ld, const int* __restrict__ idx, T* __restrict__ out,
+                                                         int out_ld, long long n_out, int C, int accumulate) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = n_out * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / CV;
+    const int c = (int)(i - r * CV) * VE;
+    const int src = idx[r];
+    float v[VE];
+    if (src >= 0) Vec<T>::load(x + (long long)src * x_ld + c, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] = 0.f;
+    }
+    if (accumulate) {
+      float o[VE];
+      Vec<T>::load(out + r * out_ld + c, o);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] += o[e];
+    }
+    Vec<T>::store(out + r * out_ld + c, v);
+  }
+}
+
+// Backward of bilinear resize (align_corners=True) [B,Hs,Ws,C] -> [B,Hd,Wd,C] as a GATHER: every source pixel collects
+// from the destination pixels whose 2x2 footprint contains it, with the forward kernel's own index / weight arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const T* __restrict__ dy, int dy_ld, T* __restrict__ dx, int dx_ld, int B, int Hs,
+                                                         int Ws, int Hd, int Wd, int C, float scale_y, float scale_x, float inv_y, float inv_x,
+                                                         int accumulate) {
+  constexpr int VE = Vec<T>::N;
+  const int CV = C / VE;
+  const long long total = (long long)B * Hs * Ws * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long long t = i / CV;
+    const int xs = (int)(t % Ws); t /= Ws;
+    const int ys = (int)(t % Hs);
+    const int b = (int)(t / Hs);
+    // candidate destination rows: those with floor(scale_y * yd) in {ys - 1, ys}
+    int yd0 = (int)floorf((float)(ys - 1) * inv_y) - 1, yd1 = (int)ceilf((float)(ys + 1) * inv_y) + 1;
+    int xd0 = (int)floorf((float)(xs - 1) * inv_x) - 1, xd1 = (int)ceilf((float)(xs + 1) * inv_x) + 1;
+    yd0 = max(yd0, 0); yd1 = min(yd1, Hd - 1); xd0 = max(xd0, 0); xd1 = min(xd1, Wd - 1);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    for (int yd = yd0; yd <= yd1; ++yd) {
+      const float fy = scale_y * (float)yd;
+      const int y0 = (int)fy;
+      const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+      const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+      const float wy = (y0 == ys ? ly0 : 0.f) + (y1 == ys ? ly1 : 0.f);
+      if (wy == 0.f && y0 != ys && y1 != ys) continue;
+      for (int xd = xd0; xd <= xd1; ++xd) {
+        const float fx = scale_x * (float)xd;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float wx = (x0 == xs ? lx0 : 0.f) + (x1 == xs ? lx1 : 0.f);
+        if (x0 != xs && x1 != xs) continue;
+        float g[VE];
+        Vec<T>::load(dy + (((long long)b * Hd + yd) * Wd + xd) * dy_ld + cv * VE, g);
+        const float w = wy * wx;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = fmaf(w, g[e], acc[e]);
+      }
+    }
+    T* dp = dx + (((long long)b * Hs + ys) * Ws + xs) * dx_ld + cv * VE;
+    if (accumulate) {
+      float o[VE];
+      Vec<T>::load(dp, o);
+#pragma unroll
+      for (int e = 0; e < VE; ++e) acc[e] += o[e];
+    }
+    Vec<T>::store(dp, acc);
+  }
+}
+
+// ---- bin head --------------------------------------------------------------------------------------------------
+// widths_normed [B][NB] -> edges [B][NB+1], centres [B][NB]  (deltar.py:53-59): one thread per image, sequential cumsum
+__global__ void bin_centers_kernel(const float* __restrict__ wn, float min_val, float max_val, float* __restrict__ edges,
+                                   float* __restrict__ centers, int B, int NB) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float e = min_val;
+  edges[(long long)b * (NB + 1)] = e;
+  for (int i = 0; i < NB; ++i) {
+    const float n = e + (max_val - min_val) * wn[(long long)b * NB + i];
+    centers[(long long)b * NB + i] = 0.5f * (e + n);
+    edges[(long long)b * (NB + 1) + i + 1] = n;
+    e = n;
+  }
+}
+// adjoint: dwn[i] = (max-min) * (0.5 * dc[i] + sum_{j > i} dc[j])
+__global__ void bin_centers_bwd_kernel(const float* __restrict__ dcenters, float min_val, float max_val, float* __restrict__ dwn, int B, int NB) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float tail = 0.f;
+  for (int i = NB - 1; i >= 0; --i) {
+    const float d = dcenters[(long long)b * NB + i];
+    dwn[(long long)b * NB + i] = (max_val - min_val) * (0.5f * d + tail);
+    tail += d;
+  }
+}
+
+// pred[r] = sum_n softmax(logits[r])[n] * centers[b][n]; one wave per pixel row (NB = 64 * NPL bins), HW rows per image.
+// Backward: dlogits[r][n] = p[n] * (c[n] - pred[r]) * dpred[r];  dcenters[b][n] = sum_r p[n] * dpred[r] (per-block partials).
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void softmax_expect_kernel(const T* __restrict__ logits, int ld, const float* __restrict__ centers,
+                                                             float* __restrict__ pred, const float* __restrict__ dpred, T* __restrict__ dlogits,
+                                                             int dl_ld, float* __restrict__ dc_partial, long long rows, int HW,
+                                                             int rows_per_block) {
+  constexpr int NB = 64 * NPL;
+  __shared__ float sdc[4][NB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const bool bwd = dpred != nullptr;
+  float dc[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) dc[k] = 0.f;
+  const int b_blk = (int)(r0 / HW);       // rows_per_block divides HW: a block stays inside one image
+  float cen[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) cen[k] = centers[(long long)b_blk * NB + lane + 64 * k];
+  for (long long r = r0 + wave; r < r1; r += 4) {
+    float v[NPL];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { v[k] = to_f32<T>(logits[r * ld + lane + 64 * k]); mx = fmaxf(mx, v[k]); }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { v[k] = __expf(v[k] - mx); s += v[k]; }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { v[k] *= inv; dot = fmaf(v[k], cen[k], dot); }
+    dot = wave_sum(dot);
+    if (!bwd) {
+      if (lane == 0) pred[r] = dot;
+    } else {
+      const float g = dpred[r];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        dlogits[r * dl_ld + lane + 64 * k] = from_f32<T>(v[k] * (cen[k] - dot) * g);
+        dc[k] = fmaf(v[k], g, dc[k]);
+      }
+    }
+  }
+  if (bwd) {
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) sdc[wave][lane + 64 * k] = dc[k];
+    __syncthreads();
+    for (int n = threadIdx.x; n < NB; n += 256)
+      dc_partial[(long long)blockIdx.x * NB + n] = (sdc[0][n] + sdc[1][n]) + (sdc[2][n] + sdc[3][n]);
+  }
+}
+
+// dcenters[b][n] = sum over the image's blocks of the partials (fixed order)
+__global__ void dc_reduce_kernel(const float* __restrict__ partial, int blocks_per_image, int NB, float* __restrict__ dcenters) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (n >= NB) return;
+  float s = 0.f;
+  for (int j = 0; j < blocks_per_image; ++j) s += partial[((long long)b * blocks_per_image + j) * NB + n];
+  dcenters[(long long)b * NB + n] = s;
+}
+
+inline int se_rows_per_block(int HW) {      // largest divisor of HW that is <= 256 (a block never straddles two images)
+  for (int r = 256; r >= 1; --r)
+    if (HW % r == 0) return r;
+  return 1;
+}
+
+}  // namespace
+
+#define T2_COMMON(name)                                          \
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, name ": bad dtype");  \
+  const int ve = vec_elems(dtype);                               \
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int cfp_index_rows(const void* x, int x_ld, const int* idx, void* out, int out_ld, long long n_out, int C, int accumulate,
+                              int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(x && idx && out && aligned16(x) && aligned16(out), CFP_EINVAL, "cfp_index_rows: bad pointer");
+  T2_COMMON("cfp_index_rows");
+  CFP_REQUIRE(n_out > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && out_ld % ve == 0 && x_ld >= C && out_ld >= C, CFP_ESHAPE,
+              "cfp_index_rows: bad shape");
+  const dim3 grid(ew_grid3(n_out * (C / ve)));
+#define L(T) hipLaunchKernelGGL(index_rows_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, idx, (T*)out, out_ld, n_out, C, accumulate)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_index_rows");
+}
+
+extern "C" int cfp_resize_bilinear_bwd(const void* dy, int dy_ld, void* dx, int dx_ld, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                                       int accumulate, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(dy && dx && aligned16(dy) && aligned16(dx), CFP_EINVAL, "cfp_resize_bilinear_bwd: bad pointer");
+  T2_COMMON("cfp_resize_bilinear_bwd");
+  CFP_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C % ve == 0 && dy_ld % ve == 0 && dx_ld % ve == 0 && dy_ld >= C &&
+                  dx_ld >= C, CFP_ESHAPE, "cfp_resize_bilinear_bwd: bad shape");
+  const float sy = Hd > 1 ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f, sx = Wd > 1 ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+  const float iy = sy > 0.f ? 1.f / sy : (float)Hd, ix = sx > 0.f ? 1.f / sx : (float)Wd;
+  const dim3 grid(ew_grid3((long long)B * Hs * Ws * (C / ve)));
+#define L(T) hipLaunchKernelGGL(resize_bwd_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, (T*)dx, dx_ld, B, Hs, Ws, Hd, Wd, C, sy, sx, iy, ix, \
+                                accumulate)
+  if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
+#undef L
+  return cfp_check_launch("cfp_resize_bilinear_bwd");
+}
+
+extern "C" int cfp_bin_centers(const float* widths_normed, float min_val, float max_val, float* edges, float* centers, int B, int NB,
+                               cfp_stream_t stream) {
+  CFP_REQUIRE(widths_normed && edges && centers && B > 0 && NB > 0, CFP_EINVAL, "cfp_bin_centers: bad argument");
+  hipLaunchKernelGGL(bin_centers_kernel, dim3(cdiv(B, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), widths_normed, min_val, max_val,
+                     edges, centers, B, NB);
+  return cfp_check_launch("cfp_bin_centers");
+}
+
+extern "C" int cfp_bin_centers_bwd(const float* dcenters, float min_val, float max_val, float* dwidths_normed, int B, int NB,
+                                   cfp_stream_t stream) {
+  CFP_REQUIRE(dcenters && dwidths_normed && B > 0 && NB > 0, CFP_EINVAL, "cfp_bin_centers_bwd: bad argument");
+  hipLaunchKernelGGL(bin_centers_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), dcenters, min_val, max_val,
+                     dwidths_normed, B, NB);
+  return cfp_check_launch("cfp_bin_centers_bwd");
+}
+
+extern "C" size_t cfp_softmax_expect_ws_bytes(int B, int HW, int NB) {
+  if (B <= 0 || HW <= 0 || NB <= 0) return 0;
+  return (size_t)B * (HW / se_rows_per_block(HW)) * NB * sizeof(float);
+}
+
+/* dpred == NULL: forward (pred out).  Otherwise backward: dlogits and dcenters out (pred unused). */
+extern "C" int cfp_softmax_expect(const void* logits, int ld, const float* centers, float* pred, const float* dpred, void* dlogits, int dl_ld,
+                                  float* dcenters, int B, int HW, int NB, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(logits && centers && aligned16(logits), CFP_EINVAL, "cfp_softmax_expect: bad pointer");
+  T2_COMMON("cfp_softmax_expect");
+  (void)ve;
+  CFP_REQUIRE(B > 0 && HW > 0 && (NB == 64 || NB == 128 || NB == 256) && ld >= NB, CFP_ESHAPE, "cfp_softmax_expect: NB must be 64, 128 or 256");
+  const bool bwd = dpred != nullptr;
+  CFP_REQUIRE(bwd ? (dlogits && dcenters && ws && dl_ld >= NB && ws_bytes >= cfp_softmax_expect_ws_bytes(B, HW, NB)) : (pred != nullptr), CFP_EINVAL,
+              "cfp_softmax_expect: missing output / workspace");
+  const int rpb = se_rows_per_block(HW);
+  const long long rows = (long long)B * HW;
+  const int blocks = (int)(rows / rpb);
+  float* partial = reinterpret_cast<float*>(ws);
+#define L(T, N) hipLaunchKernelGGL((softmax_expect_kernel<T, N>), dim3(blocks), dim3(256), 0, s, (const T*)logits, ld, centers, pred, dpred, (T*)dlogits, \
+                                   dl_ld, partial, rows, HW, rpb)
+#define LN(T) do { if (NB == 256) L(T, 4); else if (NB == 128) L(T, 2); else L(T, 1); } while (0)
+  if (dtype == CFP_BF16) LN(bf16_t); else if (dtype == CFP_F16) LN(f16_t); else LN(float);
+#undef LN
+#undef L
+  if (bwd) hipLaunchKernelGGL(dc_reduce_kernel, dim3(cdiv(NB, 64), B), dim3(64), 0, s, partial, HW / rpb, NB, dcenters);
+  return cfp_check_launch("cfp_softmax_expect");
+}

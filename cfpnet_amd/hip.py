@@ -79,6 +79,12 @@ SIGNATURES = {
     "cfp_dwconv3x3_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 11 + [_p]),
     "cfp_dwconv3x3_wgrad_ws_bytes": (_sz, [_i]),
     "cfp_dwconv3x3_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 9 + [_f, _i, _p, _sz, _p]),
+    "cfp_index_rows": (_i, [_p, _i, _p, _p, _i, C.c_longlong, _i, _i, _i, _p]),
+    "cfp_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "cfp_bin_centers": (_i, [_p, _f, _f, _p, _p, _i, _i, _p]),
+    "cfp_bin_centers_bwd": (_i, [_p, _f, _f, _p, _i, _i, _p]),
+    "cfp_softmax_expect_ws_bytes": (_sz, [_i, _i, _i]),
+    "cfp_softmax_expect": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

@@ -372,3 +372,68 @@ def dwconv3x3_wgrad(x2d, dy2d, B, H, W, stride, pad_t, pad_l, Ho, Wo, dw=None, b
     hip.call("cfp_dwconv3x3_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, C, stride, pad_t,
              pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
     return dw
+
+
+def index_rows(x2d, idx, n_out=None, out=None, accumulate=False):
+    """out[i] = x2d[idx[i]] (zeros where idx[i] < 0); idx: int32 device tensor."""
+    from . import hip, ops
+    n_out = idx.numel() if n_out is None else n_out
+    if out is None:
+        out, accumulate = torch.empty(n_out, x2d.shape[1], dtype=x2d.dtype, device=x2d.device), False
+    hip.call("cfp_index_rows", x2d.data_ptr(), x2d.stride(0), idx.data_ptr(), out.data_ptr(), out.stride(0), n_out, x2d.shape[1],
+             int(accumulate), ops.DT[x2d.dtype], hip.current_stream())
+    return out
+
+
+def inverse_index(idx: torch.Tensor, n_src: int) -> torch.Tensor:
+    """Inverse of an injective partial row map (host-side integer plumbing): inv[idx[i]] = i, -1 elsewhere."""
+    inv = torch.full((n_src,), -1, dtype=torch.int32, device=idx.device)
+    valid = idx >= 0
+    inv[idx[valid].long()] = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)[valid]
+    return inv
+
+
+def resize_bilinear_bwd(dy2d, B, Hs, Ws, Hd, Wd, dx=None, accumulate=False):
+    from . import hip, ops
+    C = dy2d.shape[1]
+    if dx is None:
+        dx, accumulate = torch.empty(B * Hs * Ws, C, dtype=dy2d.dtype, device=dy2d.device), False
+    hip.call("cfp_resize_bilinear_bwd", dy2d.data_ptr(), dy2d.stride(0), dx.data_ptr(), dx.stride(0), B, Hs, Ws, Hd, Wd, C, int(accumulate),
+             ops.DT[dy2d.dtype], hip.current_stream())
+    return dx
+
+
+def bin_centers(widths_normed, min_val, max_val):
+    from . import hip
+    B, NB = widths_normed.shape
+    edges = torch.empty(B, NB + 1, dtype=torch.float32, device=widths_normed.device)
+    centers = torch.empty(B, NB, dtype=torch.float32, device=widths_normed.device)
+    hip.call("cfp_bin_centers", widths_normed.data_ptr(), min_val, max_val, edges.data_ptr(), centers.data_ptr(), B, NB, hip.current_stream())
+    return edges, centers
+
+
+def bin_centers_bwd(dcenters, min_val, max_val):
+    from . import hip
+    B, NB = dcenters.shape
+    dw = torch.empty_like(dcenters)
+    hip.call("cfp_bin_centers_bwd", dcenters.data_ptr(), min_val, max_val, dw.data_ptr(), B, NB, hip.current_stream())
+    return dw
+
+
+def softmax_expect(logits2d, centers, B, HW, dpred=None):
+    """forward: pred [B*HW] f32; with dpred: (dlogits, dcenters)."""
+    from . import hip, ops
+    NB = centers.shape[1]
+    dev = logits2d.device
+    if dpred is None:
+        pred = torch.empty(B * HW, dtype=torch.float32, device=dev)
+        hip.call("cfp_softmax_expect", logits2d.data_ptr(), logits2d.stride(0), centers.data_ptr(), pred.data_ptr(), None, None, 0, None, B, HW,
+                 NB, ops.DT[logits2d.dtype], None, 0, hip.current_stream())
+        return pred
+    nbytes = hip.load().cfp_softmax_expect_ws_bytes(B, HW, NB)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    dlogits = torch.empty_like(logits2d)
+    dcenters = torch.empty(B, NB, dtype=torch.float32, device=dev)
+    hip.call("cfp_softmax_expect", logits2d.data_ptr(), logits2d.stride(0), centers.data_ptr(), None, dpred.data_ptr(), dlogits.data_ptr(),
+             dlogits.stride(0), dcenters.data_ptr(), B, HW, NB, ops.DT[logits2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
+    return dlogits, dcenters

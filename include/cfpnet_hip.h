@@ -385,6 +385,24 @@ size_t cfp_dwconv3x3_wgrad_ws_bytes(int C);
 int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* out[i] = idx[i] >= 0 ? x[idx[i]] : 0 (+= when accumulate), idx int32 on the device: crop / regroup / window partition /
+ * inside-outside partition of token rows (fusion.py:132-157, transformer.py:101-116,215-234); the maps are injective, so
+ * the adjoint of a gather is the gather with the inverse map. */
+int cfp_index_rows(const void* x, int x_ld, const int* idx, void* out, int out_ld, long long n_out, int C, int accumulate, int dtype,
+                   cfp_stream_t stream);
+/* Backward of the full-map bilinear resize (align_corners=True) [B,Hs,Ws,C] -> [B,Hd,Wd,C]: dx (+= when accumulate). */
+int cfp_resize_bilinear_bwd(const void* dy, int dy_ld, void* dx, int dx_ld, int B, int Hs, int Ws, int Hd, int Wd, int C,
+                            int accumulate, int dtype, cfp_stream_t stream);
+/* Adaptive bins (deltar.py:53-59): edges = cumsum(pad((max-min)*w, min)), centres = mid-points; and the adjoint. */
+int cfp_bin_centers(const float* widths_normed, float min_val, float max_val, float* edges, float* centers, int B, int NB,
+                    cfp_stream_t stream);
+int cfp_bin_centers_bwd(const float* dcenters, float min_val, float max_val, float* dwidths_normed, int B, int NB, cfp_stream_t stream);
+/* pred = sum_n softmax(logits)[n] * centres[b][n] (deltar.py:51,61) with logits [B*HW, NB] rows; with dpred != NULL the
+ * backward instead: dlogits and dcentres (pred unused).  ws: cfp_softmax_expect_ws_bytes (backward only). */
+size_t cfp_softmax_expect_ws_bytes(int B, int HW, int NB);
+int cfp_softmax_expect(const void* logits, int ld, const float* centers, float* pred, const float* dpred, void* dlogits, int dl_ld,
+                       float* dcenters, int B, int HW, int NB, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

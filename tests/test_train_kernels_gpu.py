@@ -205,3 +205,59 @@ def test_squeeze_excite_and_small_backward_pieces(dtype):
     want_tab = torch.zeros(30, Wt, C)
     want_tab[3:3 + H, 7:7 + W] = dyf.reshape(B, H, W, C).sum(0)
     assert float((tab.cpu().reshape(30, Wt, C) - want_tab).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_index_rows_and_its_adjoint(dtype):
+    n_src, n_out, C = 5000, 4200, 64
+    g = torch.Generator().manual_seed(1)
+    perm = torch.randperm(n_src, generator=g)[:n_out].to(torch.int32)
+    perm[::7] = -1                                            # padding rows
+    x, gy = rnd(n_src, C, seed=2).to(dtype), rnd(n_out, C, seed=3).to(dtype)
+    idx = perm.to(DEV)
+    y = train_ops.index_rows(x.to(DEV), idx)
+    inv = train_ops.inverse_index(idx, n_src)
+    gx = train_ops.index_rows(gy.to(DEV), inv)
+    torch.cuda.synchronize()
+    want = torch.where((perm >= 0)[:, None], x[perm.clamp(min=0).long()], torch.zeros(()).to(dtype))
+    assert torch.equal(y.cpu(), want)
+    # <gather(x), gy> == <x, gather_inv(gy)>
+    lhs = float((y.float().cpu() * gy.float()).sum()); rhs = float((x.float() * gx.float().cpu()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Hs,Ws,Hd,Wd,C", [(2, 15, 20, 30, 40, 64), (1, 28, 28, 32, 32, 32), (2, 32, 32, 28, 28, 16), (1, 7, 9, 7, 9, 8), (1, 1, 5, 4, 13, 8)])
+def test_bilinear_resize_backward(B, Hs, Ws, Hd, Wd, C, dtype):
+    x = rnd(B, C, Hs, Ws, seed=1).to(dtype).float().requires_grad_(True)
+    y = F.interpolate(x, (Hd, Wd), mode="bilinear", align_corners=True)
+    dy = rnd(*y.shape, seed=2).to(dtype).float()
+    y.backward(dy)
+    dx = train_ops.resize_bilinear_bwd(nhwc(dy).to(dtype).to(DEV), B, Hs, Ws, Hd, Wd)
+    torch.cuda.synchronize()
+    got = dx.float().cpu().reshape(B, Hs, Ws, C).permute(0, 3, 1, 2)
+    assert float((got - x.grad).abs().max()) <= (OUT_TOL[dtype] + 2e-5) * float(x.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW", [(2, 208 * 272 // 16), (3, 77)])
+def test_bin_head_forward_backward(B, HW, dtype):
+    NB = 256
+    logits = rnd(B * HW, NB, seed=1, scale=2.0).to(dtype).float().requires_grad_(True)
+    wn = torch.softmax(rnd(B, NB, seed=2), 1).requires_grad_(True)
+    widths = F.pad((10.0 - 1e-3) * wn, (1, 0), value=1e-3)
+    edges = torch.cumsum(widths, 1)
+    centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
+    pred = (torch.softmax(logits.reshape(B, HW, NB), 2) * centers[:, None]).sum(2)
+    dpred = rnd(B, HW, seed=3)
+    pred.backward(dpred)
+    e_d, c_d = train_ops.bin_centers(wn.detach().to(DEV), 1e-3, 10.0)
+    ld = logits.detach().to(dtype).to(DEV)
+    p_d = train_ops.softmax_expect(ld, c_d, B, HW)
+    dl, dc = train_ops.softmax_expect(ld, c_d, B, HW, dpred=dpred.reshape(-1).to(DEV))
+    dwn = train_ops.bin_centers_bwd(dc, 1e-3, 10.0)
+    torch.cuda.synchronize()
+    assert torch.allclose(e_d.cpu(), edges.detach(), rtol=1e-5, atol=1e-5) and torch.allclose(c_d.cpu(), centers.detach(), rtol=1e-5, atol=1e-5)
+    assert float((p_d.cpu().reshape(B, HW) - pred.detach()).abs().max()) <= 2e-5 * 10
+    assert float((dl.float().cpu() - logits.grad).abs().max()) <= (OUT_TOL[dtype] + 2e-5) * float(logits.grad.abs().max())
+    assert float((dwn.cpu() - wn.grad).abs().max()) <= 5e-5 * float(wn.grad.abs().max())
