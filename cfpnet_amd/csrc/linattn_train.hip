@@ -1,0 +1,252 @@
+// Linear attention (elu+1 feature map), training form: forward that keeps the per-(group, head) KV state, and backward.
+//
+//   reference: LinearAttention.forward (src/models/attention.py:20-52) and its autograd:
+//     Q = elu(q)+1, K = elu(k)+1, values = v / S
+//     KV = sum_s K_s (x) values_s            [d x d]     Ksum = sum_s K_s
+//     Z_l = 1 / (Q_l . Ksum + eps)           out_l = (Q_l KV) * Z_l * S
+//   Tokens are grouped contiguously: q [N*L, heads*d], k, v [N*S, heads*d] (the zone / window / inside-outside groupings
+//   are row gathers done before, cfp_index_rows).  One workgroup per (group n, head h).
+//
+//   backward, with A_l = Q_l KV:   dA_l = dout_l * S * Z_l        e_l = -Z_l^2 * S * (dout_l . A_l)
+//     dQ_l = KV dA_l + e_l Ksum     dKV = sum_l Q_l (x) dA_l       dKsum = sum_l e_l Q_l
+//     dK_s = dKV values_s + dKsum   dvalues_s = dKV^T K_s          dv = dvalues / S;   dq = dQ * elu'(q), dk = dK * elu'(k)
+//
+// The two reductions over tokens (KV over keys, dKV over queries) are the same "augmented outer product" M[i][j] =
+// sum_r X_r[i] * Y_r[j], j = 0..d with Y_r[d] = 1 (Ksum) or e_r (dKsum): rows are staged through LDS in chunks and every
+// thread owns fixed (i, j) entries, so the summation order is fixed (bit-reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int ACH = 128;     // token rows per LDS chunk
+
+__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : __expf(x); }
+
+template <int D>
+struct Outer {
+  static constexpr int NO = D * (D + 1);
+  static constexpr int G = NO >= 256 ? 1 : 256 / NO;
+  static constexpr int OPT = (NO + 255) / 256;
+};
+
+// acc += sum over the chunk's rows of X[r][i] * Y[r][j]   (sX: [ACH][D], sY: [ACH][D+1])
+template <int D>
+__device__ __forceinline__ void outer_accumulate(const float* sX, const float* sY, int nrows, float (&acc)[Outer<D>::OPT]) {
+  using O = Outer<D>;
+  const int tid = threadIdx.x;
+  if (O::G == 1) {
+#pragma unroll
+    for (int u = 0; u < O::OPT; ++u) {
+      const int o = tid + u * 256;
+      if (o < O::NO) {
+        const int i = o / (D + 1), j = o - i * (D + 1);
+        float a = acc[u];
+        for (int r = 0; r < nrows; ++r) a = fmaf(sX[r * D + i], sY[r * (D + 1) + j], a);
+        acc[u] = a;
+      }
+    }
+  } else {
+    const int g = tid / O::NO, o = tid - g * O::NO;
+    if (g < O::G) {
+      const int i = o / (D + 1), j = o - i * (D + 1);
+      float a = acc[0];
+      for (int r = g; r < nrows; r += O::G) a = fmaf(sX[r * D + i], sY[r * (D + 1) + j], a);
+      acc[0] = a;
+    }
+  }
+}
+
+// combine the per-thread partial sums into sM[D][D+1]
+template <int D>
+__device__ __forceinline__ void outer_finish(const float (&acc)[Outer<D>::OPT], float* sRed, float* sM) {
+  using O = Outer<D>;
+  const int tid = threadIdx.x;
+  if (O::G == 1) {
+#pragma unroll
+    for (int u = 0; u < O::OPT; ++u) {
+      const int o = tid + u * 256;
+      if (o < O::NO) sM[o] = acc[u];
+    }
+  } else {
+    const int g = tid / O::NO, o = tid - g * O::NO;
+    if (g < O::G) sRed[g * O::NO + o] = acc[0];
+    __syncthreads();
+    if (tid < O::NO) {
+      float a = 0.f;
+      for (int gg = 0; gg < O::G; ++gg) a += sRed[gg * O::NO + tid];
+      sM[tid] = a;
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+                                                          const T* __restrict__ v, int v_ld, T* __restrict__ out, int out_ld,
+                                                          float* __restrict__ kv_save, int L, int S, int heads, float eps) {
+  using O = Outer<D>;
+  __shared__ float sX[ACH * D], sY[ACH * (D + 1)], sM[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const float fS = (float)S;
+  float acc[O::OPT];
+#pragma unroll
+  for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
+  for (int s0 = 0; s0 < S; s0 += ACH) {
+    const int nr = min(ACH, S - s0);
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += 256) {
+      const int r = e / D, c = e - r * D;
+      const long long row = (long long)n * S + s0 + r;
+      sX[r * D + c] = elu1(to_f32<T>(k[row * k_ld + h * D + c]));
+      sY[r * (D + 1) + c] = to_f32<T>(v[row * v_ld + h * D + c]) / fS;
+      if (c == 0) sY[r * (D + 1) + D] = 1.f;
+    }
+    __syncthreads();
+    outer_accumulate<D>(sX, sY, nr, acc);
+  }
+  __syncthreads();
+  outer_finish<D>(acc, sRed, sM);
+  for (int e = tid; e < O::NO; e += 256) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
+  // queries: one token per thread
+  for (int l = tid; l < L; l += 256) {
+    const long long row = (long long)n * L + l;
+    float Q[D];
+    float den = eps;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Q[i] = elu1(to_f32<T>(q[row * q_ld + h * D + i])); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
+    const float z = 1.f / den;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) a = fmaf(Q[i], sM[i * (D + 1) + j], a);
+      out[row * out_ld + h * D + j] = from_f32<T>(a * z * fS);
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+                                                          const T* __restrict__ v, int v_ld, const T* __restrict__ dout, int do_ld,
+                                                          const float* __restrict__ kv_save, T* __restrict__ dq, int dq_ld,
+                                                          T* __restrict__ dk, int dk_ld, T* __restrict__ dv, int dv_ld, int L, int S,
+                                                          int heads, float eps) {
+  using O = Outer<D>;
+  __shared__ float sX[ACH * D], sY[ACH * (D + 1)], sM[O::NO], sG[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const float fS = (float)S;
+  for (int e = tid; e < O::NO; e += 256) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
+  float acc[O::OPT];
+#pragma unroll
+  for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
+  __syncthreads();
+  // ---- queries: dq, and the rows (Q_l, dA_l, e_l) of the dKV / dKsum reduction
+  for (int l0 = 0; l0 < L; l0 += ACH) {
+    const int nr = min(ACH, L - l0);
+    __syncthreads();
+    if (tid < nr) {
+      const long long row = (long long)n * L + l0 + tid;
+      float Q[D], qr[D], A[D], g[D];
+      float den = eps;
+#pragma unroll
+      for (int i = 0; i < D; ++i) { qr[i] = to_f32<T>(q[row * q_ld + h * D + i]); Q[i] = elu1(qr[i]); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
+      const float z = 1.f / den;
+      float dotA = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < D; ++i) a = fmaf(Q[i], sM[i * (D + 1) + j], a);
+        A[j] = a;
+        g[j] = to_f32<T>(dout[row * do_ld + h * D + j]);
+        dotA = fmaf(g[j], a, dotA);
+      }
+      const float e_l = -z * z * fS * dotA;
+#pragma unroll
+      for (int j = 0; j < D; ++j) { g[j] *= fS * z; sY[tid * (D + 1) + j] = g[j]; }     // dA_l
+      sY[tid * (D + 1) + D] = e_l;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float d = e_l * sM[i * (D + 1) + D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) d = fmaf(sM[i * (D + 1) + j], g[j], d);
+        dq[row * dq_ld + h * D + i] = from_f32<T>(d * elu1_grad(qr[i]));
+        sX[tid * D + i] = Q[i];
+      }
+    }
+    __syncthreads();
+    outer_accumulate<D>(sX, sY, nr, acc);
+  }
+  __syncthreads();
+  outer_finish<D>(acc, sRed, sG);          // sG = [dKV | dKsum]
+  // ---- keys: dk, dv
+  for (int s = tid; s < S; s += 256) {
+    const long long row = (long long)n * S + s;
+    float K[D], kr[D], val[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      kr[i] = to_f32<T>(k[row * k_ld + h * D + i]);
+      K[i] = elu1(kr[i]);
+      val[i] = to_f32<T>(v[row * v_ld + h * D + i]) / fS;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float d = sG[i * (D + 1) + D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) d = fmaf(sG[i * (D + 1) + j], val[j], d);
+      dk[row * dk_ld + h * D + i] = from_f32<T>(d * elu1_grad(kr[i]));
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) d = fmaf(K[i], sG[i * (D + 1) + j], d);
+      dv[row * dv_ld + h * D + j] = from_f32<T>(d / fS);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t cfp_linattn_state_bytes(int N, int heads, int d) { return (N > 0 && heads > 0 && d > 0) ? (size_t)N * heads * d * (d + 1) * sizeof(float) : 0; }
+
+#define LA_CHECK(name)                                                                                                     \
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, name ": bad dtype");                                                            \
+  CFP_REQUIRE(N > 0 && L > 0 && S > 0 && heads > 0 && (d == 4 || d == 8 || d == 16 || d == 32), CFP_ESHAPE, name ": head dim must be 4/8/16/32"); \
+  CFP_REQUIRE((long long)N * heads < (1ll << 31), CFP_ESHAPE, name ": too many groups");                                   \
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                                   \
+  const dim3 grid((unsigned)((long long)N * heads))
+
+extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, void* out, int out_ld, float* state,
+                               int N, int L, int S, int heads, int d, float eps, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(q && k && v && out && state, CFP_EINVAL, "cfp_linattn_fwd: null pointer");
+  LA_CHECK("cfp_linattn_fwd");
+  const int C = heads * d;
+  CFP_REQUIRE(q_ld >= C && k_ld >= C && v_ld >= C && out_ld >= C, CFP_ESHAPE, "cfp_linattn_fwd: pitch smaller than heads*d");
+#define L1(T, DD) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, \
+                                     (T*)out, out_ld, state, L, S, heads, eps)
+#define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
+  if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
+#undef LD
+#undef L1
+  return cfp_check_launch("cfp_linattn_fwd");
+}
+
+extern "C" int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, const void* dout, int do_ld,
+                               const float* state, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int N, int L, int S,
+                               int heads, int d, float eps, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(q && k && v && dout && state && dq && dk && dv, CFP_EINVAL, "cfp_linattn_bwd: null pointer");
+  LA_CHECK("cfp_linattn_bwd");
+  const int C = heads * d;
+  CFP_REQUIRE(q_ld >= C && k_ld >= C && v_ld >= C && do_ld >= C && dq_ld >= C && dk_ld >= C && dv_ld >= C, CFP_ESHAPE,
+              "cfp_linattn_bwd: pitch smaller than heads*d");
+#define L1(T, DD) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, \
+                                     (const T*)dout, do_ld, state, (T*)dq, dq_ld, (T*)dk, dk_ld, (T*)dv, dv_ld, L, S, heads, eps)
+#define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
+  if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
+#undef LD
+#undef L1
+  return cfp_check_launch("cfp_linattn_bwd");
+}

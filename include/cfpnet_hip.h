@@ -403,6 +403,16 @@ size_t cfp_softmax_expect_ws_bytes(int B, int HW, int NB);
 int cfp_softmax_expect(const void* logits, int ld, const float* centers, float* pred, const float* dpred, void* dlogits, int dl_ld,
                        float* dcenters, int B, int HW, int NB, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* Linear attention, training form (attention.py:20-52 and its autograd) on contiguously grouped tokens:
+ * q [N*L, heads*d], k, v [N*S, heads*d] -> out [N*L, heads*d]; `state` (cfp_linattn_state_bytes) keeps KV and Ksum of
+ * every (group, head) for the backward call, which returns dq, dk, dv.  d in {4, 8, 16, 32}. */
+size_t cfp_linattn_state_bytes(int N, int heads, int d);
+int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, void* out, int out_ld, float* state,
+                    int N, int L, int S, int heads, int d, float eps, int dtype, cfp_stream_t stream);
+int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, const void* dout, int do_ld,
+                    const float* state, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int N, int L, int S,
+                    int heads, int d, float eps, int dtype, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

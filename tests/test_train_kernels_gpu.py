@@ -261,3 +261,26 @@ def test_bin_head_forward_backward(B, HW, dtype):
     assert float((p_d.cpu().reshape(B, HW) - pred.detach()).abs().max()) <= 2e-5 * 10
     assert float((dl.float().cpu() - logits.grad).abs().max()) <= (OUT_TOL[dtype] + 2e-5) * float(logits.grad.abs().max())
     assert float((dwn.cpu() - wn.grad).abs().max()) <= 5e-5 * float(wn.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,L,S,heads,d", [(6, 49, 16, 4, 16), (3, 144, 144, 8, 4), (2, 1200, 30, 8, 16), (5, 36, 36, 8, 16), (2, 300, 130, 4, 32),
+                                           (4, 196, 16, 4, 8)])
+def test_linear_attention_forward_backward(N, L, S, heads, d, dtype):
+    from oracle import cfpnet_oracle as O
+    q = rnd(N, L, heads, d, seed=1).to(dtype).float().requires_grad_(True)
+    k = rnd(N, S, heads, d, seed=2).to(dtype).float().requires_grad_(True)
+    v = rnd(N, S, heads, d, seed=3).to(dtype).float().requires_grad_(True)
+    out = O.linear_attention(q, k, v)
+    dout = rnd(*out.shape, seed=4).to(dtype).float()
+    out.backward(dout)
+    f = lambda t, n: t.detach().reshape(N * n, heads * d).to(dtype).to(DEV)
+    qd, kd, vd = f(q, L), f(k, S), f(v, S)
+    o_d, state = train_ops.linattn_fwd(qd, kd, vd, N, L, S, heads, d)
+    dq, dk, dv = train_ops.linattn_bwd(qd, kd, vd, dout.reshape(N * L, heads * d).to(dtype).to(DEV), state, N, L, S, heads, d)
+    o2, _ = train_ops.linattn_fwd(qd, kd, vd, N, L, S, heads, d)
+    torch.cuda.synchronize()
+    assert torch.equal(o_d, o2)                                    # fixed summation order
+    tol = OUT_TOL[dtype] + 3e-5
+    chk = lambda got, want, n: float((got.float().cpu().reshape(N, n, heads, d) - want).abs().max()) <= tol * float(want.abs().max())
+    assert chk(o_d, out.detach(), L) and chk(dq, q.grad, L) and chk(dk, k.grad, S) and chk(dv, v.grad, S)
