@@ -269,3 +269,139 @@ extern "C" int cfp_softmax_expect(const void* logits, int ld, const float* cente
   if (bwd) hipLaunchKernelGGL(dc_reduce_kernel, dim3(cdiv(NB, 64), B), dim3(64), 0, s, partial, HW / rpb, NB, dcenters);
   return cfp_check_launch("cfp_softmax_expect");
 }
+
+// ---- large-kernel depthwise weight gradient (LKPM dwconv, k = 7 / 15 / 31) ---------------------------------------------
+// dw[c][ky][kx] = sum over (b, y, x) of dy[b,y,x,c] * x[b, y + ky - h, x + kx - h, c]   (h = (k-1)/2, zero padding)
+// One workgroup per (32 x 32 pixel tile, 16-byte channel vector): dy tile and the haloed x tile are staged in LDS once,
+// thread t owns taps t, t + 256, ...; every pixel's dy vector is an LDS broadcast, the x reads of neighbouring taps are
+// neighbouring vectors.  Per-tile partial sums are added in tile order by a second kernel (bit-reproducible).
+namespace {
+constexpr int LWT = 32;
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwlarge_wgrad_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+                                                            float* __restrict__ partial, int B, int H, int W, int C) {
+  constexpr int VE = Vec<T>::N;
+  constexpr int HALO = (K - 1) / 2, PW = LWT + K - 1;
+  constexpr int NT = (K * K + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  T* sx = reinterpret_cast<T*>(lsm);                       // [PW][PW][VE]
+  T* sd = sx + PW * PW * VE;                               // [LWT][LWT][VE]
+  const int tid = threadIdx.x;
+  const int CV = C / VE;
+  const int tiles_x = (W + LWT - 1) / LWT, tiles_y = (H + LWT - 1) / LWT;
+  int bid = blockIdx.x;
+  const int cv = bid % CV; bid /= CV;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * LWT, x0 = tx * LWT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < PW * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long long)b * H + cy) * W + cx) * x_ld + cv * VE);
+    *reinterpret_cast<u32x4*>(sx + i * VE) = ok ? v : zero4;
+  }
+  for (int i = tid; i < LWT * LWT; i += 256) {
+    const int py = i / LWT, px = i - py * LWT;
+    const int gy = y0 + py, gx = x0 + px;
+    const bool ok = gy < H && gx < W;
+    const int cy = min(gy, H - 1), cx = min(gx, W - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(dy + (((long long)b * H + cy) * W + cx) * dy_ld + cv * VE);
+    *reinterpret_cast<u32x4*>(sd + i * VE) = ok ? v : zero4;
+  }
+  __syncthreads();
+  float acc[NT][VE];
+  int toff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = min(tid + t * 256, K * K - 1);
+    toff[t] = ((tap / K) * PW + tap % K) * VE;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[t][e] = 0.f;
+  }
+  for (int py = 0; py < LWT; ++py) {
+    for (int px = 0; px < LWT; ++px) {
+      float g[VE];
+      Vec<T>::load(sd + (py * LWT + px) * VE, g);
+      const int base = (py * PW + px) * VE;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float v[VE];
+        Vec<T>::load(sx + base + toff[t], v);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[t][e] = fmaf(g[e], v[e], acc[t][e]);
+      }
+    }
+  }
+  float* dst = partial + (long long)blockIdx.x * K * K * VE;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = tid + t * 256;
+    if (tap < K * K) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) dst[tap * VE + e] = acc[t][e];
+    }
+  }
+}
+
+// dw[c][tap] = beta * dw + sum over tiles (b, ty, tx) of partial[tile][cv][tap][e]
+__global__ __launch_bounds__(256) void dwlarge_wgrad_reduce_kernel(const float* __restrict__ partial, int ntiles, int CV, int VE, int KK,
+                                                                   float* __restrict__ dw, float beta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;     // over C * KK, laid out [c][tap]
+  const int C = CV * VE;
+  if (i >= C * KK) return;
+  const int c = i / KK, tap = i - c * KK;
+  const int cv = c / VE, e = c - cv * VE;
+  float s = 0.f;
+  for (int t = 0; t < ntiles; ++t) s += partial[(((long long)t * CV + cv) * KK + tap) * VE + e];
+  dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+}
+
+template <typename T, int K>
+hipError_t launch_dwl_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* partial, int B, int H, int W, int C, hipStream_t s) {
+  constexpr int VE = Vec<T>::N, PW = LWT + K - 1;
+  constexpr size_t lds = (size_t)(PW * PW + LWT * LWT) * VE * sizeof(T);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)dwlarge_wgrad_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const long long blocks = (long long)B * cdiv(H, LWT) * cdiv(W, LWT) * (C / VE);
+  hipLaunchKernelGGL((dwlarge_wgrad_kernel<T, K>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B,
+                     H, W, C);
+  return hipSuccess;
+}
+}  // namespace
+
+extern "C" size_t cfp_dwconv_large_wgrad_ws_bytes(int B, int H, int W, int C, int k) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0) return 0;
+  return (size_t)B * cdiv(H, LWT) * cdiv(W, LWT) * C * k * k * sizeof(float);
+}
+
+extern "C" int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int k,
+                                      float beta, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  CFP_REQUIRE(x && dy && dw && ws && aligned16(x) && aligned16(dy), CFP_EINVAL, "cfp_dwconv_large_wgrad: bad pointer");
+  T2_COMMON("cfp_dwconv_large_wgrad");
+  CFP_REQUIRE(k == 7 || k == 15 || k == 31, CFP_ESHAPE, "cfp_dwconv_large_wgrad: k must be 7, 15 or 31");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && dy_ld % ve == 0 && x_ld >= C && dy_ld >= C, CFP_ESHAPE,
+              "cfp_dwconv_large_wgrad: bad shape");
+  CFP_REQUIRE(ws_bytes >= cfp_dwconv_large_wgrad_ws_bytes(B, H, W, C, k), CFP_EINVAL, "cfp_dwconv_large_wgrad: workspace too small");
+  float* partial = reinterpret_cast<float*>(ws);
+  hipError_t e;
+#define LK(T) (k == 31 ? launch_dwl_wgrad<T, 31>(x, x_ld, dy, dy_ld, partial, B, H, W, C, s) \
+             : k == 15 ? launch_dwl_wgrad<T, 15>(x, x_ld, dy, dy_ld, partial, B, H, W, C, s) \
+                       : launch_dwl_wgrad<T, 7>(x, x_ld, dy, dy_ld, partial, B, H, W, C, s))
+  if (dtype == CFP_BF16) e = LK(bf16_t); else if (dtype == CFP_F16) e = LK(f16_t); else e = LK(float);
+#undef LK
+  if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_wgrad: ") + hipGetErrorString(e)); return CFP_EHIP; }
+  const int ntiles = B * cdiv(H, LWT) * cdiv(W, LWT);
+  hipLaunchKernelGGL(dwlarge_wgrad_reduce_kernel, dim3(cdiv((long long)C * k * k, 256)), dim3(256), 0, s, partial, ntiles, C / ve, ve, k * k, dw,
+                     beta);
+  return cfp_check_launch("cfp_dwconv_large_wgrad");
+}

@@ -456,3 +456,16 @@ def linattn_bwd(q2d, k2d, v2d, dout2d, state, N, L, S, heads, d, eps=1e-6):
              dout2d.stride(0), state.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), N, L, S,
              heads, d, eps, ops.DT[q2d.dtype], hip.current_stream())
     return dq, dk, dv
+
+
+def dwconv_large_wgrad(x2d, dy2d, B, H, W, k, dw=None, beta: float = 0.0):
+    """-> dw [C, k, k] f32 (weights laid out [C][ky][kx] like the forward kernel's)."""
+    from . import hip, ops
+    C = x2d.shape[1]
+    if dw is None:
+        dw, beta = torch.empty(C, k, k, dtype=torch.float32, device=x2d.device), 0.0
+    nbytes = hip.load().cfp_dwconv_large_wgrad_ws_bytes(B, H, W, C, k)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_dwconv_large_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, C, k, beta,
+             ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
+    return dw

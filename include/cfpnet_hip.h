@@ -413,6 +413,13 @@ int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld, const void
                     const float* state, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int N, int L, int S,
                     int heads, int d, float eps, int dtype, cfp_stream_t stream);
 
+/* Weight gradient of the large-kernel depthwise convolution of LKPM (convnext.py:30, k = 7/15/31, zero padding (k-1)/2):
+ * dw[C][k][k] f32 = beta*dw + sum over pixels of dy * x(tap).  The data gradient is cfp_dwconv_large_nhwc with the kernel
+ * flipped in both axes. */
+size_t cfp_dwconv_large_wgrad_ws_bytes(int B, int H, int W, int C, int k);
+int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int k, float beta,
+                           int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,17 @@ def test_linear_attention_forward_backward(N, L, S, heads, d, dtype):
     tol = OUT_TOL[dtype] + 3e-5
     chk = lambda got, want, n: float((got.float().cpu().reshape(N, n, heads, d) - want).abs().max()) <= tol * float(want.abs().max())
     assert chk(o_d, out.detach(), L) and chk(dq, q.grad, L) and chk(dk, k.grad, S) and chk(dv, v.grad, S)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,k", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (2, 64, 32, 8, 31)])
+def test_large_depthwise_weight_gradient(B, H, W, C, k, dtype):
+    x = rnd(B, C, H, W, seed=1).to(dtype).float()
+    w = rnd(C, 1, k, k, seed=2, scale=0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, (k - 1) // 2, 1, C)
+    dy = rnd(*y.shape, seed=3).to(dtype).float()
+    y.backward(dy)
+    dw = train_ops.dwconv_large_wgrad(nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV), B, H, W, k)
+    torch.cuda.synchronize()
+    want = w.grad[:, 0]
+    assert float((dw.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
