@@ -1,0 +1,323 @@
+"""A small reverse-mode tape over the HIP kernels: what `loss.backward()` is for the reference's training step
+(`train.py:119-131`), with every forward and backward computation a `cfp_*` kernel.
+
+Values are NHWC row tensors `[rows, C]` on the device (`V.t`), gradients appear in `V.g`.  Every op runs its forward
+kernel, pushes a closure on the tape, and `Tape.backward()` runs the closures in reverse.  PyTorch only owns the memory.
+There is no CPU path: without the HIP library the first op raises.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from . import hip, ops, train_ops
+
+
+class V:
+    """A value on the tape: `t` [rows, C] device tensor, `g` its gradient (same shape) once backward reached it."""
+    __slots__ = ("t", "g", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, needs_grad: bool = True):
+        self.t, self.g, self.needs_grad = t, None, needs_grad
+
+    @property
+    def rows(self):
+        return self.t.shape[0]
+
+    @property
+    def C(self):
+        return self.t.shape[1]
+
+
+class P(V):
+    """A parameter: `t` in the layout the kernels want, `g` accumulated in float32 in the same layout;
+    `to_torch(g)` converts a gradient back to the reference's state_dict layout."""
+    __slots__ = ("name", "to_torch")
+
+    def __init__(self, name: str, t: torch.Tensor, to_torch: Callable[[torch.Tensor], torch.Tensor]):
+        super().__init__(t, True)
+        self.name, self.to_torch = name, to_torch
+
+
+def _act(t: torch.Tensor) -> ops.Act:
+    assert t.dim() == 2 and t.stride(1) == 1
+    if t.stride(0) == t.shape[1]:
+        return ops.Act(t, 0, t.shape[1])
+    raise ValueError("tape tensors must be contiguous rows")
+
+
+class Tape:
+    def __init__(self, device, dtype=torch.float32):
+        self.dev, self.dtype = torch.device(device), dtype
+        self.bw: List[Callable[[], None]] = []
+        self._const: Dict[Tuple[str, int], torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def new(self, rows: int, C: int, dtype=None) -> torch.Tensor:
+        return torch.empty(rows, C, dtype=dtype or self.dtype, device=self.dev)
+
+    def const(self, kind: str, C: int) -> torch.Tensor:
+        k = (kind, C)
+        if k not in self._const:
+            self._const[k] = (torch.ones if kind == "ones" else torch.zeros)(C, dtype=torch.float32, device=self.dev)
+        return self._const[k]
+
+    def acc(self, v: V, g: torch.Tensor, own: bool = True) -> None:
+        """v.g += g.  `own`: the caller hands the tensor over (no other reference to it)."""
+        if not v.needs_grad:
+            return
+        if v.g is None:
+            v.g = g if own else g.clone()
+        else:
+            train_ops.axpby(v.g, g, 1.0, 1.0, out=v.g)
+
+    def backward(self) -> None:
+        for f in reversed(self.bw):
+            f()
+        self.bw = []
+
+    # ------------------------------------------------------------------ dense conv / linear
+    def conv(self, x: V, w: P, bias: Optional[P], B, H, W, k, stride, pt, pl, Ho, Wo) -> V:
+        """w.t [Cout, k*k*Cin]; bias.t [Cout] f32."""
+        Cout = w.t.shape[0]
+        y = V(self.new(B * Ho * Wo, Cout))
+        ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo)
+
+        def bw():
+            g = y.g
+            if g is None:
+                return
+            if bias is not None:
+                self.acc(bias, train_ops.colsum(g))
+            self.acc(w, train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo))
+            if x.needs_grad:
+                wt = train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
+                self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
+        self.bw.append(bw)
+        return y
+
+    def linear(self, x: V, w: P, bias: Optional[P] = None) -> V:
+        return self.conv(x, w, bias, 1, 1, x.rows, 1, 1, 0, 0, 1, x.rows)
+
+    # ------------------------------------------------------------------ normalisation / activation
+    def bn_act(self, x: V, gamma: P, beta: P, running_mean, running_var, eps, momentum, act) -> V:
+        bn = train_ops.BatchNormTrain(x.C, self.dev, eps=eps, momentum=momentum)
+        y = V(bn.forward(x.t, gamma.t, beta.t, running_mean, running_var, act))
+
+        def bw():
+            if y.g is None:
+                return
+            dx, dg, db = bn.backward(x.t, y.g, act)
+            self.acc(gamma, dg); self.acc(beta, db); self.acc(x, dx)
+        self.bw.append(bw)
+        return y
+
+    def act(self, x: V, kind: int) -> V:
+        return self._affine_act(x, kind, None)
+
+    def add_const(self, x: V, shift: torch.Tensor) -> V:
+        """y = x + shift[c]  (per-channel float32 constant, not differentiated)."""
+        return self._affine_act(x, hip.ACT_NONE, shift)
+
+    def _affine_act(self, x: V, kind: int, shift: Optional[torch.Tensor]) -> V:
+        y = V(torch.empty_like(x.t))
+        sh = shift if shift is not None else self.const("zeros", x.C)
+        hip.call("cfp_scale_shift_act", x.t.data_ptr(), x.t.stride(0), self.const("ones", x.C).data_ptr(), sh.data_ptr(), kind, y.t.data_ptr(),
+                 y.t.stride(0), x.rows, x.C, ops.DT[x.t.dtype], hip.current_stream())
+
+        def bw():
+            if y.g is None:
+                return
+            if kind == hip.ACT_NONE:
+                self.acc(x, y.g, own=False)
+            else:
+                self.acc(x, train_ops.act_bwd(x.t, y.g, kind))
+        self.bw.append(bw)
+        return y
+
+    def layernorm(self, x: V, gamma: P, beta: P, eps) -> V:
+        y = V(torch.empty_like(x.t))
+        ops.layernorm(_act(x.t), gamma.t, beta.t, eps, _act(y.t), x.rows)
+
+        def bw():
+            if y.g is None:
+                return
+            dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps)
+            self.acc(gamma, dg); self.acc(beta, db); self.acc(x, dx)
+        self.bw.append(bw)
+        return y
+
+    # ------------------------------------------------------------------ depthwise
+    def dw3x3(self, x: V, w: P, B, H, W, stride, pt, pl, Ho, Wo) -> V:
+        """w.t [9, C] in the activation dtype."""
+        C = x.C
+        y = V(self.new(B * Ho * Wo, C))
+        ops.dwconv3x3(_act(x.t), w.t, self.const("ones", C), self.const("zeros", C), _act(y.t), B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_NONE)
+
+        def bw():
+            if y.g is None:
+                return
+            self.acc(w, train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo))
+            self.acc(x, train_ops.dwconv3x3_dgrad(y.g, w.t, B, H, W, stride, pt, pl, Ho, Wo))
+        self.bw.append(bw)
+        return y
+
+    def dwlarge(self, x: V, w: P, bias: P, B, H, W, k) -> V:
+        """w.t [C, k, k] f32 in torch order (ky, kx); the forward kernel wants [C][kx][ky]."""
+        C = x.C
+        y = V(torch.empty_like(x.t))
+        wk = w.t.transpose(1, 2).contiguous().reshape(C, k * k)
+        ops.dwconv_large(_act(x.t), wk, self.const("ones", C), bias.t, _act(y.t), B, H, W, k, hip.ACT_NONE)
+
+        def bw():
+            if y.g is None:
+                return
+            self.acc(bias, train_ops.colsum(y.g))
+            self.acc(w, train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k))
+            wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)          # data gradient = correlation with the flipped kernel
+            dx = torch.empty_like(x.t)
+            ops.dwconv_large(_act(y.g), wf, self.const("ones", C), self.const("zeros", C), _act(dx), B, H, W, k, hip.ACT_NONE)
+            self.acc(x, dx)
+        self.bw.append(bw)
+        return y
+
+    # ------------------------------------------------------------------ structure
+    def add(self, a: V, b: V) -> V:
+        y = V(train_ops.axpby(a.t, b.t, 1.0, 1.0))
+
+        def bw():
+            if y.g is None:
+                return
+            self.acc(a, y.g, own=False); self.acc(b, y.g, own=False)
+        self.bw.append(bw)
+        return y
+
+    def concat(self, a: V, b: V) -> V:
+        Ca, Cb = a.C, b.C
+        y = V(self.new(a.rows, Ca + Cb, a.t.dtype))
+        full = ops.Act(y.t, 0, Ca + Cb)
+        ops.copy_rows(_act(a.t), full.slice(0, Ca), a.rows)
+        ops.copy_rows(_act(b.t), full.slice(Ca, Cb), a.rows)
+
+        def bw():
+            if y.g is None:
+                return
+            gf = ops.Act(y.g, 0, Ca + Cb)
+            for v, c0, c in ((a, 0, Ca), (b, Ca, Cb)):
+                if v.needs_grad:
+                    g = self.new(v.rows, c, y.g.dtype)
+                    ops.copy_rows(gf.slice(c0, c), _act(g), v.rows)
+                    self.acc(v, g)
+        self.bw.append(bw)
+        return y
+
+    def gather(self, x: V, idx: torch.Tensor, inv: torch.Tensor) -> V:
+        """y[i] = x[idx[i]] (zero rows where idx < 0); idx injective, inv its inverse (train_ops.inverse_index)."""
+        y = V(train_ops.index_rows(x.t, idx))
+
+        def bw():
+            if y.g is not None:
+                self.acc(x, train_ops.index_rows(y.g, inv))
+        self.bw.append(bw)
+        return y
+
+    def resize(self, x: V, B, Hs, Ws, Hd, Wd) -> V:
+        y = V(self.new(B * Hd * Wd, x.C, x.t.dtype))
+        ops.resize_bilinear(_act(x.t), Hs, Ws, (0, 0, Hs, Ws), _act(y.t), Hd, Wd, (0, 0, Hd, Wd), B)
+
+        def bw():
+            if y.g is not None:
+                self.acc(x, train_ops.resize_bilinear_bwd(y.g, B, Hs, Ws, Hd, Wd))
+        self.bw.append(bw)
+        return y
+
+    def add_table(self, x: V, table: P, B, H, W, Wt, oy, ox) -> V:
+        """y[b, y, x] = x[b, y, x] + table[(oy + y) * Wt + ox + x]  (learned positional encodings)."""
+        y = V(torch.empty_like(x.t))
+        ops.add_rowtable(_act(x.t), table.t, _act(y.t), x.rows, H, W, Wt, oy, ox)
+
+        def bw():
+            if y.g is None:
+                return
+            dt = torch.zeros_like(table.t)
+            train_ops.rowtable_grad(y.g, dt, B, H, W, Wt, oy, ox)
+            self.acc(table, dt)
+            self.acc(x, y.g, own=False)
+        self.bw.append(bw)
+        return y
+
+    # ------------------------------------------------------------------ attention / squeeze-excite / head
+    def attention(self, q: V, k: V, v: V, N, L, S, heads, d) -> V:
+        out, state = train_ops.linattn_fwd(q.t, k.t, v.t, N, L, S, heads, d)
+        y = V(out)
+
+        def bw():
+            if y.g is None:
+                return
+            dq, dk, dv = train_ops.linattn_bwd(q.t, k.t, v.t, y.g, state, N, L, S, heads, d)
+            self.acc(q, dq); self.acc(k, dk); self.acc(v, dv)
+        self.bw.append(bw)
+        return y
+
+    def channel_mean(self, x: V, B, HW) -> V:
+        """[B*HW, C] -> [B, C] float32."""
+        part = torch.empty(B, x.C, dtype=torch.float32, device=self.dev)
+        ops.channel_sum(_act(x.t), part, B, HW, 1)
+        y = V(train_ops.axpby(part, None, 1.0 / HW, 0.0))
+
+        def bw():
+            if y.g is None:
+                return
+            add = train_ops.axpby(y.g, None, 1.0 / HW, 0.0)
+            self.acc(x, train_ops.bcast_fma(x.t, self.new(B, x.C, torch.float32).zero_(), add, B, HW))
+        self.bw.append(bw)
+        return y
+
+    def mul_bcast(self, x: V, gate: V, B, HW) -> V:
+        """y[b, hw, c] = x[b, hw, c] * gate[b, c]  (gate float32)."""
+        y = V(train_ops.bcast_fma(x.t, gate.t, None, B, HW))
+
+        def bw():
+            if y.g is None:
+                return
+            self.acc(gate, train_ops.channel_dot(x.t, y.g, B, HW))
+            self.acc(x, train_ops.bcast_fma(y.g, gate.t, None, B, HW))
+        self.bw.append(bw)
+        return y
+
+    def row_normalize(self, x: V) -> V:
+        y = V(torch.empty_like(x.t))
+        hip.call("cfp_row_normalize", x.t.data_ptr(), None, y.t.data_ptr(), x.rows, x.C, hip.current_stream())
+
+        def bw():
+            if y.g is None:
+                return
+            dx = torch.empty_like(x.t)
+            hip.call("cfp_row_normalize", x.t.data_ptr(), y.g.data_ptr(), dx.data_ptr(), x.rows, x.C, hip.current_stream())
+            self.acc(x, dx)
+        self.bw.append(bw)
+        return y
+
+    def bin_centers(self, wn: V, min_val, max_val):
+        edges, centers = train_ops.bin_centers(wn.t, min_val, max_val)
+        y = V(centers)
+
+        def bw():
+            if y.g is not None:
+                self.acc(wn, train_ops.bin_centers_bwd(y.g, min_val, max_val))
+        self.bw.append(bw)
+        return edges, y
+
+    def softmax_expect(self, logits: V, centers: V, B, HW) -> V:
+        """-> pred as [B*HW, 1]-shaped value (float32 vector inside)."""
+        pred = train_ops.softmax_expect(logits.t, centers.t, B, HW)
+        y = V(pred.reshape(-1, 1))
+
+        def bw():
+            if y.g is None:
+                return
+            dl, dc = train_ops.softmax_expect(logits.t, centers.t, B, HW, dpred=y.g.reshape(-1).contiguous())
+            self.acc(logits, dl); self.acc(centers, dc)
+        self.bw.append(bw)
+        return y

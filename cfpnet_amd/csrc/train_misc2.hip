@@ -405,3 +405,29 @@ extern "C" int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, i
                      beta);
   return cfp_check_launch("cfp_dwconv_large_wgrad");
 }
+
+// ---- row normalisation of the bin widths: out = x / sum_c x  (decoder.py:36) and its backward -----------------------------
+namespace {
+__global__ void row_normalize_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int rows, int C) {
+  // one wave per row; dy == NULL: forward.  backward: out = (dy - sum_c(dy * y)) / s with y = x / s
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += x[(long long)row * C + c];
+  s = wave_sum(s);
+  if (!dy) {
+    for (int c = lane; c < C; c += 64) out[(long long)row * C + c] = x[(long long)row * C + c] / s;
+    return;
+  }
+  float t = 0.f;
+  for (int c = lane; c < C; c += 64) t = fmaf(dy[(long long)row * C + c], x[(long long)row * C + c] / s, t);
+  t = wave_sum(t);
+  for (int c = lane; c < C; c += 64) out[(long long)row * C + c] = (dy[(long long)row * C + c] - t) / s;
+}
+}  // namespace
+
+extern "C" int cfp_row_normalize(const float* x, const float* dy, float* out, int rows, int C, cfp_stream_t stream) {
+  CFP_REQUIRE(x && out && rows > 0 && C > 0, CFP_EINVAL, "cfp_row_normalize: bad argument");
+  hipLaunchKernelGGL(row_normalize_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, dy, out, rows, C);
+  return cfp_check_launch("cfp_row_normalize");
+}

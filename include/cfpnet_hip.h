@@ -420,6 +420,10 @@ size_t cfp_dwconv_large_wgrad_ws_bytes(int B, int H, int W, int C, int k);
 int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int k, float beta,
                            int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* Bin-width normalisation out = x / sum_c x over f32 rows (decoder.py:36); with dy != NULL its backward
+ * out = (dy - sum_c(dy * y)) / s instead (x = the forward input). */
+int cfp_row_normalize(const float* x, const float* dy, float* out, int rows, int C, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

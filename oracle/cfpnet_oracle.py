@@ -33,10 +33,13 @@ SD = Dict[str, Tensor]
 # ----------------------------------------------------------------------------------------
 # small pieces
 # ----------------------------------------------------------------------------------------
-def _bn(sd: SD, p: str, x: Tensor, eps: float = 1e-5) -> Tensor:
-    """Inference BatchNorm with running statistics."""
+BN_TRAIN = False        # tests flip this to get the model.train() forward (batch statistics, running stats updated in `sd`)
+
+
+def _bn(sd: SD, p: str, x: Tensor, eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+    """BatchNorm: running statistics (inference) or, with BN_TRAIN, batch statistics like model.train()."""
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
-                        sd[p + ".bias"], False, 0.0, eps)
+                        sd[p + ".bias"], BN_TRAIN, momentum if BN_TRAIN else 0.0, eps)
 
 
 def _same_pad(size: int, k: int, s: int) -> Tuple[int, int]:
@@ -58,6 +61,7 @@ def _conv_same(x: Tensor, w: Tensor, stride: int, groups: int = 1) -> Tensor:
 # ----------------------------------------------------------------------------------------
 _ENC_STAGES = [("conv0.2", 1), ("conv1", 2), ("conv2", 2), ("conv3.0", 2), ("conv3.1", 1), ("conv4", 2)]
 _ENC_EPS = 1e-3
+_ENC_MOM = 0.01      # timm tf_ models: bn_momentum = 1 - 0.99 (only matters for the running statistics in BN_TRAIN mode)
 
 
 def encoder(sd: SD, x: Tensor, stem_act: bool = False) -> List[Tensor]:
@@ -66,7 +70,7 @@ def encoder(sd: SD, x: Tensor, stem_act: bool = False) -> List[Tensor]:
     `stem_act=False` reproduces the reference under its pinned timm 0.5.4: encoder.py:58-61
     takes `conv_stem, bn1, blocks[0]` and so skips the separate `act1` SiLU."""
     p = "img_encoder"
-    x = _bn(sd, f"{p}.conv0.1", _conv_same(x, sd[f"{p}.conv0.0.weight"], 2), _ENC_EPS)
+    x = _bn(sd, f"{p}.conv0.1", _conv_same(x, sd[f"{p}.conv0.0.weight"], 2), _ENC_EPS, _ENC_MOM)
     if stem_act:
         x = F.silu(x)
     taps = []
@@ -77,19 +81,19 @@ def encoder(sd: SD, x: Tensor, stem_act: bool = False) -> List[Tensor]:
             s = stride if i == 0 else 1
             inp = x
             if f"{q}.conv.weight" in sd:                       # ConvBnAct
-                x = F.silu(_bn(sd, q + ".bn1", _conv_same(x, sd[q + ".conv.weight"], s), _ENC_EPS))
+                x = F.silu(_bn(sd, q + ".bn1", _conv_same(x, sd[q + ".conv.weight"], s), _ENC_EPS, _ENC_MOM))
             elif f"{q}.conv_exp.weight" in sd:                 # EdgeResidual
-                x = F.silu(_bn(sd, q + ".bn1", _conv_same(x, sd[q + ".conv_exp.weight"], s), _ENC_EPS))
-                x = _bn(sd, q + ".bn2", F.conv2d(x, sd[q + ".conv_pwl.weight"]), _ENC_EPS)
+                x = F.silu(_bn(sd, q + ".bn1", _conv_same(x, sd[q + ".conv_exp.weight"], s), _ENC_EPS, _ENC_MOM))
+                x = _bn(sd, q + ".bn2", F.conv2d(x, sd[q + ".conv_pwl.weight"]), _ENC_EPS, _ENC_MOM)
             else:                                              # InvertedResidual + SE
-                x = F.silu(_bn(sd, q + ".bn1", F.conv2d(x, sd[q + ".conv_pw.weight"]), _ENC_EPS))
+                x = F.silu(_bn(sd, q + ".bn1", F.conv2d(x, sd[q + ".conv_pw.weight"]), _ENC_EPS, _ENC_MOM))
                 w = sd[q + ".conv_dw.weight"]
-                x = F.silu(_bn(sd, q + ".bn2", _conv_same(x, w, s, groups=w.shape[0]), _ENC_EPS))
+                x = F.silu(_bn(sd, q + ".bn2", _conv_same(x, w, s, groups=w.shape[0]), _ENC_EPS, _ENC_MOM))
                 g = x.mean((2, 3), keepdim=True)
                 g = F.silu(F.conv2d(g, sd[q + ".se.conv_reduce.weight"], sd[q + ".se.conv_reduce.bias"]))
                 g = F.conv2d(g, sd[q + ".se.conv_expand.weight"], sd[q + ".se.conv_expand.bias"])
                 x = x * torch.sigmoid(g)
-                x = _bn(sd, q + ".bn3", F.conv2d(x, sd[q + ".conv_pwl.weight"]), _ENC_EPS)
+                x = _bn(sd, q + ".bn3", F.conv2d(x, sd[q + ".conv_pwl.weight"]), _ENC_EPS, _ENC_MOM)
             if s == 1 and inp.shape[1] == x.shape[1]:
                 x = x + inp
             i += 1
@@ -113,7 +117,7 @@ def hist_encoder(sd: SD, hist_data: Tensor) -> List[Tensor]:
             w = sd[f"{q}.conv{j}.weight"][:, :, 0]
             x = x @ w.t() + sd[f"{q}.conv{j}.bias"]
             x = F.batch_norm(x, sd[f"{q}.bn{j}.running_mean"], sd[f"{q}.bn{j}.running_var"],
-                             sd[f"{q}.bn{j}.weight"], sd[f"{q}.bn{j}.bias"], False, 0.0, 1e-5)
+                             sd[f"{q}.bn{j}.weight"], sd[f"{q}.bn{j}.bias"], BN_TRAIN, 0.1 if BN_TRAIN else 0.0, 1e-5)
             x = F.relu(x)
         outs.append(x.reshape(B, Z, N, -1))
     return outs
@@ -377,11 +381,11 @@ def bins_to_depth(sd: SD, widths_normed: Tensor, ram: Tensor, min_val: float, ma
 def forward(sd: SD, input_data: dict, *, layer_names, min_val: float = 1e-3, max_val: float = 10.0,
             norm: str = "linear", change_embedding: bool = True, no_skip_inside: bool = False,
             stem_act: bool = False, pos_offsets: Optional[dict] = None, taps: Optional[dict] = None,
-            img_features: Optional[Sequence[Tensor]] = None):
+            img_features: Optional[Sequence[Tensor]] = None, grad: bool = False):
     """Eval-mode `Deltar.forward` (deltar.py:34-67): returns (bin_edges, pred, prob).
     `img_features` bypasses the RGB encoder (used to pin everything else against the reference)."""
     add = input_data["additional"]
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):     # grad=True (+ BN_TRAIN): the training forward, differentiated by autograd in the tests
         feats = list(img_features) if img_features is not None else encoder(sd, input_data["rgb"], stem_act)
         if taps is not None:
             for i, f in enumerate(feats):
