@@ -30,7 +30,7 @@ def same_pad(size: int, k: int, s: int) -> Tuple[int, int]:
 def _pad_cols(t2d: torch.Tensor, cin: int, cin_pad: int, k2: int) -> torch.Tensor:
     if cin == cin_pad:
         return t2d
-    out = torch.zeros(t2d.shape[0], k2, cin_pad, dtype=t2d.dtype)
+    out = torch.zeros(t2d.shape[0], k2, cin_pad, dtype=t2d.dtype, device=t2d.device)
     out[:, :, :cin] = t2d.reshape(t2d.shape[0], k2, cin)
     return out.reshape(t2d.shape[0], k2 * cin_pad)
 
@@ -44,12 +44,14 @@ class TrainNet:
         self.layers = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, min_val, max_val
         self.stem_act, self.change_embedding = stem_act, change_embedding
-        self.sd = state_dict
+        # parameters live on the device in the reference's layout (possibly as views of a flat optimizer buffer, see
+        # trainer.Trainer); the kernel layouts are re-derived from them at every step (`zero_grad` drops the derived copies)
+        self.sd = {k: (v.detach().float().to(self.dev) if v.is_floating_point() else v) for k, v in state_dict.items()}
         self.P: Dict[str, P] = {}
         self.buf: Dict[str, torch.Tensor] = {}          # running statistics (updated in place)
-        for k, v in state_dict.items():
+        for k, v in self.sd.items():
             if k.endswith(("running_mean", "running_var")):
-                self.buf[k] = v.detach().float().to(self.dev).clone()
+                self.buf[k] = v.clone()
         self._idx_cache: Dict = {}
 
     # ------------------------------------------------------------------ parameters
@@ -64,7 +66,7 @@ class TrainNet:
                 w = w[:, :, None, None]
             co, ci, kh, kw = w.shape
             cp, cop = cin_pad or ci, cout_pad or co
-            t = torch.zeros(cop, kh * kw * cp)
+            t = torch.zeros(cop, kh * kw * cp, device=w.device)
             t[:co] = _pad_cols(w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci), ci, cp, kh * kw)
             shape = tuple(self.sd[name].shape)
 
@@ -78,7 +80,7 @@ class TrainNet:
             v = self.sd[name].detach().float()
             n = v.numel()
             if pad_to and pad_to > n:
-                v = torch.cat([v, torch.zeros(pad_to - n)])
+                v = torch.cat([v, torch.zeros(pad_to - n, device=v.device)])
             self.P[name] = P(name, v.contiguous().to(self.dev), lambda g, n=n: g[:n])
         return self.P[name]
 
@@ -104,8 +106,9 @@ class TrainNet:
         return {n: p.to_torch(p.g) for n, p in self.P.items() if p.g is not None}
 
     def zero_grad(self):
-        for p in self.P.values():
-            p.g = None
+        """Drop the gradients AND the kernel-layout copies of the parameters (they are rebuilt from `self.sd`, which the
+        optimizer has updated in place)."""
+        self.P = {}
 
     # ------------------------------------------------------------------ building blocks
     def _bn(self, t: Tape, x: V, prefix: str, act: int, eps=1e-5, mom=0.1) -> V:

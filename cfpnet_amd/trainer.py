@@ -1,0 +1,67 @@
+"""One optimisation step of the reference's training loop (`train.py:104-135`) on the HIP path:
+training forward + SILog + backward (`train_model.TrainNet`), gradient averaging over the data-parallel ranks
+(`train_ops.allreduce_gradients`: a few large RCCL all-reduces over the flat gradient buffer), AdamW with the OneCycle
+schedule (`train_ops.FlatAdamW`).  The parameters live once, in the flat float32 optimizer buffer; the network reads them
+through views, so nothing is copied back after the update.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import spec, train_ops
+from .train_model import TrainNet
+
+
+class Trainer:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], *, lr: float, total_steps: int, weight_decay: float = 0.1,
+                 div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
+                 device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
+                 change_embedding: bool = True):
+        self.dev = torch.device(device)
+        self.dist, self.world = dist, world
+        names = [(k, tuple(v.shape)) for k, v in state_dict.items()
+                 if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
+        self.flat = train_ops.FlatParams(names, train_ops.lr_group_of(hist_encoder_10x), device=self.dev)
+        self.flat.load(state_dict)
+        sd = dict(state_dict)
+        for name, _ in names:
+            sd[name] = self.flat.view(name)                      # the network sees the optimizer's buffer
+        self.net = TrainNet(sd, layer_names, self.dev, n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding)
+        for name, _ in names:                                     # TrainNet.__init__ keeps device tensors as they are: still views
+            assert self.net.sd[name].data_ptr() == self.flat.view(name).data_ptr()
+        self.opt = train_ops.FlatAdamW(self.flat, train_ops.OneCycle(lr, total_steps, div_factor, final_div_factor), weight_decay=weight_decay,
+                                       clip_grad_norm=clip_grad_norm)
+        self.min_val = min_val
+
+    def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
+        """fusion.py:87-91: a random window into the learned positional table whenever the token map is smaller than it."""
+        offs = {}
+        for name, (_, (Hm, Wm), _) in spec.FUSION.items():
+            s = 640 // Wm
+            h, w = H // s, W // s
+            oy = int(torch.randint(0, Hm - h + 1, [1])) if h < Hm else 0
+            ox = int(torch.randint(0, Wm - w + 1, [1])) if w < Wm else 0
+            offs[name] = (oy, ox)
+        return offs
+
+    def step(self, input_data: dict, target: torch.Tensor, pos_offsets: Optional[dict] = None):
+        """-> (loss as a device scalar, lr, beta1).  `target` [B,1,H,W]; the loss mask is target > min_depth (train.py:121)."""
+        H, W = input_data["rgb"].shape[-2:]
+        offs = pos_offsets if pos_offsets is not None else self.draw_pos_offsets(H, W)
+        loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
+        self.flat.grad.zero_()
+        for name, g in self.net.grads().items():
+            self.flat.view(name, "grad").copy_(g)
+        train_ops.allreduce_gradients(self.flat, self.dist, self.world)
+        lr, beta1 = self.opt.step()
+        self.net.zero_grad()
+        return loss, lr, beta1
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """Parameters and running statistics in the reference's layout (for `model_io.save_checkpoint`)."""
+        out = {}
+        for k, v in self.net.sd.items():
+            out[k] = (self.net.buf[k] if k in self.net.buf else v).detach().clone().cpu() if torch.is_tensor(v) else v
+        return out

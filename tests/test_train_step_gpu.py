@@ -81,3 +81,33 @@ def test_training_step_matches_autograd_of_the_oracle():
     assert e_hip.max() < 0.15
     for k, v in stats64.items():                                                  # running statistics: torch's momentum update
         assert torch.allclose(net.buf[k].double().cpu(), v, rtol=1e-3, atol=1e-5), k
+
+
+def test_trainer_step_applies_adamw_to_its_gradients_and_loss_goes_down():
+    """Plumbing of Trainer.step: gradients -> flat buffer -> AdamW(OneCycle) -> the parameters the next forward reads.
+    The update must equal torch.optim.AdamW fed with the same gradients, and a few steps on one batch must reduce the loss."""
+    from cfpnet_amd.trainer import Trainer
+    from cfpnet_amd.train_model import TrainNet
+    layers, sd, inp, target, offs = _case(B=2, H=128, W=160, zn=2, zpx=32, seed=3) if False else _case()
+    tr = Trainer(sd, layers, lr=3e-4, total_steps=20, weight_decay=0.1)
+    net = TrainNet(sd, layers, "cuda:0")
+    net.forward_backward(inp, target, target > 1e-3, pos_offsets=offs)
+    grads = {k: v.detach().cpu().clone() for k, v in net.grads().items()}
+    loss0, lr, beta1 = tr.step(inp, target, pos_offsets=offs)
+    torch.cuda.synchronize()
+    sched = tr.opt.sched
+    assert (lr, beta1) == sched.at(0) and abs(lr - 3e-4 / 25) < 1e-12
+    ref = {k: torch.nn.Parameter(sd[k].detach().clone().float()) for k in grads}
+    for k, p in ref.items():
+        p.grad = grads[k].float()
+    torch.optim.AdamW(ref.values(), lr=lr, betas=(beta1, 0.999), eps=1e-8, weight_decay=0.1).step()
+    worst = max(float((tr.flat.view(k).cpu() - p.detach()).abs().max()) / max(float(p.detach().abs().max()), 1e-3) for k, p in ref.items())
+    assert worst < 1e-5, worst
+    losses = [float(loss0)]
+    for _ in range(6):
+        l, _, _ = tr.step(inp, target, pos_offsets=offs)
+        losses.append(float(l))
+    print("losses", [round(x, 4) for x in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    out = tr.state_dict()
+    assert set(out) == set(sd) and all(tuple(out[k].shape) == tuple(sd[k].shape) for k in sd if torch.is_tensor(sd[k]))
