@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Training with the reference's CLI and loop (`/root/reference/train.py:41-209`):
+
+    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py @configs/cfpnet_combine1.txt --synthetic 4096
+
+Per step: ToF simulation of the batch from its ground-truth depth (GPU), forward in training mode, SILog loss, backward of
+the whole network (HIP tape, `cfpnet_amd/train_model.py`), gradient all-reduce over the data-parallel ranks (RCCL, flat
+buffer), AdamW with OneCycle (lr and beta1 cycled like `train.py:82-94`, `clip_grad_norm_(0.1)` unless `--disable_clip_grad`).
+One process per GPU with the global batch `--bs` split over the ranks (the reference uses nn.DataParallel on one process).
+
+Differences on purpose: `--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box;
+without it a missing `filenames_file` is an error), random rotation / colour augmentation of the real loader is not
+reproduced, wandb logging and the per-epoch validation are left out (use evaluate_all.py on the saved checkpoint).
+Float32 storage.  There is no PyTorch autograd or fallback anywhere in the step.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def _pop(argv, flag, default=None, cast=str):
+    if flag in argv:
+        i = argv.index(flag)
+        v = cast(argv[i + 1])
+        del argv[i:i + 2]
+        return v
+    return default
+
+
+class SyntheticTrainSet:
+    """Seeded stand-in for the NYU train split at the training crop size: random RGB, planes-and-boxes depth with holes."""
+
+    def __init__(self, n, H, W, seed):
+        self.n, self.H, self.W, self.seed = n, H, W, seed
+
+    def batch(self, index, bs):
+        from cfpnet_amd import data, synthetic
+        imgs, deps = [], []
+        for j in range(bs):
+            i = (index * bs + j) % self.n
+            rng = np.random.default_rng(self.seed + i)
+            rgb = rng.random((3, self.H, self.W), dtype=np.float32)
+            imgs.append((rgb - data.IMAGENET_MEAN[:, None, None]) / data.IMAGENET_STD[:, None, None])
+            deps.append(synthetic.make_depth(self.H, self.W, seed=self.seed + 7919 * (i + 1), holes=0.1 * (i % 3))[None])
+        return torch.from_numpy(np.stack(imgs)), torch.from_numpy(np.stack(deps))
+
+
+def main(argv=None):
+    from cfpnet_amd import config, geometry, spec, weights
+    from cfpnet_amd.tof import TofSimulator, zone_layout
+    from cfpnet_amd.trainer import Trainer
+
+    argv = list(argv if argv is not None else sys.argv[1:])
+    n_syn = _pop(argv, "--synthetic", 0, int)
+    max_steps = _pop(argv, "--max_steps", 0, int)
+    save_path = _pop(argv, "--save", "", str)
+    log_every = _pop(argv, "--log_every", 10, int)
+    args = config.parse_args(argv) if argv else config.defaults()
+    args.mode = "train"
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        dist = dist_mod
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    H, W = int(args.input_height), int(args.input_width)
+    if n_syn <= 0:
+        fn = getattr(args, "filenames_file", None)
+        raise FileNotFoundError(f"filenames_file '{fn}' is not on this box -- pass --synthetic N to train on synthetic samples")
+    per_rank = max(1, int(args.bs) // world)
+    steps_per_epoch = max(1, n_syn // (per_rank * world))
+    total_steps = int(args.epochs) * steps_per_epoch
+    if max_steps:
+        total_steps = min(total_steps, max_steps)
+    layers = list(args.attention_layer)
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers, int(args.n_bins), int(args.zone_sample_num)))
+    wp = getattr(args, "weight_path", "") or ""
+    if wp:
+        sd.update(torch.load(wp, map_location="cpu"))
+    tr = Trainer(sd, layers, lr=float(args.lr), total_steps=max(total_steps, 2), weight_decay=float(args.wd), div_factor=float(args.div_factor),
+                 final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
+                 clip_grad_norm=None if args.disable_clip_grad else 0.1, device=dev, dist=dist, world=world, n_bins=int(args.n_bins),
+                 min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding))
+    sim = TofSimulator(args, dev)
+    zn, zp, _, _ = zone_layout(args, H, W)
+    rects = geometry.centered_zone_rects(H, W, zn, zp)
+    pi = geometry.collate_patch_info([geometry.patch_info_from_rect_data(rects, (H, W))] * per_rank)
+    patch_info = {s: {k: torch.from_numpy(v) for k, v in pi[s].items()} for s in (4, 8, 16)}
+    patch_info["zone_num"] = torch.from_numpy(pi["zone_num"])
+    ds = SyntheticTrainSet(n_syn, H, W, seed=1000 + rank)
+    rng = np.random.default_rng(4242 + rank)
+    drop = float(args.drop_hist)
+    t0, seen, step = time.perf_counter(), 0, 0
+    for epoch in range(int(args.epochs)):
+        for i in range(steps_per_epoch):
+            if step >= total_steps:
+                break
+            img, dep = ds.batch(epoch * steps_per_epoch + i, per_rank)
+            depd = dep.to(dev)
+            s = sim.simulate(depd)
+            mask = s["mask"]
+            if drop > 1e-3:                                   # nyu.py:155-158: drop int(len*drop_hist) valid zones, drawn WITH replacement
+                m = mask.cpu().numpy().copy()
+                for b in range(m.shape[0]):
+                    idx = np.where(m[b])[0]
+                    if idx.size:
+                        m[b, rng.choice(idx, int(idx.size * drop))] = False
+                mask = torch.from_numpy(m).to(dev)
+            inp = {"rgb": img, "additional": {"hist_data": s["hist_data"], "rect_data": s["rect_data"], "mask": mask, "patch_info": patch_info}}
+            loss, lr, beta1 = tr.step(inp, depd)
+            step += 1
+            seen += per_rank * world
+            if rank == 0 and (step % log_every == 0 or step == 1 or step == total_steps):
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                print(f"epoch {epoch + 1} step {step}/{total_steps} loss {float(loss):.4f} lr {lr:.2e} beta1 {beta1:.3f} {seen / dt:.1f} samples/s", flush=True)
+    torch.cuda.synchronize()
+    if rank == 0 and save_path:
+        os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
+        torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
+    if dist:
+        dist.barrier(); dist.destroy_process_group()
+    return float(loss)
+
+
+if __name__ == "__main__":
+    main()
