@@ -136,15 +136,56 @@ class Deltar(_Store):
 
     def forward(self, input_data: Dict, **kwargs):
         if self.training:
-            raise NotImplementedError(
-                "cfpnet_amd: the training step (backward kernels, batch-statistics BatchNorm) is not built yet; "
-                "call model.eval() -- see DESIGN.md 'Out of scope this round'")
+            return self._forward_train(input_data, kwargs.get("pos_offsets"))
         eng = self.engine(input_data["rgb"].device if input_data["rgb"].is_cuda else None)
         pos_offsets = kwargs.get("pos_offsets")
         if pos_offsets is None:
             pos_offsets = self.draw_pos_offsets(input_data["rgb"].shape[-2], input_data["rgb"].shape[-1])
         edges, pred, prob = eng.forward(input_data, return_prob=kwargs.get("return_prob", True), pos_offsets=pos_offsets)
         return edges, pred, prob, None
+
+
+class _TrainStep(torch.autograd.Function):
+    """`model(input_data)` in `model.train()` for callers that then run `loss.backward()` like the reference's train.py:
+    forward = the training-mode forward on the HIP tape, backward = the tape's backward; the parameter gradients come back
+    through autograd in the reference's layout, the running statistics are updated in the module's buffers."""
+
+    @staticmethod
+    def forward(ctx, model, input_data, pos_offsets, names, *params):
+        from .autograd_hip import Tape
+        from .train_model import TrainNet
+        dev = params[0].device
+        sd = {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}
+        net = TrainNet(sd, model.layer_names, dev, n_bins=model.num_classes, min_val=model.min_val, max_val=model.max_val,
+                       stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True)
+        tape = Tape(dev)
+        pred, edges, (B, h, w) = net.forward(tape, input_data, pos_offsets)
+        ctx.net, ctx.tape, ctx.pred, ctx.names = net, tape, pred, names
+        ctx.mark_non_differentiable(edges)
+        return edges, pred.t.reshape(B, 1, h, w)
+
+    @staticmethod
+    def backward(ctx, _g_edges, g_pred):
+        ctx.pred.g = g_pred.reshape(-1, 1).to(torch.float32).contiguous()
+        ctx.tape.backward()
+        grads = ctx.net.grads()
+        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+def _forward_train(self, input_data: Dict, pos_offsets=None):
+    if self.compute_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise NotImplementedError(self.compute_dtype)
+    named = [(n, p) for n, p in self.named_parameters()]
+    if not named[0][1].is_cuda:
+        raise RuntimeError("cfpnet_amd: the training step runs on the GPU -- call model.to('cuda') first (there is no CPU path)")
+    if pos_offsets is None:
+        pos_offsets = self.draw_pos_offsets(input_data["rgb"].shape[-2], input_data["rgb"].shape[-1])
+    edges, pred = _TrainStep.apply(self, input_data, pos_offsets, [n for n, _ in named], *[p for _, p in named])
+    self._version_counter += 1            # the next eval-mode engine must repack the (about to change) parameters
+    return edges, pred                     # deltar.py:64-65: training returns (bin_edges, pred)
+
+
+Deltar._forward_train = _forward_train
 
 
 def make_model(args, dtype=None):

@@ -39,7 +39,7 @@ class TrainNet:
     """Parameters of the reference's state_dict as tape parameters + the training-mode forward/backward."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], device="cuda:0", n_bins=256, min_val=1e-3,
-                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True):
+                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False):
         self.dev = torch.device(device)
         self.layers = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, min_val, max_val
@@ -51,7 +51,7 @@ class TrainNet:
         self.buf: Dict[str, torch.Tensor] = {}          # running statistics (updated in place)
         for k, v in self.sd.items():
             if k.endswith(("running_mean", "running_var")):
-                self.buf[k] = v.clone()
+                self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
 
     # ------------------------------------------------------------------ parameters
@@ -329,11 +329,9 @@ class TrainNet:
         return x
 
     # ------------------------------------------------------------------ the step
-    def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None):
-        """One forward in training mode + SILog + backward.  Returns (loss [python float after sync], pred [B,1,H/2,W/2]);
-        gradients are in `self.grads()`, running statistics in `self.buf`."""
+    def forward(self, t: Tape, input_data: dict, pos_offsets: Optional[dict] = None):
+        """Training-mode forward on tape `t`: -> (pred as a tape value [B*h*w, 1], bin edges [B, n_bins+1], (B, h, w))."""
         dev = self.dev
-        t = Tape(dev)
         rgb = input_data["rgb"].to(dev, torch.float32).contiguous()
         add = input_data["additional"]
         B, _, H, W = rgb.shape
@@ -378,6 +376,14 @@ class TrainNet:
         edges, centers = t.bin_centers(wn, self.min_val, self.max_val)
         logits = pw(ram, "conv_out.0", h0, w0)
         pred = t.softmax_expect(logits, centers, B, h0 * w0)
+        return pred, edges, (B, h0, w0)
+
+    def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None):
+        """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
+        gradients are in `self.grads()`, running statistics in `self.buf`."""
+        dev = self.dev
+        t = Tape(dev)
+        pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
         # SILog (loss.py:9-19) on the half-resolution prediction against the full-resolution target
         crit = train_ops.SILogLoss()
         pred4 = pred.t.reshape(B, 1, h0, w0)

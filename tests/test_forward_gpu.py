@@ -125,7 +125,7 @@ def test_deltar_module_boundary():
     assert edges.shape == (1, 257) and pred.shape == (1, 1, 240, 320) and prob.shape == (1, 256, 240, 320)
     assert pred.is_cuda and float(pred.min()) > 1e-3 and float(pred.max()) < 10
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):      # parameters still on the host: the training step refuses, it does not fall back
         model(inp)
     ones = [p for p in model.get_1x_lr_params()]
     tens = [p for p in model.get_10x_lr_params()]

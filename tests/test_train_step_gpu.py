@@ -111,3 +111,38 @@ def test_trainer_step_applies_adamw_to_its_gradients_and_loss_goes_down():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     out = tr.state_dict()
     assert set(out) == set(sd) and all(tuple(out[k].shape) == tuple(sd[k].shape) for k in sd if torch.is_tensor(sd[k]))
+
+
+def test_deltar_module_trains_through_torch_autograd():
+    """The reference's own loop shape: `bin_edges, pred = model(input)` in train mode, a torch loss on `pred`,
+    `loss.backward()` -- parameter .grad comes from the HIP tape through a torch.autograd.Function."""
+    from cfpnet_amd.deltar import Deltar
+    from cfpnet_amd.train_model import TrainNet
+    import types
+    layers, sd, inp, target, offs = _case()
+    args = types.SimpleNamespace(attention_layer=layers, zone_sample_num=16, change_embedding=True, no_skip_inside=False, hist_encoder_10x=True)
+    model = Deltar(n_bins=256, min_val=1e-3, max_val=10.0, norm="linear", args=args, dtype=torch.float32)
+    model.load_state_dict(sd)
+    model = model.to("cuda:0").train()
+    rm_before = model.state_dict()["decoder.up1._net.1.running_mean"].clone()
+    dinp = synthetic.to_device(inp, "cuda:0")
+    edges, pred = model(dinp, pos_offsets=offs)
+    assert pred.requires_grad and pred.shape == (2, 1, 128, 160) and edges.shape == (2, 257)
+    tgt = target.to("cuda:0")
+    loss = O.silog_loss(torch.clip(pred, 1e-3), tgt, tgt > 1e-3, interpolate=True)        # train.py:121-123 with torch ops on pred
+    loss.backward()
+    torch.cuda.synchronize()
+    net = TrainNet(sd, layers, "cuda:0")
+    loss1, _, _ = net.forward_backward(inp, target, target > 1e-3, pos_offsets=offs)
+    ref = net.grads()
+    assert abs(float(loss) - float(loss1)) < 1e-5 * float(loss1)
+    named = dict(model.named_parameters())
+    got_live = {k for k, p in named.items() if p.grad is not None}
+    assert got_live == set(ref)
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    errs = [float((named[k].grad - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-5 * gmax) for k in ref]
+    # two float32 evaluations of the loss gradient apart (torch ops vs the SILog kernel), amplified by the BatchNorms
+    assert np.median(errs) < 2e-3 and max(errs) < 0.15, (np.median(errs), max(errs))
+    assert not torch.equal(model.state_dict()["decoder.up1._net.1.running_mean"], rm_before)      # running statistics moved
+    with pytest.raises(RuntimeError):
+        Deltar(n_bins=256, min_val=1e-3, max_val=10.0, norm="linear", args=args, dtype=torch.float32).train()(inp)
