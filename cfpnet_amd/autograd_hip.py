@@ -262,8 +262,13 @@ class Tape:
 
     def channel_mean(self, x: V, B, HW) -> V:
         """[B*HW, C] -> [B, C] float32."""
-        part = torch.empty(B, x.C, dtype=torch.float32, device=self.dev)
-        ops.channel_sum(_act(x.t), part, B, HW, 1)
+        ns = max(1, min(64, HW // 256))                              # two-level sum: [B, ns, C] partials, then over ns
+        part = torch.empty(B * ns, x.C, dtype=torch.float32, device=self.dev)
+        ops.channel_sum(_act(x.t), part, B, HW, ns)
+        if ns > 1:
+            tot = torch.empty(B, x.C, dtype=torch.float32, device=self.dev)
+            ops.channel_sum(ops.Act(part, 0, x.C), tot, B, ns, 1)
+            part = tot
         y = V(train_ops.axpby(part, None, 1.0 / HW, 0.0))
 
         def bw():

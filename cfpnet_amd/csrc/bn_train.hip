@@ -104,15 +104,17 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
   }
 }
 
-// MODE 0 -> mean; MODE 1 -> var (biased) ; MODE 2 -> dbeta (which 0), dgamma (which 1)
+// MODE 0 -> mean; MODE 1 -> var (biased) ; MODE 2/3 -> dbeta (which 0), dgamma (which 1).
+// One wave per output: lanes stride over the splits, then a butterfly -- a fixed order, so still bit-reproducible.
 __global__ __launch_bounds__(256) void colfinal_kernel(const float* __restrict__ partial, int nsplit, int ns, int C, float inv_n,
                                                        float* __restrict__ out0, float* __restrict__ out1) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= C * ns) return;
   const int which = i / C, c = i - which * C;
   float s = 0.f;
-  for (int j = 0; j < nsplit; ++j) s += partial[((long long)j * ns + which) * C + c];
-  (which == 0 ? out0 : out1)[c] = s * inv_n;
+  for (int j = lane; j < nsplit; j += 64) s += partial[((long long)j * ns + which) * C + c];
+  s = wave_sum(s);
+  if (lane == 0) (which == 0 ? out0 : out1)[c] = s * inv_n;
 }
 
 __global__ void bn_fold_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
@@ -278,7 +280,7 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
   if (dtype == CFP_BF16) RL(bf16_t); else if (dtype == CFP_F16) RL(f16_t); else RL(float);
 #undef RL
   const int nsum = MODE >= 2 ? 2 : 1;
-  hipLaunchKernelGGL(colfinal_kernel, dim3(cdiv(C * nsum, 256)), dim3(256), 0, s, partial, nsplit, nsum, C, inv_n, out0, out1);
+  hipLaunchKernelGGL(colfinal_kernel, dim3(cdiv(C * nsum, 4)), dim3(256), 0, s, partial, nsplit, nsum, C, inv_n, out0, out1);
   return 0;
 }
 

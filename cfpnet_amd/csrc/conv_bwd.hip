@@ -143,8 +143,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
                                                            float beta) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += slabs[(long long)j * n + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four loads in flight; the combination order is still fixed
+    int j = 0;
+    for (; j + 3 < nsplit; j += 4) {
+      s0 += slabs[(long long)j * n + i]; s1 += slabs[(long long)(j + 1) * n + i];
+      s2 += slabs[(long long)(j + 2) * n + i]; s3 += slabs[(long long)(j + 3) * n + i];
+    }
+    for (; j < nsplit; ++j) s0 += slabs[(long long)j * n + i];
+    const float s = (s0 + s1) + (s2 + s3);
     dw[i] = beta != 0.f ? beta * dw[i] + s : s;
   }
 }
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void weight_flip_kernel(const T* __restrict__ 
 
 inline int wgrad_nsplit(int Cout, int K, int M) {
   const long long tiles = (long long)cdiv(Cout, WB) * cdiv(K, WB);
-  long long ns = (2048 + tiles - 1) / tiles;                 // ~8 workgroups per CU in total
+  long long ns = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total; every split costs a slab to add up
   const long long max_ns = cdiv(M, 4 * WM);                  // at least 128 rows per chunk
   if (ns > max_ns) ns = max_ns;
   if (ns > 1024) ns = 1024;
