@@ -212,7 +212,7 @@ def lr_group_of(hist_encoder_10x: bool):
 
 # ------------------------------------------------------------------------------------------------------------------
 # Backward building blocks of the conv / BatchNorm layers (csrc/conv_bwd.hip, csrc/bn_train.hip).  Thin wrappers over
-# the C ABI on NHWC row tensors [rows, C]; the training engine that chains them is not built yet.
+# the C ABI on NHWC row tensors [rows, C]; `autograd_hip.Tape` chains them into the backward of the whole network.
 # ------------------------------------------------------------------------------------------------------------------
 def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, dw: Optional[torch.Tensor] = None,
                  beta: float = 0.0) -> torch.Tensor:

@@ -320,8 +320,7 @@ int cfp_eval_metrics(const float* pred, int Hp, int Wp, const float* gt, int H, 
                      float lo, float hi, void* ws, size_t ws_bytes, double* out, cfp_stream_t stream);
 
 /* ---- training-step kernels: backward of the dense convolution, batch-statistics BatchNorm --------------------------
- * (building blocks of the training row of SURVEY.md section 8; the training engine that strings them together is not
- * built yet) */
+ * (the training row of SURVEY.md section 8: cfpnet_amd/autograd_hip.py chains them into the backward of the whole network) */
 
 /* Weight gradient of nn.Conv2d / nn.Linear (autograd of the layers cfp_conv2d_nhwc replaces; train.py:125):
  * dw[Cout][KH*KW*Cin] (f32) = beta * dw + sum over output pixels of dy[m][co] * x[window(m)][ci].  x [B,H,W,Cin] and
