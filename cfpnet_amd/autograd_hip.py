@@ -81,7 +81,7 @@ class Tape:
     def conv(self, x: V, w: P, bias: Optional[P], B, H, W, k, stride, pt, pl, Ho, Wo) -> V:
         """w.t [Cout, k*k*Cin]; bias.t [Cout] f32."""
         Cout = w.t.shape[0]
-        y = V(self.new(B * Ho * Wo, Cout))
+        y = V(self.new(B * Ho * Wo, Cout, x.t.dtype))
         ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo)
 
         def bw():
@@ -152,7 +152,7 @@ class Tape:
     def dw3x3(self, x: V, w: P, B, H, W, stride, pt, pl, Ho, Wo) -> V:
         """w.t [9, C] in the activation dtype."""
         C = x.C
-        y = V(self.new(B * Ho * Wo, C))
+        y = V(self.new(B * Ho * Wo, C, x.t.dtype))
         ops.dwconv3x3(_act(x.t), w.t, self.const("ones", C), self.const("zeros", C), _act(y.t), B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_NONE)
 
         def bw():

@@ -39,8 +39,12 @@ class TrainNet:
     """Parameters of the reference's state_dict as tape parameters + the training-mode forward/backward."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], device="cuda:0", n_bins=256, min_val=1e-3,
-                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False):
+                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False, dtype=torch.float32):
+        """`dtype`: storage of activations and of the matrix-core weight operands (float32 = parity mode; bfloat16 /
+        float16 = mixed precision: float32 master parameters, float32 gradients of the parameters, 16-bit activations
+        and activation gradients, float32 accumulation everywhere)."""
         self.dev = torch.device(device)
+        self.dtype = dtype
         self.layers = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, min_val, max_val
         self.stem_act, self.change_embedding = stem_act, change_embedding
@@ -55,7 +59,7 @@ class TrainNet:
         self._idx_cache: Dict = {}
 
     # ------------------------------------------------------------------ parameters
-    def _conv_w(self, name: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None) -> P:
+    def _conv_w(self, name: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None, f32: bool = False) -> P:
         """[Cout, Cin, kh, kw] / [Cout, Cin(, 1)] -> [Cout_pad, kh*kw*Cin_pad]; padding rows / columns are zero and their
         gradients are dropped (channel counts the 16-byte vectors cannot express: RGB 3, ToF 1, squeeze-excite 34 / 58)."""
         if name not in self.P:
@@ -72,7 +76,7 @@ class TrainNet:
 
             def back(g, co=co, ci=ci, kh=kh, kw=kw, cp=cp, shape=shape):
                 return g[:co].reshape(co, kh, kw, cp)[..., :ci].permute(0, 3, 1, 2).reshape(shape)
-            self.P[name] = P(name, t.contiguous().to(self.dev), back)
+            self.P[name] = P(name, t.contiguous().to(self.dev).to(torch.float32 if f32 else self.dtype), back)     # f32: layers fed by float32 [B, C] vectors
         return self.P[name]
 
     def _vec(self, name: str, pad_to: Optional[int] = None) -> P:
@@ -88,7 +92,7 @@ class TrainNet:
         if name not in self.P:
             w = self.sd[name].detach().float()
             C = w.shape[0]
-            self.P[name] = P(name, w.reshape(C, 9).t().contiguous().to(self.dev), lambda g, C=C: g.t().reshape(C, 1, 3, 3))
+            self.P[name] = P(name, w.reshape(C, 9).t().contiguous().to(self.dev).to(self.dtype), lambda g, C=C: g.t().reshape(C, 1, 3, 3))
         return self.P[name]
 
     def _dwl(self, name: str) -> P:
@@ -155,8 +159,8 @@ class TrainNet:
                     g = t.channel_mean(x, B, H * W)
                     R = self.sd[q + ".se.conv_reduce.weight"].shape[0]
                     Rp = -(-R // 4) * 4                               # zero-padded hidden units: SiLU(0) = 0 feeds zero columns
-                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_reduce.weight", cout_pad=Rp), self._vec(q + ".se.conv_reduce.bias", Rp)), hip.ACT_SILU)
-                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_expand.weight", cin_pad=Rp), self._vec(q + ".se.conv_expand.bias")), hip.ACT_SIGMOID)
+                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_reduce.weight", cout_pad=Rp, f32=True), self._vec(q + ".se.conv_reduce.bias", Rp)), hip.ACT_SILU)
+                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_expand.weight", cin_pad=Rp, f32=True), self._vec(q + ".se.conv_expand.bias")), hip.ACT_SIGMOID)
                     x = t.mul_bcast(x, g, B, H * W)
                     x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
                     x = self._bn(t, x, q + ".bn3", hip.ACT_NONE, ENC_EPS, ENC_MOM)
@@ -170,7 +174,7 @@ class TrainNet:
     def _hist_encoder(self, t: Tape, hist: torch.Tensor) -> List[V]:
         B, Z, N = hist.shape
         rows = B * Z * N
-        x8 = ops.new_act(rows, 8, torch.float32, self.dev)
+        x8 = ops.new_act(rows, 8, self.dtype, self.dev)
         ops.scalar_to_rows8(hist.reshape(-1).contiguous(), x8, rows)
         x = V(x8.buf, needs_grad=False)
         outs = []
@@ -336,7 +340,7 @@ class TrainNet:
         add = input_data["additional"]
         B, _, H, W = rgb.shape
         pos_offsets = pos_offsets or {}
-        x8 = ops.new_act(B * H * W, 8, torch.float32, dev)
+        x8 = ops.new_act(B * H * W, 8, self.dtype, dev)
         ops.rgb_to_nhwc8(rgb, x8, B, H, W)
         taps = self._encoder(t, V(x8.buf, needs_grad=False), B, H, W)
         (b0, h0, w0), (b1, h1, w1), (b2, h2, w2), (b3, h3, w3), (b4, h4, w4) = taps
@@ -368,9 +372,9 @@ class TrainNet:
         ram = self._conv3(t, unet, "depth_head.conv3x3.weight", "depth_head.conv3x3.bias", B, h0, w0)
         y = t.conv(unet, self._conv_w("depth_head.conv1x1.weight"), None, B, h0, w0, 1, 1, 0, 0, h0, w0)
         y = t.channel_mean(y, B, h0 * w0)
-        y = t.act(t.linear(y, self._conv_w("depth_head.regressor.0.weight"), self._vec("depth_head.regressor.0.bias")), hip.ACT_LRELU)
-        y = t.act(t.linear(y, self._conv_w("depth_head.regressor.2.weight"), self._vec("depth_head.regressor.2.bias")), hip.ACT_LRELU)
-        y = t.linear(y, self._conv_w("depth_head.regressor.4.weight"), self._vec("depth_head.regressor.4.bias"))
+        y = t.act(t.linear(y, self._conv_w("depth_head.regressor.0.weight", f32=True), self._vec("depth_head.regressor.0.bias")), hip.ACT_LRELU)
+        y = t.act(t.linear(y, self._conv_w("depth_head.regressor.2.weight", f32=True), self._vec("depth_head.regressor.2.bias")), hip.ACT_LRELU)
+        y = t.linear(y, self._conv_w("depth_head.regressor.4.weight", f32=True), self._vec("depth_head.regressor.4.bias"))
         y = t.add_const(t.act(y, hip.ACT_RELU), torch.full((self.n_bins,), 0.1, dtype=torch.float32, device=dev))     # norm == 'linear'
         wn = t.row_normalize(y)
         edges, centers = t.bin_centers(wn, self.min_val, self.max_val)
@@ -382,7 +386,7 @@ class TrainNet:
         """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
         gradients are in `self.grads()`, running statistics in `self.buf`."""
         dev = self.dev
-        t = Tape(dev)
+        t = Tape(dev, self.dtype)
         pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
         # SILog (loss.py:9-19) on the half-resolution prediction against the full-resolution target
         crit = train_ops.SILogLoss()
