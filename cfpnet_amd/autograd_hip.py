@@ -232,16 +232,26 @@ class Tape:
         self.bw.append(bw)
         return y
 
-    def add_table(self, x: V, table: P, B, H, W, Wt, oy, ox) -> V:
-        """y[b, y, x] = x[b, y, x] + table[(oy + y) * Wt + ox + x]  (learned positional encodings)."""
+    def add_table(self, x: V, table: P, B, H, W, Ht, Wt, off) -> V:
+        """y[b, y, x] = x[b, y, x] + table[(oy + y) * Wt + ox + x]  (learned positional encodings).  `off` = (oy, ox) on the
+        host, or an int32[2] DEVICE tensor (the window can then change between replays of a captured step)."""
         y = V(torch.empty_like(x.t))
-        ops.add_rowtable(_act(x.t), table.t, _act(y.t), x.rows, H, W, Wt, oy, ox)
+        dev_off = torch.is_tensor(off)
+        if dev_off:
+            hip.call("cfp_add_rowtable_dev", x.t.data_ptr(), x.t.stride(0), table.t.data_ptr(), y.t.data_ptr(), y.t.stride(0), x.rows, x.C, H, W,
+                     Ht, Wt, off.data_ptr(), ops.DT[x.t.dtype], hip.current_stream())
+        else:
+            ops.add_rowtable(_act(x.t), table.t, _act(y.t), x.rows, H, W, Wt, off[0], off[1])
 
         def bw():
             if y.g is None:
                 return
             dt = torch.zeros_like(table.t)
-            train_ops.rowtable_grad(y.g, dt, B, H, W, Wt, oy, ox)
+            if dev_off:
+                hip.call("cfp_rowtable_grad_dev", y.g.data_ptr(), y.g.stride(0), dt.data_ptr(), B, H, W, x.C, Ht, Wt, off.data_ptr(), 0.0,
+                         ops.DT[y.g.dtype], hip.current_stream())
+            else:
+                train_ops.rowtable_grad(y.g, dt, B, H, W, Wt, off[0], off[1])
             self.acc(table, dt)
             self.acc(x, y.g, own=False)
         self.bw.append(bw)
@@ -286,7 +296,8 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.acc(gate, train_ops.channel_dot(x.t, y.g, B, HW))
+            if gate.needs_grad:
+                self.acc(gate, train_ops.channel_dot(x.t, y.g, B, HW))
             self.acc(x, train_ops.bcast_fma(y.g, gate.t, None, B, HW))
         self.bw.append(bw)
         return y

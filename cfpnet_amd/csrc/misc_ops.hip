@@ -458,10 +458,14 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeP p) {
 template <typename T>
 __global__ __launch_bounds__(256) void add_rowtable_kernel(const T* __restrict__ in, int in_ld, const float* __restrict__ table,
                                                            T* __restrict__ out, int out_ld, long long rows, int C, int H, int W,
-                                                           int Wt, int oy, int ox) {
+                                                           int Wt, int oy, int ox, const int* __restrict__ dev_off, int Ht) {
   constexpr int VE = Vec<T>::N;
   const int CV = C / VE;
   const long long total = rows * CV;
+  if (dev_off) {          // window origin read from device memory (a captured graph replays with a new random window), clamped to the table
+    oy = min(max(dev_off[0], 0), Ht - H);
+    ox = min(max(dev_off[1], 0), Wt - W);
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     int cv = (int)(i % CV);
     long long r = i / CV;
@@ -690,25 +694,31 @@ extern "C" int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, 
   return cfp_check_launch("cfp_resize_bilinear");
 }
 
-extern "C" int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C,
-                                int H, int W, int Wt, int oy, int ox, int dtype, cfp_stream_t stream) {
-  CHECK_DTYPE("cfp_add_rowtable");
+static int add_rowtable_impl(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C, int H, int W, int Wt,
+                             int oy, int ox, const int* dev_off, int Ht, int dtype, cfp_stream_t stream, const char* who) {
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, std::string(who) + ": bad dtype");
   const int ve = vec_elems(dtype);
-  CFP_REQUIRE(in && table && out && aligned16(in) && aligned16(out), CFP_EINVAL, "cfp_add_rowtable: bad pointer");
+  CFP_REQUIRE(in && table && out && aligned16(in) && aligned16(out), CFP_EINVAL, std::string(who) + ": bad pointer");
   CFP_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && Wt >= W + ox && oy >= 0 && ox >= 0 && in_ld % ve == 0 &&
-                  out_ld % ve == 0 && in_ld >= C && out_ld >= C, CFP_ESHAPE, "cfp_add_rowtable: bad shape");
+                  out_ld % ve == 0 && in_ld >= C && out_ld >= C && (!dev_off || Ht >= H), CFP_ESHAPE, std::string(who) + ": bad shape");
   long long total = (long long)rows * (C / ve);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == CFP_BF16)
-    hipLaunchKernelGGL(add_rowtable_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, table,
-                       (bf16_t*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
-  else if (dtype == CFP_F16)
-    hipLaunchKernelGGL(add_rowtable_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const f16_t*)in, in_ld, table,
-                       (f16_t*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
-  else
-    hipLaunchKernelGGL(add_rowtable_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, table,
-                       (float*)out, out_ld, (long long)rows, C, H, W, Wt, oy, ox);
-  return cfp_check_launch("cfp_add_rowtable");
+#define AR(T) hipLaunchKernelGGL(add_rowtable_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)in, in_ld, table, (T*)out, out_ld, \
+                                 (long long)rows, C, H, W, Wt, oy, ox, dev_off, Ht)
+  if (dtype == CFP_BF16) AR(bf16_t); else if (dtype == CFP_F16) AR(f16_t); else AR(float);
+#undef AR
+  return cfp_check_launch(who);
+}
+
+extern "C" int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C,
+                                int H, int W, int Wt, int oy, int ox, int dtype, cfp_stream_t stream) {
+  return add_rowtable_impl(in, in_ld, table, out, out_ld, rows, C, H, W, Wt, oy, ox, nullptr, 0, dtype, stream, "cfp_add_rowtable");
+}
+
+extern "C" int cfp_add_rowtable_dev(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C, int H, int W,
+                                    int Ht, int Wt, const int* oyox, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(oyox, CFP_EINVAL, "cfp_add_rowtable_dev: null offset pointer");
+  return add_rowtable_impl(in, in_ld, table, out, out_ld, rows, C, H, W, Wt, 0, 0, oyox, Ht, dtype, stream, "cfp_add_rowtable_dev");
 }
 
 extern "C" int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, int C, int dtype, cfp_stream_t stream) {

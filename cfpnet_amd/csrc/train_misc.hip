@@ -38,9 +38,13 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, int
 // dtable[(oy + y) * Wt + ox + x][c] (+)= sum_b dx[b][y][x][c]   -- gradient of `x + PE[oy:oy+H, ox:ox+W]` (f32 table)
 template <typename T>
 __global__ __launch_bounds__(256) void rowtable_grad_kernel(const T* __restrict__ dx, int ld, float* __restrict__ dtable, int B, int H, int W,
-                                                            int C, int Wt, int oy, int ox, float beta) {
+                                                            int C, int Wt, int oy, int ox, float beta, const int* __restrict__ dev_off, int Ht) {
   constexpr int VE = Vec<T>::N;
   const int CV = C / VE;
+  if (dev_off) {
+    oy = min(max(dev_off[0], 0), Ht - H);
+    ox = min(max(dev_off[1], 0), Wt - W);
+  }
   const long long total = (long long)H * W * CV;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long px = i / CV;
@@ -252,17 +256,28 @@ extern "C" int cfp_axpby(const void* x, int x_ld, const void* y, int y_ld, float
   return cfp_check_launch("cfp_axpby");
 }
 
-extern "C" int cfp_rowtable_grad(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
-                                 int dtype, cfp_stream_t stream) {
+static int rowtable_grad_impl(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
+                              const int* dev_off, int Ht, int dtype, cfp_stream_t stream) {
   CFP_REQUIRE(dx && dtable && aligned16(dx), CFP_EINVAL, "cfp_rowtable_grad: bad pointer");
   TM_COMMON("cfp_rowtable_grad");
-  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0 && ld % ve == 0 && ld >= C && Wt >= ox + W && oy >= 0 && ox >= 0, CFP_ESHAPE,
-              "cfp_rowtable_grad: bad shape");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0 && ld % ve == 0 && ld >= C && Wt >= ox + W && oy >= 0 && ox >= 0 &&
+                  (!dev_off || Ht >= H), CFP_ESHAPE, "cfp_rowtable_grad: bad shape");
   const dim3 grid(ew_grid2((long long)H * W * (C / ve)));
-#define L(T) hipLaunchKernelGGL(rowtable_grad_kernel<T>, grid, dim3(256), 0, s, (const T*)dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta)
+#define L(T) hipLaunchKernelGGL(rowtable_grad_kernel<T>, grid, dim3(256), 0, s, (const T*)dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta, dev_off, Ht)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_rowtable_grad");
+}
+
+extern "C" int cfp_rowtable_grad(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
+                                 int dtype, cfp_stream_t stream) {
+  return rowtable_grad_impl(dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta, nullptr, 0, dtype, stream);
+}
+
+extern "C" int cfp_rowtable_grad_dev(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Ht, int Wt, const int* oyox,
+                                     float beta, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(oyox, CFP_EINVAL, "cfp_rowtable_grad_dev: null offset pointer");
+  return rowtable_grad_impl(dx, ld, dtable, B, H, W, C, Wt, 0, 0, beta, oyox, Ht, dtype, stream);
 }
 
 extern "C" int cfp_channel_dot(const void* x, int x_ld, const void* y, int y_ld, float* out, int B, int HW, int C, int dtype,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "cfp_dwconv_large_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "cfp_dwconv_large_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _i, _p, _sz, _p]),
     "cfp_row_normalize": (_i, [_p, _p, _p, _i, _i, _p]),
+    "cfp_add_rowtable_dev": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "cfp_rowtable_grad_dev": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _f, _i, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

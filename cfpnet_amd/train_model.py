@@ -271,11 +271,11 @@ class TrainNet:
         sy, sx, ey, ex = geo.sy_wo, geo.sx_wo, geo.ey_wo, geo.ex_wo
         tzh, tzw = geo.tzh, geo.tzw
         cy0, cy1, cx0, cx1 = geo.clipped(H, W)
-        oy, ox = pos_offset
-        emb0 = t.add_table(x, self._table(p + ".positional_encodings"), B, H, W, Wm, oy, ox)
+        emb0 = t.add_table(x, self._table(p + ".positional_encodings"), B, H, W, Hm, Wm, pos_offset)
         tok = emb0
-        src = t.add_table(feat1, self._table(p + ".positional_encodings2"), B * Z, 1, N, N, 0, 0)
-        valid = mask.reshape(-1).to("cpu").numpy().astype(bool)
+        src = t.add_table(feat1, self._table(p + ".positional_encodings2"), B * Z, 1, N, 1, N, (0, 0))
+        # zone validity as a per-(zone, channel) multiplier built on the device: no host round trip, so the step can be captured
+        valid_gate = V(mask.reshape(-1, 1).to(self.dev, torch.float32).expand(B * Z, D).contiguous(), needs_grad=False)
         for i, lname in enumerate(self.layers):
             q = f"{p}.layers.{i}"
             if lname == "image":
@@ -299,15 +299,8 @@ class TrainNet:
                 idx_z, inv_z = self._maps(("zone", B, zn, p1, p2), build_zone)
                 z = t.gather(z, idx_z, inv_z)
                 z = self._loftr(t, q, z, src, B * zn * zn, p1 * p2, N, X2I_HEADS)
-                # zero the zones without a ToF signal and go back to the map layout in one row map
-                zi = idx_z.to("cpu").numpy().copy()
-                keep = np.repeat(valid, p1 * p2)
-                back = np.full(B * zn * p1 * zn * p2, -1, dtype=np.int64)
-                rows = np.arange(zi.size)
-                back[zi[keep]] = rows[keep]
-                idx_b = torch.as_tensor(back, dtype=torch.int32).to(self.dev)
-                inv_b = train_ops.inverse_index(idx_b, zi.size)
-                z = t.gather(z, idx_b, inv_b)
+                z = t.mul_bcast(z, valid_gate, B * zn * zn, p1 * p2)           # zero the zones without a ToF signal
+                z = t.gather(z, inv_z, idx_z)                                   # back to the map layout
                 if geo.interpolate:
                     z = t.resize(z, B, zn * p1, zn * p2, tzh, tzw)
 

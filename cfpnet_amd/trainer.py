@@ -34,6 +34,7 @@ class Trainer:
         self.opt = train_ops.FlatAdamW(self.flat, train_ops.OneCycle(lr, total_steps, div_factor, final_div_factor), weight_decay=weight_decay,
                                        clip_grad_norm=clip_grad_norm)
         self.min_val = min_val
+        self._graph = None
 
     def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
         """fusion.py:87-91: a random window into the learned positional table whenever the token map is smaller than it."""
@@ -46,17 +47,56 @@ class Trainer:
             offs[name] = (oy, ox)
         return offs
 
-    def step(self, input_data: dict, target: torch.Tensor, pos_offsets: Optional[dict] = None):
-        """-> (loss as a device scalar, lr, beta1).  `target` [B,1,H,W]; the loss mask is target > min_depth (train.py:121)."""
-        H, W = input_data["rgb"].shape[-2:]
-        offs = pos_offsets if pos_offsets is not None else self.draw_pos_offsets(H, W)
+    def _grads_to_flat(self, input_data, target, offs):
+        self.net.zero_grad()
         loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
         self.flat.grad.zero_()
         for name, g in self.net.grads().items():
             self.flat.view(name, "grad").copy_(g)
+        return loss
+
+    def capture(self, input_data: dict, target: torch.Tensor):
+        """Record forward + loss + backward + gradient gathering for this batch shape into ONE HIP graph (the eager step is
+        ~5 600 launches and host-bound in 16-bit mode).  Inputs are copied into static buffers at every `step`; the random
+        positional-encoding windows are read by the kernels from a device buffer, so they still change per step."""
+        dev = self.dev
+        add = input_data["additional"]
+        self._sin = {"rgb": input_data["rgb"].to(dev, torch.float32).contiguous().clone(),
+                     "additional": {"hist_data": add["hist_data"].to(dev, torch.float32).contiguous().clone(),
+                                    "mask": add["mask"].to(dev).contiguous().clone(), "rect_data": add.get("rect_data"),
+                                    "patch_info": add["patch_info"]}}
+        self._starget = target.to(dev, torch.float32).contiguous().clone()
+        self._soffs = torch.zeros(3, 2, dtype=torch.int32, device=dev)
+        self._offs_dev = {name: self._soffs[i] for i, name in enumerate(("cross_atten3", "cross_atten2", "cross_atten1"))}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                                       # warm-up: builds the index maps, sets kernel attributes
+                self._grads_to_flat(self._sin, self._starget, self._offs_dev)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._sloss = self._grads_to_flat(self._sin, self._starget, self._offs_dev)
+        self._graph = g
+
+    def step(self, input_data: dict, target: torch.Tensor, pos_offsets: Optional[dict] = None):
+        """-> (loss as a device scalar, lr, beta1).  `target` [B,1,H,W]; the loss mask is target > min_depth (train.py:121)."""
+        H, W = input_data["rgb"].shape[-2:]
+        offs = pos_offsets if pos_offsets is not None else self.draw_pos_offsets(H, W)
+        if self._graph is not None:
+            add = input_data["additional"]
+            self._sin["rgb"].copy_(input_data["rgb"], non_blocking=True)
+            self._sin["additional"]["hist_data"].copy_(add["hist_data"], non_blocking=True)
+            self._sin["additional"]["mask"].copy_(add["mask"], non_blocking=True)
+            self._starget.copy_(target, non_blocking=True)
+            self._soffs.copy_(torch.tensor([offs[n] for n in ("cross_atten3", "cross_atten2", "cross_atten1")], dtype=torch.int32), non_blocking=True)
+            self._graph.replay()
+            loss = self._sloss
+        else:
+            loss = self._grads_to_flat(input_data, target, offs)
         train_ops.allreduce_gradients(self.flat, self.dist, self.world)
         lr, beta1 = self.opt.step()
-        self.net.zero_grad()
         return loss, lr, beta1
 
     def state_dict(self) -> Dict[str, torch.Tensor]:

@@ -423,6 +423,13 @@ int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, f
  * out = (dy - sum_c(dy * y)) / s instead (x = the forward input). */
 int cfp_row_normalize(const float* x, const float* dy, float* out, int rows, int C, cfp_stream_t stream);
 
+/* cfp_add_rowtable / cfp_rowtable_grad with the window origin (oy, ox) read from DEVICE memory (int32[2], clamped to the
+ * Ht x Wt table): the random positional-encoding window of fusion.py:87-91 can change between replays of a captured graph. */
+int cfp_add_rowtable_dev(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C, int H, int W,
+                         int Ht, int Wt, const int* oyox, int dtype, cfp_stream_t stream);
+int cfp_rowtable_grad_dev(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Ht, int Wt, const int* oyox,
+                          float beta, int dtype, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfpnet_amd import spec, synthetic, weights
 from cfpnet_amd.trainer import Trainer
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16"))
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16")); ap.add_argument("--graph", action="store_true")
 a = ap.parse_args()
 layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
@@ -16,12 +16,14 @@ inp = synthetic.to_device(synthetic.make_inputs(a.batch, H, W, 6, 64, seed=5, dr
 target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=50 + i, holes=0.1) for i in range(a.batch)]))[:, None].cuda()
 DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[a.dtype]
 tr = Trainer(sd, layers, lr=3e-4, total_steps=100, dtype=DT)
+if a.graph:
+    tr.capture(inp, target)
 for _ in range(2):
     tr.step(inp, target)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     loss, _, _ = tr.step(inp, target)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-res = dict(batch=a.batch, ms_per_step=dt * 1e3, samples_per_s=a.batch / dt, loss=float(loss), peak_mem_GB=torch.cuda.max_memory_allocated() / 2**30, dtype=a.dtype)
+res = dict(batch=a.batch, ms_per_step=dt * 1e3, samples_per_s=a.batch / dt, loss=float(loss), peak_mem_GB=torch.cuda.max_memory_allocated() / 2**30, dtype=a.dtype, graph=a.graph)
 print(json.dumps(res))
 os.makedirs("gpurun_out", exist_ok=True); json.dump(res, open("gpurun_out/train_bench.json", "w"))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training with the reference's CLI and loop (`/root/reference/train.py:41-209`):
 
-    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt]
+    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py @configs/cfpnet_combine1.txt --synthetic 4096
 
 Per step: ToF simulation of the batch from its ground-truth depth (GPU), forward in training mode, SILog loss, backward of
@@ -12,7 +12,8 @@ One process per GPU with the global batch `--bs` split over the ranks (the refer
 Differences on purpose: `--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box;
 without it a missing `filenames_file` is an error), random rotation / colour augmentation of the real loader is not
 reproduced, wandb logging and the per-epoch validation are left out (use evaluate_all.py on the saved checkpoint).
-Float32 storage.  There is no PyTorch autograd or fallback anywhere in the step.
+bf16 activations with float32 master parameters by default (`--dtype`); the step is replayed as one HIP graph unless
+`--eager`.  There is no PyTorch autograd or fallback anywhere in the step.
 """
 import os
 import sys
@@ -59,6 +60,9 @@ def main(argv=None):
     max_steps = _pop(argv, "--max_steps", 0, int)
     save_path = _pop(argv, "--save", "", str)
     log_every = _pop(argv, "--log_every", 10, int)
+    dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[_pop(argv, "--dtype", "bf16")]
+    eager = "--eager" in argv
+    argv = [a for a in argv if a != "--eager"]
     args = config.parse_args(argv) if argv else config.defaults()
     args.mode = "train"
 
@@ -89,7 +93,7 @@ def main(argv=None):
     tr = Trainer(sd, layers, lr=float(args.lr), total_steps=max(total_steps, 2), weight_decay=float(args.wd), div_factor=float(args.div_factor),
                  final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
                  clip_grad_norm=None if args.disable_clip_grad else 0.1, device=dev, dist=dist, world=world, n_bins=int(args.n_bins),
-                 min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding))
+                 min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding), dtype=dtype)
     sim = TofSimulator(args, dev)
     zn, zp, _, _ = zone_layout(args, H, W)
     rects = geometry.centered_zone_rects(H, W, zn, zp)
@@ -116,6 +120,8 @@ def main(argv=None):
                         m[b, rng.choice(idx, int(idx.size * drop))] = False
                 mask = torch.from_numpy(m).to(dev)
             inp = {"rgb": img, "additional": {"hist_data": s["hist_data"], "rect_data": s["rect_data"], "mask": mask, "patch_info": patch_info}}
+            if step == 0 and not eager:
+                tr.capture(inp, depd)                         # the whole step as one HIP graph from here on
             loss, lr, beta1 = tr.step(inp, depd)
             step += 1
             seen += per_rank * world
