@@ -140,6 +140,120 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
       }
 }
 
+// 16-bit inputs on the 16-bit matrix cores (v_mfma_f32_16x16x32_bf16/_f16): the tiles are staged as they lie in memory
+// ([pixel row][channel]) and the operands -- which want the pixel axis along k -- are read with the hardware transpose
+// read ds_read_b64_tr_b16 (a 16-lane group fetches 4 rows x 16 columns and every lane receives one column of it).
+constexpr int W16M = 64;            // pixel rows per staging step (two k = 32 MFMA steps)
+constexpr int W16P = WB + 8;        // LDS row pitch in elements (144 B: 16-byte aligned rows, 2-way bank conflicts at worst)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename H>
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sD[W16M * W16P];    // dY tile  [m][co]
+  __shared__ __attribute__((aligned(16))) unsigned short sX[W16M * W16P];    // im2col tile [m][k']
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_k = (p.K + WB - 1) / WB;
+  const int tile_co = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_co * tiles_k;
+  const int co0 = tile_co * WB, k0 = tile_k * WB;
+  const int m_begin = blockIdx.y * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(p.x);
+  const unsigned short* __restrict__ DY = reinterpret_cast<const unsigned short*>(p.dy);
+  constexpr int NV = W16M * (WB / 8) / 256;        // 16-byte vectors per thread and operand per step (2)
+  int s_row[NV], s_col[NV], x_kh[NV], x_kw[NV], x_ci[NV];
+  bool k_ok[NV], co_ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = tid + i * 256;
+    s_row[i] = q / (WB / 8);
+    s_col[i] = (q - s_row[i] * (WB / 8)) * 8;
+    const int kk = k0 + s_col[i];
+    k_ok[i] = kk < p.K;
+    const int tap = kk / p.Cin;
+    x_ci[i] = kk - tap * p.Cin;
+    x_kh[i] = tap / p.KW;
+    x_kw[i] = tap - x_kh[i] * p.KW;
+    co_ok[i] = co0 + s_col[i] < p.Cout;
+  }
+  const int HoWo = p.Ho * p.Wo;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 rD[NV], rX[NV];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m0 + s_row[i];
+      const bool m_ok = m < m_end;
+      const int mm = m_ok ? m : m_begin;
+      const int b = mm / HoWo, r = mm - b * HoWo;
+      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
+      const bool in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(X + ((long long)(b * p.H + hic) * p.W + wic) * p.x_ld + (k_ok[i] ? x_ci[i] : 0));
+      const u32x4 vd = *reinterpret_cast<const u32x4*>(DY + (long long)mm * p.dy_ld + (co_ok[i] ? co0 + s_col[i] : 0));
+      rX[i] = in_ok ? vx : zero4;
+      rD[i] = (m_ok && co_ok[i]) ? vd : zero4;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      *reinterpret_cast<u32x4*>(&sX[s_row[i] * W16P + s_col[i]]) = rX[i];
+      *reinterpret_cast<u32x4*>(&sD[s_row[i] * W16P + s_col[i]]) = rD[i];
+    }
+  };
+  const int qa = (wave >> 1) * 32, qb = (wave & 1) * 32;
+  const int g = lane >> 4, idx = lane & 15, tq = idx >> 2, tp = idx & 3;
+  // this lane's address inside a 4-row x 16-column block (rows 8g .. of a k = 32 step): row tq, columns 4 tp .. 4 tp + 3
+  const int blk = (8 * g + tq) * W16P + 4 * tp;
+  auto tr = [&](const unsigned short* base) -> s16x4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (m_begin < m_end) fetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += W16M) {
+    __syncthreads();
+    stash();
+    __syncthreads();
+    if (m0 + W16M < m_end) fetch(m0 + W16M);
+#pragma unroll
+    for (int ks = 0; ks < W16M / 32; ++ks) {
+      s16x8 a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned short* base = sD + ks * 32 * W16P + blk + qa + i * 16;
+        const s16x4 lo = tr(base), hi = tr(base + 4 * W16P);
+        a[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned short* base = sX + ks * 32 * W16P + blk + qb + j * 16;
+        const s16x4 lo = tr(base), hi = tr(base + 4 * W16P);
+        bb[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<H>(a[i], bb[j], acc[i][j]);
+    }
+  }
+  const int fr = lane & 15, fk = lane >> 4;
+  float* __restrict__ slab = p.slabs + (long long)blockIdx.y * p.Cout * p.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + qa + i * 16 + fk * 4 + r, kk = k0 + qb + j * 16 + fr;
+        if (co < p.Cout && kk < p.K) slab[(long long)co * p.K + kk] = acc[i][j][r];
+      }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
                                                            float beta) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -206,12 +320,13 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K;
   p.nsplit = wgrad_nsplit(Cout, (int)K, (int)M);
-  p.rows_per_split = cdiv(cdiv(M, p.nsplit), WM) * WM;
+  const int mstep = is16(dtype) ? W16M : WM;
+  p.rows_per_split = cdiv(cdiv(M, p.nsplit), mstep) * mstep;
   p.nsplit = cdiv(M, p.rows_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(cdiv(Cout, WB) * cdiv(K, WB), p.nsplit);
-  if (dtype == CFP_BF16) hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-  else if (dtype == CFP_F16) hipLaunchKernelGGL(conv_wgrad_kernel<f16_t>, grid, dim3(256), 0, s, p);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(conv_wgrad16_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(conv_wgrad16_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
   const long long n = (long long)Cout * K;
   int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
