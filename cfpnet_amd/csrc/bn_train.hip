@@ -133,22 +133,35 @@ __global__ void bn_fold_kernel(const float* __restrict__ mean, const float* __re
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var[c] * unbias;
 }
 
+// Elementwise sweeps with per-channel constants: a thread keeps ONE 16-byte channel vector (its constants live in registers)
+// and walks rows -- 32 vector columns x 8 row lanes per workgroup, grid = (column blocks, row chunks).
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, int ld, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int act, T* __restrict__ out, int out_ld,
-                                                              long long rows, int C) {
+                                                              long long rows, int C, long long rows_per_chunk, int colbits) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  with_act(act, [&](auto A) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-      const long long r = i / CV;
-      const int c = (int)(i - r * CV) * VE;
-      float v[VE];
-      Vec<T>::load(x + r * ld + c, v);
+  const int cols = 1 << colbits, lanes = 256 >> colbits;       // narrow tensors: fewer column lanes, more row lanes
+  const int cl = threadIdx.x & (cols - 1), rl = threadIdx.x >> colbits;
+  const int c = (blockIdx.x * cols + cl) * VE;
+  if (c >= C) return;
+  float sc[VE], sh[VE];
 #pragma unroll
-      for (int e = 0; e < VE; ++e) v[e] = act_c<decltype(A)::value>(v[e] * scale[c + e] + shift[c + e]);
-      Vec<T>::store(out + r * out_ld + c, v);
+  for (int e = 0; e < VE; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  with_act(act, [&](auto A) {
+    constexpr int U = 4;
+    for (long long r = r0 + rl; r < r1; r += lanes * U) {
+      float v[U][VE];
+#pragma unroll
+      for (int u = 0; u < U; ++u) Vec<T>::load(x + min(r + (long long)u * lanes, r1 - 1) * ld + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long rr = r + (long long)u * lanes;
+        if (rr >= r1) continue;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[u][e] = act_c<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
+        Vec<T>::store(out + rr * out_ld + c, v[u]);
+      }
     }
   });
 }
@@ -159,23 +172,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_n,
-                                                           int act, T* __restrict__ dx, int dx_ld, long long rows, int C) {
+                                                           int act, T* __restrict__ dx, int dx_ld, long long rows, int C,
+                                                           long long rows_per_chunk, int colbits) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
-    float v[VE], g[VE];
-    Vec<T>::load(x + r * ld + c, v);
-    Vec<T>::load(dy + r * dy_ld + c, g);
+  const int cols = 1 << colbits, lanes = 256 >> colbits;       // narrow tensors: fewer column lanes, more row lanes
+  const int cl = threadIdx.x & (cols - 1), rl = threadIdx.x >> colbits;
+  const int c = (blockIdx.x * cols + cl) * VE;
+  if (c >= C) return;
+  float sc[VE], sh[VE], mu[VE], is[VE], k0[VE], k1[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) {
-      const float dz = g[e] * act_grad(v[e] * scale[c + e] + shift[c + e], act);
-      const float xh = (v[e] - mean[c + e]) * invstd[c + e];
-      v[e] = scale[c + e] * (dz - dbeta[c + e] * inv_n - xh * dgamma[c + e] * inv_n);      // scale = gamma * invstd
+  for (int e = 0; e < VE; ++e) {
+    sc[e] = scale[c + e]; sh[e] = shift[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e];
+    k0[e] = dbeta[c + e] * inv_n; k1[e] = dgamma[c + e] * inv_n;
+  }
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  constexpr int U = 2;
+  for (long long r = r0 + rl; r < r1; r += lanes * U) {
+    float v[U][VE], g[U][VE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = min(r + (long long)u * lanes, r1 - 1);
+      Vec<T>::load(x + rr * ld + c, v[u]);
+      Vec<T>::load(dy + rr * dy_ld + c, g[u]);
     }
-    Vec<T>::store(dx + r * dx_ld + c, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + (long long)u * lanes;
+      if (rr >= r1) continue;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float dz = g[u][e] * act_grad(v[u][e] * sc[e] + sh[e], act);
+        const float xh = (v[u][e] - mu[e]) * is[e];
+        v[u][e] = sc[e] * (dz - k0[e] - xh * k1[e]);                     // scale = gamma * invstd
+      }
+      Vec<T>::store(dx + rr * dx_ld + c, v[u]);
+    }
   }
 }
 
@@ -264,6 +295,21 @@ inline int red_splits(long long rows, int C, int ve) {
   if (ns < 1) ns = 1;
   return (int)ns;
 }
+struct EwGrid { unsigned gx, gy; long long rpc; int colbits; };
+inline EwGrid ew_cols(long long rows, int C, int ve) {
+  const int cv = C / ve;
+  int colbits = 0;
+  while ((1 << colbits) < cv && colbits < 5) ++colbits;            // 1 .. 32 column lanes
+  const int cols = 1 << colbits, lanes = 256 >> colbits;
+  const unsigned gx = (unsigned)cdiv(cv, cols);
+  long long ns = 2048 / gx;                                          // ~8 workgroups per CU over the launch
+  const long long mx = (rows + 4 * lanes - 1) / (4 * lanes);
+  if (ns > mx) ns = mx;
+  if (ns > 65535) ns = 65535;
+  if (ns < 1) ns = 1;
+  const long long rpc = (rows + ns - 1) / ns;
+  return EwGrid{gx, (unsigned)((rows + rpc - 1) / rpc), rpc, colbits};
+}
 inline int ew_grid(long long total) { long long b = (total + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 template <int MODE>
@@ -315,8 +361,10 @@ extern "C" int cfp_scale_shift_act(const void* x, int ld, const float* scale, co
   CFP_REQUIRE(x && scale && shift && out && aligned16(x) && aligned16(out), CFP_EINVAL, "cfp_scale_shift_act: bad pointer");
   BN_COMMON("cfp_scale_shift_act");
   CFP_REQUIRE(out_ld % ve == 0 && out_ld >= C, CFP_ESHAPE, "cfp_scale_shift_act: bad out_ld");
-  const dim3 grid(ew_grid(rows * (C / ve)));
-#define SL(T) hipLaunchKernelGGL(scale_shift_act_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, scale, shift, act, (T*)out, out_ld, rows, C)
+  const EwGrid eg = ew_cols(rows, C, ve);
+  const long long rpc = eg.rpc;
+  const dim3 grid(eg.gx, eg.gy);
+#define SL(T) hipLaunchKernelGGL(scale_shift_act_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, scale, shift, act, (T*)out, out_ld, rows, C, rpc, eg.colbits)
   if (dtype == CFP_BF16) SL(bf16_t); else if (dtype == CFP_F16) SL(f16_t); else SL(float);
 #undef SL
   return cfp_check_launch("cfp_scale_shift_act");
@@ -333,10 +381,12 @@ extern "C" int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld
   float* partial = reinterpret_cast<float*>(ws);
   // dbeta = sum dz, dgamma = sum dz * xhat (unscaled sums: inv_n = 1)
   launch_reduce<2>(x, ld, dy, dy_ld, rows, C, mean, invstd, scale, shift, act, dtype, partial, dbeta, dgamma, 1.f, s);
-  const dim3 grid(ew_grid(rows * (C / ve)));
+  const EwGrid eg = ew_cols(rows, C, ve);
+  const long long rpc = eg.rpc;
+  const dim3 grid(eg.gx, eg.gy);
   const float inv_n = 1.f / (float)rows;
 #define BL(T) hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, (const T*)dy, dy_ld, mean, invstd, scale, shift, \
-                                 dbeta, dgamma, inv_n, act, (T*)dx, dx_ld, rows, C)
+                                 dbeta, dgamma, inv_n, act, (T*)dx, dx_ld, rows, C, rpc, eg.colbits)
   if (dtype == CFP_BF16) BL(bf16_t); else if (dtype == CFP_F16) BL(f16_t); else BL(float);
 #undef BL
   return cfp_check_launch("cfp_bn_train_bwd");
