@@ -74,3 +74,49 @@ def test_encoder_shapes():
     # odd sizes exercise the symmetric branch of TF-SAME padding
     taps = O.encoder(sd, torch.zeros(1, 3, 50, 70))
     assert [tuple(t.shape[2:]) for t in taps] == [(25, 35), (13, 18), (7, 9), (4, 5), (2, 3)]
+
+
+def test_oracle_training_step_matches_the_reference_in_train_mode():
+    """BN_TRAIN + autograd of the oracle against the reference's own modules in `.train()` + SILogLoss + loss.backward()
+    (oracle/gen_golden_train.py; encoder bypassed with stand-in features): loss, prediction, the gradient statistics of all
+    413 live parameters after the encoder and a dozen full gradient tensors."""
+    import json
+    import os
+    from helpers import GOLDEN
+    from cfpnet_amd import spec, synthetic, weights
+    z = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    layers = spec.COMBINE1_LAYERS
+    sd0 = weights.make_torch_state_dict(spec.model_manifest(layers))
+    sd = {}
+    for k, v in sd0.items():
+        v = v.detach().clone()
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+        sd[k] = v
+    inp = synthetic.make_inputs(meta["B"], meta["H"], meta["W"], meta["zn"], meta["zpx"], seed=meta["seed"], drop_hist=meta["drop"])
+    feats = synthetic.make_img_features(meta["B"], meta["H"], meta["W"], seed=meta["seed"] + 1)
+    target = torch.from_numpy(np.stack([synthetic.make_depth(meta["H"], meta["W"], seed=meta["seed"] + 5 + i, holes=0.1) for i in range(meta["B"])]))[:, None]
+    d = [int(x) for x in z["draws"]]
+    offs = {"cross_atten3": (d[0], d[1]), "cross_atten2": (d[2], d[3]), "cross_atten1": (d[4], d[5])}
+    O.BN_TRAIN = True
+    try:
+        edges, pred, prob = O.forward(sd, inp, layer_names=layers, pos_offsets=offs, img_features=feats, grad=True)
+        loss = O.silog_loss(torch.clip(pred, 1e-3), target, target > 1e-3, interpolate=True)
+        loss.backward()
+    finally:
+        O.BN_TRAIN = False
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-5 * float(z["loss"])
+    assert rel_l1(pred.detach()[:, :, ::4, ::4].numpy(), z["pred_slice"]) < 1e-5
+    live = {k for k, v in sd.items() if getattr(v, "grad", None) is not None and float(v.grad.abs().max()) > 0}
+    assert live == set(meta["names"])                                     # the same parameters get a gradient (the dead ones do not)
+    gmax = float(z["grad_stats"][:, 3].max())
+    for name, (mean, amean, rms, amax) in zip(meta["names"], z["grad_stats"]):
+        g = sd[name].grad.double()
+        assert abs(float((g * g).mean().sqrt()) - rms) <= 2e-2 * rms + 1e-6 * gmax, name       # f32 autograd on two builds of the same graph
+    for name in meta["full"]:
+        want = torch.from_numpy(z["grad." + name])
+        got = sd[name].grad
+        assert float((got - want).abs().max()) <= 2e-2 * max(float(want.abs().max()), 1e-5 * gmax), name
+    assert np.allclose(sd["decoder.up1._net.1.running_mean"][:8].numpy(), meta["running"]["up1"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(sd["hist_encoder.hist_extractor1.pointnet_encoder.bn1.running_var"][:8].numpy(), meta["running"]["hist"], rtol=1e-4, atol=1e-6)
