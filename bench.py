@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--dtype", choices=("bf16", "f16"), default="bf16",
                     help="16-bit storage format of the headline line (BASELINE.json quotes bf16; f16 = IEEE half, same MFMA rate)")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra fp16 measurement appended to the bf16 line")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement appended to the line (N = 1 only)")
+    ap.add_argument("--train-batch", type=int, default=16, help="per-GPU batch of the training-step measurement (configs[2..3]: 16)")
     return ap.parse_args()
 
 
@@ -179,6 +181,34 @@ def job_value(world: int, batch: int, steps: int, elapsed: float):
     collective; whole-job throughput = all maps of all ranks / slowest rank's time."""
     maps = world * batch * steps
     return maps / elapsed, maps / elapsed / world
+
+
+def training_step_rate(batch: int, dev, steps: int = 6):
+    """BASELINE.json configs[2..3] shape on ONE GPU: 416x544 crops, 6x6 zones of 64 px, `batch` samples, bf16 activations with
+    float32 master parameters; one step = training forward + SILog + backward + AdamW/OneCycle, replayed as one HIP graph.
+    (Single process: the RCCL gradient all-reduce of the multi-GPU run is not part of this number.)"""
+    import numpy as np
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.trainer import Trainer
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    H, W = 416, 544
+    inp = synthetic.to_device(synthetic.make_inputs(batch, H, W, 6, 64, seed=5, drop_hist=0.34), dev)
+    target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=50 + i, holes=0.1) for i in range(batch)]))[:, None].to(dev)
+    tr = Trainer(sd, layers, lr=3e-4, total_steps=100, dtype=torch.bfloat16, device=dev)
+    tr.capture(inp, target)
+    l0 = float(tr.step(inp, target)[0])
+    tr.step(inp, target)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _, _ = tr.step(inp, target)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights",
+            "config": {"workload": f"batch={batch} 416x544 crops + 6x6-zone ToF, training forward + SILog + backward + AdamW/OneCycle",
+                       "launch": "one HIP graph per step", "n_gpus": 1},
+            "loss_first_step": l0, "loss_after_%d_steps" % (steps + 2): float(loss)}
 
 
 def main():
@@ -321,6 +351,8 @@ def main():
                 line["f16"] = {"value": a.batch * a.steps / el16, "unit": "maps/s", "ms_per_step": el16 / a.steps * 1e3, "dtype": "f16",
                                "abs_rel": float(np.mean(np.abs(p0.numpy() - q1) / p0.numpy())),
                                "rel_l1": float(np.abs(p0.numpy() - q1).sum() / np.abs(p0.numpy()).sum())}
+        if world == 1 and not a.no_train and not a.no_cpu_baseline:
+            line["training"] = training_step_rate(a.train_batch, dev)
         print(json.dumps(line))
     if dist:
         dist.barrier()

@@ -88,7 +88,7 @@ def test_trainer_step_applies_adamw_to_its_gradients_and_loss_goes_down():
     The update must equal torch.optim.AdamW fed with the same gradients, and a few steps on one batch must reduce the loss."""
     from cfpnet_amd.trainer import Trainer
     from cfpnet_amd.train_model import TrainNet
-    layers, sd, inp, target, offs = _case(B=2, H=128, W=160, zn=2, zpx=32, seed=3) if False else _case()
+    layers, sd, inp, target, offs = _case()
     tr = Trainer(sd, layers, lr=3e-4, total_steps=20, weight_decay=0.1)
     net = TrainNet(sd, layers, "cuda:0")
     net.forward_backward(inp, target, target > 1e-3, pos_offsets=offs)
