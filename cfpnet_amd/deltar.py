@@ -11,9 +11,10 @@ Mirrors what the reference's callers use (`/root/reference/src/models/deltar.py:
     including the 48 dead tensors, so the authors' checkpoints load unchanged
   * `get_1x_lr_params()` / `get_10x_lr_params()` parameter groups
 
-It is a parameter container: no submodule has arithmetic of its own.  `forward` hands the
-parameters to `cfpnet_amd.engine.Engine`, which runs the hand-written HIP kernels.  There is no
-PyTorch fallback: without a GPU and the built extension `forward` raises.
+It is a parameter container: no submodule has arithmetic of its own.  In eval mode `forward` hands the
+parameters to `cfpnet_amd.engine.Engine` (inference kernels, HIP graphs); in training mode it is a
+`torch.autograd.Function` over `cfpnet_amd.train_model.TrainNet` (training-mode forward and the backward of
+every op as HIP kernels).  There is no PyTorch fallback: without a GPU and the built extension `forward` raises.
 """
 from __future__ import annotations
 

@@ -1,7 +1,6 @@
-"""Training-step pieces that exist so far: the SILog loss
-(forward + backward HIP kernels), the OneCycle schedule, a flat-buffer AdamW and the gradient
-all-reduce plan for data-parallel training.  The backward kernels of the network itself are not
-built yet, so `Deltar.forward` still raises in training mode.
+"""Training-step pieces: the SILog loss (forward + backward HIP kernels), the OneCycle
+schedule, a flat-buffer AdamW, the gradient all-reduce plan for data-parallel training, and thin wrappers over the backward
+kernels of the network ops (`autograd_hip.Tape` chains them; `train_model.TrainNet` is the model; `trainer.Trainer` the step).
 
 torch is used for device memory, the stream and `torch.distributed` (RCCL) only.
 """
