@@ -20,15 +20,22 @@ namespace {
 constexpr int RC_COLS = 32;     // 16-byte vector columns per workgroup
 constexpr int RC_LANES = 8;     // row lanes per workgroup
 
+// The training path uses the full-precision expf and true division: the inference kernels' v_exp_f32 / v_rcp_f32 forms carry
+// ~1e-6 relative error, which the batch-statistics BatchNorms of this network amplify into ~1e-2 of a gradient tensor.
 __device__ __forceinline__ float act_grad(float z, int act) {
   switch (act) {
     case CFP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
     case CFP_ACT_LRELU: return z > 0.f ? 1.f : 0.01f;
-    case CFP_ACT_SILU: { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f + z * (1.f - s)); }
-    case CFP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
-    case CFP_ACT_SIGMOID: { const float s = 1.f / (1.f + __expf(-z)); return s * (1.f - s); }
+    case CFP_ACT_SILU: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
+    case CFP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
+    case CFP_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
     default: return 1.f;
   }
+}
+template <int ACT> __device__ __forceinline__ float act_precise(float x) {
+  if constexpr (ACT == CFP_ACT_SILU) return x / (1.f + expf(-x));
+  else if constexpr (ACT == CFP_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+  else return act_c<ACT>(x);
 }
 
 // MODE 0: s1 = sum x                         (aux unused)
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
         const long long rr = r + (long long)u * lanes;
         if (rr >= r1) continue;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[u][e] = act_c<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
+        for (int e = 0; e < VE; ++e) v[u][e] = act_precise<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
         Vec<T>::store(out + rr * out_ld + c, v[u]);
       }
     }

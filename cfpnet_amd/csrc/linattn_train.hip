@@ -20,7 +20,8 @@ namespace {
 
 constexpr int ACH = 128;     // token rows per LDS chunk
 
-__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : __expf(x); }
+__device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+__device__ __forceinline__ float elu1p(float x) { return x > 0.f ? x + 1.f : expf(x); }      // full-precision elu(x)+1 (training parity)
 
 template <int D>
 struct Outer {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
     for (int e = tid; e < nr * D; e += 256) {
       const int r = e / D, c = e - r * D;
       const long long row = (long long)n * S + s0 + r;
-      sX[r * D + c] = elu1(to_f32<T>(k[row * k_ld + h * D + c]));
+      sX[r * D + c] = elu1p(to_f32<T>(k[row * k_ld + h * D + c]));
       sY[r * (D + 1) + c] = to_f32<T>(v[row * v_ld + h * D + c]) / fS;
       if (c == 0) sY[r * (D + 1) + D] = 1.f;
     }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
     float Q[D];
     float den = eps;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { Q[i] = elu1(to_f32<T>(q[row * q_ld + h * D + i])); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
+    for (int i = 0; i < D; ++i) { Q[i] = elu1p(to_f32<T>(q[row * q_ld + h * D + i])); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
     const float z = 1.f / den;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ 
       float Q[D], qr[D], A[D], g[D];
       float den = eps;
 #pragma unroll
-      for (int i = 0; i < D; ++i) { qr[i] = to_f32<T>(q[row * q_ld + h * D + i]); Q[i] = elu1(qr[i]); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
+      for (int i = 0; i < D; ++i) { qr[i] = to_f32<T>(q[row * q_ld + h * D + i]); Q[i] = elu1p(qr[i]); den = fmaf(Q[i], sM[i * (D + 1) + D], den); }
       const float z = 1.f / den;
       float dotA = 0.f;
 #pragma unroll
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       kr[i] = to_f32<T>(k[row * k_ld + h * D + i]);
-      K[i] = elu1(kr[i]);
+      K[i] = elu1p(kr[i]);
       val[i] = to_f32<T>(v[row * v_ld + h * D + i]) / fS;
     }
 #pragma unroll

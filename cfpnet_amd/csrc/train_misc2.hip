@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void softmax_expect_kernel(const T* __restrict
     mx = wave_max(mx);
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) { v[k] = __expf(v[k] - mx); s += v[k]; }
+    for (int k = 0; k < NPL; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }      // full-precision exp: training parity
     s = wave_sum(s);
     const float inv = 1.f / s;
     float dot = 0.f;

@@ -57,6 +57,7 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self.record: Optional[Dict[str, V]] = None       # debugging: name -> tape value (tools/train_grad_check.py compares their .g)
 
     # ------------------------------------------------------------------ parameters
     def _conv_w(self, name: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None, f32: bool = False) -> P:
@@ -315,6 +316,8 @@ class TrainNet:
                 tok = self._lkpm(t, q + ".large_kernel_path", tok, B, H, W)
             else:
                 raise NotImplementedError(lname)
+            if self.record is not None:
+                self.record[q] = tok
         return tok
 
     def _up(self, t: Tape, p: str, x: V, Hs, Ws, skip: V, B, H, W) -> V:

@@ -46,13 +46,14 @@ def _oracle_step(layers, sd, inp, target, offs, dtype=torch.float32):
     return float(loss.detach()), pred.detach().double(), grads, stats
 
 
-def test_training_step_matches_autograd_of_the_oracle():
+@pytest.mark.parametrize("geom", [dict(), dict(B=1, zn=4, zpx=56, seed=23)], ids=["zones64", "zones56_interp"])
+def test_training_step_matches_autograd_of_the_oracle(geom):
     """Ground truth = float64 autograd of the oracle.  The float32 HIP step must be as close to it as PyTorch's own
     float32 autograd of the same model is (batch-statistics BatchNorm amplifies float32 summation-order noise to ~3e-3 of a
     tensor's largest gradient entry on this network; a conv bias in front of such a BatchNorm has an exactly-zero true
     gradient, so errors are measured against max(|g|_max, 1e-5 x the model's largest gradient entry))."""
     from cfpnet_amd.train_model import TrainNet
-    layers, sd, inp, target, offs = _case()
+    layers, sd, inp, target, offs = _case(**geom)          # 56-px zones: 3.5-token zones at 1/16 -> the bilinear regroup path of hist2image
     loss64, pred64, g64, stats64 = _oracle_step(layers, sd, inp, target, offs, torch.float64)
     loss32, pred32, g32, _ = _oracle_step(layers, sd, inp, target, offs, torch.float32)
     net = TrainNet(sd, layers, "cuda:0")
