@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training with the reference's CLI and loop (`/root/reference/train.py:41-209`):
 
-    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager]
+    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager] [--validate N]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py @configs/cfpnet_combine1.txt --synthetic 4096
 
 Per step: ToF simulation of the batch from its ground-truth depth (GPU), forward in training mode, SILog loss, backward of
@@ -11,7 +11,8 @@ One process per GPU with the global batch `--bs` split over the ranks (the refer
 
 Differences on purpose: `--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box;
 without it a missing `filenames_file` is an error), random rotation / colour augmentation of the real loader is not
-reproduced, wandb logging and the per-epoch validation are left out (use evaluate_all.py on the saved checkpoint).
+reproduced, wandb logging is left out and validation runs once at the end (`--validate N` synthetic eval samples through the inference
+engine and the device-side metrics; or evaluate_all.py on the saved checkpoint).
 bf16 activations with float32 master parameters by default (`--dtype`); the step is replayed as one HIP graph unless
 `--eager`.  There is no PyTorch autograd or fallback anywhere in the step.
 """
@@ -60,6 +61,7 @@ def main(argv=None):
     max_steps = _pop(argv, "--max_steps", 0, int)
     save_path = _pop(argv, "--save", "", str)
     log_every = _pop(argv, "--log_every", 10, int)
+    n_val = _pop(argv, "--validate", 0, int)
     dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[_pop(argv, "--dtype", "bf16")]
     eager = "--eager" in argv
     argv = [a for a in argv if a != "--eager"]
@@ -130,6 +132,19 @@ def main(argv=None):
                 dt = time.perf_counter() - t0
                 print(f"epoch {epoch + 1} step {step}/{total_steps} loss {float(loss):.4f} lr {lr:.2e} beta1 {beta1:.3f} {seen / dt:.1f} samples/s", flush=True)
     torch.cuda.synchronize()
+    if rank == 0 and n_val > 0:
+        # train.py:163-199 (validate): eval-mode forward of the trained weights (inference engine), metrics on the device
+        from cfpnet_amd import data, metrics
+        from cfpnet_amd.engine import Engine
+        eng = Engine(tr.state_dict(), layer_names=layers, n_bins=int(args.n_bins), min_val=float(args.min_depth), max_val=float(args.max_depth),
+                     dtype=torch.float16 if dtype == torch.float32 else dtype, device=dev)
+        build = data.EvalInputBuilder(args, dev)
+        avg = metrics.RunningAverageDict()
+        for img, dep, _ in data.batches(data.SyntheticEvalSamples(n_val, 480, 640, seed=99), 8):
+            inp, gt = build(img, dep)
+            _, pred, _ = eng.forward(inp, return_prob=False)
+            avg.update(metrics.eval_metrics(pred, gt, float(args.min_depth_eval), float(args.max_depth_eval), mode=metrics.VALIDATE))
+        print("Validation metrics:", {k: round(v, 3) for k, v in avg.get_value().items()}, flush=True)
     if rank == 0 and save_path:
         os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
         torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
