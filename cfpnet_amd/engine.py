@@ -53,6 +53,9 @@ def concurrent_streams(device, want: int = 4, pool: int = 12) -> list:
         return got[:want]
     cand = [torch.cuda.Stream(device=device) for _ in range(pool)]
     cycles = 1_000_000
+    if not hasattr(torch.cuda, "_sleep"):          # no spin kernel to probe with: take the streams as they come
+        _CONCURRENT[key] = cand[:max(want, 4)]
+        return _CONCURRENT[key][:want]
 
     def spin(ids):
         torch.cuda.synchronize(device)
