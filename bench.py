@@ -57,6 +57,9 @@ def parse():
                     help="16-bit storage format of the headline line (BASELINE.json quotes bf16; f16 = IEEE half, same MFMA rate)")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra fp16 measurement appended to the bf16 line")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement appended to the line (N = 1 only)")
+    ap.add_argument("--train", action="store_true",
+                    help="measure the TRAINING step instead (BASELINE.json configs[2..3]: per-GPU batch --train-batch at 416x544, bf16, "
+                         "data parallel over --gpus ranks with the RCCL gradient all-reduce inside the timed region)")
     ap.add_argument("--train-batch", type=int, default=16, help="per-GPU batch of the training-step measurement (configs[2..3]: 16)")
     return ap.parse_args()
 
@@ -183,7 +186,7 @@ def job_value(world: int, batch: int, steps: int, elapsed: float):
     return maps / elapsed, maps / elapsed / world
 
 
-def training_step_rate(batch: int, dev, steps: int = 6):
+def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2):
     """BASELINE.json configs[2..3] shape on ONE GPU: 416x544 crops, 6x6 zones of 64 px, `batch` samples, bf16 activations with
     float32 master parameters; one step = training forward + SILog + backward + AdamW/OneCycle, replayed as one HIP graph.
     (Single process: the RCCL gradient all-reduce of the multi-GPU run is not part of this number.)"""
@@ -195,19 +198,27 @@ def training_step_rate(batch: int, dev, steps: int = 6):
     H, W = 416, 544
     inp = synthetic.to_device(synthetic.make_inputs(batch, H, W, 6, 64, seed=5, drop_hist=0.34), dev)
     target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=50 + i, holes=0.1) for i in range(batch)]))[:, None].to(dev)
-    tr = Trainer(sd, layers, lr=3e-4, total_steps=100, dtype=torch.bfloat16, device=dev)
+    tr = Trainer(sd, layers, lr=3e-4, total_steps=max(100, steps + warmup + 1), dtype=torch.bfloat16, device=dev, dist=dist, world=world)
     tr.capture(inp, target)
     l0 = float(tr.step(inp, target)[0])
-    tr.step(inp, target)
+    for _ in range(max(warmup - 1, 0)):
+        tr.step(inp, target)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _, _ = tr.step(inp, target)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights",
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, dev) / steps
+    return {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights",
             "config": {"workload": f"batch={batch} 416x544 crops + 6x6-zone ToF, training forward + SILog + backward + AdamW/OneCycle",
-                       "launch": "one HIP graph per step", "n_gpus": 1},
+                       "launch": "one HIP graph per step" + (", flat-gradient RCCL all-reduce (3 x 32 MB buckets) + AdamW after it" if world > 1 else ""),
+                       "n_gpus": world, "global_batch": world * batch},
             "loss_first_step": l0, "loss_after_%d_steps" % (steps + 2): float(loss)}
 
 
@@ -217,6 +228,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if a.train:
+        r = training_step_rate(a.train_batch, dev, steps=a.steps, dist=dist, world=world, warmup=a.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "training samples/sec @ 416x544 bf16 (whole job: forward + SILog + backward + gradient all-reduce + AdamW)",
+                              "value": r["value"], "unit": "samples/s", "per_gpu": r["value"] / world, "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": r["config"],
+                              "loss_first_step": r["loss_first_step"]}))
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from cfpnet_amd import spec, synthetic, weights
     from cfpnet_amd.engine import Engine
     layers = spec.COMBINE1_LAYERS
