@@ -158,7 +158,8 @@ class _TrainStep(torch.autograd.Function):
         dev = params[0].device
         sd = {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}
         net = TrainNet(sd, model.layer_names, dev, n_bins=model.num_classes, min_val=model.min_val, max_val=model.max_val,
-                       stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True, dtype=model.compute_dtype)
+                       stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True, dtype=model.compute_dtype,
+                       no_skip_inside=model.no_skip_inside, norm=model.norm)
         tape = Tape(dev, model.compute_dtype)
         pred, edges, (B, h, w) = net.forward(tape, input_data, pos_offsets)
         ctx.net, ctx.tape, ctx.pred, ctx.names = net, tape, pred, names

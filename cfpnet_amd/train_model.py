@@ -39,7 +39,8 @@ class TrainNet:
     """Parameters of the reference's state_dict as tape parameters + the training-mode forward/backward."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], device="cuda:0", n_bins=256, min_val=1e-3,
-                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False, dtype=torch.float32):
+                 max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False, dtype=torch.float32,
+                 no_skip_inside: bool = False, norm: str = "linear"):
         """`dtype`: storage of activations and of the matrix-core weight operands (float32 = parity mode; bfloat16 /
         float16 = mixed precision: float32 master parameters, float32 gradients of the parameters, 16-bit activations
         and activation gradients, float32 accumulation everywhere)."""
@@ -47,7 +48,9 @@ class TrainNet:
         self.dtype = dtype
         self.layers = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, min_val, max_val
-        self.stem_act, self.change_embedding = stem_act, change_embedding
+        self.stem_act, self.change_embedding, self.no_skip_inside = stem_act, change_embedding, no_skip_inside
+        if norm != "linear":
+            raise NotImplementedError(f"bin-width normalisation '{norm}': only 'linear' (every shipped config) has a training path")
         # parameters live on the device in the reference's layout (possibly as views of a flat optimizer buffer, see
         # trainer.Trainer); the kernel layouts are re-derived from them at every step (`zero_grad` drops the derived copies)
         self.sd = {k: (v.detach().float().to(self.dev) if v.is_floating_point() else v) for k, v in state_dict.items()}
@@ -310,6 +313,14 @@ class TrainNet:
                     ins = (y >= cy0) & (y < cy1) & (xx >= cx0) & (xx < cx1)
                     return np.where(ins, (b * tzh + (y - sy)) * tzw + (xx - sx), -1).reshape(-1), B * tzh * tzw
                 idx_p, inv_p = self._maps(("paste", B, H, W, sy, sx, tzh, tzw, cy0, cy1, cx0, cx1), build_paste)
+                if self.no_skip_inside:                                 # fusion.py:156: the rectangle is REPLACED, not added to
+
+                    def build_keep():
+                        b, y, xx = np.meshgrid(np.arange(B), np.arange(H), np.arange(W), indexing="ij")
+                        ins = (y >= cy0) & (y < cy1) & (xx >= cx0) & (xx < cx1)
+                        return np.where(ins, -1, (b * H + y) * W + xx).reshape(-1), B * H * W
+                    idx_k, inv_k = self._maps(("keep_out", B, H, W, cy0, cy1, cx0, cx1), build_keep)
+                    tok = t.gather(tok, idx_k, inv_k)
                 tok = t.add(tok, t.gather(z, idx_p, inv_p))
             elif lname == "combine1":
                 tok = self._dapm(t, q + ".transformer_path", tok, B, H, W, (cy0, cy1, cx0, cx1), 4)

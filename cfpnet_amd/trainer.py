@@ -18,7 +18,7 @@ class Trainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], *, lr: float, total_steps: int, weight_decay: float = 0.1,
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
-                 change_embedding: bool = True, dtype=torch.float32):
+                 change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear"):
         self.dev = torch.device(device)
         self.dist, self.world = dist, world
         names = [(k, tuple(v.shape)) for k, v in state_dict.items()
@@ -28,7 +28,8 @@ class Trainer:
         sd = dict(state_dict)
         for name, _ in names:
             sd[name] = self.flat.view(name)                      # the network sees the optimizer's buffer
-        self.net = TrainNet(sd, layer_names, self.dev, n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype)
+        self.net = TrainNet(sd, layer_names, self.dev, n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
+                            no_skip_inside=no_skip_inside, norm=norm)
         for name, _ in names:                                     # TrainNet.__init__ keeps device tensors as they are: still views
             assert self.net.sd[name].data_ptr() == self.flat.view(name).data_ptr()
         self.opt = train_ops.FlatAdamW(self.flat, train_ops.OneCycle(lr, total_steps, div_factor, final_div_factor), weight_decay=weight_decay,

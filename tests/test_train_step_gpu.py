@@ -195,3 +195,35 @@ def test_captured_training_step_equals_the_eager_one():
         torch.cuda.synchronize()
         assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l0)), (float(l0), float(l1))
     assert torch.equal(eager.flat.param, graph.flat.param)            # same kernels, same order: bit-identical parameters
+
+
+def test_training_step_variants_no_skip_inside_and_stale_embedding():
+    """`--no_skip_inside` (fusion.py:156: the zone rectangle is replaced, not added to) and `change_embedding=False`
+    (hist2image reads the first embedding): loss and gradients against float32 autograd of the oracle run the same way."""
+    from cfpnet_amd.train_model import TrainNet
+    layers, sd, inp, target, offs = _case()
+    for kw in (dict(no_skip_inside=True, change_embedding=True), dict(no_skip_inside=False, change_embedding=False)):
+        sdg = {}
+        for k, v in sd.items():
+            v = v.detach().clone()
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+            sdg[k] = v
+        O.BN_TRAIN = True
+        try:
+            _, pred, _ = O.forward(sdg, inp, layer_names=layers, pos_offsets=offs, grad=True, **kw)
+            loss0 = O.silog_loss(pred, target, target > 1e-3)
+            loss0.backward()
+        finally:
+            O.BN_TRAIN = False
+        net = TrainNet(sd, layers, "cuda:0", **kw)
+        loss1, _, _ = net.forward_backward(inp, target, target > 1e-3, pos_offsets=offs)
+        g1 = net.grads()
+        assert abs(float(loss1) - float(loss0.detach())) < 1e-5 * float(loss0.detach()), kw
+        g0 = {k: v.grad for k, v in sdg.items() if getattr(v, "grad", None) is not None and float(v.grad.abs().max()) > 0}
+        assert set(g0) == set(g1), kw
+        gmax = max(float(g.abs().max()) for g in g0.values())
+        errs = [float((g1[k].cpu() - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-5 * gmax) for k in g0]
+        assert np.median(errs) < 1e-2 and max(errs) < 0.2, (kw, np.median(errs), max(errs))
+    with pytest.raises(NotImplementedError):
+        TrainNet(sd, layers, "cuda:0", norm="softmax")

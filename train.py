@@ -95,7 +95,8 @@ def main(argv=None):
     tr = Trainer(sd, layers, lr=float(args.lr), total_steps=max(total_steps, 2), weight_decay=float(args.wd), div_factor=float(args.div_factor),
                  final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
                  clip_grad_norm=None if args.disable_clip_grad else 0.1, device=dev, dist=dist, world=world, n_bins=int(args.n_bins),
-                 min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding), dtype=dtype)
+                 min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding), dtype=dtype, no_skip_inside=bool(getattr(args, "no_skip_inside", False)),
+                 norm=str(args.norm))
     sim = TofSimulator(args, dev)
     zn, zp, _, _ = zone_layout(args, H, W)
     rects = geometry.centered_zone_rects(H, W, zn, zp)
