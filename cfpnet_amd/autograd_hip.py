@@ -16,10 +16,10 @@ from . import hip, ops, train_ops
 
 class V:
     """A value on the tape: `t` [rows, C] device tensor, `g` its gradient (same shape) once backward reached it."""
-    __slots__ = ("t", "g", "needs_grad")
+    __slots__ = ("t", "g", "needs_grad", "g_owned")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
-        self.t, self.g, self.needs_grad = t, None, needs_grad
+        self.t, self.g, self.needs_grad, self.g_owned = t, None, needs_grad, True
 
     @property
     def rows(self):
@@ -64,13 +64,16 @@ class Tape:
         return self._const[k]
 
     def acc(self, v: V, g: torch.Tensor, own: bool = True) -> None:
-        """v.g += g.  `own`: the caller hands the tensor over (no other reference to it)."""
+        """v.g += g.  `own`: the caller hands the tensor over (no other reference to it).  A gradient that is only passed
+        through (skip connections, identity ops) is shared, not copied: it is copied on the first accumulation into it."""
         if not v.needs_grad:
             return
         if v.g is None:
-            v.g = g if own else g.clone()
-        else:
+            v.g, v.g_owned = g, own
+        elif v.g_owned:
             train_ops.axpby(v.g, g, 1.0, 1.0, out=v.g)
+        else:
+            v.g, v.g_owned = train_ops.axpby(v.g, g, 1.0, 1.0), True
 
     def backward(self) -> None:
         for f in reversed(self.bw):
