@@ -430,6 +430,16 @@ int cfp_add_rowtable_dev(const void* in, int in_ld, const float* table, void* ou
 int cfp_rowtable_grad_dev(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Ht, int Wt, const int* oyox,
                           float beta, int dtype, cfp_stream_t stream);
 
+/* NYU training augmentation in one pass (src/dataloader/nyu.py:128-136,204-245,266-285): crop to H x W at (x0, y0), optional
+ * horizontal flip, optional gamma / brightness / per-channel colour gain + clip, /255, ImageNet normalisation; depth
+ * millimetres -> metres.  rgb_u8 [B,H0,W0,3] and depth_mm [B,H0,W0] uint16 (may be NULL together with depth_out) on the device;
+ * params_i [B,4] int32 = (x0, y0, flip, do_augment), params_f [B,2] f32 = (gamma, brightness), colors [B,3] f64 on the
+ * device -- the draws themselves stay on the host like in the reference; mean3 / std3 are HOST arrays of 3 floats.
+ * image_out [B,3,H,W] f32, depth_out [B,1,H,W] f32.  Crop origins are clamped to the source image. */
+int cfp_nyu_augment(const unsigned char* rgb_u8, const unsigned short* depth_mm, int B, int H0, int W0, const int* params_i,
+                    const float* params_f, const double* colors, int H, int W, const float* mean3, const float* std3, float* image_out,
+                    float* depth_out, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
