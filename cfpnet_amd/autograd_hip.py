@@ -33,11 +33,12 @@ class V:
 class P(V):
     """A parameter: `t` in the layout the kernels want, `g` accumulated in float32 in the same layout;
     `to_torch(g)` converts a gradient back to the reference's state_dict layout."""
-    __slots__ = ("name", "to_torch")
+    __slots__ = ("name", "to_torch", "gview")
 
-    def __init__(self, name: str, t: torch.Tensor, to_torch: Callable[[torch.Tensor], torch.Tensor]):
+    def __init__(self, name: str, t: torch.Tensor, to_torch: Callable[[torch.Tensor], torch.Tensor], gview: Optional[torch.Tensor] = None):
         super().__init__(t, True)
         self.name, self.to_torch = name, to_torch
+        self.gview = gview          # preallocated (zeroed) float32 gradient in the kernel layout: kernels write into it directly
 
 
 def _act(t: torch.Tensor) -> ops.Act:
@@ -75,6 +76,28 @@ class Tape:
         else:
             v.g, v.g_owned = train_ops.axpby(v.g, g, 1.0, 1.0), True
 
+    def pgrad(self, p: P, compute) -> None:
+        """Parameter gradient: `compute(out, beta)` must produce beta*out + grad (out=None: return a fresh tensor).  With a
+        preallocated view the kernel writes straight into the optimizer's flat gradient buffer (no copy afterwards)."""
+        if p.gview is None:
+            self.acc(p, compute(None, 0.0))
+        elif p.g is None:
+            compute(p.gview, 0.0)
+            p.g = p.gview
+        else:
+            compute(p.gview, 1.0)
+
+    @staticmethod
+    def _direct(p: P) -> Optional[torch.Tensor]:
+        """The parameter's preallocated gradient view if a kernel may write it directly (first and only write so far)."""
+        return p.gview if (p.gview is not None and p.g is None) else None
+
+    def _pvec(self, p: P, g: torch.Tensor, direct: Optional[torch.Tensor]) -> None:
+        if direct is not None:
+            p.g = direct
+        else:
+            self.pgrad(p, lambda out, b: train_ops.into(g, out, b))
+
     def backward(self) -> None:
         for f in reversed(self.bw):
             f()
@@ -92,8 +115,8 @@ class Tape:
             if g is None:
                 return
             if bias is not None:
-                self.acc(bias, train_ops.colsum(g))
-            self.acc(w, train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo))
+                self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
+            self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
             if x.needs_grad:
                 wt = train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
                 self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
@@ -111,8 +134,9 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            dx, dg, db = bn.backward(x.t, y.g, act)
-            self.acc(gamma, dg); self.acc(beta, db); self.acc(x, dx)
+            go, bo = self._direct(gamma), self._direct(beta)
+            dx, dg, db = bn.backward(x.t, y.g, act, dgamma_out=go, dbeta_out=bo)
+            self._pvec(gamma, dg, go); self._pvec(beta, db, bo); self.acc(x, dx)
         self.bw.append(bw)
         return y
 
@@ -146,8 +170,9 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps)
-            self.acc(gamma, dg); self.acc(beta, db); self.acc(x, dx)
+            go, bo = self._direct(gamma), self._direct(beta)
+            dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps, dgamma_out=go, dbeta_out=bo)
+            self._pvec(gamma, dg, go); self._pvec(beta, db, bo); self.acc(x, dx)
         self.bw.append(bw)
         return y
 
@@ -161,7 +186,7 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.acc(w, train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo))
+            self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
             self.acc(x, train_ops.dwconv3x3_dgrad(y.g, w.t, B, H, W, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y
@@ -176,8 +201,8 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.acc(bias, train_ops.colsum(y.g))
-            self.acc(w, train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k))
+            self.pgrad(bias, lambda out, beta: train_ops.colsum(y.g, out=out, beta=beta))
+            self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k, dw=out, beta=beta))
             wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)          # data gradient = correlation with the flipped kernel
             dx = torch.empty_like(x.t)
             ops.dwconv_large(_act(y.g), wf, self.const("ones", C), self.const("zeros", C), _act(dx), B, H, W, k, hip.ACT_NONE)
@@ -249,13 +274,17 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            dt = torch.zeros_like(table.t)
-            if dev_off:
-                hip.call("cfp_rowtable_grad_dev", y.g.data_ptr(), y.g.stride(0), dt.data_ptr(), B, H, W, x.C, Ht, Wt, off.data_ptr(), 0.0,
-                         ops.DT[y.g.dtype], hip.current_stream())
-            else:
-                train_ops.rowtable_grad(y.g, dt, B, H, W, Wt, off[0], off[1])
-            self.acc(table, dt)
+            def table_grad(out, beta):
+                dt = torch.zeros_like(table.t) if out is None else out
+                if out is not None and beta == 0.0:
+                    out.zero_()                      # persistent view: last step's window (the offsets move) must not survive
+                if dev_off:
+                    hip.call("cfp_rowtable_grad_dev", y.g.data_ptr(), y.g.stride(0), dt.data_ptr(), B, H, W, x.C, Ht, Wt, off.data_ptr(), beta,
+                             ops.DT[y.g.dtype], hip.current_stream())
+                else:
+                    train_ops.rowtable_grad(y.g, dt, B, H, W, Wt, off[0], off[1], beta=beta)
+                return dt
+            self.pgrad(table, table_grad)
             self.acc(x, y.g, own=False)
         self.bw.append(bw)
         return y

@@ -60,53 +60,82 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self._bound = None                                # (FlatParams in kernel layouts, 16-bit shadow) once `bind` was called
+        self.discovered: Optional[Dict[str, tuple]] = None    # set to {} to collect name -> (float32 kernel layout, to_torch, is16)
         self.record: Optional[Dict[str, V]] = None       # debugging: name -> tape value (tools/train_grad_check.py compares their .g)
 
     # ------------------------------------------------------------------ parameters
+    def _param(self, name: str, make32, to_torch, is16: bool) -> P:
+        """Tape parameter `name`.  Unbound (default): the kernel layout is derived from the reference-layout tensor in `self.sd`
+        by `make32()` (float32) and cast to the storage dtype when `is16`.  Bound (`bind`): the parameter IS a view of the
+        trainer's kernel-layout buffers -- nothing is derived, and its gradient is written in place."""
+        p = self.P.get(name)
+        if p is None:
+            if self._bound is not None:
+                flat, shadow = self._bound
+                s = flat._by_name[name]
+                src = shadow if (is16 and shadow is not None) else flat.param
+                p = P(name, src[s.start:s.start + s.numel].view(s.shape), to_torch, gview=flat.view(name, "grad"))
+            else:
+                t32 = make32().contiguous().to(self.dev)
+                if self.discovered is not None:
+                    self.discovered[name] = (t32, to_torch, is16)
+                p = P(name, t32.to(self.dtype) if is16 else t32, to_torch)
+            self.P[name] = p
+        return p
+
+    def bind(self, flat, shadow: Optional[torch.Tensor]) -> None:
+        """Read the parameters from `flat.param` (float32, kernel layouts, see trainer.Trainer) -- the 16-bit operands from
+        `shadow`, its per-step cast copy -- and write their gradients into `flat.grad`."""
+        self._bound = (flat, shadow)
+        self.P = {}
+
     def _conv_w(self, name: str, cin_pad: Optional[int] = None, cout_pad: Optional[int] = None, f32: bool = False) -> P:
         """[Cout, Cin, kh, kw] / [Cout, Cin(, 1)] -> [Cout_pad, kh*kw*Cin_pad]; padding rows / columns are zero and their
         gradients are dropped (channel counts the 16-byte vectors cannot express: RGB 3, ToF 1, squeeze-excite 34 / 58)."""
-        if name not in self.P:
-            w = self.sd[name].detach().float()
-            if w.dim() == 3:
-                w = w[:, :, :, None]
-            if w.dim() == 2:
-                w = w[:, :, None, None]
-            co, ci, kh, kw = w.shape
-            cp, cop = cin_pad or ci, cout_pad or co
+        if name in self.P:
+            return self.P[name]
+        shape = tuple(self.sd[name].shape)
+        co, ci = shape[0], shape[1]
+        kh, kw = (shape[2], shape[3]) if len(shape) == 4 else ((shape[2], 1) if len(shape) == 3 else (1, 1))
+        cp, cop = cin_pad or ci, cout_pad or co
+
+        def make32():
+            w = self.sd[name].detach().float().reshape(co, ci, kh, kw)
             t = torch.zeros(cop, kh * kw * cp, device=w.device)
             t[:co] = _pad_cols(w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci), ci, cp, kh * kw)
-            shape = tuple(self.sd[name].shape)
+            return t
 
-            def back(g, co=co, ci=ci, kh=kh, kw=kw, cp=cp, shape=shape):
-                return g[:co].reshape(co, kh, kw, cp)[..., :ci].permute(0, 3, 1, 2).reshape(shape)
-            self.P[name] = P(name, t.contiguous().to(self.dev).to(torch.float32 if f32 else self.dtype), back)     # f32: layers fed by float32 [B, C] vectors
-        return self.P[name]
+        def back(g):
+            return g[:co].reshape(co, kh, kw, cp)[..., :ci].permute(0, 3, 1, 2).reshape(shape)
+        return self._param(name, make32, back, not f32)     # f32: layers fed by float32 [B, C] vectors
 
     def _vec(self, name: str, pad_to: Optional[int] = None) -> P:
-        if name not in self.P:
-            v = self.sd[name].detach().float()
-            n = v.numel()
-            if pad_to and pad_to > n:
-                v = torch.cat([v, torch.zeros(pad_to - n, device=v.device)])
-            self.P[name] = P(name, v.contiguous().to(self.dev), lambda g, n=n: g[:n])
-        return self.P[name]
+        if name in self.P:
+            return self.P[name]
+        shape = tuple(self.sd[name].shape)
+        n = self.sd[name].numel()
+
+        def make32():
+            v = self.sd[name].detach().float().reshape(-1)
+            return torch.cat([v, torch.zeros(pad_to - n, device=v.device)]) if (pad_to and pad_to > n) else v.clone()
+        return self._param(name, make32, lambda g: g[:n].reshape(shape), False)
 
     def _dw3(self, name: str) -> P:
-        if name not in self.P:
-            w = self.sd[name].detach().float()
-            C = w.shape[0]
-            self.P[name] = P(name, w.reshape(C, 9).t().contiguous().to(self.dev).to(self.dtype), lambda g, C=C: g.t().reshape(C, 1, 3, 3))
-        return self.P[name]
+        if name in self.P:
+            return self.P[name]
+        C = self.sd[name].shape[0]
+        return self._param(name, lambda: self.sd[name].detach().float().reshape(C, 9).t(), lambda g: g.t().reshape(C, 1, 3, 3), True)
 
     def _dwl(self, name: str) -> P:
-        if name not in self.P:
-            w = self.sd[name].detach().float()
-            self.P[name] = P(name, w[:, 0].contiguous().to(self.dev), lambda g: g.unsqueeze(1))
-        return self.P[name]
+        if name in self.P:
+            return self.P[name]
+        return self._param(name, lambda: self.sd[name].detach().float()[:, 0].clone(), lambda g: g.unsqueeze(1), False)
 
     def _table(self, name: str) -> P:
-        return self._vec(name)
+        if name in self.P:
+            return self.P[name]
+        return self._param(name, lambda: self.sd[name].detach().float().clone(), lambda g: g, False)
 
     def grads(self) -> Dict[str, torch.Tensor]:
         """Gradients in the reference's state_dict layout (float32, on the device); parameters the forward never touched
@@ -115,7 +144,7 @@ class TrainNet:
 
     def zero_grad(self):
         """Drop the gradients AND the kernel-layout copies of the parameters (they are rebuilt from `self.sd`, which the
-        optimizer has updated in place)."""
+        optimizer has updated in place -- or, when bound, re-viewed from the trainer's buffers)."""
         self.P = {}
 
     # ------------------------------------------------------------------ building blocks

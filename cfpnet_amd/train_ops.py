@@ -103,7 +103,7 @@ class FlatParams:
     (transformer.py:183-194, convnext.py:38) sit in a tail that is neither reduced nor stepped (their .grad is None in
     the reference, so torch.optim.AdamW skips them too)."""
 
-    def __init__(self, named_shapes: Sequence[Tuple[str, Tuple[int, ...]]], group_of, device="cpu"):
+    def __init__(self, named_shapes: Sequence[Tuple[str, Tuple[int, ...]]], group_of, device="cpu", align: int = 4):
         self.segments: List[Segment] = []
         off = 0
         self.group_range: Dict[int, Tuple[int, int]] = {}
@@ -114,7 +114,7 @@ class FlatParams:
                     continue
                 n = int(math.prod(shape)) if len(shape) else 1
                 self.segments.append(Segment(name, off, n, tuple(shape), grp))
-                off += (n + 3) // 4 * 4
+                off += (n + align - 1) // align * align
             self.group_range[grp] = (g0, off)
         self.total = off
         self.live = self.group_range[1][1]          # [0, live) gets gradients
@@ -271,11 +271,12 @@ class BatchNormTrain:
                  y.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.current_stream())
         return y
 
-    def backward(self, x2d, dy2d, act: int):
+    def backward(self, x2d, dy2d, act: int, dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None):
+        """-> (dx, dgamma, dbeta); the two parameter gradients are written into the given float32 tensors when provided."""
         from . import hip, ops
         rows = x2d.shape[0]
-        dgamma = torch.empty(self.C, dtype=torch.float32, device=x2d.device)
-        dbeta = torch.empty_like(dgamma)
+        dgamma = dgamma_out if dgamma_out is not None else torch.empty(self.C, dtype=torch.float32, device=x2d.device)
+        dbeta = dbeta_out if dbeta_out is not None else torch.empty(self.C, dtype=torch.float32, device=x2d.device)
         dx = torch.empty_like(x2d)
         hip.call("cfp_bn_train_bwd", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), rows, self.C, ops.DT[x2d.dtype],
                  self.mean.data_ptr(), self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), act, dgamma.data_ptr(),
@@ -283,16 +284,27 @@ class BatchNormTrain:
         return dx, dgamma, dbeta
 
 
-def colsum(x2d: torch.Tensor) -> torch.Tensor:
-    """Sum over rows per channel (f32): the bias gradient."""
+def into(src: torch.Tensor, out: Optional[torch.Tensor], beta: float) -> torch.Tensor:
+    """out = beta*out + src over float32 vectors (out=None: src itself).  `out` may be longer than `src` (zero-padded layouts)."""
+    if out is None:
+        return src
+    n = src.numel()
+    dst = out.reshape(-1)[:n].reshape(1, n)
+    axpby(src.reshape(1, n), dst if beta != 0.0 else None, 1.0, beta, out=dst)
+    return out
+
+
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """Sum over rows per channel (f32): the bias gradient (out = beta*out + sum when `out` is given)."""
     from . import hip, ops
     C = x2d.shape[1]
     nbytes = hip.load().cfp_bn_ws_bytes(C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
-    out = torch.empty(C, dtype=torch.float32, device=x2d.device)
-    hip.call("cfp_colsum", x2d.data_ptr(), x2d.stride(0), x2d.shape[0], C, ops.DT[x2d.dtype], out.data_ptr(), ws.data_ptr(), nbytes,
+    direct = out is not None and beta == 0.0 and out.numel() == C and out.is_contiguous()
+    res = out if direct else torch.empty(C, dtype=torch.float32, device=x2d.device)
+    hip.call("cfp_colsum", x2d.data_ptr(), x2d.stride(0), x2d.shape[0], C, ops.DT[x2d.dtype], res.data_ptr(), ws.data_ptr(), nbytes,
              hip.current_stream())
-    return out
+    return out if direct else into(res, out, beta)
 
 
 def act_bwd(z2d: torch.Tensor, dy2d: torch.Tensor, act: int) -> torch.Tensor:
@@ -304,7 +316,7 @@ def act_bwd(z2d: torch.Tensor, dy2d: torch.Tensor, act: int) -> torch.Tensor:
 
 
 def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, eps: float, dx: Optional[torch.Tensor] = None,
-                  accumulate: bool = False):
+                  accumulate: bool = False, dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None):
     """-> (dx, dgamma, dbeta)"""
     from . import hip, ops
     rows, C = x2d.shape
@@ -312,8 +324,8 @@ def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, ep
         dx, accumulate = torch.empty_like(x2d), False
     nbytes = hip.load().cfp_layernorm_bwd_ws_bytes(rows, C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x2d.device)
-    dbeta = torch.empty_like(dgamma)
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=x2d.device)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=x2d.device)
     hip.call("cfp_layernorm_bwd", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), gamma.data_ptr(), eps, dx.data_ptr(),
              dx.stride(0), int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ops.DT[x2d.dtype], ws.data_ptr(), nbytes,
              hip.current_stream())

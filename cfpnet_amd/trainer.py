@@ -3,6 +3,12 @@ training forward + SILog + backward (`train_model.TrainNet`), gradient averaging
 (`train_ops.allreduce_gradients`: a few large RCCL all-reduces over the flat gradient buffer), AdamW with the OneCycle
 schedule (`train_ops.FlatAdamW`).  The parameters live once, in the flat float32 optimizer buffer; the network reads them
 through views, so nothing is copied back after the update.
+
+`kernel_layout=True` (default) keeps that buffer in the KERNELS' layouts ([Cout_pad, kh*kw*Cin_pad] GEMM operands, [9, C]
+depthwise taps, zero-padded vectors): the per-step work outside the network is then ONE cast of the buffer to the 16-bit
+storage type, the backward kernels write every parameter gradient at its final address, and the ~330 per-parameter
+re-layouts / casts / gradient copies of the reference-layout mode disappear (AdamW, weight decay and the gradient norm are
+elementwise, so the update is the same numbers; padding elements are and stay zero).  `state_dict()` converts back.
 """
 from __future__ import annotations
 
@@ -18,8 +24,15 @@ class Trainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], *, lr: float, total_steps: int, weight_decay: float = 0.1,
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
-                 change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear"):
+                 change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True):
         self.dev = torch.device(device)
+        self.dtype, self.kernel_layout, self._hist10 = dtype, kernel_layout, hist_encoder_10x
+        self._net_kw = dict(n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
+                            no_skip_inside=no_skip_inside, norm=norm)
+        self._layers = list(layer_names)
+        self._opt_kw = dict(lr=lr, total_steps=total_steps, div_factor=div_factor, final_div_factor=final_div_factor, weight_decay=weight_decay,
+                            clip_grad_norm=clip_grad_norm)
+        self._shadow, self._to_torch = None, None
         self.dist, self.world = dist, world
         names = [(k, tuple(v.shape)) for k, v in state_dict.items()
                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
@@ -37,6 +50,34 @@ class Trainer:
         self.min_val = min_val
         self._graph = None
 
+    def _bind_kernel_layout(self, input_data: dict, offs) -> None:
+        """First batch: one forward on a scratch copy of the network records every live parameter's kernel layout (they
+        depend on how the forward uses the tensor, not on the batch); the optimizer state moves to a flat buffer of those."""
+        from .autograd_hip import Tape
+        scratch = TrainNet(self.net.sd, self._layers, self.dev, **self._net_kw)              # own copy of the running statistics
+        scratch.discovered = {}
+        scratch.forward(Tape(self.dev, self.dtype), input_data, offs)
+        found = scratch.discovered
+        kflat = train_ops.FlatParams([(n, tuple(t32.shape)) for n, (t32, _, _) in found.items()], train_ops.lr_group_of(self._hist10),
+                                     device=self.dev, align=8)                                  # 8 elements: 16-byte rows in the 16-bit shadow too
+        assert kflat.group_range[2][0] == kflat.group_range[2][1], "a dead tensor was used by the forward"
+        for n, (t32, _, _) in found.items():
+            kflat.view(n).copy_(t32)
+        self._to_torch = {n: f for n, (_, f, _) in found.items()}
+        self._ref_flat, self.flat = self.flat, kflat
+        self._shadow = torch.empty(kflat.total, dtype=self.dtype, device=self.dev) if self.dtype != torch.float32 else None
+        self.net.bind(kflat, self._shadow)
+        k = self._opt_kw
+        assert self.opt.step_count == 0
+        self.opt = train_ops.FlatAdamW(kflat, train_ops.OneCycle(k["lr"], k["total_steps"], k["div_factor"], k["final_div_factor"]),
+                                       weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"])
+
+    def param(self, name: str) -> torch.Tensor:
+        """Parameter `name` in the reference's layout (a copy when the master is kept in kernel layout)."""
+        if self._to_torch is not None and name in self._to_torch:
+            return self._to_torch[name](self.flat.view(name)).contiguous()
+        return self.net.sd[name]
+
     def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
         """fusion.py:87-91: a random window into the learned positional table whenever the token map is smaller than it."""
         offs = {}
@@ -49,7 +90,14 @@ class Trainer:
         return offs
 
     def _grads_to_flat(self, input_data, target, offs):
+        if self.kernel_layout and self._to_torch is None:
+            self._bind_kernel_layout(input_data, offs)
         self.net.zero_grad()
+        if self._to_torch is not None:
+            if self._shadow is not None:
+                self._shadow.copy_(self.flat.param)                 # the one cast of the step
+            loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
+            return loss                                             # every gradient is already at its flat address
         loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
         self.flat.grad.zero_()
         for name, g in self.net.grads().items():
@@ -104,5 +152,7 @@ class Trainer:
         """Parameters and running statistics in the reference's layout (for `model_io.save_checkpoint`)."""
         out = {}
         for k, v in self.net.sd.items():
+            if self._to_torch is not None and k in self._to_torch:
+                v = self.param(k)
             out[k] = (self.net.buf[k] if k in self.net.buf else v).detach().clone().cpu() if torch.is_tensor(v) else v
         return out

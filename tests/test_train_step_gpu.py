@@ -102,7 +102,7 @@ def test_trainer_step_applies_adamw_to_its_gradients_and_loss_goes_down():
     for k, p in ref.items():
         p.grad = grads[k].float()
     torch.optim.AdamW(ref.values(), lr=lr, betas=(beta1, 0.999), eps=1e-8, weight_decay=0.1).step()
-    worst = max(float((tr.flat.view(k).cpu() - p.detach()).abs().max()) / max(float(p.detach().abs().max()), 1e-3) for k, p in ref.items())
+    worst = max(float((tr.param(k).cpu() - p.detach()).abs().max()) / max(float(p.detach().abs().max()), 1e-3) for k, p in ref.items())
     assert worst < 1e-5, worst
     losses = [float(loss0)]
     for _ in range(6):
