@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--dtype", choices=("bf16", "f16"), default="bf16",
                     help="16-bit storage format of the headline line (BASELINE.json quotes bf16; f16 = IEEE half, same MFMA rate)")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE.json configs[4] instead of configs[1]: 640x960 input, 16x16 ToF zones of 40 px, per-GPU batch 2 "
+                         "(16 over 8 GPUs), fp16 storage, positional tables sized for 640x960 (the reference cannot run this shape)")
     ap.add_argument("--no-f16", action="store_true", help="skip the extra fp16 measurement appended to the bf16 line")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement appended to the line (N = 1 only)")
     ap.add_argument("--train", action="store_true",
@@ -243,10 +246,15 @@ def main():
     from cfpnet_amd import spec, synthetic, weights
     from cfpnet_amd.engine import Engine
     layers = spec.COMBINE1_LAYERS
-    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    base, zones, zone_px = spec.BASE_RESOLUTION, 8, 56
+    if a.config5:
+        base, zones, zone_px = (640, 960), 16, 40
+        a.batch, a.height, a.width, a.dtype = 2, 640, 960, "f16"
+        a.no_f16 = a.no_train = a.no_cpu_baseline = a.no_kernel_times = True     # those appendices describe configs[1]
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers, base_resolution=base))
     TDT = {"bf16": torch.bfloat16, "f16": torch.float16}
-    engine = Engine(sd, layer_names=layers, dtype=TDT[a.dtype], device=dev)
-    inputs = synthetic.to_device(synthetic.make_inputs(a.batch, a.height, a.width, 8, 56, seed=synthetic.SEED + rank), dev)
+    engine = Engine(sd, layer_names=layers, dtype=TDT[a.dtype], device=dev, base_resolution=base)
+    inputs = synthetic.to_device(synthetic.make_inputs(a.batch, a.height, a.width, zones, zone_px, seed=synthetic.SEED + rank, image_hw=base), dev)
     return_prob = not a.no_prob
 
     if dist:
@@ -307,12 +315,12 @@ def main():
     if rank == 0:
         value, per_gpu = job_value(world, a.batch, a.steps, elapsed)
         line = {
-            "metric": f"depth maps/sec @ 480x640 {a.dtype} (whole job; per_gpu = value / n_gpus); abs_rel vs CPU oracle",
+            "metric": f"depth maps/sec @ {a.height}x{a.width} {a.dtype} (whole job; per_gpu = value / n_gpus); abs_rel vs CPU oracle",
             "value": value, "unit": "maps/s", "per_gpu": per_gpu,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward incl. prob output"
-                                   if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + 8x8-zone ToF, eval forward, prob output skipped",
+            "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + {zones}x{zones}-zone ToF, eval forward incl. prob output"
+                                   if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + {zones}x{zones}-zone ToF, eval forward, prob output skipped",
                        "layers": "hist2image combine1 image x2 (CFPNet)", "launch": ("eager" if a.eager else "hipGraph replay") + (f", {a.lanes} concurrent batch lanes" if a.lanes > 1 else "")
                                  + (f", {a.inflight} batches in flight on concurrently scheduled HIP streams (one graph, buffer set and output set per slot)" if a.inflight > 1 else ""),
                        "parallelism": "replicas only" if world > 1 else "single GPU",

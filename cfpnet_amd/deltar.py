@@ -53,7 +53,8 @@ class _Store(nn.Module):
 
 class Deltar(_Store):
     def __init__(self, n_bins: int = 100, min_val: float = 0.1, max_val: float = 10, norm: str = "linear", *,
-                 args=None, dtype=torch.bfloat16, stem_act: bool = False, init: str = "deterministic"):
+                 args=None, dtype=torch.bfloat16, stem_act: bool = False, init: str = "deterministic",
+                 base_resolution=spec.BASE_RESOLUTION):
         super().__init__()
         a = args if args is not None else _global_args
         self.num_classes = n_bins
@@ -70,7 +71,8 @@ class Deltar(_Store):
                 raise NotImplementedError(ln)      # fusion.py:37
         self.compute_dtype = dtype
         self.stem_act = stem_act
-        self._manifest = spec.model_manifest(self.layer_names, n_bins, self.zone_sample_num)
+        self.base_resolution = tuple(base_resolution)     # decoder.py:82-88 hard-codes 480x640; larger tables are a generalisation
+        self._manifest = spec.model_manifest(self.layer_names, n_bins, self.zone_sample_num, self.base_resolution)
         for key, shape, kind in self._manifest:
             if init == "deterministic":
                 t = torch.from_numpy(weights.make_tensor(key, shape, kind).copy())
@@ -117,18 +119,17 @@ class Deltar(_Store):
             self._engine = Engine(sd, layer_names=self.layer_names, n_bins=self.num_classes, min_val=self.min_val,
                                   max_val=self.max_val, norm=self.norm, change_embedding=self.change_embedding,
                                   no_skip_inside=self.no_skip_inside, stem_act=self.stem_act, dtype=self.compute_dtype,
-                                  device=dev, zone_sample_num=self.zone_sample_num)
+                                  device=dev, zone_sample_num=self.zone_sample_num, base_resolution=self.base_resolution)
             self._engine_version = self._version_counter
         return self._engine
 
-    @staticmethod
-    def draw_pos_offsets(H: int, W: int) -> Dict[str, tuple]:
+    def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
         """Window into the learned positional tables.  When the feature map is smaller than the
         table (416x544 crops) the reference draws the offset with `torch.randint` on the CPU
         generator, y then x, coarsest scale first (fusion.py:87-91); same draws here."""
         out = {}
         for name, s in (("cross_atten3", 16), ("cross_atten2", 8), ("cross_atten1", 4)):
-            Hm, Wm = spec.FUSION[name][1]
+            Hm, Wm = spec.fusion_table(self.base_resolution)[name][1]
             h, w = H // s, W // s
             oy = int(torch.randint(0, Hm - h + 1, [1])) if h < Hm else 0
             ox = int(torch.randint(0, Wm - w + 1, [1])) if w < Wm else 0
@@ -159,7 +160,7 @@ class _TrainStep(torch.autograd.Function):
         sd = {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}
         net = TrainNet(sd, model.layer_names, dev, n_bins=model.num_classes, min_val=model.min_val, max_val=model.max_val,
                        stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True, dtype=model.compute_dtype,
-                       no_skip_inside=model.no_skip_inside, norm=model.norm)
+                       no_skip_inside=model.no_skip_inside, norm=model.norm, base_resolution=model.base_resolution)
         tape = Tape(dev, model.compute_dtype)
         pred, edges, (B, h, w) = net.forward(tape, input_data, pos_offsets)
         ctx.net, ctx.tape, ctx.pred, ctx.names = net, tape, pred, names

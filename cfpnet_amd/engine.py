@@ -96,8 +96,10 @@ class Engine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, layer_names: Sequence[str], n_bins: int = 256,
                  min_val: float = 1e-3, max_val: float = 10.0, norm: str = "linear", change_embedding: bool = True,
                  no_skip_inside: bool = False, stem_act: bool = False, dtype=torch.bfloat16, device="cuda:0",
-                 zone_sample_num: int = 16):
+                 zone_sample_num: int = 16, base_resolution=spec.BASE_RESOLUTION):
         hip.load()   # fail loudly if the HIP extension is missing
+        self.base_resolution = tuple(base_resolution)
+        self.fusion = spec.fusion_table(self.base_resolution)    # decoder.py:82-94 generalised to other table sizes (configs[4])
         if not torch.cuda.is_available():
             raise RuntimeError("cfpnet_amd.Engine needs a GPU: the product path has no CPU fallback")
         assert dtype in (torch.bfloat16, torch.float16, torch.float32)
@@ -214,7 +216,7 @@ class Engine:
             self._conv(sd, f"{d}.up{i}.b", q + ".3.weight", q + ".3.bias", bn=q + ".4")
         for n in ("conv3", "conv2", "conv1", "conv0"):
             self._conv(sd, f"{d}.{n}", f"{d}.{n}.weight", f"{d}.{n}.bias")
-        for name in spec.FUSION:
+        for name in self.fusion:
             q = f"{d}.{name}"
             self.P[q + ".pe"] = self._dev(sd[q + ".positional_encodings"])
             self.P[q + ".pe2"] = self._dev(sd[q + ".positional_encodings2"])
@@ -405,7 +407,7 @@ class Engine:
     def _fusion(self, plan, name: str, x: Act, feat1: Act, zone_valid: torch.Tensor, geo: FusionGeometry, B, H, W, out: Act,
                 pos_offset, taps):
         """fusion.py:52-188."""
-        D, (Hm, Wm), lk = spec.FUSION[name]
+        D, (Hm, Wm), lk = self.fusion[name]
         p = f"decoder.{name}"
         ws = spec.window_size((Hm, Wm))
         M = B * H * W
@@ -805,8 +807,8 @@ class Engine:
         pinfo = add["patch_info"]
 
         def fuse(name, x, feat, hh, ww, out):
-            Wm = spec.FUSION[name][1][1]
-            geo = FusionGeometry.from_patch_info(pinfo, 640 / Wm)
+            Wm = self.fusion[name][1][1]
+            geo = FusionGeometry.from_patch_info(pinfo, self.base_resolution[1] / Wm)      # fusion.py:41 (the stride: 16 / 8 / 4)
             assert geo.zone_num * geo.zone_num == Z
             self._fusion(plan, name, x, feat, zone_valid, geo, B, hh, ww, out, pos_offsets.get(name, (0, 0)), taps)
 

@@ -136,11 +136,23 @@ def hist_manifest() -> List[Tuple[str, Tuple[int, ...], str]]:
 DEC_ENC_CH = [232, 136, 56, 40, 16]      # decoder.py:67
 DEC_CH = [256, 256, 128, 64, 32]         # decoder.py:68
 # fusion module name -> (embedding dim, max_resolution, large kernel)   decoder.py:82-94
-FUSION = {
-    "cross_atten3": (128, (30, 40), 7),
-    "cross_atten2": (64, (60, 80), 15),
-    "cross_atten1": (32, (120, 160), 31),
-}
+BASE_RESOLUTION = (480, 640)             # decoder.py:82-88: the tables are sized for this image size
+
+
+def fusion_table(base_resolution=BASE_RESOLUTION):
+    """name -> (embedding dim, max_resolution, large kernel) for a model whose positional tables cover images up to
+    `base_resolution` (H, W).  The reference hard-codes 480x640 (decoder.py:82-88); BASELINE configs[4] (640x960) is the
+    same construction with a larger base -- table, window size and sr-conv kernel all follow from it."""
+    bh, bw = base_resolution
+    assert bh % 16 == 0 and bw % 16 == 0, base_resolution
+    return {
+        "cross_atten3": (128, (bh // 16, bw // 16), 7),
+        "cross_atten2": (64, (bh // 8, bw // 8), 15),
+        "cross_atten1": (32, (bh // 4, bw // 4), 31),
+    }
+
+
+FUSION = fusion_table()
 X2I_HEADS = 4     # fusion.py:13,26,35
 TWINS_HEADS = 8   # transformer.py:78,122 defaults (TwinsTransformer drops its num_heads arg)
 
@@ -165,8 +177,8 @@ def _loftr_keys(q: str, d: int) -> List[Tuple[str, Tuple[int, ...], str]]:
     ]
 
 
-def fusion_manifest(name: str, layer_names: List[str], zone_sample_num: int = 16):
-    d, maxres, lk = FUSION[name]
+def fusion_manifest(name: str, layer_names: List[str], zone_sample_num: int = 16, base_resolution=BASE_RESOLUTION):
+    d, maxres, lk = fusion_table(base_resolution)[name]
     q = f"decoder.{name}"
     ws = window_size(maxres)
     m = [
@@ -219,7 +231,7 @@ def is_dead_param(key: str) -> bool:
     return any(s in key for s in DEAD_PARAM_MARKERS)
 
 
-def decoder_manifest(layer_names: List[str], zone_sample_num: int = 16):
+def decoder_manifest(layer_names: List[str], zone_sample_num: int = 16, base_resolution=BASE_RESOLUTION):
     m = []
     e, c = DEC_ENC_CH, DEC_CH
     m.append(("decoder.conv4.weight", (c[0], e[0], 1, 1), "conv_lin"))
@@ -242,7 +254,7 @@ def decoder_manifest(layer_names: List[str], zone_sample_num: int = 16):
     m.append(("decoder.conv0.weight", (128, c[4], 3, 3), "conv_lin"))
     m.append(("decoder.conv0.bias", (128,), "bias"))
     for name in ("cross_atten1", "cross_atten2", "cross_atten3"):
-        m += fusion_manifest(name, layer_names, zone_sample_num)
+        m += fusion_manifest(name, layer_names, zone_sample_num, base_resolution)
     return m
 
 
@@ -266,13 +278,13 @@ COMBINE1_LAYERS = ["hist2image", "combine1", "image", "hist2image", "combine1", 
 BASELINE_LAYERS = ["hist2image", "image", "hist2image", "image"]
 
 
-def model_manifest(layer_names=None, n_bins: int = 256, zone_sample_num: int = 16):
+def model_manifest(layer_names=None, n_bins: int = 256, zone_sample_num: int = 16, base_resolution=BASE_RESOLUTION):
     """(key, shape, init-kind) for every entry of `Deltar.state_dict()` in registration order of
     the reference (deltar.py:14-19): img_encoder, hist_encoder, depth_head, decoder, conv_out."""
     layer_names = list(layer_names or COMBINE1_LAYERS)
     head = head_manifest(n_bins)
     return (encoder_manifest() + hist_manifest() + head[:9]
-            + decoder_manifest(layer_names, zone_sample_num) + head[9:])
+            + decoder_manifest(layer_names, zone_sample_num, base_resolution) + head[9:])
 
 
 def param_count(manifest) -> int:

@@ -40,12 +40,14 @@ class TrainNet:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], device="cuda:0", n_bins=256, min_val=1e-3,
                  max_val=10.0, stem_act: bool = False, change_embedding: bool = True, share_buffers: bool = False, dtype=torch.float32,
-                 no_skip_inside: bool = False, norm: str = "linear"):
+                 no_skip_inside: bool = False, norm: str = "linear", base_resolution=spec.BASE_RESOLUTION):
         """`dtype`: storage of activations and of the matrix-core weight operands (float32 = parity mode; bfloat16 /
         float16 = mixed precision: float32 master parameters, float32 gradients of the parameters, 16-bit activations
         and activation gradients, float32 accumulation everywhere)."""
         self.dev = torch.device(device)
         self.dtype = dtype
+        self.base_resolution = tuple(base_resolution)
+        self.fusion = spec.fusion_table(self.base_resolution)
         self.layers = list(layer_names)
         self.n_bins, self.min_val, self.max_val = n_bins, min_val, max_val
         self.stem_act, self.change_embedding, self.no_skip_inside = stem_act, change_embedding, no_skip_inside
@@ -297,9 +299,9 @@ class TrainNet:
 
     def _fusion(self, t: Tape, name: str, x: V, feat1: V, mask: torch.Tensor, patch_info, B, H, W, Z, N, pos_offset) -> V:
         p = f"decoder.{name}"
-        D, (Hm, Wm), _ = spec.FUSION[name]
+        D, (Hm, Wm), _ = self.fusion[name]
         ws = spec.window_size((Hm, Wm))
-        geo = FusionGeometry.from_patch_info(patch_info, 640 / Wm)
+        geo = FusionGeometry.from_patch_info(patch_info, self.base_resolution[1] / Wm)
         zn, p1, p2 = geo.zone_num, geo.p1, geo.p2
         sy, sx, ey, ex = geo.sy_wo, geo.sx_wo, geo.ey_wo, geo.ex_wo
         tzh, tzw = geo.tzh, geo.tzw

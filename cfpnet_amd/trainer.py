@@ -24,11 +24,12 @@ class Trainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], *, lr: float, total_steps: int, weight_decay: float = 0.1,
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
-                 change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True):
+                 change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True,
+                 base_resolution=spec.BASE_RESOLUTION):
         self.dev = torch.device(device)
         self.dtype, self.kernel_layout, self._hist10 = dtype, kernel_layout, hist_encoder_10x
         self._net_kw = dict(n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
-                            no_skip_inside=no_skip_inside, norm=norm)
+                            no_skip_inside=no_skip_inside, norm=norm, base_resolution=base_resolution)
         self._layers = list(layer_names)
         self._opt_kw = dict(lr=lr, total_steps=total_steps, div_factor=div_factor, final_div_factor=final_div_factor, weight_decay=weight_decay,
                             clip_grad_norm=clip_grad_norm)
@@ -41,8 +42,7 @@ class Trainer:
         sd = dict(state_dict)
         for name, _ in names:
             sd[name] = self.flat.view(name)                      # the network sees the optimizer's buffer
-        self.net = TrainNet(sd, layer_names, self.dev, n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
-                            no_skip_inside=no_skip_inside, norm=norm)
+        self.net = TrainNet(sd, layer_names, self.dev, **self._net_kw)
         for name, _ in names:                                     # TrainNet.__init__ keeps device tensors as they are: still views
             assert self.net.sd[name].data_ptr() == self.flat.view(name).data_ptr()
         self.opt = train_ops.FlatAdamW(self.flat, train_ops.OneCycle(lr, total_steps, div_factor, final_div_factor), weight_decay=weight_decay,
@@ -81,8 +81,8 @@ class Trainer:
     def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
         """fusion.py:87-91: a random window into the learned positional table whenever the token map is smaller than it."""
         offs = {}
-        for name, (_, (Hm, Wm), _) in spec.FUSION.items():
-            s = 640 // Wm
+        for name, (_, (Hm, Wm), _) in self.net.fusion.items():
+            s = self.net.base_resolution[1] // Wm
             h, w = H // s, W // s
             oy = int(torch.randint(0, Hm - h + 1, [1])) if h < Hm else 0
             ox = int(torch.randint(0, Wm - w + 1, [1])) if w < Wm else 0

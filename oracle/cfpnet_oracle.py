@@ -245,7 +245,7 @@ def _batch_geometry(patch_info, key):
 
 
 def fusion(sd: SD, p: str, x: Tensor, feat1: Tensor, mask: Tensor, patch_info, *,
-           max_resolution: Tuple[int, int], layer_names: Sequence[str], change_embedding: bool = True,
+           max_resolution: Tuple[int, int], layer_names: Sequence[str], patch_key: float, change_embedding: bool = True,
            no_skip_inside: bool = False, pos_offset: Tuple[int, int] = (0, 0),
            taps: Optional[dict] = None) -> Tensor:
     """x [B,D,H,W] image features, feat1 [B,Z,N,D] ToF embeddings, mask [B,Z] zone validity.
@@ -255,7 +255,7 @@ def fusion(sd: SD, p: str, x: Tensor, feat1: Tensor, mask: Tensor, patch_info, *
     B, D, H, W = x.shape
     Hm, Wm = max_resolution
     ws = math.ceil(math.sqrt(math.sqrt(Hm * Wm)))
-    zn, pad_h, pad_w, p1, p2, sy, sx, ey, ex = _batch_geometry(patch_info, 640 / Wm)
+    zn, pad_h, pad_w, p1, p2, sy, sx, ey, ex = _batch_geometry(patch_info, patch_key)
     tzh, tzw = ey - sy, ex - sx
     interp = tzh != p1 * zn or tzw != p2 * zn
     cy0, cy1 = min(max(sy, 0), H), min(max(ey, 0), H)
@@ -305,7 +305,7 @@ def fusion(sd: SD, p: str, x: Tensor, feat1: Tensor, mask: Tensor, patch_info, *
 # ----------------------------------------------------------------------------------------
 # U0 / U1: decoder  (decoder.py:51-58,96-128)
 # ----------------------------------------------------------------------------------------
-_FUSION_RES = {"cross_atten1": (120, 160), "cross_atten2": (60, 80), "cross_atten3": (30, 40)}
+_FUSION_STRIDE = {"cross_atten1": 4, "cross_atten2": 8, "cross_atten3": 16}      # max_resolution = base / stride (decoder.py:82-94)
 
 
 def _up(sd: SD, p: str, x: Tensor, skip: Tensor) -> Tensor:
@@ -319,14 +319,17 @@ def _up(sd: SD, p: str, x: Tensor, skip: Tensor) -> Tensor:
 
 def decoder(sd: SD, img_features: Sequence[Tensor], hist_features: Sequence[Tensor], mask: Tensor,
             patch_info, *, layer_names, change_embedding=True, no_skip_inside=False,
-            pos_offsets: Optional[dict] = None, taps: Optional[dict] = None) -> Tensor:
+            pos_offsets: Optional[dict] = None, taps: Optional[dict] = None, base_resolution=(480, 640)) -> Tensor:
     b0, b1, b2, b3, b4 = img_features
     f1, f2, f3 = hist_features
     pos_offsets = pos_offsets or {}
     kw = dict(layer_names=layer_names, change_embedding=change_embedding, no_skip_inside=no_skip_inside, taps=taps)
 
     def fuse(name, x, feat):
-        return fusion(sd, f"decoder.{name}", x, feat, mask, patch_info, max_resolution=_FUSION_RES[name],
+        s = _FUSION_STRIDE[name]
+        Hm, Wm = base_resolution[0] // s, base_resolution[1] // s
+        # fusion.py:41: patch_info is indexed with 640 / max_resolution[1], i.e. the stride of the scale
+        return fusion(sd, f"decoder.{name}", x, feat, mask, patch_info, max_resolution=(Hm, Wm), patch_key=base_resolution[1] / Wm,
                       pos_offset=pos_offsets.get(name, (0, 0)), **kw)
 
     def rec(k, v):
@@ -381,7 +384,7 @@ def bins_to_depth(sd: SD, widths_normed: Tensor, ram: Tensor, min_val: float, ma
 def forward(sd: SD, input_data: dict, *, layer_names, min_val: float = 1e-3, max_val: float = 10.0,
             norm: str = "linear", change_embedding: bool = True, no_skip_inside: bool = False,
             stem_act: bool = False, pos_offsets: Optional[dict] = None, taps: Optional[dict] = None,
-            img_features: Optional[Sequence[Tensor]] = None, grad: bool = False):
+            img_features: Optional[Sequence[Tensor]] = None, grad: bool = False, base_resolution=(480, 640)):
     """Eval-mode `Deltar.forward` (deltar.py:34-67): returns (bin_edges, pred, prob).
     `img_features` bypasses the RGB encoder (used to pin everything else against the reference)."""
     add = input_data["additional"]
@@ -396,7 +399,7 @@ def forward(sd: SD, input_data: dict, *, layer_names, min_val: float = 1e-3, max
                 taps[f"hist{i}"] = f
         unet = decoder(sd, feats, hfeat, add["mask"], add["patch_info"], layer_names=layer_names,
                        change_embedding=change_embedding, no_skip_inside=no_skip_inside,
-                       pos_offsets=pos_offsets, taps=taps)
+                       pos_offsets=pos_offsets, taps=taps, base_resolution=base_resolution)
         widths, ram = depth_head(sd, unet, norm)
         if taps is not None:
             taps["ram"] = ram

@@ -71,6 +71,42 @@ def test_full_model_vs_oracle_f32(B, H, W, zn, zpx, drop):
     assert p1.shape == (B, 1, H // 2, W // 2) and pr1.shape == (B, 256, H // 2, W // 2)
 
 
+def test_config5_640x960_with_16x16_zones():
+    """BASELINE.json configs[4]: 640x960 input, 16x16 ToF zones (40 px), fp16.  The reference cannot run it (its positional
+    tables are hard-coded for 480x640); the same construction with tables sized for 640x960
+    (`base_resolution`: windows of 7 / 10 / 14 tokens, 256 zones of 10x10 / 5x5 / 3x3 tokens, bilinear zone resampling
+    at 2.5 tokens per zone) is checked HIP <-> CPU oracle: f32 parity mode to the north-star gate, fp16 storage bounded."""
+    base = (640, 960)
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers, base_resolution=base))
+    inp = synthetic.make_inputs(2, 640, 960, 16, 40, seed=31, drop_hist=0.2, image_hw=base)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    otaps, taps = {}, {}
+    e0, p0, pr0 = O.forward(sd, inp, layer_names=layers, base_resolution=base, taps=otaps)
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, base_resolution=base)
+    e1, p1, pr1 = eng.forward(inp, taps=taps)
+    torch.cuda.synchronize()
+    for k in ("enc4", "hist2", "cross_atten3", "cross_atten2", "cross_atten1", "unet_out"):
+        r = rel_l1(taps[k].numpy().reshape(otaps[k].shape), otaps[k].numpy())
+        print(f"  {k}: relL1 {r:.3e}")
+        assert r < TOL_F32, k
+    r = rel_l1(p1.cpu().numpy(), p0.numpy())
+    print(f"config5 f32: pred relL1 vs oracle = {r:.3e}")
+    assert r < TOL_F32 and p1.shape == (2, 1, 320, 480) and pr1.shape == (2, 256, 320, 480)
+    assert torch.allclose(e1.cpu(), e0, rtol=1e-4, atol=1e-4)
+    del eng
+    e16 = Engine(sd, layer_names=layers, dtype=torch.float16, base_resolution=base)
+    _, p2, _ = e16.forward(inp)
+    e16.capture(inp)
+    _, p3, _ = e16.replay()
+    torch.cuda.synchronize()
+    r16 = rel_l1(p2.cpu().numpy(), p0.numpy())
+    print(f"config5 fp16: pred relL1 vs oracle = {r16:.3e}")
+    assert r16 < TOL_F16 and torch.equal(p2, p3)
+    with pytest.raises(Exception):                       # the 480x640 tables cannot hold a 640x960 map: loud, like the reference
+        Engine(weights.make_torch_state_dict(spec.model_manifest(layers)), layer_names=layers, dtype=torch.float32).forward(inp)
+
+
 @pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, TOL_BF16), (torch.float16, TOL_F16)])
 def test_full_model_16bit_error_is_bounded(dtype, bound):
     """16-bit storage (f32 accumulation): the error is storage rounding accumulated over ~90 layers.  fp16 (10 mantissa
