@@ -77,3 +77,37 @@ def test_weights_are_reproducible_and_key_addressed():
     c = weights.make_tensor("decoder.conv2.weight", (128, 256, 1, 1), "conv_lin")
     assert (a == b).all() and not (a == c).all()
     assert a.tobytes()[:8].hex() == weights.make_tensor("decoder.conv3.weight", (128, 256, 1, 1), "conv_lin").tobytes()[:8].hex()
+
+
+def test_base_resolution_generalises_the_hard_coded_tables():
+    """decoder.py:82-94 at 480x640 is the default; configs[4] (640x960) scales tables, windows (fusion.py:28) and the
+    sr-conv kernels, and nothing else in the state dict."""
+    assert spec.fusion_table() == spec.FUSION == {"cross_atten3": (128, (30, 40), 7), "cross_atten2": (64, (60, 80), 15),
+                                                 "cross_atten1": (32, (120, 160), 31)}
+    big = spec.fusion_table((640, 960))
+    assert [big[k][1] for k in ("cross_atten3", "cross_atten2", "cross_atten1")] == [(40, 60), (80, 120), (160, 240)]
+    assert [spec.window_size(big[k][1]) for k in ("cross_atten3", "cross_atten2", "cross_atten1")] == [7, 10, 14]
+    m0 = {k: s for k, s, _ in spec.model_manifest(spec.COMBINE1_LAYERS)}
+    m1 = {k: s for k, s, _ in spec.model_manifest(spec.COMBINE1_LAYERS, base_resolution=(640, 960))}
+    assert list(m0) == list(m1)
+    changed = sorted(k for k in m0 if m0[k] != m1[k])
+    assert changed and all(k.endswith(("positional_encodings", "gsa.sr.weight")) for k in changed)
+    assert m1["decoder.cross_atten1.positional_encodings"] == (160 * 240, 32)
+    with pytest.raises(AssertionError):
+        spec.fusion_table((500, 640))
+
+
+def test_oracle_runs_config5_shape():
+    """640x960 with 16x16 zones of 40 px through the CPU oracle (the GPU test compares the HIP engine against this)."""
+    import torch
+    from cfpnet_amd import synthetic
+    from oracle import cfpnet_oracle as O
+    base = (640, 960)
+    sd = weights.make_torch_state_dict(spec.model_manifest(spec.COMBINE1_LAYERS, base_resolution=base))
+    inp = synthetic.make_inputs(1, 640, 960, 16, 40, seed=3, drop_hist=0.2, image_hw=base)
+    assert inp["additional"]["hist_data"].shape == (1, 256, 16)
+    assert inp["additional"]["patch_info"][16]["patch_size"][0].tolist() == [3, 3]        # ceil(40 / 16): interpolated zones
+    edges, pred, prob = O.forward(sd, inp, layer_names=spec.COMBINE1_LAYERS, base_resolution=base)
+    assert pred.shape == (1, 1, 320, 480) and prob.shape == (1, 256, 320, 480) and bool(torch.isfinite(pred).all())
+    with pytest.raises(RuntimeError):        # the reference's own tables (480x640) cannot take this map: broadcast error, as in fusion.py:94
+        O.forward(weights.make_torch_state_dict(spec.model_manifest(spec.COMBINE1_LAYERS)), inp, layer_names=spec.COMBINE1_LAYERS)
