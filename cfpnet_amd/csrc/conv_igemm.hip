@@ -200,6 +200,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+
+// Few-row f32 GEMM: out[m, n] = act(scale[n] * sum_k x[m, k] w[n, k] + shift[n]) (+ res) for M <= 64 rows -- the squeeze-excite
+// FCs of the training step on [B, C] vectors and their data gradients, where a 128x64 tile leaves one or two workgroups walking
+// K alone (31 us per call).  One wave per output column: the lanes split K in 16-byte pieces (the weight row is read once,
+// the <= 16 input rows come from L2), partial sums meet in a wave reduction; 4 columns per workgroup.
+__global__ __launch_bounds__(256) void rowgemm_f32_kernel(ConvP p) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= p.Cout) return;
+  const float* __restrict__ x = reinterpret_cast<const float*>(p.in);
+  const float* __restrict__ w = reinterpret_cast<const float*>(p.w) + (long long)n * p.K;
+  const float* __restrict__ res = reinterpret_cast<const float*>(p.res);
+  float* __restrict__ out = reinterpret_cast<float*>(p.out);
+  const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+  for (int m0 = 0; m0 < p.M; m0 += 16) {
+    const int mc = min(16, p.M - m0);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k = lane * 4; k < p.K; k += 256) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < mc) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)(m0 + i) * p.in_ld + k);
+          acc[i] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[i]))));
+        }
+      }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float t = wave_sum(acc[i]);
+      if (lane == i) mine = t;
+    }
+    if (lane < mc) {
+      float v = 0.f;
+      with_act(p.act, [&](auto A) { v = act_c<decltype(A)::value>(mine * sc + sh); });
+      const long long m = m0 + lane;
+      if (res) v += res[m * p.res_ld + n];
+      out[m * p.out_ld + n] = v;
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 void launch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
   int tiles = cdiv(p.M, BM) * cdiv(p.Cout, BN);
@@ -429,6 +474,10 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
 gen1_path:
   // first-generation kernels (f32 parity mode, short-K bf16): per-image weights run image by image,
   // LayerNorm as a second kernel
+  if (dtype == CFP_F32 && p.pointwise && p.M <= 64 && !per_image_weights && !ln_gamma && !g_use_v1) {
+    hipLaunchKernelGGL(rowgemm_f32_kernel, dim3(cdiv(Cout, 4)), dim3(256), 0, s, p);
+    return cfp_check_launch("cfp_conv2d_nhwc");
+  }
   if (ln_gamma) p.res = nullptr;
   const int nimg = per_image_weights ? B : 1;
   const size_t esz = is16(dtype) ? 2 : 4;

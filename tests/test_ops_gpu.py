@@ -67,6 +67,10 @@ CONV_CASES = [
     (1, 1, 70, 8, 32, 1, 1, (0, 0, 0, 0)),        # K = 8 (ToF first layer)
     (2, 60, 80, 64, 64, 9, 9, (0, 0, 0, 0)),      # GSA sr conv at 1/8: M = 96, K = 5184 -> split-K
     (2, 15, 20, 1392, 232, 1, 1, (0, 0, 0, 0)),   # 1/32-scale project conv: M = 600, K = 1392 -> split-K
+    (16, 1, 1, 1056, 40, 1, 1, (0, 0, 0, 0)),     # squeeze-excite reduce FC on [B, C] vectors: f32 takes the few-row kernel (M <= 64)
+    (1, 1, 17, 136, 528, 1, 1, (0, 0, 0, 0)),     # ... expand FC, 17 rows = two row chunks
+    (4, 1, 16, 2064, 88, 1, 1, (0, 0, 0, 0)),     # ... M = 64, the last few-row size
+    (1, 1, 1, 48, 16, 1, 1, (0, 0, 0, 0)),        # ... a single row
 ]
 
 
