@@ -81,20 +81,26 @@ __device__ __forceinline__ void outer_finish(const float (&acc)[Outer<D>::OPT], 
   __syncthreads();
 }
 
-template <typename T, int D>
+// SPLIT 0: one workgroup per (group, head) does both phases.  When there are few groups (global attention: N = batch) the token
+// axis is split over blockIdx.y instead: SPLIT 1 = the key phase of one chunk of S, partial KV to `partial`; SPLIT 2 = the
+// query phase of one chunk of L, which first adds the partials up in chunk order (so the result does not depend on the split
+// only through the fixed summation tree: bit-reproducible for a given shape).
+template <typename T, int D, int SPLIT>
 __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
                                                           const T* __restrict__ v, int v_ld, T* __restrict__ out, int out_ld,
-                                                          float* __restrict__ kv_save, int L, int S, int heads, float eps) {
+                                                          float* __restrict__ kv_save, int L, int S, int heads, float eps,
+                                                          float* __restrict__ partial, int nchunks, int chunk_len) {
   using O = Outer<D>;
-  __shared__ float sX[ACH * D], sY[ACH * (D + 1)], sM[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
+  __shared__ float sX[SPLIT == 2 ? 1 : ACH * D], sY[SPLIT == 2 ? 1 : ACH * (D + 1)], sM[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
   const int tid = threadIdx.x;
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const float fS = (float)S;
   float acc[O::OPT];
 #pragma unroll
   for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
-  for (int s0 = 0; s0 < S; s0 += ACH) {
-    const int nr = min(ACH, S - s0);
+  const int s_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 1 ? min(S, s_begin + chunk_len) : (SPLIT == 2 ? 0 : S);
+  for (int s0 = s_begin; s0 < s_end; s0 += ACH) {
+    const int nr = min(ACH, s_end - s0);
     __syncthreads();
     for (int e = tid; e < nr * D; e += 256) {
       const int r = e / D, c = e - r * D;
@@ -107,10 +113,25 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
     outer_accumulate<D>(sX, sY, nr, acc);
   }
   __syncthreads();
-  outer_finish<D>(acc, sRed, sM);
-  for (int e = tid; e < O::NO; e += 256) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
+  if (SPLIT == 2) {
+    for (int e = tid; e < O::NO; e += 256) {
+      float a = 0.f;
+      for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
+      sM[e] = a;
+    }
+    __syncthreads();
+  } else {
+    outer_finish<D>(acc, sRed, sM);
+  }
+  if (SPLIT == 1) {
+    for (int e = tid; e < O::NO; e += 256) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sM[e];
+    return;
+  }
+  if (SPLIT == 0 || blockIdx.y == 0)
+    for (int e = tid; e < O::NO; e += 256) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
   // queries: one token per thread
-  for (int l = tid; l < L; l += 256) {
+  const int l_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 2 ? min(L, l_begin + chunk_len) : L;
+  for (int l = l_begin + tid; l < l_end; l += 256) {
     const long long row = (long long)n * L + l;
     float Q[D];
     float den = eps;
@@ -127,25 +148,30 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T, int D>
+// SPLIT as in the forward: 0 = both phases in one workgroup per (group, head); 1 = the query phase of one chunk of L (dq, partial
+// [dKV | dKsum] to `partial`); 2 = the key phase of one chunk of S after adding the partials up in chunk order.
+template <typename T, int D, int SPLIT>
 __global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
                                                           const T* __restrict__ v, int v_ld, const T* __restrict__ dout, int do_ld,
                                                           const float* __restrict__ kv_save, T* __restrict__ dq, int dq_ld,
                                                           T* __restrict__ dk, int dk_ld, T* __restrict__ dv, int dv_ld, int L, int S,
-                                                          int heads, float eps) {
+                                                          int heads, float eps, float* __restrict__ partial, int nchunks, int chunk_len) {
   using O = Outer<D>;
-  __shared__ float sX[ACH * D], sY[ACH * (D + 1)], sM[O::NO], sG[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
+  __shared__ float sX[SPLIT == 2 ? 1 : ACH * D], sY[SPLIT == 2 ? 1 : ACH * (D + 1)], sM[SPLIT == 2 ? 1 : O::NO], sG[O::NO],
+      sRed[O::G > 1 ? O::G * O::NO : 1];
   const int tid = threadIdx.x;
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const float fS = (float)S;
-  for (int e = tid; e < O::NO; e += 256) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
+  if (SPLIT != 2)
+    for (int e = tid; e < O::NO; e += 256) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
   float acc[O::OPT];
 #pragma unroll
   for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
   __syncthreads();
   // ---- queries: dq, and the rows (Q_l, dA_l, e_l) of the dKV / dKsum reduction
-  for (int l0 = 0; l0 < L; l0 += ACH) {
-    const int nr = min(ACH, L - l0);
+  const int l_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 1 ? min(L, l_begin + chunk_len) : (SPLIT == 2 ? 0 : L);
+  for (int l0 = l_begin; l0 < l_end; l0 += ACH) {
+    const int nr = min(ACH, l_end - l0);
     __syncthreads();
     if (tid < nr) {
       const long long row = (long long)n * L + l0 + tid;
@@ -181,9 +207,23 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ 
     outer_accumulate<D>(sX, sY, nr, acc);
   }
   __syncthreads();
-  outer_finish<D>(acc, sRed, sG);          // sG = [dKV | dKsum]
+  if (SPLIT == 2) {
+    for (int e = tid; e < O::NO; e += 256) {
+      float a = 0.f;
+      for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
+      sG[e] = a;
+    }
+    __syncthreads();
+  } else {
+    outer_finish<D>(acc, sRed, sG);          // sG = [dKV | dKsum]
+  }
+  if (SPLIT == 1) {
+    for (int e = tid; e < O::NO; e += 256) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sG[e];
+    return;
+  }
   // ---- keys: dk, dv
-  for (int s = tid; s < S; s += 256) {
+  const int s_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 2 ? min(S, s_begin + chunk_len) : S;
+  for (int s = s_begin + tid; s < s_end; s += 256) {
     const long long row = (long long)n * S + s;
     float K[D], kr[D], val[D];
 #pragma unroll
@@ -220,14 +260,50 @@ extern "C" size_t cfp_linattn_state_bytes(int N, int heads, int d) { return (N >
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);                                                                   \
   const dim3 grid((unsigned)((long long)N * heads))
 
+// Few groups (global attention: N = batch, 64-128 workgroups for 256 CUs): split the token axes over blockIdx.y.
+struct LaSplit { int c1, len1, c2, len2; };
+static bool la_plan(long long groups, int R, int A, LaSplit* p) {      // R: tokens of the reduction phase, A: of the apply phase
+  if (groups >= 512) return false;
+  const int want = (int)((1024 + groups - 1) / groups);
+  int c1 = std::min(want, cdiv(R, ACH));
+  p->len1 = cdiv(cdiv(R, c1), ACH) * ACH;
+  p->c1 = cdiv(R, p->len1);
+  int c2 = std::min(want, cdiv(A, 256));
+  p->len2 = cdiv(cdiv(A, c2), 256) * 256;
+  p->c2 = cdiv(A, p->len2);
+  return p->c1 > 1 || p->c2 > 1;
+}
+
+extern "C" size_t cfp_linattn_ws_bytes(int N, int L, int S, int heads, int d) {
+  if (N <= 0 || L <= 0 || S <= 0 || heads <= 0 || d <= 0) return 0;
+  const long long groups = (long long)N * heads;
+  LaSplit f, b;
+  size_t need = 0;
+  if (la_plan(groups, S, L, &f)) need = std::max(need, (size_t)groups * f.c1 * d * (d + 1) * sizeof(float));
+  if (la_plan(groups, L, S, &b)) need = std::max(need, (size_t)groups * b.c1 * d * (d + 1) * sizeof(float));
+  return need;
+}
+
 extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, void* out, int out_ld, float* state,
-                               int N, int L, int S, int heads, int d, float eps, int dtype, cfp_stream_t stream) {
+                               int N, int L, int S, int heads, int d, float eps, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   CFP_REQUIRE(q && k && v && out && state, CFP_EINVAL, "cfp_linattn_fwd: null pointer");
   LA_CHECK("cfp_linattn_fwd");
   const int C = heads * d;
   CFP_REQUIRE(q_ld >= C && k_ld >= C && v_ld >= C && out_ld >= C, CFP_ESHAPE, "cfp_linattn_fwd: pitch smaller than heads*d");
-#define L1(T, DD) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, \
-                                     (T*)out, out_ld, state, L, S, heads, eps)
+  LaSplit sp;
+  const bool split = la_plan((long long)N * heads, S, L, &sp) && ws &&
+                     ws_bytes >= (size_t)N * heads * sp.c1 * d * (d + 1) * sizeof(float);
+  float* partial = reinterpret_cast<float*>(ws);
+#define L1(T, DD) do {                                                                                                              \
+    if (!split) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, \
+                                   v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);                                   \
+    else {                                                                                                                          \
+      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 1>), dim3(grid.x, sp.c1), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
+                         (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len1);                      \
+      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 2>), dim3(grid.x, sp.c2), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
+                         (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len2);                      \
+    }                                                                                                                               \
+  } while (0)
 #define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
@@ -237,17 +313,29 @@ extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld,
 
 extern "C" int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, const void* dout, int do_ld,
                                const float* state, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int N, int L, int S,
-                               int heads, int d, float eps, int dtype, cfp_stream_t stream) {
+                               int heads, int d, float eps, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   CFP_REQUIRE(q && k && v && dout && state && dq && dk && dv, CFP_EINVAL, "cfp_linattn_bwd: null pointer");
   LA_CHECK("cfp_linattn_bwd");
   const int C = heads * d;
   CFP_REQUIRE(q_ld >= C && k_ld >= C && v_ld >= C && do_ld >= C && dq_ld >= C && dk_ld >= C && dv_ld >= C, CFP_ESHAPE,
               "cfp_linattn_bwd: pitch smaller than heads*d");
-#define L1(T, DD) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, \
-                                     (const T*)dout, do_ld, state, (T*)dq, dq_ld, (T*)dk, dk_ld, (T*)dv, dv_ld, L, S, heads, eps)
+  LaSplit sp;
+  const bool split = la_plan((long long)N * heads, L, S, &sp) && ws &&
+                     ws_bytes >= (size_t)N * heads * sp.c1 * d * (d + 1) * sizeof(float);
+  float* partial = reinterpret_cast<float*>(ws);
+#define BARGS(T) (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, (const T*)dout, do_ld, state, (T*)dq, dq_ld, (T*)dk, dk_ld, (T*)dv, \
+                 dv_ld, L, S, heads, eps
+#define L1(T, DD) do {                                                                                                              \
+    if (!split) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0>), grid, dim3(256), 0, s, BARGS(T), nullptr, 0, 0);                  \
+    else {                                                                                                                          \
+      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 1>), dim3(grid.x, sp.c1), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len1);   \
+      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 2>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);   \
+    }                                                                                                                               \
+  } while (0)
 #define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
 #undef L1
+#undef BARGS
   return cfp_check_launch("cfp_linattn_bwd");
 }

@@ -86,8 +86,9 @@ SIGNATURES = {
     "cfp_softmax_expect_ws_bytes": (_sz, [_i, _i, _i]),
     "cfp_softmax_expect": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "cfp_linattn_state_bytes": (_sz, [_i, _i, _i]),
-    "cfp_linattn_fwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "cfp_linattn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "cfp_linattn_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "cfp_linattn_fwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _i, _p, _sz, _p]),
+    "cfp_linattn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz, _p]),
     "cfp_dwconv_large_wgrad_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "cfp_dwconv_large_wgrad": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _i, _p, _sz, _p]),
     "cfp_row_normalize": (_i, [_p, _p, _p, _i, _i, _p]),

@@ -450,22 +450,30 @@ def softmax_expect(logits2d, centers, B, HW, dpred=None):
     return dlogits, dcenters
 
 
-def linattn_fwd(q2d, k2d, v2d, N, L, S, heads, d, eps=1e-6):
-    """-> (out [N*L, heads*d], state) for linattn_bwd."""
+def _linattn_ws(N, L, S, heads, d, device, split: bool):
+    from . import hip
+    nbytes = hip.load().cfp_linattn_ws_bytes(N, L, S, heads, d) if split else 0
+    return (torch.empty(nbytes // 4, dtype=torch.float32, device=device), nbytes) if nbytes else (None, 0)
+
+
+def linattn_fwd(q2d, k2d, v2d, N, L, S, heads, d, eps=1e-6, split: bool = True):
+    """-> (out [N*L, heads*d], state) for linattn_bwd.  `split=False`: one workgroup per (group, head) whatever the shape."""
     from . import hip, ops
     out = torch.empty(N * L, heads * d, dtype=q2d.dtype, device=q2d.device)
     state = torch.empty(hip.load().cfp_linattn_state_bytes(N, heads, d) // 4, dtype=torch.float32, device=q2d.device)
+    ws, nbytes = _linattn_ws(N, L, S, heads, d, q2d.device, split)
     hip.call("cfp_linattn_fwd", q2d.data_ptr(), q2d.stride(0), k2d.data_ptr(), k2d.stride(0), v2d.data_ptr(), v2d.stride(0), out.data_ptr(),
-             out.stride(0), state.data_ptr(), N, L, S, heads, d, eps, ops.DT[q2d.dtype], hip.current_stream())
+             out.stride(0), state.data_ptr(), N, L, S, heads, d, eps, ops.DT[q2d.dtype], hip.ptr(ws), nbytes, hip.current_stream())
     return out, state
 
 
-def linattn_bwd(q2d, k2d, v2d, dout2d, state, N, L, S, heads, d, eps=1e-6):
+def linattn_bwd(q2d, k2d, v2d, dout2d, state, N, L, S, heads, d, eps=1e-6, split: bool = True):
     from . import hip, ops
     dq, dk, dv = torch.empty_like(q2d), torch.empty_like(k2d), torch.empty_like(v2d)
+    ws, nbytes = _linattn_ws(N, L, S, heads, d, q2d.device, split)
     hip.call("cfp_linattn_bwd", q2d.data_ptr(), q2d.stride(0), k2d.data_ptr(), k2d.stride(0), v2d.data_ptr(), v2d.stride(0), dout2d.data_ptr(),
              dout2d.stride(0), state.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), N, L, S,
-             heads, d, eps, ops.DT[q2d.dtype], hip.current_stream())
+             heads, d, eps, ops.DT[q2d.dtype], hip.ptr(ws), nbytes, hip.current_stream())
     return dq, dk, dv
 
 

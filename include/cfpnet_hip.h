@@ -404,13 +404,17 @@ int cfp_softmax_expect(const void* logits, int ld, const float* centers, float* 
 
 /* Linear attention, training form (attention.py:20-52 and its autograd) on contiguously grouped tokens:
  * q [N*L, heads*d], k, v [N*S, heads*d] -> out [N*L, heads*d]; `state` (cfp_linattn_state_bytes) keeps KV and Ksum of
- * every (group, head) for the backward call, which returns dq, dk, dv.  d in {4, 8, 16, 32}. */
+ * every (group, head) for the backward call, which returns dq, dk, dv.  d in {4, 8, 16, 32}.
+ * ws (cfp_linattn_ws_bytes, may be 0 / NULL): with fewer than 512 (group, head) pairs -- the global attentions, N = batch --
+ * the token axes are split over more workgroups and the partial [d x (d+1)] states meet in ws, added in a fixed order;
+ * without ws one workgroup per (group, head) walks all tokens (same values up to float32 summation order). */
 size_t cfp_linattn_state_bytes(int N, int heads, int d);
+size_t cfp_linattn_ws_bytes(int N, int L, int S, int heads, int d);
 int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, void* out, int out_ld, float* state,
-                    int N, int L, int S, int heads, int d, float eps, int dtype, cfp_stream_t stream);
+                    int N, int L, int S, int heads, int d, float eps, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld, const void* v, int v_ld, const void* dout, int do_ld,
                     const float* state, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int N, int L, int S,
-                    int heads, int d, float eps, int dtype, cfp_stream_t stream);
+                    int heads, int d, float eps, int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
 /* Weight gradient of the large-kernel depthwise convolution of LKPM (convnext.py:30, k = 7/15/31, zero padding (k-1)/2):
  * dw[C][k][k] f32 = beta*dw + sum over pixels of dy * x(tap).  The data gradient is cfp_dwconv_large_nhwc with the kernel

@@ -265,7 +265,7 @@ def test_bin_head_forward_backward(B, HW, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,L,S,heads,d", [(6, 49, 16, 4, 16), (3, 144, 144, 8, 4), (2, 1200, 30, 8, 16), (5, 36, 36, 8, 16), (2, 300, 130, 4, 32),
-                                           (4, 196, 16, 4, 8)])
+                                           (4, 196, 16, 4, 8), (2, 884, 884, 4, 32), (2, 3536, 500, 4, 16), (130, 36, 16, 4, 8)])
 def test_linear_attention_forward_backward(N, L, S, heads, d, dtype):
     from oracle import cfpnet_oracle as O
     q = rnd(N, L, heads, d, seed=1).to(dtype).float().requires_grad_(True)
@@ -284,6 +284,13 @@ def test_linear_attention_forward_backward(N, L, S, heads, d, dtype):
     tol = OUT_TOL[dtype] + 3e-5
     chk = lambda got, want, n: float((got.float().cpu().reshape(N, n, heads, d) - want).abs().max()) <= tol * float(want.abs().max())
     assert chk(o_d, out.detach(), L) and chk(dq, q.grad, L) and chk(dk, k.grad, S) and chk(dv, v.grad, S)
+    # the token-split launch (few groups) against one workgroup per (group, head): same values up to f32 summation order
+    o1, st1 = train_ops.linattn_fwd(qd, kd, vd, N, L, S, heads, d, split=False)
+    g1 = train_ops.linattn_bwd(qd, kd, vd, dout.reshape(N * L, heads * d).to(dtype).to(DEV), st1, N, L, S, heads, d, split=False)
+    torch.cuda.synchronize()
+    assert chk(o1, out.detach(), L) and chk(g1[0], q.grad, L) and chk(g1[1], k.grad, S) and chk(g1[2], v.grad, S)
+    assert float((state - st1).abs().max()) <= 1e-5 * float(st1.abs().max())
+    assert (hip.load().cfp_linattn_ws_bytes(N, L, S, heads, d) == 0) == (N * heads >= 512 or (L <= 128 and S <= 128))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
