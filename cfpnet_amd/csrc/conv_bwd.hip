@@ -254,18 +254,38 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
       }
 }
 
+// dw = beta * dw + sum over the splits, in a fixed order.  EW consecutive elements per workgroup, 256 / EW lanes over the splits:
+// a small weight tensor split 768 ways (32x32 Linear over 2*10^5 rows) is a long dependent chain per element, so the splits are
+// walked by up to 8 lanes with 4 loads in flight each, and the lanes meet in LDS in lane order.
+template <int EW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
                                                            float beta) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  constexpr int LANES = 256 / EW;
+  __shared__ float red[LANES][EW];
+  const int e = threadIdx.x % EW, sl = threadIdx.x / EW;
+  for (long long i0 = (long long)blockIdx.x * EW; i0 < n; i0 += (long long)gridDim.x * EW) {
+    const long long i = i0 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four loads in flight; the combination order is still fixed
-    int j = 0;
-    for (; j + 3 < nsplit; j += 4) {
-      s0 += slabs[(long long)j * n + i]; s1 += slabs[(long long)(j + 1) * n + i];
-      s2 += slabs[(long long)(j + 2) * n + i]; s3 += slabs[(long long)(j + 3) * n + i];
+    if (i < n) {
+      int j = sl;
+      for (; j + 3 * LANES < nsplit; j += 4 * LANES) {
+        s0 += slabs[(long long)j * n + i]; s1 += slabs[(long long)(j + LANES) * n + i];
+        s2 += slabs[(long long)(j + 2 * LANES) * n + i]; s3 += slabs[(long long)(j + 3 * LANES) * n + i];
+      }
+      for (; j < nsplit; j += LANES) s0 += slabs[(long long)j * n + i];
     }
-    for (; j < nsplit; ++j) s0 += slabs[(long long)j * n + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+    float s = (s0 + s1) + (s2 + s3);
+    if (LANES > 1) {
+      red[sl][e] = s;
+      __syncthreads();
+      if (sl == 0) {
+        s = 0.f;
+#pragma unroll
+        for (int l = 0; l < LANES; ++l) s += red[l][e];
+      }
+    }
+    if (sl == 0 && i < n) dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+    if (LANES > 1) __syncthreads();
   }
 }
 
@@ -324,13 +344,20 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.rows_per_split = cdiv(cdiv(M, p.nsplit), mstep) * mstep;
   p.nsplit = cdiv(M, p.rows_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (p.nsplit == 1 && beta == 0.f) p.slabs = dw;            // a single slab IS the result: written in place, no second kernel
   const dim3 grid(cdiv(Cout, WB) * cdiv(K, WB), p.nsplit);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(conv_wgrad16_kernel<bf16_t>, grid, dim3(256), 0, s, p);
   else if (dtype == CFP_F16) hipLaunchKernelGGL(conv_wgrad16_kernel<f16_t>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
   const long long n = (long long)Cout * K;
-  int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+  if (p.nsplit > 1 || beta != 0.f) {
+    // enough workgroups first, then as few split lanes as that allows
+    const int ew = (n >= 256 * 512 || p.nsplit < 8) ? 256 : (n >= 64 * 512 || p.nsplit < 32) ? 64 : 32;
+    const int blocks = (int)std::min<long long>(2048, (n + ew - 1) / ew);
+    if (ew == 256) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+    else if (ew == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+  }
   return cfp_check_launch("cfp_conv2d_wgrad");
 }
 

@@ -348,17 +348,32 @@ __global__ __launch_bounds__(256) void dwlarge_wgrad_kernel(const T* __restrict_
   }
 }
 
-// dw[c][tap] = beta * dw + sum over tiles (b, ty, tx) of partial[tile][cv][tap][e]
+// dw[c][tap] = beta * dw + sum over tiles (b, ty, tx) of partial[tile][cv][tap][e]; 64 outputs per workgroup, 4 lanes over the
+// tiles with 4 loads in flight each (a chain of hundreds of dependent adds per output otherwise), combined in lane order.
 __global__ __launch_bounds__(256) void dwlarge_wgrad_reduce_kernel(const float* __restrict__ partial, int ntiles, int CV, int VE, int KK,
                                                                    float* __restrict__ dw, float beta) {
-  const int i = blockIdx.x * 256 + threadIdx.x;     // over C * KK, laid out [c][tap]
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;     // over C * KK, laid out [c][tap]
   const int C = CV * VE;
-  if (i >= C * KK) return;
-  const int c = i / KK, tap = i - c * KK;
-  const int cv = c / VE, e = c - cv * VE;
-  float s = 0.f;
-  for (int t = 0; t < ntiles; ++t) s += partial[(((long long)t * CV + cv) * KK + tap) * VE + e];
-  dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+  const bool ok = i < C * KK;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ok) {
+    const int c = i / KK, tap = i - c * KK;
+    const int cv = c / VE, e = c - cv * VE;
+    const long long off = ((long long)cv * KK + tap) * VE + e, ts = (long long)CV * KK * VE;
+    int t = sl;
+    for (; t + 12 < ntiles; t += 16) {
+      s0 += partial[t * ts + off]; s1 += partial[(t + 4) * ts + off]; s2 += partial[(t + 8) * ts + off]; s3 += partial[(t + 12) * ts + off];
+    }
+    for (; t < ntiles; t += 4) s0 += partial[t * ts + off];
+  }
+  red[sl][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && ok) {
+    const float s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+  }
 }
 
 template <typename T, int K>
@@ -401,7 +416,7 @@ extern "C" int cfp_dwconv_large_wgrad(const void* x, int x_ld, const void* dy, i
 #undef LK
   if (e != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_wgrad: ") + hipGetErrorString(e)); return CFP_EHIP; }
   const int ntiles = B * cdiv(H, LWT) * cdiv(W, LWT);
-  hipLaunchKernelGGL(dwlarge_wgrad_reduce_kernel, dim3(cdiv((long long)C * k * k, 256)), dim3(256), 0, s, partial, ntiles, C / ve, ve, k * k, dw,
+  hipLaunchKernelGGL(dwlarge_wgrad_reduce_kernel, dim3(cdiv((long long)C * k * k, 64)), dim3(256), 0, s, partial, ntiles, C / ve, ve, k * k, dw,
                      beta);
   return cfp_check_launch("cfp_dwconv_large_wgrad");
 }
