@@ -23,22 +23,24 @@ constexpr int ACH = 128;     // token rows per LDS chunk
 __device__ __forceinline__ float elu1_grad(float x) { return x > 0.f ? 1.f : expf(x); }
 __device__ __forceinline__ float elu1p(float x) { return x > 0.f ? x + 1.f : expf(x); }      // full-precision elu(x)+1 (training parity)
 
-template <int D>
+// NT threads per workgroup (256, or one wave for groups of at most 64 tokens), RCH token rows per LDS chunk
+template <int D, int NT>
 struct Outer {
   static constexpr int NO = D * (D + 1);
-  static constexpr int G = NO >= 256 ? 1 : 256 / NO;
-  static constexpr int OPT = (NO + 255) / 256;
+  static constexpr int G = NO >= NT ? 1 : NT / NO;
+  static constexpr int OPT = (NO + NT - 1) / NT;
+  static constexpr int RCH = NT == 64 ? 64 : ACH;
 };
 
 // acc += sum over the chunk's rows of X[r][i] * Y[r][j]   (sX: [ACH][D], sY: [ACH][D+1])
-template <int D>
-__device__ __forceinline__ void outer_accumulate(const float* sX, const float* sY, int nrows, float (&acc)[Outer<D>::OPT]) {
-  using O = Outer<D>;
+template <int D, int NT>
+__device__ __forceinline__ void outer_accumulate(const float* sX, const float* sY, int nrows, float (&acc)[Outer<D, NT>::OPT]) {
+  using O = Outer<D, NT>;
   const int tid = threadIdx.x;
   if (O::G == 1) {
 #pragma unroll
     for (int u = 0; u < O::OPT; ++u) {
-      const int o = tid + u * 256;
+      const int o = tid + u * NT;
       if (o < O::NO) {
         const int i = o / (D + 1), j = o - i * (D + 1);
         float a = acc[u];
@@ -58,14 +60,14 @@ __device__ __forceinline__ void outer_accumulate(const float* sX, const float* s
 }
 
 // combine the per-thread partial sums into sM[D][D+1]
-template <int D>
-__device__ __forceinline__ void outer_finish(const float (&acc)[Outer<D>::OPT], float* sRed, float* sM) {
-  using O = Outer<D>;
+template <int D, int NT>
+__device__ __forceinline__ void outer_finish(const float (&acc)[Outer<D, NT>::OPT], float* sRed, float* sM) {
+  using O = Outer<D, NT>;
   const int tid = threadIdx.x;
   if (O::G == 1) {
 #pragma unroll
     for (int u = 0; u < O::OPT; ++u) {
-      const int o = tid + u * 256;
+      const int o = tid + u * NT;
       if (o < O::NO) sM[o] = acc[u];
     }
   } else {
@@ -85,13 +87,14 @@ __device__ __forceinline__ void outer_finish(const float (&acc)[Outer<D>::OPT], 
 // axis is split over blockIdx.y instead: SPLIT 1 = the key phase of one chunk of S, partial KV to `partial`; SPLIT 2 = the
 // query phase of one chunk of L, which first adds the partials up in chunk order (so the result does not depend on the split
 // only through the fixed summation tree: bit-reproducible for a given shape).
-template <typename T, int D, int SPLIT>
-__global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+template <typename T, int D, int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void linattn_fwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
                                                           const T* __restrict__ v, int v_ld, T* __restrict__ out, int out_ld,
                                                           float* __restrict__ kv_save, int L, int S, int heads, float eps,
                                                           float* __restrict__ partial, int nchunks, int chunk_len) {
-  using O = Outer<D>;
-  __shared__ float sX[SPLIT == 2 ? 1 : ACH * D], sY[SPLIT == 2 ? 1 : ACH * (D + 1)], sM[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
+  using O = Outer<D, NT>;
+  constexpr int RCH = O::RCH;
+  __shared__ float sX[SPLIT == 2 ? 1 : RCH * D], sY[SPLIT == 2 ? 1 : RCH * (D + 1)], sM[O::NO], sRed[O::G > 1 ? O::G * O::NO : 1];
   const int tid = threadIdx.x;
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const float fS = (float)S;
@@ -99,10 +102,10 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
   for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
   const int s_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 1 ? min(S, s_begin + chunk_len) : (SPLIT == 2 ? 0 : S);
-  for (int s0 = s_begin; s0 < s_end; s0 += ACH) {
-    const int nr = min(ACH, s_end - s0);
+  for (int s0 = s_begin; s0 < s_end; s0 += RCH) {
+    const int nr = min(RCH, s_end - s0);
     __syncthreads();
-    for (int e = tid; e < nr * D; e += 256) {
+    for (int e = tid; e < nr * D; e += NT) {
       const int r = e / D, c = e - r * D;
       const long long row = (long long)n * S + s0 + r;
       sX[r * D + c] = elu1p(to_f32<T>(k[row * k_ld + h * D + c]));
@@ -110,28 +113,28 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
       if (c == 0) sY[r * (D + 1) + D] = 1.f;
     }
     __syncthreads();
-    outer_accumulate<D>(sX, sY, nr, acc);
+    outer_accumulate<D, NT>(sX, sY, nr, acc);
   }
   __syncthreads();
   if (SPLIT == 2) {
-    for (int e = tid; e < O::NO; e += 256) {
+    for (int e = tid; e < O::NO; e += NT) {
       float a = 0.f;
       for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
       sM[e] = a;
     }
     __syncthreads();
   } else {
-    outer_finish<D>(acc, sRed, sM);
+    outer_finish<D, NT>(acc, sRed, sM);
   }
   if (SPLIT == 1) {
-    for (int e = tid; e < O::NO; e += 256) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sM[e];
+    for (int e = tid; e < O::NO; e += NT) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sM[e];
     return;
   }
   if (SPLIT == 0 || blockIdx.y == 0)
-    for (int e = tid; e < O::NO; e += 256) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
+    for (int e = tid; e < O::NO; e += NT) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
   // queries: one token per thread
   const int l_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 2 ? min(L, l_begin + chunk_len) : L;
-  for (int l = l_begin + tid; l < l_end; l += 256) {
+  for (int l = l_begin + tid; l < l_end; l += NT) {
     const long long row = (long long)n * L + l;
     float Q[D];
     float den = eps;
@@ -150,28 +153,29 @@ __global__ __launch_bounds__(256) void linattn_fwd_kernel(const T* __restrict__ 
 
 // SPLIT as in the forward: 0 = both phases in one workgroup per (group, head); 1 = the query phase of one chunk of L (dq, partial
 // [dKV | dKsum] to `partial`); 2 = the key phase of one chunk of S after adding the partials up in chunk order.
-template <typename T, int D, int SPLIT>
-__global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+template <typename T, int D, int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void linattn_bwd_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
                                                           const T* __restrict__ v, int v_ld, const T* __restrict__ dout, int do_ld,
                                                           const float* __restrict__ kv_save, T* __restrict__ dq, int dq_ld,
                                                           T* __restrict__ dk, int dk_ld, T* __restrict__ dv, int dv_ld, int L, int S,
                                                           int heads, float eps, float* __restrict__ partial, int nchunks, int chunk_len) {
-  using O = Outer<D>;
-  __shared__ float sX[SPLIT == 2 ? 1 : ACH * D], sY[SPLIT == 2 ? 1 : ACH * (D + 1)], sM[SPLIT == 2 ? 1 : O::NO], sG[O::NO],
+  using O = Outer<D, NT>;
+  constexpr int RCH = O::RCH;
+  __shared__ float sX[SPLIT == 2 ? 1 : RCH * D], sY[SPLIT == 2 ? 1 : RCH * (D + 1)], sM[SPLIT == 2 ? 1 : O::NO], sG[O::NO],
       sRed[O::G > 1 ? O::G * O::NO : 1];
   const int tid = threadIdx.x;
   const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
   const float fS = (float)S;
   if (SPLIT != 2)
-    for (int e = tid; e < O::NO; e += 256) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
+    for (int e = tid; e < O::NO; e += NT) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
   float acc[O::OPT];
 #pragma unroll
   for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
   __syncthreads();
   // ---- queries: dq, and the rows (Q_l, dA_l, e_l) of the dKV / dKsum reduction
   const int l_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 1 ? min(L, l_begin + chunk_len) : (SPLIT == 2 ? 0 : L);
-  for (int l0 = l_begin; l0 < l_end; l0 += ACH) {
-    const int nr = min(ACH, l_end - l0);
+  for (int l0 = l_begin; l0 < l_end; l0 += RCH) {
+    const int nr = min(RCH, l_end - l0);
     __syncthreads();
     if (tid < nr) {
       const long long row = (long long)n * L + l0 + tid;
@@ -204,26 +208,26 @@ __global__ __launch_bounds__(256) void linattn_bwd_kernel(const T* __restrict__ 
       }
     }
     __syncthreads();
-    outer_accumulate<D>(sX, sY, nr, acc);
+    outer_accumulate<D, NT>(sX, sY, nr, acc);
   }
   __syncthreads();
   if (SPLIT == 2) {
-    for (int e = tid; e < O::NO; e += 256) {
+    for (int e = tid; e < O::NO; e += NT) {
       float a = 0.f;
       for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
       sG[e] = a;
     }
     __syncthreads();
   } else {
-    outer_finish<D>(acc, sRed, sG);          // sG = [dKV | dKsum]
+    outer_finish<D, NT>(acc, sRed, sG);          // sG = [dKV | dKsum]
   }
   if (SPLIT == 1) {
-    for (int e = tid; e < O::NO; e += 256) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sG[e];
+    for (int e = tid; e < O::NO; e += NT) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sG[e];
     return;
   }
   // ---- keys: dk, dv
   const int s_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 2 ? min(S, s_begin + chunk_len) : S;
-  for (int s = s_begin + tid; s < s_end; s += 256) {
+  for (int s = s_begin + tid; s < s_end; s += NT) {
     const long long row = (long long)n * S + s;
     float K[D], kr[D], val[D];
 #pragma unroll
@@ -294,13 +298,16 @@ extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld,
   const bool split = la_plan((long long)N * heads, S, L, &sp) && ws &&
                      ws_bytes >= (size_t)N * heads * sp.c1 * d * (d + 1) * sizeof(float);
   float* partial = reinterpret_cast<float*>(ws);
+  const bool wave = L <= 64 && S <= 64;      // zone / window groups of a few tokens: one wave per (group, head)
 #define L1(T, DD) do {                                                                                                              \
-    if (!split) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, \
-                                   v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);                                   \
+    if (!split && wave) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0, 64>), grid, dim3(64), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,      \
+                                           (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);             \
+    else if (!split) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0, 256>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,     \
+                                        (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);                \
     else {                                                                                                                          \
-      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 1>), dim3(grid.x, sp.c1), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
+      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
                          (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len1);                      \
-      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 2>), dim3(grid.x, sp.c2), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
+      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
                          (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len2);                      \
     }                                                                                                                               \
   } while (0)
@@ -323,13 +330,15 @@ extern "C" int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld,
   const bool split = la_plan((long long)N * heads, L, S, &sp) && ws &&
                      ws_bytes >= (size_t)N * heads * sp.c1 * d * (d + 1) * sizeof(float);
   float* partial = reinterpret_cast<float*>(ws);
+  const bool wave = L <= 64 && S <= 64;
 #define BARGS(T) (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, (const T*)dout, do_ld, state, (T*)dq, dq_ld, (T*)dk, dk_ld, (T*)dv, \
                  dv_ld, L, S, heads, eps
 #define L1(T, DD) do {                                                                                                              \
-    if (!split) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0>), grid, dim3(256), 0, s, BARGS(T), nullptr, 0, 0);                  \
+    if (!split && wave) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0, 64>), grid, dim3(64), 0, s, BARGS(T), nullptr, 0, 0);       \
+    else if (!split) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0, 256>), grid, dim3(256), 0, s, BARGS(T), nullptr, 0, 0);        \
     else {                                                                                                                          \
-      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 1>), dim3(grid.x, sp.c1), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len1);   \
-      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 2>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);   \
+      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len1);   \
+      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);   \
     }                                                                                                                               \
   } while (0)
 #define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)

@@ -101,22 +101,39 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ 
 }
 
 // dx = dy * gate[b][c] + add[b][c]      (squeeze-excite backward: gate path + the broadcast gradient of the mean)
+// A thread keeps its channel vector and walks rows (no index division per element); gate / add are re-read only when the
+// image changes.  2^colbits column lanes, the rest of the workgroup are row lanes; blockIdx.y = row chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy, int dy_ld, const float* __restrict__ gate,
                                                         const float* __restrict__ add, T* __restrict__ dx, int dx_ld, int HW, int C,
-                                                        long long rows) {
+                                                        int rows, int rows_per_chunk, int colbits) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
-    const long long b = r / HW;
-    float v[VE];
-    Vec<T>::load(dy + r * dy_ld + c, v);
+  const int cols = 1 << colbits, lanes = 256 >> colbits;
+  const int cl = threadIdx.x & (cols - 1), rl = threadIdx.x >> colbits;
+  const int c = (blockIdx.x * cols + cl) * VE;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float g[VE], a[VE];
+  int bcur = -1;
+  constexpr int U = 4;
+  for (int r = r0 + rl; r < r1; r += lanes * U) {
+    float v[U][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) v[e] = v[e] * gate[b * C + c + e] + (add ? add[b * C + c + e] : 0.f);
-    Vec<T>::store(dx + r * dx_ld + c, v);
+    for (int u = 0; u < U; ++u) Vec<T>::load(dy + (long long)min(r + u * lanes, r1 - 1) * dy_ld + c, v[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + u * lanes;
+      if (rr >= r1) continue;
+      const int b = rr / HW;
+      if (b != bcur) {
+        bcur = b;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { g[e] = gate[(long long)b * C + c + e]; a[e] = add ? add[(long long)b * C + c + e] : 0.f; }
+      }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[u][e] = v[u][e] * g[e] + a[e];
+      Vec<T>::store(dx + (long long)rr * dx_ld + c, v[u]);
+    }
   }
 }
 
@@ -299,9 +316,19 @@ extern "C" int cfp_bcast_fma(const void* dy, int dy_ld, const float* gate, const
   TM_COMMON("cfp_bcast_fma");
   CFP_REQUIRE(B > 0 && HW > 0 && C > 0 && C % ve == 0 && dy_ld % ve == 0 && dx_ld % ve == 0 && dy_ld >= C && dx_ld >= C, CFP_ESHAPE,
               "cfp_bcast_fma: bad shape");
-  const long long rows = (long long)B * HW;
-  const dim3 grid(ew_grid2(rows * (C / ve)));
-#define L(T) hipLaunchKernelGGL(bcast_fma_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, gate, add, (T*)dx, dx_ld, HW, C, rows)
+  CFP_REQUIRE((long long)B * HW < (1ll << 31), CFP_ESHAPE, "cfp_bcast_fma: too many rows");
+  const int rows = B * HW;
+  const int cv = C / ve;
+  int colbits = 0;
+  while ((1 << colbits) < cv && colbits < 5) ++colbits;                 // 1 .. 32 column lanes
+  const int lanes = 256 >> colbits;
+  const unsigned gx = (unsigned)cdiv(cv, 1 << colbits);
+  long long ns = std::max<long long>(1, 2048 / gx);                      // ~8 workgroups per CU over the launch
+  ns = std::min<long long>(ns, cdiv(rows, 4 * lanes));
+  ns = std::max<long long>(1, std::min<long long>(ns, 65535));
+  const int rpc = cdiv(rows, (int)ns);
+  const dim3 grid(gx, cdiv(rows, rpc));
+#define L(T) hipLaunchKernelGGL(bcast_fma_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, gate, add, (T*)dx, dx_ld, HW, C, rows, rpc, colbits)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_bcast_fma");

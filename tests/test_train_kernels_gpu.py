@@ -265,7 +265,7 @@ def test_bin_head_forward_backward(B, HW, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,L,S,heads,d", [(6, 49, 16, 4, 16), (3, 144, 144, 8, 4), (2, 1200, 30, 8, 16), (5, 36, 36, 8, 16), (2, 300, 130, 4, 32),
-                                           (4, 196, 16, 4, 8), (2, 884, 884, 4, 32), (2, 3536, 500, 4, 16), (130, 36, 16, 4, 8)])
+                                           (4, 196, 16, 4, 8), (2, 884, 884, 4, 32), (2, 3536, 500, 4, 16), (130, 36, 16, 4, 8), (3, 16, 16, 4, 32), (2, 64, 64, 8, 4)])
 def test_linear_attention_forward_backward(N, L, S, heads, d, dtype):
     from oracle import cfpnet_oracle as O
     q = rnd(N, L, heads, d, seed=1).to(dtype).float().requires_grad_(True)
