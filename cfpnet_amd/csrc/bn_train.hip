@@ -17,8 +17,11 @@
 
 namespace {
 
-constexpr int RC_COLS = 32;     // 16-byte vector columns per workgroup
-constexpr int RC_LANES = 8;     // row lanes per workgroup
+inline int rc_colbits(int C, int ve) {          // column lanes of the column reductions: 2^bits >= C / ve, at most 32
+  int b = 0;
+  while ((1 << b) < C / ve && b < 5) ++b;
+  return b;
+}
 
 // The training path uses the full-precision expf and true division: the inference kernels' v_exp_f32 / v_rcp_f32 forms carry
 // ~1e-6 relative error, which the batch-statistics BatchNorms of this network amplify into ~1e-2 of a gradient tensor.
@@ -46,12 +49,15 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x, int ld, const T* __restrict__ dy, int dy_ld, long long rows,
                                                         int C, const float* __restrict__ aux0, const float* __restrict__ aux1,
                                                         const float* __restrict__ aux2, const float* __restrict__ aux3, int act,
-                                                        float* __restrict__ partial, long long rows_per_split) {
+                                                        float* __restrict__ partial, long long rows_per_split, int colbits) {
   constexpr int VE = Vec<T>::N;
   constexpr int NS = MODE >= 2 ? 2 : 1;
-  __shared__ float red[RC_LANES][RC_COLS * 8 * 2];
+  __shared__ float red[256][8 * 2];
   const int tid = threadIdx.x;
-  const int cl = tid & (RC_COLS - 1), rl = tid / RC_COLS;
+  // 2^colbits column lanes (<= 32), the other threads are row lanes: narrow tensors (C = 16 .. 64 at full resolution, the most
+  // rows of the network) keep every lane busy instead of 1/8 of them
+  const int RC_COLS = 1 << colbits, RC_LANES = 256 >> colbits;
+  const int cl = tid & (RC_COLS - 1), rl = tid >> colbits;
   const int c0 = (blockIdx.x * RC_COLS + cl) * VE;
   const bool c_ok = c0 < C;
   const int cc = c_ok ? c0 : 0;
@@ -96,17 +102,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
     }
   }
 #pragma unroll
-  for (int e = 0; e < VE; ++e) { red[rl][(cl * 8 + e) * 2] = s1[e]; red[rl][(cl * 8 + e) * 2 + 1] = s2[e]; }
+  for (int e = 0; e < VE; ++e) { red[tid][e * 2] = s1[e]; red[tid][e * 2 + 1] = s2[e]; }
   __syncthreads();
-  // fixed-order combination of the 8 row lanes
+  // fixed-order combination of the row lanes
   for (int i = tid; i < RC_COLS * VE * NS; i += 256) {
     const int which = i / (RC_COLS * VE), k = i - which * (RC_COLS * VE);
     const int c_l = k / VE, e = k - c_l * VE;
     const int c = (blockIdx.x * RC_COLS + c_l) * VE + e;
     if (c >= C) continue;
     float s = 0.f;
-#pragma unroll
-    for (int l = 0; l < RC_LANES; ++l) s += red[l][(c_l * 8 + e) * 2 + which];
+    for (int l = 0; l < RC_LANES; ++l) s += red[(l << colbits) + c_l][e * 2 + which];
     partial[((long long)blockIdx.y * NS + which) * C + c] = s;
   }
 }
@@ -294,9 +299,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, i
 }
 
 inline int red_splits(long long rows, int C, int ve) {
-  const int colblk = cdiv(C, RC_COLS * ve);
+  const int colbits = rc_colbits(C, ve);
+  const int colblk = cdiv(C, ve << colbits);
   long long ns = 1024 / colblk;
-  const long long mx = (rows + 63) / 64;
+  const long long mx = (rows + 8 * (256 >> colbits) - 1) / (8 * (256 >> colbits));      // at least 8 rows per row lane
   if (ns > mx) ns = mx;
   if (ns > 4096) ns = 4096;
   if (ns < 1) ns = 1;
@@ -327,9 +333,10 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
   const int ns = red_splits(rows, C, ve);
   const long long rps = (rows + ns - 1) / ns;
   const int nsplit = (int)((rows + rps - 1) / rps);
-  const dim3 grid(cdiv(C, RC_COLS * ve), nsplit);
+  const int colbits = rc_colbits(C, ve);
+  const dim3 grid(cdiv(C, ve << colbits), nsplit);
 #define RL(T) hipLaunchKernelGGL((colreduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)x, ld, (const T*)dy, dy_ld, rows, C, a0, a1, a2, a3, \
-                                 act, partial, rps)
+                                 act, partial, rps, colbits)
   if (dtype == CFP_BF16) RL(bf16_t); else if (dtype == CFP_F16) RL(f16_t); else RL(float);
 #undef RL
   const int nsum = MODE >= 2 ? 2 : 1;
