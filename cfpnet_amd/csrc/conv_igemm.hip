@@ -203,31 +203,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Few-row f32 GEMM: out[m, n] = act(scale[n] * sum_k x[m, k] w[n, k] + shift[n]) (+ res) for M <= 64 rows -- the squeeze-excite
 // FCs of the training step on [B, C] vectors and their data gradients, where a 128x64 tile leaves one or two workgroups walking
-// K alone (31 us per call).  One wave per output column: the lanes split K in 16-byte pieces (the weight row is read once,
-// the <= 16 input rows come from L2), partial sums meet in a wave reduction; 4 columns per workgroup.
+// K alone (31 us per call).  WPC waves per output column split K in 16-byte pieces (the weight row is read once, the <= 16
+// input rows come from L2; all 17 loads of a step are issued before the first FMA), partial sums meet in a wave reduction and,
+// for WPC = 4 (long K, few columns), in LDS in wave order.  256 threads = 4 / WPC columns per workgroup.
+template <int WPC>
 __global__ __launch_bounds__(256) void rowgemm_f32_kernel(ConvP p) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= p.Cout) return;
+  __shared__ float red[4][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = WPC == 4 ? blockIdx.x : blockIdx.x * 4 + wave;
+  const bool n_ok = n < p.Cout;
+  const int nn = n_ok ? n : 0;
   const float* __restrict__ x = reinterpret_cast<const float*>(p.in);
-  const float* __restrict__ w = reinterpret_cast<const float*>(p.w) + (long long)n * p.K;
+  const float* __restrict__ w = reinterpret_cast<const float*>(p.w) + (long long)nn * p.K;
   const float* __restrict__ res = reinterpret_cast<const float*>(p.res);
   float* __restrict__ out = reinterpret_cast<float*>(p.out);
-  const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+  const float sc = p.scale ? p.scale[nn] : 1.f, sh = p.shift ? p.shift[nn] : 0.f;
+  const int kstart = (WPC == 4 ? threadIdx.x : lane) * 4, kstep = WPC == 4 ? 1024 : 256;
   for (int m0 = 0; m0 < p.M; m0 += 16) {
     const int mc = min(16, p.M - m0);
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int k = lane * 4; k < p.K; k += 256) {
+    for (int k = kstart; k < p.K; k += kstep) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+      f32x4 xv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (i < mc) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long long)(m0 + i) * p.in_ld + k);
-          acc[i] = fmaf(xv[0], wv[0], fmaf(xv[1], wv[1], fmaf(xv[2], wv[2], fmaf(xv[3], wv[3], acc[i]))));
-        }
-      }
+      for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const f32x4*>(x + (long long)(m0 + min(i, mc - 1)) * p.in_ld + k);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(xv[i][0], wv[0], fmaf(xv[i][1], wv[1], fmaf(xv[i][2], wv[2], fmaf(xv[i][3], wv[3], acc[i]))));
     }
     float mine = 0.f;
 #pragma unroll
@@ -235,7 +238,13 @@ __global__ __launch_bounds__(256) void rowgemm_f32_kernel(ConvP p) {
       const float t = wave_sum(acc[i]);
       if (lane == i) mine = t;
     }
-    if (lane < mc) {
+    if (WPC == 4) {
+      if (m0 > 0) __syncthreads();
+      if (lane < 16) red[wave][lane] = mine;
+      __syncthreads();
+      mine = lane < 16 ? ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane] : 0.f;
+    }
+    if (lane < mc && n_ok && (WPC == 1 || wave == 0)) {
       float v = 0.f;
       with_act(p.act, [&](auto A) { v = act_c<decltype(A)::value>(mine * sc + sh); });
       const long long m = m0 + lane;
@@ -475,7 +484,8 @@ gen1_path:
   // first-generation kernels (f32 parity mode, short-K bf16): per-image weights run image by image,
   // LayerNorm as a second kernel
   if (dtype == CFP_F32 && p.pointwise && p.M <= 64 && !per_image_weights && !ln_gamma && !g_use_v1) {
-    hipLaunchKernelGGL(rowgemm_f32_kernel, dim3(cdiv(Cout, 4)), dim3(256), 0, s, p);
+    if (p.K >= 512 && Cout <= 1024) hipLaunchKernelGGL(rowgemm_f32_kernel<4>, dim3(Cout), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(rowgemm_f32_kernel<1>, dim3(cdiv(Cout, 4)), dim3(256), 0, s, p);
     return cfp_check_launch("cfp_conv2d_nhwc");
   }
   if (ln_gamma) p.res = nullptr;
