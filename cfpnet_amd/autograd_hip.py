@@ -33,12 +33,14 @@ class V:
 class P(V):
     """A parameter: `t` in the layout the kernels want, `g` accumulated in float32 in the same layout;
     `to_torch(g)` converts a gradient back to the reference's state_dict layout."""
-    __slots__ = ("name", "to_torch", "gview")
+    __slots__ = ("name", "to_torch", "gview", "wt", "geom")
 
     def __init__(self, name: str, t: torch.Tensor, to_torch: Callable[[torch.Tensor], torch.Tensor], gview: Optional[torch.Tensor] = None):
         super().__init__(t, True)
         self.name, self.to_torch = name, to_torch
         self.gview = gview          # preallocated (zeroed) float32 gradient in the kernel layout: kernels write into it directly
+        self.wt = None              # conv weights: the flipped copy for the data gradient, when the trainer refreshes all of them in one launch
+        self.geom = None            # conv weights whose data gradient is needed: (Cout, KH, KW, Cin), recorded by Tape.conv
 
 
 def _act(t: torch.Tensor) -> ops.Act:
@@ -118,7 +120,8 @@ class Tape:
                 self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
             self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
             if x.needs_grad:
-                wt = train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
+                w.geom = (Cout, k, k, x.C)
+                wt = w.wt if w.wt is not None else train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
                 self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y

@@ -303,6 +303,34 @@ __global__ __launch_bounds__(256) void weight_flip_kernel(const T* __restrict__ 
   }
 }
 
+// Every convolution's flipped copy in ONE launch (the training step flips ~290 weight tensors per step, 5 us each when launched
+// one by one).  desc[t] = {src offset, dst offset (elements from the base pointers), Cout, KH, KW, Cin, first block, blocks};
+// a workgroup finds its tensor by bisection over the first-block column and flips FLIP_PER_BLOCK consecutive outputs of it.
+constexpr int FLIP_PER_BLOCK = 2048;
+template <typename T>
+__global__ __launch_bounds__(256) void weight_flip_batch_kernel(const T* __restrict__ src, T* __restrict__ dst, const long long* __restrict__ desc,
+                                                                int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * 8 + 6] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + lo * 8;
+  const T* __restrict__ w = src + d[0];
+  T* __restrict__ wt = dst + d[1];
+  const int Cout = (int)d[2], KH = (int)d[3], KW = (int)d[4], Cin = (int)d[5];
+  const long long total = (long long)Cout * KH * KW * Cin;
+  const long long i0 = ((long long)blockIdx.x - d[6]) * FLIP_PER_BLOCK;
+  for (long long i = i0 + threadIdx.x; i < min(total, i0 + FLIP_PER_BLOCK); i += 256) {
+    const int co = (int)(i % Cout);
+    long long t = i / Cout;
+    const int kw2 = (int)(t % KW); t /= KW;
+    const int kh2 = (int)(t % KH);
+    const int ci = (int)(t / KH);
+    wt[i] = w[(((long long)co * KH + (KH - 1 - kh2)) * KW + (KW - 1 - kw2)) * Cin + ci];
+  }
+}
+
 inline int wgrad_nsplit(int Cout, int K, int M) {
   const long long tiles = (long long)cdiv(Cout, WB) * cdiv(K, WB);
   long long ns = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total; every split costs a slab to add up
@@ -375,4 +403,20 @@ extern "C" int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH,
     hipLaunchKernelGGL(weight_flip_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, (const unsigned short*)w, (unsigned short*)wt,
                        Cout, KH, KW, Cin);
   return cfp_check_launch("cfp_conv2d_weight_flip");
+}
+
+extern "C" int cfp_weight_flip_blocks(long long elems) { return elems > 0 ? (int)((elems + FLIP_PER_BLOCK - 1) / FLIP_PER_BLOCK) : 0; }
+
+extern "C" int cfp_conv2d_weight_flip_batch(const void* src_base, void* dst_base, const long long* desc, int n, int total_blocks, int dtype,
+                                            cfp_stream_t stream) {
+  CFP_REQUIRE(src_base && dst_base && desc && src_base != dst_base, CFP_EINVAL, "cfp_conv2d_weight_flip_batch: bad pointer");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_weight_flip_batch: bad dtype");
+  CFP_REQUIRE(n > 0 && total_blocks > 0, CFP_ESHAPE, "cfp_conv2d_weight_flip_batch: empty batch");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_F32)
+    hipLaunchKernelGGL(weight_flip_batch_kernel<float>, dim3(total_blocks), dim3(256), 0, s, (const float*)src_base, (float*)dst_base, desc, n);
+  else
+    hipLaunchKernelGGL(weight_flip_batch_kernel<unsigned short>, dim3(total_blocks), dim3(256), 0, s, (const unsigned short*)src_base,
+                       (unsigned short*)dst_base, desc, n);
+  return cfp_check_launch("cfp_conv2d_weight_flip_batch");
 }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libcfpnet_hip.so")
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
 
-_p, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_p, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
 # name -> (restype, argtypes); must list every symbol of include/cfpnet_hip.h
 SIGNATURES = {
@@ -63,6 +63,8 @@ SIGNATURES = {
     "cfp_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "cfp_conv2d_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 12 + [_f, _i, _p, _sz, _p]),
     "cfp_conv2d_weight_flip": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_weight_flip_blocks": (_i, [_ll]),
+    "cfp_conv2d_weight_flip_batch": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "cfp_conv2d_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
     "cfp_bn_ws_bytes": (_sz, [_i]),
     "cfp_bn_train_stats": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _f, _f] + [_p] * 7 + [_p, _sz, _p]),

@@ -62,6 +62,7 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self.flipped: Dict[str, torch.Tensor] = {}        # bound mode: name -> flipped conv weight, refreshed by the trainer every step
         self._bound = None                                # (FlatParams in kernel layouts, 16-bit shadow) once `bind` was called
         self.discovered: Optional[Dict[str, tuple]] = None    # set to {} to collect name -> (float32 kernel layout, to_torch, is16)
         self.record: Optional[Dict[str, V]] = None       # debugging: name -> tape value (tools/train_grad_check.py compares their .g)
@@ -78,6 +79,7 @@ class TrainNet:
                 s = flat._by_name[name]
                 src = shadow if (is16 and shadow is not None) else flat.param
                 p = P(name, src[s.start:s.start + s.numel].view(s.shape), to_torch, gview=flat.view(name, "grad"))
+                p.wt = self.flipped.get(name)
             else:
                 t32 = make32().contiguous().to(self.dev)
                 if self.discovered is not None:

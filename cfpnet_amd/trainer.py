@@ -34,6 +34,7 @@ class Trainer:
         self._opt_kw = dict(lr=lr, total_steps=total_steps, div_factor=div_factor, final_div_factor=final_div_factor, weight_decay=weight_decay,
                             clip_grad_norm=clip_grad_norm)
         self._shadow, self._to_torch = None, None
+        self._flip_jobs = None           # [(source buffer, flipped buffer, device descriptors, n, workgroups, dtype code)]
         self.dist, self.world = dist, world
         names = [(k, tuple(v.shape)) for k, v in state_dict.items()
                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
@@ -72,6 +73,40 @@ class Trainer:
         self.opt = train_ops.FlatAdamW(kflat, train_ops.OneCycle(k["lr"], k["total_steps"], k["div_factor"], k["final_div_factor"]),
                                        weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"])
 
+    def _plan_weight_flips(self) -> None:
+        """After the first bound step every convolution whose data gradient is needed has recorded its geometry: from now on
+        their flipped copies ([Cin][KH][KW][Cout], both kernel axes reversed) are refreshed by ONE launch per storage type at the
+        start of the step instead of one launch per convolution in the backward."""
+        from . import hip, ops
+        lib = hip.load()
+        jobs = []
+        sources = ([self._shadow] if self._shadow is not None else []) + [self.flat.param]      # 16-bit operands / float32 ones
+        for src in sources:
+            rows, off, blocks = [], 0, 0
+            for name, p in self.net.P.items():
+                if p.geom is None or p.t.dtype != src.dtype:
+                    continue
+                co, kh, kw, ci = p.geom
+                n = co * kh * kw * ci
+                assert n == p.t.numel(), name
+                nb = int(lib.cfp_weight_flip_blocks(n))
+                rows.append((name, [self.flat._by_name[name].start, off, co, kh, kw, ci, blocks, nb], (ci, kh * kw * co)))
+                off += (n + 7) // 8 * 8
+                blocks += nb
+            if not rows:
+                continue
+            dst = torch.empty(off, dtype=src.dtype, device=self.dev)
+            desc = torch.tensor([r[1] for r in rows], dtype=torch.int64).to(self.dev)
+            for name, d, shape in rows:
+                self.net.flipped[name] = dst[d[1]:d[1] + shape[0] * shape[1]].view(shape)
+            jobs.append((src, dst, desc, len(rows), blocks, ops.DT[src.dtype]))
+        self._flip_jobs = jobs
+
+    def _refresh_weight_flips(self) -> None:
+        from . import hip
+        for src, dst, desc, n, blocks, dt in self._flip_jobs:
+            hip.call("cfp_conv2d_weight_flip_batch", src.data_ptr(), dst.data_ptr(), desc.data_ptr(), n, blocks, dt, hip.current_stream())
+
     def param(self, name: str) -> torch.Tensor:
         """Parameter `name` in the reference's layout (a copy when the master is kept in kernel layout)."""
         if self._to_torch is not None and name in self._to_torch:
@@ -96,7 +131,11 @@ class Trainer:
         if self._to_torch is not None:
             if self._shadow is not None:
                 self._shadow.copy_(self.flat.param)                 # the one cast of the step
+            if self._flip_jobs is not None:
+                self._refresh_weight_flips()
             loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
+            if self._flip_jobs is None:
+                self._plan_weight_flips()
             return loss                                             # every gradient is already at its flat address
         loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
         self.flat.grad.zero_()

@@ -332,6 +332,13 @@ int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
                      size_t ws_bytes, cfp_stream_t stream);
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: the weights the data gradient convolves with. */
 int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream);
+/* The same for n weight tensors in one launch (a training step flips every convolution's weights once).  `desc` is a DEVICE
+ * array of n rows of 8 int64: {source offset, destination offset (elements from src_base / dst_base), Cout, KH, KW, Cin,
+ * first workgroup, workgroups}; a tensor of E elements takes cfp_weight_flip_blocks(E) workgroups, rows sorted by first
+ * workgroup, total_blocks = their sum. */
+int cfp_weight_flip_blocks(long long elems);
+int cfp_conv2d_weight_flip_batch(const void* src_base, void* dst_base, const long long* desc, int n, int total_blocks, int dtype,
+                                 cfp_stream_t stream);
 /* Data gradient: dx [B,H,W,Cin] (+= when accumulate) from dy [B,Ho,Wo,Cout] and the flipped weights, for the forward
  * geometry (KH,KW,stride,pad_t,pad_l): a stride-1 convolution over dy with `stride - 1` zeros stuffed between its pixels. */
 int cfp_conv2d_dgrad(const void* dy, int dy_ld, const void* wt, void* dx, int dx_ld, int B, int H, int W, int Cin, int Cout,

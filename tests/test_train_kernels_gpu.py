@@ -305,3 +305,28 @@ def test_large_depthwise_weight_gradient(B, H, W, C, k, dtype):
     torch.cuda.synchronize()
     want = w.grad[:, 0]
     assert float((dw.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_weight_flip_equals_the_single_launches(dtype):
+    """cfp_conv2d_weight_flip_batch: every tensor of a flat parameter buffer flipped in one launch == one launch per tensor."""
+    geoms = [(40, 3, 3, 16), (8, 1, 1, 264), (128, 1, 1, 128), (24, 7, 7, 8), (256, 3, 3, 392), (16, 1, 1, 8)]
+    lib = hip.load()
+    src_parts, rows, off_s, off_d, blocks = [], [], 0, 0, 0
+    for i, (co, kh, kw, ci) in enumerate(geoms):
+        n = co * kh * kw * ci
+        src_parts.append(rnd(n + 24, seed=10 + i).to(dtype))                   # gaps between the tensors, as in the flat buffer
+        nb = int(lib.cfp_weight_flip_blocks(n))
+        rows.append([off_s + 8, off_d, co, kh, kw, ci, blocks, nb])
+        off_s += n + 24; off_d += (n + 7) // 8 * 8; blocks += nb
+    src = torch.cat(src_parts).to(DEV)
+    dst = torch.zeros(off_d, dtype=dtype, device=DEV)
+    desc = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    hip.call("cfp_conv2d_weight_flip_batch", src.data_ptr(), dst.data_ptr(), desc.data_ptr(), len(rows), blocks, ops.DT[dtype], hip.current_stream())
+    torch.cuda.synchronize()
+    for (co, kh, kw, ci), r in zip(geoms, rows):
+        n = co * kh * kw * ci
+        w = src[r[0]:r[0] + n].clone().view(co, kh * kw * ci)
+        want = train_ops.conv2d_weight_flip(w, co, kh, kw, ci)
+        ref = w.view(co, kh, kw, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, kh * kw * co)
+        assert torch.equal(want, ref) and torch.equal(dst[r[1]:r[1] + n].view(ci, kh * kw * co), want)
