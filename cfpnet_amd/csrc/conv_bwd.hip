@@ -143,11 +143,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 // 16-bit inputs on the 16-bit matrix cores (v_mfma_f32_16x16x32_bf16/_f16): the tiles are staged as they lie in memory
 // ([pixel row][channel]) and the operands -- which want the pixel axis along k -- are read with the hardware transpose
 // read ds_read_b64_tr_b16 (a 16-lane group fetches 4 rows x 16 columns and every lane receives one column of it).
-constexpr int W16M = 64;            // pixel rows per staging step (two k = 32 MFMA steps)
+constexpr int W16M = 128;           // pixel rows per staging step (four k = 32 MFMA steps per barrier pair)
 constexpr int W16P = WB + 8;        // LDS row pitch in elements (144 B: 16-byte aligned rows, 2-way bank conflicts at worst)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-template <typename H>
+// PW: pointwise stride-1 convolution / Linear (the majority of the layers): im2col row m IS input row m, no (b, ho, wo) split.
+template <typename H, bool PW>
 __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
   __shared__ __attribute__((aligned(16))) unsigned short sD[W16M * W16P];    // dY tile  [m][co]
   __shared__ __attribute__((aligned(16))) unsigned short sX[W16M * W16P];    // im2col tile [m][k']
@@ -184,12 +185,20 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
       const int m = m0 + s_row[i];
       const bool m_ok = m < m_end;
       const int mm = m_ok ? m : m_begin;
-      const int b = mm / HoWo, r = mm - b * HoWo;
-      const int ho = r / p.Wo, wo = r - ho * p.Wo;
-      const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
-      const bool in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(X + ((long long)(b * p.H + hic) * p.W + wic) * p.x_ld + (k_ok[i] ? x_ci[i] : 0));
+      bool in_ok;
+      long long xrow;
+      if (PW) {
+        in_ok = m_ok && k_ok[i];
+        xrow = mm;
+      } else {
+        const int b = mm / HoWo, r = mm - b * HoWo;
+        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
+        in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
+        xrow = (long long)(b * p.H + hic) * p.W + wic;
+      }
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(X + xrow * p.x_ld + (k_ok[i] ? x_ci[i] : 0));
       const u32x4 vd = *reinterpret_cast<const u32x4*>(DY + (long long)mm * p.dy_ld + (co_ok[i] ? co0 + s_col[i] : 0));
       rX[i] = in_ok ? vx : zero4;
       rD[i] = (m_ok && co_ok[i]) ? vd : zero4;
@@ -374,8 +383,11 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.nsplit == 1 && beta == 0.f) p.slabs = dw;            // a single slab IS the result: written in place, no second kernel
   const dim3 grid(cdiv(Cout, WB) * cdiv(K, WB), p.nsplit);
-  if (dtype == CFP_BF16) hipLaunchKernelGGL(conv_wgrad16_kernel<bf16_t>, grid, dim3(256), 0, s, p);
-  else if (dtype == CFP_F16) hipLaunchKernelGGL(conv_wgrad16_kernel<f16_t>, grid, dim3(256), 0, s, p);
+  const bool pw = KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W;
+  if (dtype == CFP_BF16 && pw) hipLaunchKernelGGL((conv_wgrad16_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
+  else if (dtype == CFP_BF16) hipLaunchKernelGGL((conv_wgrad16_kernel<bf16_t, false>), grid, dim3(256), 0, s, p);
+  else if (dtype == CFP_F16 && pw) hipLaunchKernelGGL((conv_wgrad16_kernel<f16_t, true>), grid, dim3(256), 0, s, p);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL((conv_wgrad16_kernel<f16_t, false>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
   const long long n = (long long)Cout * K;
   if (p.nsplit > 1 || beta != 0.f) {
