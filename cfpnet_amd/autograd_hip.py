@@ -51,10 +51,14 @@ def _act(t: torch.Tensor) -> ops.Act:
 
 
 class Tape:
-    def __init__(self, device, dtype=torch.float32):
+    def __init__(self, device, dtype=torch.float32, side: Optional[torch.cuda.Stream] = None):
+        """`side`: a second stream for the parameter-gradient kernels (weight / bias gradients): nothing later in the backward
+        reads them, so they leave the critical path dY -> dX -> ... and run beside it (forked and joined inside a captured step
+        as graph edges).  Every tensor they read stays referenced by the tape until `backward()` has joined the streams."""
         self.dev, self.dtype = torch.device(device), dtype
         self.bw: List[Callable[[], None]] = []
         self._const: Dict[Tuple[str, int], torch.Tensor] = {}
+        self.side, self._forked = side, False
 
     # ------------------------------------------------------------------ helpers
     def new(self, rows: int, C: int, dtype=None) -> torch.Tensor:
@@ -100,9 +104,23 @@ class Tape:
         else:
             self.pgrad(p, lambda out, b: train_ops.into(g, out, b))
 
+    def off_path(self, fn: Callable[[], None]) -> None:
+        """Run `fn` (parameter-gradient kernels of the op whose backward is executing) on the side stream, after everything
+        issued so far on the current stream."""
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            fn()
+        self._forked = True
+
     def backward(self) -> None:
         for f in reversed(self.bw):
             f()
+        if self._forked:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._forked = False
         self.bw = []
 
     # ------------------------------------------------------------------ dense conv / linear
@@ -116,9 +134,11 @@ class Tape:
             g = y.g
             if g is None:
                 return
-            if bias is not None:
-                self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
-            self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
+            def param_grads():
+                if bias is not None:
+                    self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
+                self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
+            self.off_path(param_grads)
             if x.needs_grad:
                 w.geom = (Cout, k, k, x.C)
                 wt = w.wt if w.wt is not None else train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
@@ -189,7 +209,7 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
+            self.off_path(lambda: self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta)))
             self.acc(x, train_ops.dwconv3x3_dgrad(y.g, w.t, B, H, W, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y
@@ -204,8 +224,10 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.pgrad(bias, lambda out, beta: train_ops.colsum(y.g, out=out, beta=beta))
-            self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k, dw=out, beta=beta))
+            def param_grads():
+                self.pgrad(bias, lambda out, beta: train_ops.colsum(y.g, out=out, beta=beta))
+                self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k, dw=out, beta=beta))
+            self.off_path(param_grads)
             wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)          # data gradient = correlation with the flipped kernel
             dx = torch.empty_like(x.t)
             ops.dwconv_large(_act(y.g), wf, self.const("ones", C), self.const("zeros", C), _act(dx), B, H, W, k, hip.ACT_NONE)

@@ -62,6 +62,7 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self.side_stream: Optional[torch.cuda.Stream] = None      # set by the trainer: parameter gradients beside the dY -> dX chain
         self.flipped: Dict[str, torch.Tensor] = {}        # bound mode: name -> flipped conv weight, refreshed by the trainer every step
         self._bound = None                                # (FlatParams in kernel layouts, 16-bit shadow) once `bind` was called
         self.discovered: Optional[Dict[str, tuple]] = None    # set to {} to collect name -> (float32 kernel layout, to_torch, is16)
@@ -426,7 +427,7 @@ class TrainNet:
         """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
         gradients are in `self.grads()`, running statistics in `self.buf`."""
         dev = self.dev
-        t = Tape(dev, self.dtype)
+        t = Tape(dev, self.dtype, side=self.side_stream)
         pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
         # SILog (loss.py:9-19) on the half-resolution prediction against the full-resolution target
         crit = train_ops.SILogLoss()

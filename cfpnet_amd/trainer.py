@@ -25,7 +25,7 @@ class Trainer:
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
                  change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True,
-                 base_resolution=spec.BASE_RESOLUTION):
+                 base_resolution=spec.BASE_RESOLUTION, overlap_param_grads: bool = False):
         self.dev = torch.device(device)
         self.dtype, self.kernel_layout, self._hist10 = dtype, kernel_layout, hist_encoder_10x
         self._net_kw = dict(n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
@@ -50,6 +50,8 @@ class Trainer:
                                        clip_grad_norm=clip_grad_norm)
         self.min_val = min_val
         self._graph = None
+        if overlap_param_grads:        # measured SLOWER inside a captured step (48.8 vs 45.2 ms): off by default, see DESIGN 4.0
+            self.net.side_stream = torch.cuda.Stream(device=self.dev)
 
     def _bind_kernel_layout(self, input_data: dict, offs) -> None:
         """First batch: one forward on a scratch copy of the network records every live parameter's kernel layout (they
