@@ -116,6 +116,107 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
   }
 }
 
+// ---- batch statistics in ONE pass over x ---------------------------------------------------------------------------------
+// (count, mean, M2 = sum (x - mean)^2) triples merge exactly (Chan et al.):  n = nA + nB, d = mB - mA,
+//   mean = mA + d * nB / n,   M2 = M2A + M2B + d^2 * nA * nB / n.
+// A thread sums (x - c) and (x - c)^2 with c = the first value IT reads (a sample of the same channel, so |mean - c| is a few
+// standard deviations at most and s2 - s1^2/n loses no more than a few ulps -- the textbook E[x^2] - E[x]^2 cancellation needs
+// |mean| >> std relative to the shift), converts to a triple, and triples are merged in fixed orders: row lanes in LDS, row
+// splits by one wave per channel.  Same tolerance as the two-pass form in the tests, one read of x instead of two.
+struct Mom { float n, mean, m2; };
+__device__ __forceinline__ Mom mom_merge(const Mom& a, const Mom& b) {
+  const float n = a.n + b.n;
+  if (n == 0.f) return Mom{0.f, 0.f, 0.f};
+  const float d = b.mean - a.mean, f = b.n / n;
+  return Mom{n, a.mean + d * f, a.m2 + b.m2 + d * d * a.n * f};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colmoments_kernel(const T* __restrict__ x, int ld, long long rows, int C, float* __restrict__ partial,
+                                                         long long rows_per_split, int colbits) {
+  constexpr int VE = Vec<T>::N;
+  __shared__ float red[256][8 * 2];
+  __shared__ float cnt[256];
+  const int tid = threadIdx.x;
+  const int cols = 1 << colbits, lanes = 256 >> colbits;
+  const int cl = tid & (cols - 1), rl = tid >> colbits;
+  const int c0 = (blockIdx.x * cols + cl) * VE;
+  const int cc = c0 < C ? c0 : 0;
+  const long long r0 = (long long)blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+  float sh[VE], s1[VE], s2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  Vec<T>::load(x + min(r0 + rl, r1 - 1) * ld + cc, sh);
+  float n = 0.f;
+  constexpr int U = 4;
+  for (long long r = r0 + rl; r < r1; r += lanes * U) {
+    float v[U][VE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) Vec<T>::load(x + min(r + (long long)u * lanes, r1 - 1) * ld + cc, v[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r + (long long)u * lanes >= r1) continue;
+      n += 1.f;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { const float d = v[u][e] - sh[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+    }
+  }
+  const float inv = n > 0.f ? 1.f / n : 0.f;
+#pragma unroll
+  for (int e = 0; e < VE; ++e) {
+    const float m = s1[e] * inv;
+    red[tid][e * 2] = sh[e] + m;                       // the thread's mean
+    red[tid][e * 2 + 1] = fmaxf(s2[e] - s1[e] * m, 0.f);   // and M2
+  }
+  cnt[tid] = n;
+  __syncthreads();
+  for (int i = tid; i < cols * VE; i += 256) {
+    const int c_l = i / VE, e = i - c_l * VE;
+    const int c = (blockIdx.x * cols + c_l) * VE + e;
+    if (c >= C) continue;
+    Mom a{0.f, 0.f, 0.f};
+    for (int l = 0; l < lanes; ++l) {
+      const int t = (l << colbits) + c_l;
+      a = mom_merge(a, Mom{cnt[t], red[t][e * 2], red[t][e * 2 + 1]});
+    }
+    partial[((long long)blockIdx.y * 2 + 0) * C + c] = a.mean;
+    partial[((long long)blockIdx.y * 2 + 1) * C + c] = a.m2;
+  }
+}
+
+// One wave per channel merges the splits' triples (lanes stride over the splits, then a butterfly: a fixed tree), and finishes
+// the layer's constants in the same launch: mean, biased variance, 1/std, the folded scale / shift of the apply pass and the
+// running statistics (momentum update with the unbiased variance, like torch).
+__global__ __launch_bounds__(256) void colmoments_final_kernel(const float* __restrict__ partial, int nsplit, long long rows,
+                                                               long long rows_per_split, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
+                                                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  Mom a{0.f, 0.f, 0.f};
+  for (int j = lane; j < nsplit; j += 64) {
+    const long long r0 = (long long)j * rows_per_split;
+    const float n = (float)(min(rows, r0 + rows_per_split) - r0);
+    a = mom_merge(a, Mom{n, partial[((long long)j * 2 + 0) * C + c], partial[((long long)j * 2 + 1) * C + c]});
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    Mom b{__shfl_xor(a.n, o, 64), __shfl_xor(a.mean, o, 64), __shfl_xor(a.m2, o, 64)};
+    a = (lane & o) ? mom_merge(b, a) : mom_merge(a, b);      // both partners compute the same (lower lane first) merge
+  }
+  if (lane != 0) return;
+  const float v = a.m2 / (float)rows;
+  const float is = 1.f / sqrtf(v + eps);
+  const float g = gamma ? gamma[c] : 1.f, b0 = beta ? beta[c] : 0.f;
+  mean[c] = a.mean; var[c] = v; invstd[c] = is;
+  scale[c] = g * is; shift[c] = b0 - a.mean * g * is;
+  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * a.mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * unbias;
+}
+
 // MODE 0 -> mean; MODE 1 -> var (biased) ; MODE 2/3 -> dbeta (which 0), dgamma (which 1).
 // One wave per output: lanes stride over the splits, then a butterfly -- a fixed order, so still bit-reproducible.
 __global__ __launch_bounds__(256) void colfinal_kernel(const float* __restrict__ partial, int nsplit, int ns, int C, float inv_n,
@@ -127,22 +228,6 @@ __global__ __launch_bounds__(256) void colfinal_kernel(const float* __restrict__
   for (int j = lane; j < nsplit; j += 64) s += partial[((long long)j * ns + which) * C + c];
   s = wave_sum(s);
   if (lane == 0) (which == 0 ? out0 : out1)[c] = s * inv_n;
-}
-
-__global__ void bn_fold_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, float eps, float momentum, float unbias, float* __restrict__ running_mean,
-                               float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
-                               float* __restrict__ invstd, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float is = 1.f / sqrtf(var[c] + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  const float sc = g * is;
-  scale[c] = sc;
-  shift[c] = b - mean[c] * sc;
-  invstd[c] = is;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var[c] * unbias;
 }
 
 // Elementwise sweeps with per-channel constants: a thread keeps ONE 16-byte channel vector (its constants live in registers)
@@ -361,12 +446,18 @@ extern "C" int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, 
   BN_COMMON("cfp_bn_train_stats");
   CFP_REQUIRE(ws_bytes >= cfp_bn_ws_bytes(C), CFP_EINVAL, "cfp_bn_train_stats: workspace too small");
   float* partial = reinterpret_cast<float*>(ws);
-  const float inv_n = 1.f / (float)rows;
-  launch_reduce<0>(x, ld, nullptr, 0, rows, C, nullptr, nullptr, nullptr, nullptr, 0, dtype, partial, mean, nullptr, inv_n, s);
-  launch_reduce<1>(x, ld, nullptr, 0, rows, C, mean, nullptr, nullptr, nullptr, 0, dtype, partial, var, nullptr, inv_n, s);
-  const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, mean, var, gamma, beta, eps, momentum, unbias, running_mean,
-                     running_var, scale, shift, invstd, C);
+  {
+    const int ns = red_splits(rows, C, ve);
+    const long long rps = (rows + ns - 1) / ns;
+    const int nsplit = (int)((rows + rps - 1) / rps);
+    const int colbits = rc_colbits(C, ve);
+    const dim3 grid(cdiv(C, ve << colbits), nsplit);
+#define ML(T) hipLaunchKernelGGL(colmoments_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, rows, C, partial, rps, colbits)
+    if (dtype == CFP_BF16) ML(bf16_t); else if (dtype == CFP_F16) ML(f16_t); else ML(float);
+#undef ML
+    hipLaunchKernelGGL(colmoments_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, partial, nsplit, rows, rps, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, var, invstd, scale, shift);
+  }
   return cfp_check_launch("cfp_bn_train_stats");
 }
 

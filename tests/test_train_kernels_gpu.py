@@ -122,6 +122,30 @@ def test_batchnorm_training_forward_backward(rows, C, act, dtype):
     assert float((dbeta.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("rows,C", [(20000, 16), (333, 264), (1, 8), (200000, 8)])
+def test_batchnorm_statistics_one_pass_is_stable(rows, C):
+    """The statistics are taken in one pass over x (shifted sums per thread + exact merging of (n, mean, M2) triples): data whose
+    mean is 2*10^4 standard deviations away from zero -- where E[x^2] - E[x]^2 in float32 returns noise -- plus a few far
+    outliers must still give the float64 mean / variance."""
+    g = torch.Generator().manual_seed(3)
+    x = (1000.0 + 0.05 * torch.randn(rows, C, generator=g)).float()
+    if rows > 100:
+        x[7, :] += 3.0
+        x[rows // 2, ::2] -= 5.0
+    x64 = x.double()
+    bn = train_ops.BatchNormTrain(C, DEV, eps=1e-5, momentum=0.1)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y = bn.forward(x.to(DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV), rm, rv, hip.ACT_NONE)
+    torch.cuda.synchronize()
+    mean64, var64 = x64.mean(0), x64.var(0, unbiased=False)
+    assert float((bn.mean.cpu().double() - mean64).abs().max()) <= 2e-7 * 1000.0
+    assert float(((bn.var.cpu().double() - var64).abs() / var64.clamp(min=1e-12)).max()) <= (2e-3 if rows > 1 else 1.0)
+    want = (x64 - mean64) / (var64 + 1e-5).sqrt()
+    assert float((y.cpu().double() - want).abs().max()) <= 2e-3 * float(want.abs().max()) + 1e-3
+    unb = rows / max(rows - 1, 1)
+    assert torch.allclose(rv.cpu().double(), 0.9 + 0.1 * var64 * unb, rtol=2e-3, atol=1e-6) and torch.allclose(rm.cpu().double(), 0.1 * mean64, rtol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,C", [(4800, 128), (257, 32), (19200, 64), (1, 256)])
 def test_layernorm_backward(rows, C, dtype):
