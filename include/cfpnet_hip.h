@@ -346,7 +346,7 @@ int cfp_conv2d_dgrad(const void* dy, int dy_ld, const void* wt, void* dx, int dx
                      size_t ws_bytes, cfp_stream_t stream);
 
 /* Training-mode BatchNorm over `rows` NHWC rows (nn.BatchNorm2d/1d in model.train()): batch mean / biased variance
- * (two-pass), running statistics updated with `momentum` (running_var from the unbiased variance), and the folded
+ * (one pass: shifted sums merged as exact (n, mean, M2) triples), running statistics updated with `momentum` (running_var from the unbiased variance), and the folded
  * per-channel scale = gamma*invstd, shift = beta - mean*scale that cfp_scale_shift_act applies with the activation. */
 size_t cfp_bn_ws_bytes(int C);
 int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, int dtype, const float* gamma, const float* beta, float eps,
