@@ -46,6 +46,60 @@ __global__ __launch_bounds__(256) void nyu_augment_kernel(AugP p) {
   }
 }
 
+
+// ---- random rotation (nyu.py:121-124: PIL Image.rotate, BILINEAR on the RGB image, NEAREST on the 16-bit depth) --------------
+// Pillow's arithmetic restated (Image.rotate builds the destination->source matrix on the host; libImaging/Geometry.c:
+// ImagingGenericTransform + affine_transform + bilinear_filter32RGB / nearest_filter16), all in float64 with the same operation
+// order (the build has FMA contraction off), so the result equals Pillow's byte for byte.
+struct RotP {
+  const unsigned char* rgb; const unsigned short* dep; unsigned char* rgb_out; unsigned short* dep_out;
+  const double* m;      // [B][6]
+  int B, H, W;
+};
+__global__ __launch_bounds__(256) void nyu_rotate_kernel(RotP p) {
+  const long long total = (long long)p.B * p.H * p.W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % p.W);
+    const long long t = i / p.W;
+    const int y = (int)(t % p.H), b = (int)(t / p.H);
+    const double* m = p.m + b * 6;
+    const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+    const double xin = m[0] * xc + m[1] * yc + m[2];
+    const double yin = m[3] * xc + m[4] * yc + m[5];
+    if (p.rgb) {
+      unsigned char* o = p.rgb_out + i * 3;
+      if (xin < 0.0 || xin >= (double)p.W || yin < 0.0 || yin >= (double)p.H) {
+        o[0] = 0; o[1] = 0; o[2] = 0;
+      } else {
+        const double xf = xin - 0.5, yf = yin - 0.5;
+        const int xq = (int)floor(xf), yq = (int)floor(yf);
+        const double dx = xf - (double)xq, dy = yf - (double)yq;
+        const int x0 = min(max(xq, 0), p.W - 1), x1 = min(max(xq + 1, 0), p.W - 1);
+        const int y0 = min(max(yq, 0), p.H - 1);
+        const bool has_y1 = yq + 1 >= 0 && yq + 1 < p.H;
+        const unsigned char* r0 = p.rgb + ((long long)b * p.H + y0) * p.W * 3;
+        const unsigned char* r1 = p.rgb + ((long long)b * p.H + (has_y1 ? yq + 1 : y0)) * p.W * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double a0 = (double)r0[x0 * 3 + c], a1 = (double)r0[x1 * 3 + c];
+          const double v1 = a0 + (a1 - a0) * dx;
+          double v2 = v1;
+          if (has_y1) {
+            const double b0 = (double)r1[x0 * 3 + c], b1 = (double)r1[x1 * 3 + c];
+            v2 = b0 + (b1 - b0) * dx;
+          }
+          o[c] = (unsigned char)(v1 + (v2 - v1) * dy);
+        }
+      }
+    }
+    if (p.dep) {
+      const int xs = xin < 0.0 ? -1 : (int)xin, ys = yin < 0.0 ? -1 : (int)yin;
+      const bool ok = xs >= 0 && xs < p.W && ys >= 0 && ys < p.H;
+      p.dep_out[i] = ok ? p.dep[((long long)b * p.H + ys) * p.W + xs] : (unsigned short)0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cfp_nyu_augment(const unsigned char* rgb_u8, const unsigned short* depth_mm, int B, int H0, int W0, const int* params_i,
@@ -62,4 +116,19 @@ extern "C" int cfp_nyu_augment(const unsigned char* rgb_u8, const unsigned short
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(nyu_augment_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
   return cfp_check_launch("cfp_nyu_augment");
+}
+
+extern "C" int cfp_nyu_rotate(const unsigned char* rgb_u8, const unsigned short* depth_mm, unsigned char* rgb_out, unsigned short* depth_out,
+                              int B, int H, int W, const double* matrices, cfp_stream_t stream) {
+  CFP_REQUIRE(matrices && (rgb_u8 || depth_mm), CFP_EINVAL, "cfp_nyu_rotate: null pointer");
+  CFP_REQUIRE((rgb_u8 == nullptr) == (rgb_out == nullptr) && (depth_mm == nullptr) == (depth_out == nullptr), CFP_EINVAL,
+              "cfp_nyu_rotate: every input needs its output");
+  CFP_REQUIRE(rgb_u8 != rgb_out || !rgb_u8, CFP_EINVAL, "cfp_nyu_rotate: not in place");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0, CFP_ESHAPE, "cfp_nyu_rotate: bad shape");
+  RotP p;
+  p.rgb = rgb_u8; p.dep = depth_mm; p.rgb_out = rgb_out; p.dep_out = depth_out; p.m = matrices; p.B = B; p.H = H; p.W = W;
+  const long long total = (long long)B * H * W;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(nyu_rotate_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return cfp_check_launch("cfp_nyu_rotate");
 }

@@ -97,6 +97,7 @@ SIGNATURES = {
     "cfp_add_rowtable_dev": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "cfp_rowtable_grad_dev": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _f, _i, _p]),
     "cfp_nyu_augment": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p]),
+    "cfp_nyu_rotate": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

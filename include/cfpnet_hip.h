@@ -451,6 +451,14 @@ int cfp_nyu_augment(const unsigned char* rgb_u8, const unsigned short* depth_mm,
                     const float* params_f, const double* colors, int H, int W, const float* mean3, const float* std3, float* image_out,
                     float* depth_out, cfp_stream_t stream);
 
+/* The random rotation that precedes it (nyu.py:121-124, 200-202): PIL `Image.rotate(angle, BILINEAR)` on the RGB image and
+ * `rotate(angle, NEAREST)` on the 16-bit depth, same size, zero fill, byte-exact with Pillow 12 (float64 arithmetic in
+ * Pillow's operation order).  matrices [B,6] f64 on the device = Pillow's destination->source affine matrix per sample
+ * (computed on the host from the drawn angle exactly as Image.rotate does, cfpnet_amd/augment.py: rotate_matrix).
+ * rgb_u8 / rgb_out [B,H,W,3] uint8, depth_mm / depth_out [B,H,W] uint16; either pair may be NULL.  Not in place. */
+int cfp_nyu_rotate(const unsigned char* rgb_u8, const unsigned short* depth_mm, unsigned char* rgb_out, unsigned short* depth_out,
+                   int B, int H, int W, const double* matrices, cfp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

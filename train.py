@@ -10,8 +10,10 @@ buffer), AdamW with OneCycle (lr and beta1 cycled like `train.py:82-94`, `clip_g
 One process per GPU with the global batch `--bs` split over the ranks (the reference uses nn.DataParallel on one process).
 
 Differences on purpose: `--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box;
-without it a missing `filenames_file` is an error), random rotation / colour augmentation of the real loader is not
-reproduced, wandb logging is left out and validation runs once at the end (`--validate N` synthetic eval samples through the inference
+without it a missing `filenames_file` is an error) -- generated like the loader's PIL images (uint8 RGB and 16-bit depth at
+456x608, the frame after the Kinect-border crop of nyu.py:117-118) and put through the loader's augmentation ON THE DEVICE:
+random rotation when `--do_random_rotate` (Pillow-exact), random crop to the input size, flip, gamma / brightness / colour
+jitter, normalisation (`cfpnet_amd/augment.py`; `--no_augment` feeds pre-cropped tensors instead); wandb logging is left out and validation runs once at the end (`--validate N` synthetic eval samples through the inference
 engine and the device-side metrics; or evaluate_all.py on the saved checkpoint).
 bf16 activations with float32 master parameters by default (`--dtype`); the step is replayed as one HIP graph unless
 `--eager`.  There is no PyTorch autograd or fallback anywhere in the step.
@@ -39,6 +41,19 @@ class SyntheticTrainSet:
     def __init__(self, n, H, W, seed):
         self.n, self.H, self.W, self.seed = n, H, W, seed
 
+    def raw_batch(self, index, bs, H0=456, W0=608):
+        """What the NYU loader holds after opening + border-cropping the files (nyu.py:105-118): uint8 RGB [bs,H0,W0,3] and
+        16-bit depth in millimetres [bs,H0,W0]."""
+        from cfpnet_amd import synthetic
+        imgs, deps = [], []
+        for j in range(bs):
+            i = (index * bs + j) % self.n
+            rng = np.random.default_rng(self.seed + i)
+            imgs.append(rng.integers(0, 256, (H0, W0, 3), dtype=np.uint8))
+            d = synthetic.make_depth(H0, W0, seed=self.seed + 7919 * (i + 1), holes=0.1 * (i % 3))
+            deps.append(np.clip(np.rint(d * 1000.0), 0, 65535).astype(np.uint16))
+        return torch.from_numpy(np.stack(imgs)), torch.from_numpy(np.stack(deps).view(np.int16))
+
     def batch(self, index, bs):
         from cfpnet_amd import data, synthetic
         imgs, deps = [], []
@@ -64,7 +79,8 @@ def main(argv=None):
     n_val = _pop(argv, "--validate", 0, int)
     dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[_pop(argv, "--dtype", "bf16")]
     eager = "--eager" in argv
-    argv = [a for a in argv if a != "--eager"]
+    no_augment = "--no_augment" in argv
+    argv = [a for a in argv if a not in ("--eager", "--no_augment")]
     args = config.parse_args(argv) if argv else config.defaults()
     args.mode = "train"
 
@@ -111,8 +127,20 @@ def main(argv=None):
         for i in range(steps_per_epoch):
             if step >= total_steps:
                 break
-            img, dep = ds.batch(epoch * steps_per_epoch + i, per_rank)
-            depd = dep.to(dev)
+            if no_augment:
+                img, dep = ds.batch(epoch * steps_per_epoch + i, per_rank)
+                depd = dep.to(dev)
+            else:                                             # nyu.py:120-136 on the device, draws on the host in the loader's order
+                from cfpnet_amd import augment
+                raw_rgb, raw_dep = ds.raw_batch(epoch * steps_per_epoch + i, per_rank)
+                raw_rgb, raw_dep = raw_rgb.to(dev), raw_dep.to(dev)
+                angles, params = [], []
+                for _ in range(per_rank):
+                    angles.append(augment.draw_rotation(float(args.degree)) if args.do_random_rotate else 0.0)
+                    params.append(augment.draw_params(raw_rgb.shape[1], raw_rgb.shape[2], H, W))
+                if args.do_random_rotate:
+                    raw_rgb, raw_dep = augment.rotate(raw_rgb, raw_dep, angles)
+                img, depd = augment.augment(raw_rgb, raw_dep, params, H, W)
             s = sim.simulate(depd)
             mask = s["mask"]
             if drop > 1e-3:                                   # nyu.py:155-158: drop int(len*drop_hist) valid zones, drawn WITH replacement
