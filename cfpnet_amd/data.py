@@ -47,6 +47,78 @@ class NYUEvalFiles:
             yield torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))), torch.from_numpy(dep)[None], s["filename"]
 
 
+class NYUTrainFiles:
+    """The train split of `filenames_file` (json, key 'train') under `data_path`, opened the way the reference's loader does
+    (nyu.py:93-99,105-118): `rgb_XXXXX.jpg` + `sync_depth_XXXXX.png`, both cropped to (16, 12, 640-16, 480-12) "to avoid blank
+    boundaries due to pixel registration".  Pixels stay what the files hold -- uint8 RGB and 16-bit millimetres: rotation,
+    random crop, flip, jitter, /255, /1000 and normalisation happen on the device (`cfpnet_amd.augment`).
+
+    `epoch_batches(bs)` yields (rgb [bs,456,608,3] uint8, depth [bs,456,608] int16 storage of uint16, names) in a fresh random
+    order per epoch (`torch.randperm`, i.e. DataLoader(shuffle=True) semantics, incomplete last batch dropped), decoded by
+    `num_threads` worker threads one batch ahead of the consumer."""
+
+    CROP = (16, 12, 640 - 16, 480 - 12)
+
+    def __init__(self, args, rank: int = 0, world: int = 1):
+        with open(args.filenames_file, "r") as f:
+            self.samples = json.load(f)["train"]
+        self.root = args.data_path
+        self.threads = max(1, int(getattr(args, "num_threads", 4) or 4))
+        self.rank, self.world = rank, world
+
+    def __len__(self):
+        return len(self.samples)
+
+    def paths(self, i: int):
+        path = os.path.join(self.root, "/".join(self.samples[i]["filename"].split("/")[1:]))
+        num = path.split("/")[-1].split(".")[0]
+        base = "/".join(path.split("/")[:-1])
+        return os.path.join(base, f"rgb_{num}.jpg"), os.path.join(base, f"sync_depth_{num}.png")
+
+    def load(self, i: int):
+        from PIL import Image
+        rgb_path, depth_path = self.paths(i)
+        with Image.open(rgb_path) as im:
+            rgb = np.asarray(im.convert("RGB").crop(self.CROP), dtype=np.uint8)
+        with Image.open(depth_path) as dm:
+            dep = np.asarray(dm.crop(self.CROP)).astype(np.uint16)
+        return rgb, dep
+
+    def _batch(self, idx):
+        from concurrent.futures import ThreadPoolExecutor
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(self.threads)
+        items = list(self._pool.map(self.load, idx))
+        rgb = torch.from_numpy(np.stack([a for a, _ in items]))
+        dep = torch.from_numpy(np.stack([b for _, b in items]).view(np.int16))
+        return rgb, dep, [self.samples[i]["filename"] for i in idx]
+
+    def epoch_batches(self, bs: int, generator: Optional[torch.Generator] = None) -> Iterator[tuple]:
+        """This rank's share of one epoch: the global permutation is cut into global batches of bs * world samples and every
+        rank takes its slice of each (the reference's DataParallel splits each batch over the GPUs the same way)."""
+        import threading, queue
+        order = torch.randperm(len(self.samples), generator=generator).tolist()
+        gb = bs * self.world
+        chunks = [order[k * gb + self.rank * bs:k * gb + (self.rank + 1) * bs] for k in range(len(order) // gb)]
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def producer():
+            try:
+                for idx in chunks:
+                    q.put(self._batch(idx))
+                q.put(None)
+            except BaseException as e:           # surfaces in the consumer
+                q.put(e)
+        threading.Thread(target=producer, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+
 class SyntheticEvalSamples:
     """Seeded stand-in for a dataset that is not on the box: random RGB, a planes-and-boxes depth map with holes."""
 

@@ -61,3 +61,44 @@ def test_missing_dataset_is_an_error_not_a_fallback():
     import evaluate_all
     with pytest.raises(FileNotFoundError):
         evaluate_all.main(["@configs/cfpnet_combine1.txt", "--selected_epoch", "best"])
+
+
+def test_nyu_train_files_loader(tmp_path):
+    """`NYUTrainFiles` (nyu.py:93-118): file naming, the Kinect-border crop, raw uint8 / 16-bit pixels, per-rank slices of a
+    shuffled epoch -- on files written here in the dataset's layout."""
+    import json
+    import types
+    from PIL import Image
+    from cfpnet_amd import data
+    rng = np.random.default_rng(0)
+    root = tmp_path / "nyu" / "train"
+    names = []
+    for scene, num in (("kitchen_0001", "00012"), ("kitchen_0001", "00045"), ("office_0003", "00007"), ("office_0003", "00100"), ("bath_0002", "00001")):
+        (root / scene).mkdir(parents=True, exist_ok=True)
+        dep = rng.integers(0, 10000, (480, 640), dtype=np.uint16)
+        rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+        Image.fromarray(dep).save(root / scene / f"sync_depth_{num}.png")
+        Image.fromarray(rgb, "RGB").save(root / scene / f"rgb_{num}.jpg", quality=95)
+        names.append({"filename": f"train/{scene}/{num}.h5"})
+    fn = tmp_path / "nyu.json"
+    fn.write_text(json.dumps({"train": names, "test": []}))
+    args = types.SimpleNamespace(filenames_file=str(fn), data_path=str(root), num_threads=2)
+    ds = data.NYUTrainFiles(args)
+    assert len(ds) == 5 and ds.paths(2) == (str(root / "office_0003" / "rgb_00007.jpg"), str(root / "office_0003" / "sync_depth_00007.png"))
+    rgb, dep = ds.load(1)
+    with Image.open(root / "kitchen_0001" / "sync_depth_00045.png") as dm:                       # the reference's own calls (nyu.py:117-118)
+        want_d = np.array(dm.crop((16, 12, 640 - 16, 480 - 12)))
+    with Image.open(root / "kitchen_0001" / "rgb_00045.jpg") as im:
+        want_i = np.array(im.crop((16, 12, 640 - 16, 480 - 12)))
+    assert rgb.shape == (456, 608, 3) and rgb.dtype == np.uint8 and np.array_equal(rgb, want_i)
+    assert dep.shape == (456, 608) and dep.dtype == np.uint16 and np.array_equal(dep, want_d)
+    seen = []
+    for r in range(2):                                                                             # two ranks, batch 1 each: disjoint slices
+        d = data.NYUTrainFiles(args, rank=r, world=2)
+        got = list(d.epoch_batches(1, generator=torch.Generator().manual_seed(7)))
+        assert len(got) == 2 and all(b[0].shape == (1, 456, 608, 3) and b[0].dtype == torch.uint8 and b[1].dtype == torch.int16 for b in got)
+        seen += [b[2][0] for b in got]
+    assert len(set(seen)) == 4
+    bad = types.SimpleNamespace(filenames_file=str(fn), data_path=str(tmp_path / "nowhere"), num_threads=1)
+    with pytest.raises(FileNotFoundError):
+        list(data.NYUTrainFiles(bad).epoch_batches(1))

@@ -7,7 +7,11 @@ import numpy as np
 import pytest
 import torch
 
+import os
+
 from cfpnet_amd import spec, synthetic, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import cfpnet_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -227,3 +231,36 @@ def test_training_step_variants_no_skip_inside_and_stale_embedding():
         assert np.median(errs) < 1e-2 and max(errs) < 0.2, (kw, np.median(errs), max(errs))
     with pytest.raises(NotImplementedError):
         TrainNet(sd, layers, "cuda:0", norm="softmax")
+
+
+def test_train_cli_on_dataset_files(tmp_path):
+    """train.py without --synthetic: files in the NYU layout -> PIL decode + border crop (worker threads) -> rotation, crop, flip,
+    jitter on the device -> ToF simulation -> captured training step; saves a checkpoint the inference engine loads."""
+    import json
+    import sys
+    from PIL import Image
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import train as train_cli
+    from cfpnet_amd.engine import Engine
+    rng = np.random.default_rng(1)
+    root = tmp_path / "nyu" / "train" / "room_0001"
+    root.mkdir(parents=True)
+    names = []
+    for i in range(4):
+        dep = (synthetic.make_depth(480, 640, seed=300 + i, holes=0.05) * 1000).astype(np.uint16)
+        Image.fromarray(dep).save(root / f"sync_depth_{i:05d}.png")
+        Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8), "RGB").save(root / f"rgb_{i:05d}.jpg")
+        names.append({"filename": f"train/room_0001/{i:05d}.h5"})
+    fn = tmp_path / "split.json"
+    fn.write_text(json.dumps({"train": names}))
+    out = tmp_path / "w" / "last.pt"
+    loss = train_cli.main(["@" + os.path.join(ROOT, "configs", "cfpnet_combine1.txt"),
+                           "--filenames_file", str(fn), "--data_path", str(tmp_path / "nyu" / "train"), "--bs", "2", "--epochs", "2",
+                           "--do_random_rotate", "--save", str(out), "--log_every", "1"])
+    assert np.isfinite(loss) and out.exists()
+    sd = torch.load(out, map_location="cpu")
+    layers = spec.COMBINE1_LAYERS
+    eng = Engine(sd, layer_names=layers, dtype=torch.bfloat16)
+    _, pred, _ = eng.forward(synthetic.to_device(synthetic.make_inputs(1, 480, 640, 8, 56, seed=3), "cuda:0"), return_prob=False)
+    assert bool(torch.isfinite(pred).all())

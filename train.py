@@ -9,8 +9,10 @@ the whole network (HIP tape, `cfpnet_amd/train_model.py`), gradient all-reduce o
 buffer), AdamW with OneCycle (lr and beta1 cycled like `train.py:82-94`, `clip_grad_norm_(0.1)` unless `--disable_clip_grad`).
 One process per GPU with the global batch `--bs` split over the ranks (the reference uses nn.DataParallel on one process).
 
-Differences on purpose: `--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box;
-without it a missing `filenames_file` is an error) -- generated like the loader's PIL images (uint8 RGB and 16-bit depth at
+Without `--synthetic` the train split of `--filenames_file` under `--data_path` is read like the reference's loader does
+(`cfpnet_amd.data.NYUTrainFiles`: PIL decode + border crop in worker threads, one batch ahead).  Differences on purpose:
+`--synthetic N` trains on N seeded synthetic samples per epoch (the NYU files are not on this box; without it a missing
+`filenames_file` is an error) -- generated like the loader's PIL images (uint8 RGB and 16-bit depth at
 456x608, the frame after the Kinect-border crop of nyu.py:117-118) and put through the loader's augmentation ON THE DEVICE:
 random rotation when `--do_random_rotate` (Pillow-exact), random crop to the input size, flip, gamma / brightness / colour
 jitter, normalisation (`cfpnet_amd/augment.py`; `--no_augment` feeds pre-cropped tensors instead); wandb logging is left out and validation runs once at the end (`--validate N` synthetic eval samples through the inference
@@ -95,10 +97,15 @@ def main(argv=None):
     dev = torch.device("cuda", local)
 
     H, W = int(args.input_height), int(args.input_width)
-    if n_syn <= 0:
-        fn = getattr(args, "filenames_file", None)
-        raise FileNotFoundError(f"filenames_file '{fn}' is not on this box -- pass --synthetic N to train on synthetic samples")
     per_rank = max(1, int(args.bs) // world)
+    files = None
+    if n_syn <= 0:
+        from cfpnet_amd import data as data_mod
+        fn = getattr(args, "filenames_file", None)
+        if not fn or not os.path.exists(fn):
+            raise FileNotFoundError(f"filenames_file '{fn}' is not on this box -- pass --synthetic N to train on synthetic samples")
+        files = data_mod.NYUTrainFiles(args, rank, world)         # nyu.py:62-136: the real train split, decoded by worker threads
+        n_syn = len(files)
     steps_per_epoch = max(1, n_syn // (per_rank * world))
     total_steps = int(args.epochs) * steps_per_epoch
     if max_steps:
@@ -124,15 +131,19 @@ def main(argv=None):
     drop = float(args.drop_hist)
     t0, seen, step = time.perf_counter(), 0, 0
     for epoch in range(int(args.epochs)):
+        file_batches = files.epoch_batches(per_rank) if files is not None else None
         for i in range(steps_per_epoch):
             if step >= total_steps:
                 break
-            if no_augment:
+            if no_augment and files is None:
                 img, dep = ds.batch(epoch * steps_per_epoch + i, per_rank)
                 depd = dep.to(dev)
             else:                                             # nyu.py:120-136 on the device, draws on the host in the loader's order
                 from cfpnet_amd import augment
-                raw_rgb, raw_dep = ds.raw_batch(epoch * steps_per_epoch + i, per_rank)
+                if file_batches is not None:
+                    raw_rgb, raw_dep, _ = next(file_batches)
+                else:
+                    raw_rgb, raw_dep = ds.raw_batch(epoch * steps_per_epoch + i, per_rank)
                 raw_rgb, raw_dep = raw_rgb.to(dev), raw_dep.to(dev)
                 angles, params = [], []
                 for _ in range(per_rank):
