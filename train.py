@@ -15,8 +15,9 @@ Without `--synthetic` the train split of `--filenames_file` under `--data_path` 
 `filenames_file` is an error) -- generated like the loader's PIL images (uint8 RGB and 16-bit depth at
 456x608, the frame after the Kinect-border crop of nyu.py:117-118) and put through the loader's augmentation ON THE DEVICE:
 random rotation when `--do_random_rotate` (Pillow-exact), random crop to the input size, flip, gamma / brightness / colour
-jitter, normalisation (`cfpnet_amd/augment.py`; `--no_augment` feeds pre-cropped tensors instead); wandb logging is left out and validation runs once at the end (`--validate N` synthetic eval samples through the inference
-engine and the device-side metrics; or evaluate_all.py on the saved checkpoint).
+jitter, normalisation (`cfpnet_amd/augment.py`; `--no_augment` feeds pre-cropped tensors instead); wandb logging is left out; validation (`--validate N`: N synthetic eval samples through the inference engine and the device-side
+metrics) runs at the end of every epoch whose step count is a multiple of `--validate_every`, as in train.py:137-156, writing
+`<epoch>_<rmse>.pt` and `best.pt` next to `--save`, and once more at the end.
 bf16 activations with float32 master parameters by default (`--dtype`); the step is replayed as one HIP graph unless
 `--eager`.  There is no PyTorch autograd or fallback anywhere in the step.
 """
@@ -129,6 +130,38 @@ def main(argv=None):
     ds = SyntheticTrainSet(n_syn, H, W, seed=1000 + rank)
     rng = np.random.default_rng(4242 + rank)
     drop = float(args.drop_hist)
+    best_rmse, last_validated = float("inf"), -1
+
+    def validate(at_step, epoch=None):
+        """train.py:137-156,163-199: eval-mode forward of the current weights (inference engine), metrics on the device; with
+        `--save` the epoch's weights go next to it as `<epoch>_<rmse>.pt` and the best ones (by rmse) as `best.pt`."""
+        nonlocal best_rmse, last_validated
+        from cfpnet_amd import data, metrics
+        from cfpnet_amd.engine import Engine
+        torch.cuda.synchronize()
+        weights_now = tr.state_dict()
+        eng = Engine(weights_now, layer_names=layers, n_bins=int(args.n_bins), min_val=float(args.min_depth), max_val=float(args.max_depth),
+                     dtype=torch.float16 if dtype == torch.float32 else dtype, device=dev)
+        build = data.EvalInputBuilder(args, dev)
+        avg = metrics.RunningAverageDict()
+        for img, dep, _ in data.batches(data.SyntheticEvalSamples(n_val, 480, 640, seed=99), 8):
+            inp, gt = build(img, dep)
+            _, pred, _ = eng.forward(inp, return_prob=False)
+            avg.update(metrics.eval_metrics(pred, gt, float(args.min_depth_eval), float(args.max_depth_eval), mode=metrics.VALIDATE))
+        m = avg.get_value()
+        print(f"Validation metrics (step {at_step}):", {k: round(v, 3) for k, v in m.items()}, flush=True)
+        if save_path:
+            d = os.path.dirname(os.path.abspath(save_path))
+            os.makedirs(d, exist_ok=True)
+            if epoch is not None:
+                torch.save(weights_now, os.path.join(d, f"{epoch}_{m['rmse']:.3f}.pt"))
+            if m["rmse"] < best_rmse:
+                torch.save(weights_now, os.path.join(d, "best.pt"))
+        best_rmse = min(best_rmse, m["rmse"])
+        last_validated = at_step
+        del eng
+        return m
+
     t0, seen, step = time.perf_counter(), 0, 0
     for epoch in range(int(args.epochs)):
         file_batches = files.epoch_batches(per_rank) if files is not None else None
@@ -171,20 +204,11 @@ def main(argv=None):
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 print(f"epoch {epoch + 1} step {step}/{total_steps} loss {float(loss):.4f} lr {lr:.2e} beta1 {beta1:.3f} {seen / dt:.1f} samples/s", flush=True)
+        if rank == 0 and n_val > 0 and step % max(1, int(args.validate_every)) == 0 and step != last_validated:      # train.py:137: end of epoch
+            validate(step, epoch)
     torch.cuda.synchronize()
-    if rank == 0 and n_val > 0:
-        # train.py:163-199 (validate): eval-mode forward of the trained weights (inference engine), metrics on the device
-        from cfpnet_amd import data, metrics
-        from cfpnet_amd.engine import Engine
-        eng = Engine(tr.state_dict(), layer_names=layers, n_bins=int(args.n_bins), min_val=float(args.min_depth), max_val=float(args.max_depth),
-                     dtype=torch.float16 if dtype == torch.float32 else dtype, device=dev)
-        build = data.EvalInputBuilder(args, dev)
-        avg = metrics.RunningAverageDict()
-        for img, dep, _ in data.batches(data.SyntheticEvalSamples(n_val, 480, 640, seed=99), 8):
-            inp, gt = build(img, dep)
-            _, pred, _ = eng.forward(inp, return_prob=False)
-            avg.update(metrics.eval_metrics(pred, gt, float(args.min_depth_eval), float(args.max_depth_eval), mode=metrics.VALIDATE))
-        print("Validation metrics:", {k: round(v, 3) for k, v in avg.get_value().items()}, flush=True)
+    if rank == 0 and n_val > 0 and last_validated != step:
+        validate(step)
     if rank == 0 and save_path:
         os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
         torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
