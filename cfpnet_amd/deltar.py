@@ -82,6 +82,8 @@ class Deltar(_Store):
         self._engine = None
         self._engine_version = -1
         self._version_counter = 0
+        self.train_graphs = True          # .train() forward / backward replayed as HIP graphs (captured per batch geometry)
+        self._train_captures: Dict = {}
 
     # -- reference API ------------------------------------------------------------------
     def _get_name(self):
@@ -147,28 +149,122 @@ class Deltar(_Store):
         return edges, pred, prob, None
 
 
+_OFFSET_NAMES = ("cross_atten3", "cross_atten2", "cross_atten1")
+
+
+def _patch_signature(pinfo) -> tuple:
+    out = []
+    for s in (4, 8, 16):
+        e = pinfo[s] if s in pinfo else pinfo[float(s)]
+        out.append(tuple(tuple(int(v) for v in torch.as_tensor(e[k]).reshape(-1).tolist()) for k in ("pad_size", "patch_size", "index_wo_pad")))
+    return tuple(out) + (tuple(int(v) for v in torch.as_tensor(pinfo["zone_num"]).reshape(-1).tolist()),)
+
+
+class _CapturedTrainStep:
+    """Forward and backward of the training step as two HIP graphs sharing one memory pool, for a fixed batch geometry.
+    The eager tape is ~3 500 launches plus ~1 400 small re-layout kernels per step and host-bound (178 ms per step of 16 crops);
+    replayed, the same work is ~50 ms.  Inputs are copied into static buffers, the parameters are read in place (torch
+    optimizers update them in place), the random positional-encoding windows come from a device buffer, the running
+    statistics are the module's own buffers."""
+
+    def __init__(self, model, input_data, names, params):
+        from .autograd_hip import Tape
+        from .train_model import TrainNet
+        dev = params[0].device
+        add = input_data["additional"]
+        self.inp = {"rgb": input_data["rgb"].to(dev, torch.float32).contiguous().clone(),
+                    "additional": {"hist_data": add["hist_data"].to(dev, torch.float32).contiguous().clone(),
+                                   "mask": add["mask"].to(dev).contiguous().clone(), "rect_data": add.get("rect_data"),
+                                   "patch_info": add["patch_info"]}}
+        self.offs = torch.zeros(3, 2, dtype=torch.int32, device=dev)
+        offs_dev = {n: self.offs[i] for i, n in enumerate(_OFFSET_NAMES)}
+        sd = {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}
+        self.net = TrainNet(sd, model.layer_names, dev, n_bins=model.num_classes, min_val=model.min_val, max_val=model.max_val,
+                            stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True, dtype=model.compute_dtype,
+                            no_skip_inside=model.no_skip_inside, norm=model.norm, base_resolution=model.base_resolution)
+        self.names = list(names)
+        # one real execution before the capture (sets kernel attributes, builds the index maps); its update of the running
+        # statistics is undone, capture itself only records
+        saved = {k: v.clone() for k, v in self.net.buf.items()}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            t = Tape(dev, model.compute_dtype)
+            pred, _, (B, h, w) = self.net.forward(t, self.inp, offs_dev)
+            pred.g = torch.zeros(B * h * w, 1, dtype=torch.float32, device=dev)
+            t.backward()
+            self.net.zero_grad()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for k, v in saved.items():
+            self.net.buf[k].copy_(v)
+        self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gf):
+            self.tape = Tape(dev, model.compute_dtype)
+            self.pred, self.edges, (B, h, w) = self.net.forward(self.tape, self.inp, offs_dev)
+        self.shape = (B, 1, h, w)
+        self.gpred = torch.zeros(B * h * w, 1, dtype=torch.float32, device=dev)
+        with torch.cuda.graph(self.gb, pool=self.gf.pool()):
+            self.pred.g = self.gpred
+            self.tape.backward()
+            g = self.net.grads()
+            self.grads = [g.get(n) for n in self.names]
+        self.ptrs = tuple(p.data_ptr() for p in params)
+
+    def forward(self, input_data, pos_offsets):
+        add = input_data["additional"]
+        self.inp["rgb"].copy_(input_data["rgb"], non_blocking=True)
+        self.inp["additional"]["hist_data"].copy_(add["hist_data"], non_blocking=True)
+        self.inp["additional"]["mask"].copy_(add["mask"], non_blocking=True)
+        self.offs.copy_(torch.tensor([pos_offsets.get(n, (0, 0)) for n in _OFFSET_NAMES], dtype=torch.int32), non_blocking=True)
+        self.gf.replay()
+        return self.edges.clone(), self.pred.t.reshape(self.shape).clone()
+
+    def backward(self, g_pred):
+        self.gpred.copy_(g_pred.reshape(-1, 1))
+        self.gb.replay()
+        # a contiguous gradient could be adopted by autograd as `.grad` without a copy and would then alias this static buffer
+        return tuple(None if g is None else (g.clone() if g.is_contiguous() else g) for g in self.grads)
+
+
 class _TrainStep(torch.autograd.Function):
     """`model(input_data)` in `model.train()` for callers that then run `loss.backward()` like the reference's train.py:
     forward = the training-mode forward on the HIP tape, backward = the tape's backward; the parameter gradients come back
-    through autograd in the reference's layout, the running statistics are updated in the module's buffers."""
+    through autograd in the reference's layout, the running statistics are updated in the module's buffers.  With
+    `model.train_graphs` (default) both halves are replayed as HIP graphs captured per batch geometry."""
 
     @staticmethod
     def forward(ctx, model, input_data, pos_offsets, names, *params):
         from .autograd_hip import Tape
         from .train_model import TrainNet
         dev = params[0].device
+        ctx.names = names
+        if model.train_graphs:
+            add = input_data["additional"]
+            key = (tuple(input_data["rgb"].shape), tuple(add["hist_data"].shape), _patch_signature(add["patch_info"]), model.compute_dtype)
+            cap = model._train_captures.get(key)
+            if cap is None or cap.ptrs != tuple(p.data_ptr() for p in params):
+                model._train_captures.clear()                     # one geometry at a time: a capture pins ~25 GB of activations
+                cap = model._train_captures[key] = _CapturedTrainStep(model, input_data, names, params)
+            ctx.cap = cap
+            edges, pred = cap.forward(input_data, pos_offsets)
+            ctx.mark_non_differentiable(edges)
+            return edges, pred
+        ctx.cap = None
         sd = {k: v.detach() for k, v in model.state_dict(keep_vars=True).items()}
         net = TrainNet(sd, model.layer_names, dev, n_bins=model.num_classes, min_val=model.min_val, max_val=model.max_val,
                        stem_act=model.stem_act, change_embedding=model.change_embedding, share_buffers=True, dtype=model.compute_dtype,
                        no_skip_inside=model.no_skip_inside, norm=model.norm, base_resolution=model.base_resolution)
         tape = Tape(dev, model.compute_dtype)
         pred, edges, (B, h, w) = net.forward(tape, input_data, pos_offsets)
-        ctx.net, ctx.tape, ctx.pred, ctx.names = net, tape, pred, names
+        ctx.net, ctx.tape, ctx.pred = net, tape, pred
         ctx.mark_non_differentiable(edges)
         return edges, pred.t.reshape(B, 1, h, w)
 
     @staticmethod
     def backward(ctx, _g_edges, g_pred):
+        if ctx.cap is not None:
+            return (None, None, None, None) + ctx.cap.backward(g_pred.to(torch.float32))
         ctx.pred.g = g_pred.reshape(-1, 1).to(torch.float32).contiguous()
         ctx.tape.backward()
         grads = ctx.net.grads()

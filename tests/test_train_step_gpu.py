@@ -153,6 +153,43 @@ def test_deltar_module_trains_through_torch_autograd():
         Deltar(n_bins=256, min_val=1e-3, max_val=10.0, norm="linear", args=args, dtype=torch.float32).train()(inp)
 
 
+def test_deltar_module_graph_replay_equals_eager_tape():
+    """`Deltar.train_graphs` (default): forward and backward of the module's training step replayed as two HIP graphs.  Three
+    optimizer steps with NEW inputs and positional windows per step must leave exactly the parameters and running statistics
+    of the same loop run launch by launch."""
+    from cfpnet_amd.deltar import Deltar
+    import types
+    layers, sd, inp, target, offs = _case()
+    args = types.SimpleNamespace(attention_layer=layers, zone_sample_num=16, change_embedding=True, no_skip_inside=False, hist_encoder_10x=True)
+    batches = []
+    for s_ in range(3):
+        i2 = synthetic.make_inputs(2, 256, 320, 3, 64, seed=170 + s_, drop_hist=0.25 * (s_ % 2))
+        t2 = torch.from_numpy(np.stack([synthetic.make_depth(256, 320, seed=190 + 2 * s_ + i, holes=0.1) for i in range(2)]))[:, None]
+        o2 = {"cross_atten3": (s_, 2 * s_), "cross_atten2": (3 * s_, s_), "cross_atten1": (5 * s_, 7 * s_)}
+        batches.append((synthetic.to_device(i2, "cuda:0"), t2.cuda(), o2))
+    results = []
+    for graphs in (False, True):
+        model = Deltar(n_bins=256, min_val=1e-3, max_val=10.0, norm="linear", args=args, dtype=torch.float32)
+        model.load_state_dict(sd)
+        model = model.to("cuda:0").train()
+        model.train_graphs = graphs
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.1)
+        losses = []
+        for dinp, tgt, o2 in batches:
+            opt.zero_grad()
+            edges, pred = model(dinp, pos_offsets=o2)
+            loss = O.silog_loss(torch.clip(pred, 1e-3), tgt, tgt > 1e-3, interpolate=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert graphs == bool(model._train_captures)
+        results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = results
+    assert l0 == l1, (l0, l1)
+    assert all(torch.equal(s0[k], s1[k]) for k in s0), [k for k in s0 if not torch.equal(s0[k], s1[k])][:5]
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_mixed_precision_training_step(dtype):
     """16-bit activations / matrix-core operands with float32 master parameters and parameter gradients: the loss stays within
