@@ -62,7 +62,7 @@ class Trainer:
         scratch.forward(Tape(self.dev, self.dtype), input_data, offs)
         found = scratch.discovered
         kflat = train_ops.FlatParams([(n, tuple(t32.shape)) for n, (t32, _, _) in found.items()], train_ops.lr_group_of(self._hist10),
-                                     device=self.dev, align=8)                                  # 8 elements: 16-byte rows in the 16-bit shadow too
+                                     device=self.dev, align=128)                                # 128 elements: every tensor starts on a 256-byte line in the 16-bit shadow too
         assert kflat.group_range[2][0] == kflat.group_range[2][1], "a dead tensor was used by the forward"
         for n, (t32, _, _) in found.items():
             kflat.view(n).copy_(t32)
