@@ -139,12 +139,36 @@ class Tape:
                     self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
                 self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
             self.off_path(param_grads)
-            if x.needs_grad:
+            if x.needs_grad and k == stride and k > 1 and pt == 0 and pl == 0:
+                # non-overlapping patches (the GSA sub-sampling conv, kernel = stride = window size): every input pixel belongs to
+                # ONE output pixel and one tap, so dX is a plain GEMM  dY [M_out, Cout] x W [Cout, k*k*Cin]  followed by a
+                # depth-to-space row gather -- the generic route (stride-1 conv over the zero-stuffed dY) multiplies 1 - 1/k^2
+                # zeros (k = 12: 369 us instead of ~20)
+                Cin = x.C
+                tmp = self.new(B * Ho * Wo, k * k * Cin, g.dtype)
+                ops.conv2d(_act(g), w.t.t().contiguous(), None, None, _act(tmp), 1, 1, B * Ho * Wo, 1, 1, 1, 0, 0, 1, B * Ho * Wo)
+                self.acc(x, train_ops.index_rows(tmp.view(B * Ho * Wo * k * k, Cin), self._patch_map(B, H, W, k, Ho, Wo)))
+            elif x.needs_grad:
                 w.geom = (Cout, k, k, x.C)
                 wt = w.wt if w.wt is not None else train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
                 self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y
+
+    _patch_maps: Dict[tuple, torch.Tensor] = {}
+
+    def _patch_map(self, B, H, W, k, Ho, Wo) -> torch.Tensor:
+        """Row map of the depth-to-space step above: input pixel (b, y, x) <- row ((b, y // k, x // k), y % k, x % k) of the
+        [B*Ho*Wo*k*k, Cin] GEMM result, -1 (zero gradient) for the pixels right / below the last full patch."""
+        key = (str(self.dev), B, H, W, k, Ho, Wo)
+        if key not in Tape._patch_maps:
+            y, x = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+            ho, wo = y // k, x // k
+            idx = ((ho * Wo + wo) * k + y % k) * k + x % k
+            idx = torch.where((ho < Ho) & (wo < Wo), idx, torch.full_like(idx, -1))
+            full = torch.cat([torch.where(idx >= 0, idx + b * Ho * Wo * k * k, idx).reshape(-1) for b in range(B)])
+            Tape._patch_maps[key] = full.to(torch.int32).to(self.dev)
+        return Tape._patch_maps[key]
 
     def linear(self, x: V, w: P, bias: Optional[P] = None) -> V:
         return self.conv(x, w, bias, 1, 1, x.rows, 1, 1, 0, 0, 1, x.rows)

@@ -354,3 +354,36 @@ def test_batched_weight_flip_equals_the_single_launches(dtype):
         want = train_ops.conv2d_weight_flip(w, co, kh, kw, ci)
         ref = w.view(co, kh, kw, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, kh * kw * co)
         assert torch.equal(want, ref) and torch.equal(dst[r[1]:r[1] + n].view(ci, kh * kw * co), want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [(2, 26, 34, 32, 32, 6), (1, 52, 68, 16, 24, 9), (2, 24, 36, 8, 40, 12), (1, 7, 7, 8, 8, 7)])
+def test_tape_conv_with_kernel_equal_stride(B, H, W, Cin, Cout, k, dtype):
+    """The GSA sub-sampling convolution (kernel = stride = window size, floor output size): its data gradient takes the
+    GEMM + depth-to-space route of the tape, checked with the weight / bias gradients against torch autograd -- including the
+    rows and columns past the last full patch, whose gradient is zero."""
+    from cfpnet_amd.autograd_hip import P, Tape, V
+    x = rnd(B, Cin, H, W, seed=1).to(dtype).float().requires_grad_(True)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k)).to(dtype).float().requires_grad_(True)
+    b = rnd(Cout, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=k)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy = rnd(*y.shape, seed=4).to(dtype).float()
+    y.backward(dy)
+    t = Tape(DEV, dtype)
+    xv = V(nhwc(x.detach()).to(dtype).to(DEV))
+    wp = P("w", w.detach().permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV), lambda g: g)
+    bp = P("b", b.detach().to(DEV), lambda g: g)
+    yv = t.conv(xv, wp, bp, B, H, W, k, k, 0, 0, Ho, Wo)
+    yv.g = nhwc(dy).to(dtype).to(DEV)
+    t.backward()
+    torch.cuda.synchronize()
+    tol = OUT_TOL[dtype] + 3e-5
+    got_y = yv.t.float().cpu().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    assert float((got_y - y.detach()).abs().max()) <= tol * float(y.detach().abs().max())
+    got_dx = xv.g.float().cpu().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    assert float((got_dx - x.grad).abs().max()) <= tol * float(x.grad.abs().max())
+    assert float(got_dx[:, :, Ho * k:, :].abs().max() if Ho * k < H else 0.0) == 0.0
+    want_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin)
+    assert float((wp.g.cpu() - want_dw).abs().max()) <= (3e-5 + (2e-2 if dtype != torch.float32 else 0)) * float(want_dw.abs().max())
+    assert float((bp.g.cpu() - b.grad).abs().max()) <= 3e-5 * float(b.grad.abs().max()) + 1e-5
