@@ -33,7 +33,7 @@ struct Outer {
 };
 
 // acc += sum over the chunk's rows of X[r][i] * Y[r][j]   (sX: [ACH][D], sY: [ACH][D+1])
-template <int D, int NT>
+template <int D, int NT, int PX = D>
 __device__ __forceinline__ void outer_accumulate(const float* sX, const float* sY, int nrows, float (&acc)[Outer<D, NT>::OPT]) {
   using O = Outer<D, NT>;
   const int tid = threadIdx.x;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void outer_accumulate(const float* sX, const float* s
       if (o < O::NO) {
         const int i = o / (D + 1), j = o - i * (D + 1);
         float a = acc[u];
-        for (int r = 0; r < nrows; ++r) a = fmaf(sX[r * D + i], sY[r * (D + 1) + j], a);
+        for (int r = 0; r < nrows; ++r) a = fmaf(sX[r * PX + i], sY[r * (D + 1) + j], a);
         acc[u] = a;
       }
     }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void outer_accumulate(const float* sX, const float* s
     if (g < O::G) {
       const int i = o / (D + 1), j = o - i * (D + 1);
       float a = acc[0];
-      for (int r = g; r < nrows; r += O::G) a = fmaf(sX[r * D + i], sY[r * (D + 1) + j], a);
+      for (int r = g; r < nrows; r += O::G) a = fmaf(sX[r * PX + i], sY[r * (D + 1) + j], a);
       acc[0] = a;
     }
   }
@@ -253,6 +253,189 @@ __global__ __launch_bounds__(NT) void linattn_bwd_kernel(const T* __restrict__ q
   }
 }
 
+
+// ---- head dims 16 / 32: staged form ------------------------------------------------------------------------------------------
+// The kernels above keep a token's whole head (Q, A, dA, ... = 4 D floats) in the registers of ONE lane and unroll D x (D+1)
+// products per lane: at D = 32 that is 256 VGPRs plus 1.3 KB of scratch per lane and one wave per SIMD (296 us for the 2 304
+// 16-token zone groups of the 1/16 scale).  Here every per-token product is a thread-per-OUTPUT loop over operands staged in
+// LDS (pitch D+1: conflict-free both along a row and down a column), so all lanes work whatever the group size and nothing
+// spills.  Same mathematics, same fixed summation orders (each output is one sequential fma chain).
+template <typename T, int D, int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void linattn_fwd2_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+                                                           const T* __restrict__ v, int v_ld, T* __restrict__ out, int out_ld,
+                                                           float* __restrict__ kv_save, int L, int S, int heads, float eps,
+                                                           float* __restrict__ partial, int nchunks, int chunk_len) {
+  using O = Outer<D, NT>;
+  constexpr int RCH = NT == 64 ? 32 : 64, P = D + 1;
+  __shared__ float sX[RCH * P], sY[SPLIT == 2 ? 1 : RCH * P], sM[O::NO], sZ[RCH], sRed[O::G > 1 ? O::G * O::NO : 1];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const float fS = (float)S;
+  float acc[O::OPT];
+#pragma unroll
+  for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
+  const int s_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 1 ? min(S, s_begin + chunk_len) : (SPLIT == 2 ? 0 : S);
+  for (int s0 = s_begin; s0 < s_end; s0 += RCH) {
+    const int nr = min(RCH, s_end - s0);
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      const long long row = (long long)n * S + s0 + r;
+      sX[r * P + c] = elu1p(to_f32<T>(k[row * k_ld + h * D + c]));
+      sY[r * P + c] = to_f32<T>(v[row * v_ld + h * D + c]) / fS;
+      if (c == 0) sY[r * P + D] = 1.f;
+    }
+    __syncthreads();
+    outer_accumulate<D, NT, P>(sX, sY, nr, acc);
+  }
+  __syncthreads();
+  if (SPLIT == 2) {
+    for (int e = tid; e < O::NO; e += NT) {
+      float a = 0.f;
+      for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
+      sM[e] = a;
+    }
+    __syncthreads();
+  } else {
+    outer_finish<D, NT>(acc, sRed, sM);
+  }
+  if (SPLIT == 1) {
+    for (int e = tid; e < O::NO; e += NT) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sM[e];
+    return;
+  }
+  if (SPLIT == 0 || blockIdx.y == 0)
+    for (int e = tid; e < O::NO; e += NT) kv_save[(long long)blockIdx.x * O::NO + e] = sM[e];
+  const int l_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 2 ? min(L, l_begin + chunk_len) : L;
+  for (int l0 = l_begin; l0 < l_end; l0 += RCH) {
+    const int nr = min(RCH, l_end - l0);
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      sX[r * P + c] = elu1p(to_f32<T>(q[((long long)n * L + l0 + r) * q_ld + h * D + c]));
+    }
+    __syncthreads();
+    if (tid < nr) {
+      float den = eps;
+#pragma unroll 8
+      for (int i = 0; i < D; ++i) den = fmaf(sX[tid * P + i], sM[i * P + D], den);
+      sZ[tid] = 1.f / den;
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, j = e - r * D;
+      float a = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < D; ++i) a = fmaf(sX[r * P + i], sM[i * P + j], a);
+      out[((long long)n * L + l0 + r) * out_ld + h * D + j] = from_f32<T>(a * sZ[r] * fS);
+    }
+  }
+}
+
+template <typename T, int D, int SPLIT, int NT>
+__global__ __launch_bounds__(NT) void linattn_bwd2_kernel(const T* __restrict__ q, int q_ld, const T* __restrict__ k, int k_ld,
+                                                           const T* __restrict__ v, int v_ld, const T* __restrict__ dout, int do_ld,
+                                                           const float* __restrict__ kv_save, T* __restrict__ dq, int dq_ld,
+                                                           T* __restrict__ dk, int dk_ld, T* __restrict__ dv, int dv_ld, int L, int S,
+                                                           int heads, float eps, float* __restrict__ partial, int nchunks, int chunk_len) {
+  using O = Outer<D, NT>;
+  constexpr int RCH = NT == 64 ? 32 : 64, P = D + 1;
+  __shared__ float sX[RCH * P], sY[RCH * P], sT[SPLIT == 2 ? 1 : RCH * P], sM[SPLIT == 2 ? 1 : O::NO], sG[O::NO], sZ[RCH], sE[RCH],
+      sRed[O::G > 1 ? O::G * O::NO : 1];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x / heads, h = blockIdx.x - n * heads;
+  const float fS = (float)S;
+  if (SPLIT != 2)
+    for (int e = tid; e < O::NO; e += NT) sM[e] = kv_save[(long long)blockIdx.x * O::NO + e];
+  float acc[O::OPT];
+#pragma unroll
+  for (int u = 0; u < O::OPT; ++u) acc[u] = 0.f;
+  __syncthreads();
+  // ---- queries: dq, and the rows (Q_l, dA_l, e_l) of the dKV / dKsum reduction
+  const int l_begin = SPLIT == 1 ? blockIdx.y * chunk_len : 0, l_end = SPLIT == 1 ? min(L, l_begin + chunk_len) : (SPLIT == 2 ? 0 : L);
+  for (int l0 = l_begin; l0 < l_end; l0 += RCH) {
+    const int nr = min(RCH, l_end - l0);
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      const long long row = (long long)n * L + l0 + r;
+      sX[r * P + c] = elu1p(to_f32<T>(q[row * q_ld + h * D + c]));
+      sY[r * P + c] = to_f32<T>(dout[row * do_ld + h * D + c]);
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {           // T[r][i] = sum_j KV[i][j] dout[r][j]
+      const int r = e / D, i = e - r * D;
+      float a = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < D; ++j) a = fmaf(sM[i * P + j], sY[r * P + j], a);
+      sT[r * P + i] = a;
+    }
+    __syncthreads();
+    if (tid < nr) {                                    // Z_l, e_l:  dout_l . A_l = Q_l . T_l
+      float den = eps, dot = 0.f;
+#pragma unroll 8
+      for (int i = 0; i < D; ++i) {
+        const float qv = sX[tid * P + i];
+        den = fmaf(qv, sM[i * P + D], den);
+        dot = fmaf(qv, sT[tid * P + i], dot);
+      }
+      const float z = 1.f / den;
+      sZ[tid] = fS * z;
+      sE[tid] = -z * z * fS * dot;
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {           // dQ = S Z T + e Ksum, times elu'(q);  dA = dout S Z in place
+      const int r = e / D, i = e - r * D;
+      const long long row = (long long)n * L + l0 + r;
+      const float d = sZ[r] * sT[r * P + i] + sE[r] * sM[i * P + D];
+      dq[row * dq_ld + h * D + i] = from_f32<T>(d * elu1_grad(to_f32<T>(q[row * q_ld + h * D + i])));
+      sY[r * P + i] *= sZ[r];
+    }
+    if (tid < nr) sY[tid * P + D] = sE[tid];
+    __syncthreads();
+    outer_accumulate<D, NT, P>(sX, sY, nr, acc);
+  }
+  __syncthreads();
+  if (SPLIT == 2) {
+    for (int e = tid; e < O::NO; e += NT) {
+      float a = 0.f;
+      for (int c = 0; c < nchunks; ++c) a += partial[((long long)blockIdx.x * nchunks + c) * O::NO + e];
+      sG[e] = a;
+    }
+    __syncthreads();
+  } else {
+    outer_finish<D, NT>(acc, sRed, sG);          // sG = [dKV | dKsum]
+  }
+  if (SPLIT == 1) {
+    for (int e = tid; e < O::NO; e += NT) partial[((long long)blockIdx.x * gridDim.y + blockIdx.y) * O::NO + e] = sG[e];
+    return;
+  }
+  // ---- keys: dk, dv
+  const int s_begin = SPLIT == 2 ? blockIdx.y * chunk_len : 0, s_end = SPLIT == 2 ? min(S, s_begin + chunk_len) : S;
+  for (int s0 = s_begin; s0 < s_end; s0 += RCH) {
+    const int nr = min(RCH, s_end - s0);
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, c = e - r * D;
+      const long long row = (long long)n * S + s0 + r;
+      sX[r * P + c] = elu1p(to_f32<T>(k[row * k_ld + h * D + c]));
+      sY[r * P + c] = to_f32<T>(v[row * v_ld + h * D + c]) / fS;
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * D; e += NT) {
+      const int r = e / D, i = e - r * D;
+      const long long row = (long long)n * S + s0 + r;
+      float a = sG[i * P + D];
+#pragma unroll 8
+      for (int j = 0; j < D; ++j) a = fmaf(sG[i * P + j], sY[r * P + j], a);
+      dk[row * dk_ld + h * D + i] = from_f32<T>(a * elu1_grad(to_f32<T>(k[row * k_ld + h * D + i])));
+      float b = 0.f;                                   // here the output index is j = i
+#pragma unroll 8
+      for (int ii = 0; ii < D; ++ii) b = fmaf(sX[r * P + ii], sG[ii * P + i], b);
+      dv[row * dv_ld + h * D + i] = from_f32<T>(b / fS);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cfp_linattn_state_bytes(int N, int heads, int d) { return (N > 0 && heads > 0 && d > 0) ? (size_t)N * heads * d * (d + 1) * sizeof(float) : 0; }
@@ -299,22 +482,21 @@ extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld,
                      ws_bytes >= (size_t)N * heads * sp.c1 * d * (d + 1) * sizeof(float);
   float* partial = reinterpret_cast<float*>(ws);
   const bool wave = L <= 64 && S <= 64;      // zone / window groups of a few tokens: one wave per (group, head)
-#define L1(T, DD) do {                                                                                                              \
-    if (!split && wave) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0, 64>), grid, dim3(64), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,      \
-                                           (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);             \
-    else if (!split) hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 0, 256>), grid, dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,     \
-                                        (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, nullptr, 0, 0);                \
+#define FARGS(T) (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps
+#define L1(T, DD, KERN) do {                                                                                                        \
+    if (!split && wave) hipLaunchKernelGGL((KERN<T, DD, 0, 64>), grid, dim3(64), 0, s, FARGS(T), nullptr, 0, 0);                     \
+    else if (!split) hipLaunchKernelGGL((KERN<T, DD, 0, 256>), grid, dim3(256), 0, s, FARGS(T), nullptr, 0, 0);                      \
     else {                                                                                                                          \
-      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
-                         (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len1);                      \
-      hipLaunchKernelGGL((linattn_fwd_kernel<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, (const T*)q, q_ld, (const T*)k, k_ld,        \
-                         (const T*)v, v_ld, (T*)out, out_ld, state, L, S, heads, eps, partial, sp.c1, sp.len2);                      \
+      hipLaunchKernelGGL((KERN<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, FARGS(T), partial, sp.c1, sp.len1);            \
+      hipLaunchKernelGGL((KERN<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, FARGS(T), partial, sp.c1, sp.len2);            \
     }                                                                                                                               \
   } while (0)
-#define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
+#define LD(T) do { if (d == 4) L1(T, 4, linattn_fwd_kernel); else if (d == 8) L1(T, 8, linattn_fwd_kernel);                         \
+                   else if (d == 16) L1(T, 16, linattn_fwd2_kernel); else L1(T, 32, linattn_fwd2_kernel); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
 #undef L1
+#undef FARGS
   return cfp_check_launch("cfp_linattn_fwd");
 }
 
@@ -333,15 +515,16 @@ extern "C" int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld,
   const bool wave = L <= 64 && S <= 64;
 #define BARGS(T) (const T*)q, q_ld, (const T*)k, k_ld, (const T*)v, v_ld, (const T*)dout, do_ld, state, (T*)dq, dq_ld, (T*)dk, dk_ld, (T*)dv, \
                  dv_ld, L, S, heads, eps
-#define L1(T, DD) do {                                                                                                              \
-    if (!split && wave) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0, 64>), grid, dim3(64), 0, s, BARGS(T), nullptr, 0, 0);       \
-    else if (!split) hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 0, 256>), grid, dim3(256), 0, s, BARGS(T), nullptr, 0, 0);        \
+#define L1(T, DD, KERN) do {                                                                                                        \
+    if (!split && wave) hipLaunchKernelGGL((KERN<T, DD, 0, 64>), grid, dim3(64), 0, s, BARGS(T), nullptr, 0, 0);                     \
+    else if (!split) hipLaunchKernelGGL((KERN<T, DD, 0, 256>), grid, dim3(256), 0, s, BARGS(T), nullptr, 0, 0);                      \
     else {                                                                                                                          \
-      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len1);   \
-      hipLaunchKernelGGL((linattn_bwd_kernel<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);   \
+      hipLaunchKernelGGL((KERN<T, DD, 1, 256>), dim3(grid.x, sp.c1), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len1);            \
+      hipLaunchKernelGGL((KERN<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);            \
     }                                                                                                                               \
   } while (0)
-#define LD(T) do { if (d == 4) L1(T, 4); else if (d == 8) L1(T, 8); else if (d == 16) L1(T, 16); else L1(T, 32); } while (0)
+#define LD(T) do { if (d == 4) L1(T, 4, linattn_bwd_kernel); else if (d == 8) L1(T, 8, linattn_bwd_kernel);                         \
+                   else if (d == 16) L1(T, 16, linattn_bwd2_kernel); else L1(T, 32, linattn_bwd2_kernel); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
 #undef L1
