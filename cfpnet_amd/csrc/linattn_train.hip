@@ -491,7 +491,7 @@ extern "C" int cfp_linattn_fwd(const void* q, int q_ld, const void* k, int k_ld,
       hipLaunchKernelGGL((KERN<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, FARGS(T), partial, sp.c1, sp.len2);            \
     }                                                                                                                               \
   } while (0)
-#define LD(T) do { if (d == 4) L1(T, 4, linattn_fwd_kernel); else if (d == 8) L1(T, 8, linattn_fwd_kernel);                         \
+#define LD(T) do { if (d == 4) L1(T, 4, linattn_fwd_kernel); else if (d == 8) L1(T, 8, linattn_fwd2_kernel);                         \
                    else if (d == 16) L1(T, 16, linattn_fwd2_kernel); else L1(T, 32, linattn_fwd2_kernel); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
@@ -523,7 +523,7 @@ extern "C" int cfp_linattn_bwd(const void* q, int q_ld, const void* k, int k_ld,
       hipLaunchKernelGGL((KERN<T, DD, 2, 256>), dim3(grid.x, sp.c2), dim3(256), 0, s, BARGS(T), partial, sp.c1, sp.len2);            \
     }                                                                                                                               \
   } while (0)
-#define LD(T) do { if (d == 4) L1(T, 4, linattn_bwd_kernel); else if (d == 8) L1(T, 8, linattn_bwd_kernel);                         \
+#define LD(T) do { if (d == 4) L1(T, 4, linattn_bwd_kernel); else if (d == 8) L1(T, 8, linattn_bwd2_kernel);                         \
                    else if (d == 16) L1(T, 16, linattn_bwd2_kernel); else L1(T, 32, linattn_bwd2_kernel); } while (0)
   if (dtype == CFP_BF16) LD(bf16_t); else if (dtype == CFP_F16) LD(f16_t); else LD(float);
 #undef LD
