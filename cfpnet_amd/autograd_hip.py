@@ -242,8 +242,14 @@ class Tape:
         """w.t [C, k, k] f32 in torch order (ky, kx); the forward kernel wants [C][kx][ky]."""
         C = x.C
         y = V(torch.empty_like(x.t))
-        wk = w.t.transpose(1, 2).contiguous().reshape(C, k * k)
-        ops.dwconv_large(_act(x.t), wk, self.const("ones", C), bias.t, _act(y.t), B, H, W, k, hip.ACT_NONE)
+        # 16-bit storage: the banded-Toeplitz matrix-core kernel of the inference path (4x faster than the VALU form at k = 31);
+        # its band table is re-derived from the float32 master weights by one device gather per step
+        mfma = x.t.dtype != torch.float32 and k in (7, 15, 31) and C % 16 == 0
+        if mfma:
+            ops.dwconv_large_mfma(_act(x.t), ops.toeplitz_bands_dev(w.t, x.t.dtype), self.const("ones", C), bias.t, _act(y.t), B, H, W, k, hip.ACT_NONE)
+        else:
+            wk = w.t.transpose(1, 2).contiguous().reshape(C, k * k)
+            ops.dwconv_large(_act(x.t), wk, self.const("ones", C), bias.t, _act(y.t), B, H, W, k, hip.ACT_NONE)
 
         def bw():
             if y.g is None:
@@ -252,9 +258,13 @@ class Tape:
                 self.pgrad(bias, lambda out, beta: train_ops.colsum(y.g, out=out, beta=beta))
                 self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k, dw=out, beta=beta))
             self.off_path(param_grads)
-            wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)          # data gradient = correlation with the flipped kernel
-            dx = torch.empty_like(x.t)
-            ops.dwconv_large(_act(y.g), wf, self.const("ones", C), self.const("zeros", C), _act(dx), B, H, W, k, hip.ACT_NONE)
+            dx = torch.empty_like(x.t)                                                   # data gradient = correlation with the flipped kernel
+            if mfma:
+                ops.dwconv_large_mfma(_act(y.g), ops.toeplitz_bands_dev(w.t.flip(1, 2), x.t.dtype), self.const("ones", C), self.const("zeros", C),
+                                      _act(dx), B, H, W, k, hip.ACT_NONE)
+            else:
+                wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)
+                ops.dwconv_large(_act(y.g), wf, self.const("ones", C), self.const("zeros", C), _act(dx), B, H, W, k, hip.ACT_NONE)
             self.acc(x, dx)
         self.bw.append(bw)
         return y
