@@ -363,7 +363,7 @@ class Tape:
 
     def channel_mean(self, x: V, B, HW) -> V:
         """[B*HW, C] -> [B, C] float32."""
-        ns = max(1, min(64, HW // 256))                              # two-level sum: [B, ns, C] partials, then over ns
+        ns = max(1, min(64, HW // 16, -(-1024 // B)))                # two-level sum: [B, ns, C] partials (~1000 workgroups), then over ns
         part = torch.empty(B * ns, x.C, dtype=torch.float32, device=self.dev)
         ops.channel_sum(_act(x.t), part, B, HW, ns)
         if ns > 1:

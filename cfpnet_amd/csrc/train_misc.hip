@@ -66,20 +66,22 @@ __global__ __launch_bounds__(256) void rowtable_grad_kernel(const T* __restrict_
 }
 
 // out[b][c] = sum over the HW rows of image b of x * y  (squeeze-excite: d gate = sum dy * x).  One workgroup per
-// (image, 32 vector columns): 8 row lanes, fixed-order combination.
+// (image, 2^colbits vector columns): 256 / 2^colbits row lanes, fixed-order combination.  Fewer columns per workgroup when the
+// launch would otherwise be a few dozen workgroups (C = 1392 at batch 16: 96 with 32 columns, 352 with 8).
 template <typename T>
 __global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ y, int y_ld,
-                                                          float* __restrict__ out, int HW, int C) {
+                                                          float* __restrict__ out, int HW, int C, int colbits) {
   constexpr int VE = Vec<T>::N;
-  __shared__ float red[8][32 * 8];
-  const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
-  const int c0 = (blockIdx.x * 32 + cl) * VE;
+  __shared__ float red[256][8];
+  const int cols = 1 << colbits, lanes = 256 >> colbits;
+  const int tid = threadIdx.x, cl = tid & (cols - 1), rl = tid >> colbits;
+  const int c0 = (blockIdx.x * cols + cl) * VE;
   const int cc = c0 < C ? c0 : 0;
   const long long base = (long long)blockIdx.y * HW;
   float s[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) s[e] = 0.f;
-  for (int r = rl; r < HW; r += 8) {
+  for (int r = rl; r < HW; r += lanes) {
     float a[VE], b[VE];
     Vec<T>::load(x + (base + r) * x_ld + cc, a);
     Vec<T>::load(y + (base + r) * y_ld + cc, b);
@@ -87,15 +89,14 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ 
     for (int e = 0; e < VE; ++e) s[e] = fmaf(a[e], b[e], s[e]);
   }
 #pragma unroll
-  for (int e = 0; e < VE; ++e) red[rl][cl * 8 + e] = s[e];
+  for (int e = 0; e < VE; ++e) red[tid][e] = s[e];
   __syncthreads();
-  for (int i = tid; i < 32 * VE; i += 256) {
+  for (int i = tid; i < cols * VE; i += 256) {
     const int c_l = i / VE, e = i - c_l * VE;
-    const int c = (blockIdx.x * 32 + c_l) * VE + e;
+    const int c = (blockIdx.x * cols + c_l) * VE + e;
     if (c >= C) continue;
     float t = 0.f;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) t += red[l][c_l * 8 + e];
+    for (int l = 0; l < lanes; ++l) t += red[(l << colbits) + c_l][e];
     out[(long long)blockIdx.y * C + c] = t;
   }
 }
@@ -303,8 +304,10 @@ extern "C" int cfp_channel_dot(const void* x, int x_ld, const void* y, int y_ld,
   TM_COMMON("cfp_channel_dot");
   CFP_REQUIRE(B > 0 && B <= 65535 && HW > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && y_ld % ve == 0 && x_ld >= C && y_ld >= C, CFP_ESHAPE,
               "cfp_channel_dot: bad shape");
-  const dim3 grid(cdiv(C, 32 * ve), B);
-#define L(T) hipLaunchKernelGGL(channel_dot_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, out, HW, C)
+  int colbits = 5;
+  while (colbits > 2 && (long long)cdiv(C, ve << colbits) * B < 512 && (256 >> colbits) * 4 <= HW) --colbits;
+  const dim3 grid(cdiv(C, ve << colbits), B);
+#define L(T) hipLaunchKernelGGL(channel_dot_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, out, HW, C, colbits)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_channel_dot");
