@@ -36,32 +36,49 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, int
 }
 
 // dtable[(oy + y) * Wt + ox + x][c] (+)= sum_b dx[b][y][x][c]   -- gradient of `x + PE[oy:oy+H, ox:ox+W]` (f32 table)
+// 2^ibits (pixel, channel vector) items per workgroup, the other threads are lanes over the batch: the second table of a fusion
+// block is [16, D] against B * Z = 576 "images", one thread per item would add 576 rows alone (150 us); lanes meet in LDS in
+// lane order.
 template <typename T>
 __global__ __launch_bounds__(256) void rowtable_grad_kernel(const T* __restrict__ dx, int ld, float* __restrict__ dtable, int B, int H, int W,
-                                                            int C, int Wt, int oy, int ox, float beta, const int* __restrict__ dev_off, int Ht) {
+                                                            int C, int Wt, int oy, int ox, float beta, const int* __restrict__ dev_off, int Ht,
+                                                            int ibits) {
   constexpr int VE = Vec<T>::N;
+  __shared__ float red[256][8];
   const int CV = C / VE;
   if (dev_off) {
     oy = min(max(dev_off[0], 0), Ht - H);
     ox = min(max(dev_off[1], 0), Wt - W);
   }
+  const int items = 1 << ibits, lanes = 256 >> ibits;
+  const int il = threadIdx.x & (items - 1), bl = threadIdx.x >> ibits;
   const long long total = (long long)H * W * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long px = i / CV;
-    const int c = (int)(i - px * CV) * VE;
-    const int y = (int)(px / W), x = (int)(px - (long long)y * W);
-    float s[VE];
+  const long long i = (long long)blockIdx.x * items + il;
+  const bool ok = i < total;
+  const long long px = ok ? i / CV : 0;
+  const int c = ok ? (int)(i - px * CV) * VE : 0;
+  float s[VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s[e] = 0.f;
-    for (int b = 0; b < B; ++b) {
+  for (int e = 0; e < VE; ++e) s[e] = 0.f;
+  if (ok)
+    for (int b = bl; b < B; b += lanes) {
       float v[VE];
       Vec<T>::load(dx + ((long long)b * H * W + px) * ld + c, v);
 #pragma unroll
       for (int e = 0; e < VE; ++e) s[e] += v[e];
     }
+#pragma unroll
+  for (int e = 0; e < VE; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  if (bl == 0 && ok) {
+    const int y = (int)(px / W), x = (int)(px - (long long)y * W);
     float* d = dtable + ((long long)(oy + y) * Wt + ox + x) * C + c;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) d[e] = beta != 0.f ? beta * d[e] + s[e] : s[e];
+    for (int e = 0; e < VE; ++e) {
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += red[(l << ibits) + il][e];
+      d[e] = beta != 0.f ? beta * d[e] + t : t;
+    }
   }
 }
 
@@ -235,19 +252,39 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const T* __restrict__ 
   }
 }
 
+// out = beta * out + sum over the splits, fixed order: 32 consecutive outputs per workgroup, 8 lanes over the splits with 4 loads
+// in flight each (hundreds of splits of a few thousand outputs: one thread per output would walk them alone), lanes meet in LDS.
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nsplit, long long n, float* __restrict__ out,
                                                            float beta) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int j = 0; j < nsplit; ++j) s += partial[(long long)j * n + i];
-    out[i] = beta != 0.f ? beta * out[i] + s : s;
+  __shared__ float red[8][32];
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long long i0 = (long long)blockIdx.x * 32; i0 < n; i0 += (long long)gridDim.x * 32) {
+    const long long i = i0 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int j = sl;
+      for (; j + 24 < nsplit; j += 32) {
+        s0 += partial[(long long)j * n + i]; s1 += partial[(long long)(j + 8) * n + i];
+        s2 += partial[(long long)(j + 16) * n + i]; s3 += partial[(long long)(j + 24) * n + i];
+      }
+      for (; j < nsplit; j += 8) s0 += partial[(long long)j * n + i];
+    }
+    red[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < n) {
+      float s = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) s += red[l][e];
+      out[i] = beta != 0.f ? beta * out[i] + s : s;
+    }
+    __syncthreads();
   }
 }
 
 inline int dw_wgrad_splits(long long M, int C, int ve) {
   const int colblk = cdiv(C, 32 * ve);
   long long ns = 1024 / colblk;
-  const long long mx = (M + 127) / 128;
+  const long long mx = (M + 31) / 32;                        // at least 32 rows (4 per row lane) per split
   if (ns > mx) ns = mx;
   if (ns > 2048) ns = 2048;
   if (ns < 1) ns = 1;
@@ -280,8 +317,12 @@ static int rowtable_grad_impl(const void* dx, int ld, float* dtable, int B, int 
   TM_COMMON("cfp_rowtable_grad");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0 && ld % ve == 0 && ld >= C && Wt >= ox + W && oy >= 0 && ox >= 0 &&
                   (!dev_off || Ht >= H), CFP_ESHAPE, "cfp_rowtable_grad: bad shape");
-  const dim3 grid(ew_grid2((long long)H * W * (C / ve)));
-#define L(T) hipLaunchKernelGGL(rowtable_grad_kernel<T>, grid, dim3(256), 0, s, (const T*)dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta, dev_off, Ht)
+  const long long total = (long long)H * W * (C / ve);
+  int ibits = 8;                                             // fewer items per workgroup (more batch lanes) while the launch is small
+  while (ibits > 3 && (total >> ibits) < 512 && (256 >> (ibits - 1)) <= B) --ibits;
+  CFP_REQUIRE(((total + (1 << ibits) - 1) >> ibits) < (1ll << 31), CFP_ESHAPE, "cfp_rowtable_grad: table too large");
+  const dim3 grid((unsigned)cdiv(total, 1 << ibits));
+#define L(T) hipLaunchKernelGGL(rowtable_grad_kernel<T>, grid, dim3(256), 0, s, (const T*)dx, ld, dtable, B, H, W, C, Wt, oy, ox, beta, dev_off, Ht, ibits)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_rowtable_grad");
@@ -372,6 +413,6 @@ extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int 
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   const long long n = 9ll * C;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, partial, nsplit, n, dw, beta);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<long long>(4096, cdiv(n, 32))), dim3(256), 0, s, partial, nsplit, n, dw, beta);
   return cfp_check_launch("cfp_dwconv3x3_wgrad");
 }
