@@ -128,7 +128,10 @@ class Tape:
         """w.t [Cout, k*k*Cin]; bias.t [Cout] f32."""
         Cout = w.t.shape[0]
         y = V(self.new(B * Ho * Wo, Cout, x.t.dtype))
-        ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo)
+        # split-K slabs (few rows, long K: the sr convs) in the 16-bit modes; float32 parity mode keeps its single summation chain
+        nws = ops.conv2d_ws_bytes(B * Ho * Wo, Cout, w.t.shape[1], ops.DT[x.t.dtype]) if x.t.dtype != torch.float32 else 0
+        ws = torch.empty(nws // 4, dtype=torch.float32, device=self.dev) if nws else None
+        ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo, ws=ws)
 
         def bw():
             g = y.g

@@ -359,7 +359,7 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
     else pl.variant = 4;
   }
   if (rpb > 0) { pl.gen1 = false; pl.direct = -1; if (pl.variant != 12) pl.variant = 4; }
-  if (allow_split && M <= 1100 && K >= 2048) { pl.variant = 4; pl.splits = 8; pl.gen1 = false; pl.direct = -1; }
+  if (allow_split && K >= 2048 && (M <= 1100 || ((M + 63) / 64) * ((N + 63) / 64) <= 48)) { pl.variant = 4; pl.splits = 8; pl.gen1 = false; pl.direct = -1; }
   if (g_force_variant >= 200 && conv3x3s1 && g_force_variant - 200 < conv3x3_num_variants()) { pl.direct = g_force_variant - 200; pl.gen1 = false; pl.splits = 1; }
   else if (g_force_variant >= 0) pl.direct = -1;
   if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }
