@@ -154,7 +154,17 @@ class Tape:
             elif x.needs_grad:
                 w.geom = (Cout, k, k, x.C)
                 wt = w.wt if w.wt is not None else train_ops.conv2d_weight_flip(w.t, Cout, k, k, x.C)
-                self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
+                if x.g is not None and x.g_owned:
+                    # a gradient is already there (q / k / v projections of one input, a block and its skip): add inside the
+                    # GEMM's epilogue instead of a separate pass
+                    train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo, dx=x.g, accumulate=True)
+                elif x.g is not None and stride == 1:
+                    # shared (not ours to overwrite): read it as the residual of the stride-1 data-gradient conv, write a fresh tensor
+                    dx = self.new(B * H * W, x.C, g.dtype)
+                    ops.conv2d(_act(g), wt, None, None, _act(dx), B, Ho, Wo, k, k, 1, k - 1 - pt, k - 1 - pl, H, W, residual=_act(x.g))
+                    x.g, x.g_owned = dx, True
+                else:
+                    self.acc(x, train_ops.conv2d_dgrad(g, wt, B, H, W, x.C, k, k, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y
 
