@@ -210,8 +210,10 @@ class _CapturedTrainStep:
             g = self.net.grads()
             self.grads = [g.get(n) for n in self.names]
         self.ptrs = tuple(p.data_ptr() for p in params)
+        self.generation = 0              # the captured activations belong to the LAST forward only
 
     def forward(self, input_data, pos_offsets):
+        self.generation += 1
         add = input_data["additional"]
         self.inp["rgb"].copy_(input_data["rgb"], non_blocking=True)
         self.inp["additional"]["hist_data"].copy_(add["hist_data"], non_blocking=True)
@@ -248,6 +250,7 @@ class _TrainStep(torch.autograd.Function):
                 cap = model._train_captures[key] = _CapturedTrainStep(model, input_data, names, params)
             ctx.cap = cap
             edges, pred = cap.forward(input_data, pos_offsets)
+            ctx.generation = cap.generation
             ctx.mark_non_differentiable(edges)
             return edges, pred
         ctx.cap = None
@@ -264,6 +267,9 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_edges, g_pred):
         if ctx.cap is not None:
+            if ctx.generation != ctx.cap.generation:
+                raise RuntimeError("cfpnet_amd: backward of a training-mode forward whose activations were overwritten by a later forward "
+                                   "of the same captured step (two forwards before one backward); set model.train_graphs = False for that pattern")
             return (None, None, None, None) + ctx.cap.backward(g_pred.to(torch.float32))
         ctx.pred.g = g_pred.reshape(-1, 1).to(torch.float32).contiguous()
         ctx.tape.backward()

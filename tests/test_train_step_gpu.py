@@ -187,6 +187,12 @@ def test_deltar_module_graph_replay_equals_eager_tape():
         results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
     (l0, s0), (l1, s1) = results
     assert l0 == l1, (l0, l1)
+    # two forwards before one backward would read overwritten activations: refused loudly
+    e1, p1 = model(batches[0][0], pos_offsets=batches[0][2])
+    e2, p2 = model(batches[1][0], pos_offsets=batches[1][2])
+    with pytest.raises(RuntimeError, match="overwritten"):
+        p1.sum().backward()
+    p2.sum().backward()
     assert all(torch.equal(s0[k], s1[k]) for k in s0), [k for k in s0 if not torch.equal(s0[k], s1[k])][:5]
 
 
