@@ -102,3 +102,28 @@ def test_nyu_train_files_loader(tmp_path):
     bad = types.SimpleNamespace(filenames_file=str(fn), data_path=str(tmp_path / "nowhere"), num_threads=1)
     with pytest.raises(FileNotFoundError):
         list(data.NYUTrainFiles(bad).epoch_batches(1))
+
+
+def test_nyu_eval_files_loader(tmp_path):
+    """`NYUEvalFiles` (nyu.py:72-76,101-107, online_eval branch): file naming under data_path_eval, no border crop, ToTensor
+    normalisation, depth in metres."""
+    import json
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    root = tmp_path / "nyu" / "test" / "bathroom"
+    root.mkdir(parents=True)
+    dep = rng.integers(0, 10000, (480, 640), dtype=np.uint16)
+    rgb = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    Image.fromarray(dep).save(root / "sync_depth_00045.png")
+    Image.fromarray(rgb, "RGB").save(root / "rgb_00045.jpg", quality=95)
+    fn = tmp_path / "nyu.json"
+    fn.write_text(json.dumps({"test": [{"filename": "test/bathroom/00045.h5"}], "train": []}))
+    args = types.SimpleNamespace(filenames_file_eval=str(fn), data_path_eval=str(tmp_path / "nyu" / "test"))
+    items = list(data.NYUEvalFiles(args))
+    assert len(items) == 1
+    img, d, name = items[0]
+    assert name == "test/bathroom/00045.h5" and img.shape == (3, 480, 640) and d.shape == (1, 480, 640)
+    with Image.open(root / "rgb_00045.jpg") as im:
+        want = (np.asarray(im, dtype=np.float32) / 255.0 - data.IMAGENET_MEAN) / data.IMAGENET_STD
+    assert np.allclose(img.numpy(), want.transpose(2, 0, 1), atol=1e-6)
+    assert np.array_equal(d.numpy()[0], dep.astype(np.float32) / 1000.0)
