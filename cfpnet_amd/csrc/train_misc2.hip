@@ -348,6 +348,85 @@ __global__ __launch_bounds__(256) void dwlarge_wgrad_kernel(const T* __restrict_
   }
 }
 
+// k = 31: a thread owns FOUR CONSECUTIVE taps of one kernel row (31 rows x 8 threads) and slides a 4-vector window along the
+// pixel row: per pixel one new x vector and the dy vector are read and unpacked instead of four x vectors (the generic kernel
+// above spends more VALU issue on bf16 unpacking and LDS reads than on the 32 FMAs).  Same staging, same partial layout.
+template <typename T>
+__global__ __launch_bounds__(256) void dwlarge_wgrad31_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
+                                                              float* __restrict__ partial, int B, int H, int W, int C) {
+  constexpr int VE = Vec<T>::N, K = 31;
+  constexpr int HALO = (K - 1) / 2, PW = LWT + K - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  T* sx = reinterpret_cast<T*>(lsm);                       // [PW][PW][VE]
+  T* sd = sx + PW * PW * VE;                               // [LWT][LWT][VE]
+  const int tid = threadIdx.x;
+  const int CV = C / VE;
+  const int tiles_x = (W + LWT - 1) / LWT, tiles_y = (H + LWT - 1) / LWT;
+  int bid = blockIdx.x;
+  const int cv = bid % CV; bid /= CV;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * LWT, x0 = tx * LWT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = tid; i < PW * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+    const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((long long)b * H + cy) * W + cx) * x_ld + cv * VE);
+    *reinterpret_cast<u32x4*>(sx + i * VE) = ok ? v : zero4;
+  }
+  for (int i = tid; i < LWT * LWT; i += 256) {
+    const int py = i / LWT, px = i - py * LWT;
+    const int gy = y0 + py, gx = x0 + px;
+    const bool ok = gy < H && gx < W;
+    const int cy = min(gy, H - 1), cx = min(gx, W - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(dy + (((long long)b * H + cy) * W + cx) * dy_ld + cv * VE);
+    *reinterpret_cast<u32x4*>(sd + i * VE) = ok ? v : zero4;
+  }
+  __syncthreads();
+  const int ky = min(tid >> 3, K - 1), kx0 = (tid & 7) * 4;          // threads 248..255 repeat row 30 and store nothing
+  float acc[4][VE];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[j][e] = 0.f;
+  for (int py = 0; py < LWT; ++py) {
+    // x[py + ky][kx0 + px + j]: the last lanes' window runs up to 3 vectors past the row end (into the next row / the dy tile,
+    // inside the LDS allocation); those products land in taps that are not stored
+    const T* row = sx + ((py + ky) * PW + kx0) * VE;
+    const T* drow = sd + py * LWT * VE;
+    float w[4][VE];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Vec<T>::load(row + j * VE, w[j]);
+#pragma unroll 2
+    for (int p4 = 0; p4 < LWT; p4 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float g[VE];
+        Vec<T>::load(drow + (p4 + u) * VE, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[j][e] = fmaf(g[e], w[(u + j) & 3][e], acc[j][e]);
+        Vec<T>::load(row + (p4 + u + 4) * VE, w[u]);           // x[.. + px + 4] replaces x[.. + px]
+      }
+    }
+  }
+  if (tid < K * 8) {
+    float* dst = partial + (long long)blockIdx.x * K * K * VE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kx = kx0 + j;
+      if (kx < K) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) dst[(ky * K + kx) * VE + e] = acc[j][e];
+      }
+    }
+  }
+}
+
 // dw[c][tap] = beta * dw + sum over tiles (b, ty, tx) of partial[tile][cv][tap][e]; 64 outputs per workgroup, 4 lanes over the
 // tiles with 4 loads in flight each (a chain of hundreds of dependent adds per output otherwise), combined in lane order.
 __global__ __launch_bounds__(256) void dwlarge_wgrad_reduce_kernel(const float* __restrict__ partial, int ntiles, int CV, int VE, int KK,
@@ -388,8 +467,19 @@ hipError_t launch_dwl_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, 
     attr = true;
   }
   const long long blocks = (long long)B * cdiv(H, LWT) * cdiv(W, LWT) * (C / VE);
-  hipLaunchKernelGGL((dwlarge_wgrad_kernel<T, K>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B,
-                     H, W, C);
+  if constexpr (K == 31) {
+    static bool attr31 = false;
+    if (!attr31) {
+      hipError_t e = hipFuncSetAttribute((const void*)dwlarge_wgrad31_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr31 = true;
+    }
+    hipLaunchKernelGGL((dwlarge_wgrad31_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B,
+                       H, W, C);
+  } else {
+    hipLaunchKernelGGL((dwlarge_wgrad_kernel<T, K>), dim3((unsigned)blocks), dim3(256), lds, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B,
+                       H, W, C);
+  }
   return hipSuccess;
 }
 }  // namespace
