@@ -29,7 +29,22 @@ struct WgP {
   int x_ld, dy_ld;
   int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
   int M, K, rows_per_split, nsplit;
+  unsigned mg_hw, sh_hw, mg_w, sh_w;           // floor(m / (Ho*Wo)) and floor(r / Wo) as multiply-high + shift (m < 2^31)
 };
+
+// q = floor(m / d) for 0 <= m < 2^31 without an integer division (~40 VALU instructions each, and the im2col row split needs
+// two per staged vector): with s = ceil(log2 d) and magic = floor(2^(31+s) / d) + 1 < 2^32,  q = mulhi(m, magic) >> (s - 1)
+// (the error term e = magic * d - 2^(31+s) is in (0, d], so m * e < 2^(31+s) and the quotient is exact).  d = 1: magic 0.
+inline void fastdiv_make(unsigned d, unsigned* magic, unsigned* shift) {
+  if (d <= 1) { *magic = 0u; *shift = 0u; return; }
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  *magic = (unsigned)(((1ull << (31 + s)) / d) + 1ull);
+  *shift = s - 1;
+}
+__device__ __forceinline__ int fastdiv(int m, unsigned magic, unsigned shift) {
+  return magic ? (int)(__umulhi((unsigned)m, magic) >> shift) : m;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
@@ -73,8 +88,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
       const int m = m0 + s_row[i];
       const bool m_ok = m < m_end;
       const int mm = m_ok ? m : m_begin;
-      const int b = mm / HoWo, r = mm - b * HoWo;
-      const int ho = r / p.Wo, wo = r - ho * p.Wo;
+      const int b = fastdiv(mm, p.mg_hw, p.sh_hw), r = mm - b * HoWo;
+      const int ho = fastdiv(r, p.mg_w, p.sh_w), wo = r - ho * p.Wo;
       const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
       const bool in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
@@ -191,8 +206,8 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
         in_ok = m_ok && k_ok[i];
         xrow = mm;
       } else {
-        const int b = mm / HoWo, r = mm - b * HoWo;
-        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        const int b = fastdiv(mm, p.mg_hw, p.sh_hw), r = mm - b * HoWo;
+        const int ho = fastdiv(r, p.mg_w, p.sh_w), wo = r - ho * p.Wo;
         const int hi = ho * p.stride - p.pad_t + x_kh[i], wi = wo * p.stride - p.pad_l + x_kw[i];
         in_ok = m_ok && k_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
         const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);
@@ -376,6 +391,8 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.x = x; p.dy = dy; p.slabs = reinterpret_cast<float*>(ws); p.x_ld = x_ld; p.dy_ld = dy_ld;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K;
+  fastdiv_make((unsigned)(Ho * Wo), &p.mg_hw, &p.sh_hw);
+  fastdiv_make((unsigned)Wo, &p.mg_w, &p.sh_w);
   p.nsplit = wgrad_nsplit(Cout, (int)K, (int)M);
   const int mstep = is16(dtype) ? W16M : WM;
   p.rows_per_split = cdiv(cdiv(M, p.nsplit), mstep) * mstep;
