@@ -104,15 +104,30 @@ __device__ __forceinline__ void igemm_mainloop(const ConvP& p, int m0, int n0, i
   u32x4 ra[A_ROWS], rb[B_ROWS];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // im2col position of this thread's chunk, advanced from K-step to K-step (they are issued in order) instead of two integer
+  // divisions per step; a jump (first step, split-K start) recomputes it
+  int t_k = -1, t_cc = 0, t_kh = 0, t_kw = 0;
+  const bool dil_pow2 = (p.dil & (p.dil - 1)) == 0;
+  const int dil_shift = 31 - __clz(p.dil);
   auto load_tiles = [&](int k0) {
     int k = k0 + ld_chunk * VE;
     bool kok = k < p.K;
     int kh = 0, kw = 0, cc = k;
     if (!p.pointwise) {
-      int tap = k / p.Cin;
-      cc = k - tap * p.Cin;
-      kh = tap / p.KW;
-      kw = tap - kh * p.KW;
+      if (k == t_k + BK && t_k >= 0) {
+        t_cc += BK;
+        while (t_cc >= p.Cin) {
+          t_cc -= p.Cin;
+          if (++t_kw == p.KW) { t_kw = 0; ++t_kh; }
+        }
+      } else {
+        int tap = k / p.Cin;
+        t_cc = k - tap * p.Cin;
+        t_kh = tap / p.KW;
+        t_kw = tap - t_kh * p.KW;
+      }
+      t_k = k;
+      cc = t_cc; kh = t_kh; kw = t_kw;
     }
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
@@ -120,7 +135,10 @@ __device__ __forceinline__ void igemm_mainloop(const ConvP& p, int m0, int n0, i
       bool ok = a_ok[i] && kok;
       long long off = a_base[i] + cc;
       if (!p.pointwise) {
-        if (p.dil > 1) {        // uniform: (hi, wi) are coordinates of the zero-stuffed input
+        if (p.dil > 1 && dil_pow2) {   // uniform: (hi, wi) are coordinates of the zero-stuffed input; stride 2 in every shipped model
+          ok = ok && hi >= 0 && wi >= 0 && ((hi | wi) & (p.dil - 1)) == 0;
+          hi >>= dil_shift; wi >>= dil_shift;
+        } else if (p.dil > 1) {
           ok = ok && hi >= 0 && wi >= 0 && hi % p.dil == 0 && wi % p.dil == 0;
           hi /= p.dil; wi /= p.dil;
         }
