@@ -367,13 +367,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // dz = dy * act'(z)  (z = the pre-activation the forward kernel saw)
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, int ld, const T* __restrict__ dy, int dy_ld, int act,
-                                                      T* __restrict__ dz, int dz_ld, long long rows, int C) {
+                                                      T* __restrict__ dz, int dz_ld, long long rows, int C, FastDiv fcv) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
+  const unsigned total = (unsigned)(rows * fcv.d);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned ru, cvu;
+    fd_rowcol(i, fcv, ru, cvu);
+    const long long r = ru;
+    const int c = (int)cvu * VE;
     float v[VE], g[VE];
     Vec<T>::load(z + r * ld + c, v);
     Vec<T>::load(dy + r * dy_ld + c, g);
@@ -512,7 +513,9 @@ extern "C" int cfp_act_bwd(const void* z, int ld, const void* dy, int dy_ld, int
   BN_COMMON("cfp_act_bwd");
   CFP_REQUIRE(dy_ld % ve == 0 && dy_ld >= C && dz_ld % ve == 0 && dz_ld >= C, CFP_ESHAPE, "cfp_act_bwd: bad pitch");
   const dim3 grid(ew_grid(rows * (C / ve)));
-#define AL(T) hipLaunchKernelGGL(act_bwd_kernel<T>, grid, dim3(256), 0, s, (const T*)z, ld, (const T*)dy, dy_ld, act, (T*)dz, dz_ld, rows, C)
+  CFP_REQUIRE(rows * (C / ve) < (1ll << 31), CFP_ESHAPE, "cfp_act_bwd: too many elements");
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve));
+#define AL(T) hipLaunchKernelGGL(act_bwd_kernel<T>, grid, dim3(256), 0, s, (const T*)z, ld, (const T*)dy, dy_ld, act, (T*)dz, dz_ld, rows, C, fcv)
   if (dtype == CFP_BF16) AL(bf16_t); else if (dtype == CFP_F16) AL(f16_t); else AL(float);
 #undef AL
   return cfp_check_launch("cfp_act_bwd");

@@ -172,3 +172,24 @@ static inline bool is16(int dtype) { return dtype == CFP_BF16 || dtype == CFP_F1
 static inline bool dtype_ok(int dtype) { return dtype == CFP_F32 || is16(dtype); }
 static inline int vec_elems(int dtype) { return is16(dtype) ? 8 : 4; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Division of a non-negative 32-bit index by a launch-constant divisor without the division sequence: with s = ceil(log2 d) and
+// magic = floor(2^(31+s) / d) + 1 < 2^32,  floor(m / d) = mulhi(m, magic) >> (s - 1)  exactly for 0 <= m < 2^31 (the error term
+// magic * d - 2^(31+s) lies in (0, d]).  d = 1 is magic 0.  The elementwise kernels split a flat vector index into (row, channel
+// vector) once per 16 bytes moved; the compiler's 64-bit division there is a few dozen VALU instructions per vector.
+struct FastDiv { unsigned d, magic, shift; };
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f{d, 0u, 0u};
+  if (d <= 1) return f;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.magic = (unsigned)(((1ull << (31 + s)) / d) + 1ull);
+  f.shift = s - 1;
+  return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned fd_div(unsigned m, const FastDiv& f) { return f.magic ? (__umulhi(m, f.magic) >> f.shift) : m; }
+// flat index -> (row, channel vector) with CV = f.d vectors per row
+__device__ __forceinline__ void fd_rowcol(unsigned i, const FastDiv& f, unsigned& row, unsigned& cv) { row = fd_div(i, f); cv = i - row * f.d; }
+#endif
+

@@ -481,13 +481,14 @@ __global__ __launch_bounds__(256) void add_rowtable_kernel(const T* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ in, int in_ld, T* __restrict__ out, int out_ld,
-                                                        long long rows, int C) {
+                                                        long long rows, int C, FastDiv fcv) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int cv = (int)(i % CV);
-    long long r = i / CV;
+  const unsigned total = (unsigned)(rows * fcv.d);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned ru, cvu;
+    fd_rowcol(i, fcv, ru, cvu);
+    const long long r = ru;
+    const int cv = (int)cvu;
     *reinterpret_cast<u32x4*>(out + r * out_ld + cv * VE) = *reinterpret_cast<const u32x4*>(in + r * in_ld + cv * VE);
   }
 }
@@ -728,13 +729,15 @@ extern "C" int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, i
   CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && in_ld % ve == 0 && out_ld % ve == 0 && in_ld >= C && out_ld >= C, CFP_ESHAPE,
               "cfp_copy_rows: bad shape");
   long long total = (long long)rows * (C / ve);
+  CFP_REQUIRE(total < (1ll << 31), CFP_ESHAPE, "cfp_copy_rows: too many elements");
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16)
-    hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, (bf16_t*)out, out_ld, (long long)rows, C);
+    hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)in, in_ld, (bf16_t*)out, out_ld, (long long)rows, C, fcv);
   else if (dtype == CFP_F16)
-    hipLaunchKernelGGL(copy_rows_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const f16_t*)in, in_ld, (f16_t*)out, out_ld, (long long)rows, C);
+    hipLaunchKernelGGL(copy_rows_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, (const f16_t*)in, in_ld, (f16_t*)out, out_ld, (long long)rows, C, fcv);
   else
-    hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, (long long)rows, C);
+    hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, (long long)rows, C, fcv);
   return cfp_check_launch("cfp_copy_rows");
 }
 

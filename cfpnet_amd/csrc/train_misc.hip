@@ -14,13 +14,14 @@ inline int ew_grid2(long long total) { long long b = (total + 255) / 256; return
 // out = a * x + b * y   (y may be null: out = a * x)
 template <typename T>
 __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ y, int y_ld, float a, float b,
-                                                    T* __restrict__ out, int out_ld, long long rows, int C) {
+                                                    T* __restrict__ out, int out_ld, long long rows, int C, FastDiv fcv) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
+  const unsigned total = (unsigned)(rows * fcv.d);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned ru, cvu;
+    fd_rowcol(i, fcv, ru, cvu);
+    const long long r = ru;
+    const int c = (int)cvu * VE;
     float v[VE], w[VE];
     Vec<T>::load(x + r * x_ld + c, v);
     if (y) {
@@ -305,7 +306,9 @@ extern "C" int cfp_axpby(const void* x, int x_ld, const void* y, int y_ld, float
   CFP_REQUIRE(rows > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && out_ld % ve == 0 && x_ld >= C && out_ld >= C && (!y || (y_ld % ve == 0 && y_ld >= C)),
               CFP_ESHAPE, "cfp_axpby: bad shape");
   const dim3 grid(ew_grid2(rows * (C / ve)));
-#define L(T) hipLaunchKernelGGL(axpby_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, a, b, (T*)out, out_ld, rows, C)
+  CFP_REQUIRE(rows * (C / ve) < (1ll << 31), CFP_ESHAPE, "cfp_axpby: too many elements");
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve));
+#define L(T) hipLaunchKernelGGL(axpby_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)y, y_ld, a, b, (T*)out, out_ld, rows, C, fcv)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_axpby");

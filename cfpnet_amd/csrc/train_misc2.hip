@@ -15,13 +15,14 @@ inline int ew_grid3(long long total) { long long b = (total + 255) / 256; return
 // injective partial map of token rows, so the adjoint of a gather with map m is the gather with m's inverse map.
 template <typename T>
 __global__ __launch_bounds__(256) void index_rows_kernel(const T* __restrict__ x, int x_ld, const int* __restrict__ idx, T* __restrict__ out,
-                                                         int out_ld, long long n_out, int C, int accumulate) {
+                                                         int out_ld, long long n_out, int C, int accumulate, FastDiv fcv) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = n_out * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / CV;
-    const int c = (int)(i - r * CV) * VE;
+  const unsigned total = (unsigned)(n_out * fcv.d);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned ru, cvu;
+    fd_rowcol(i, fcv, ru, cvu);
+    const long long r = ru;
+    const int c = (int)cvu * VE;
     const int src = idx[r];
     float v[VE];
     if (src >= 0) Vec<T>::load(x + (long long)src * x_ld + c, v);
@@ -203,7 +204,9 @@ extern "C" int cfp_index_rows(const void* x, int x_ld, const int* idx, void* out
   CFP_REQUIRE(n_out > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && out_ld % ve == 0 && x_ld >= C && out_ld >= C, CFP_ESHAPE,
               "cfp_index_rows: bad shape");
   const dim3 grid(ew_grid3(n_out * (C / ve)));
-#define L(T) hipLaunchKernelGGL(index_rows_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, idx, (T*)out, out_ld, n_out, C, accumulate)
+  CFP_REQUIRE(n_out * (C / ve) < (1ll << 31), CFP_ESHAPE, "cfp_index_rows: too many elements");
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve));
+#define L(T) hipLaunchKernelGGL(index_rows_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, idx, (T*)out, out_ld, n_out, C, accumulate, fcv)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_index_rows");
