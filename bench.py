@@ -67,7 +67,7 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_times(engine, inputs, return_prob, reps=3):
+def kernel_times(engine, inputs, return_prob, reps=5):
     """Instrumented eager passes: HIP events (on the launch stream) around every C-ABI call."""
     from cfpnet_amd import hip, ops
     recs = []
@@ -104,23 +104,30 @@ def kernel_times(engine, inputs, return_prob, reps=3):
         recs.append((fam, e0, e1, flops, byts))
     hip.call = timed_call
     try:
-        agg = {}
+        per_rep = []
         for _ in range(reps):
             recs.clear()
             engine.forward(inputs, return_prob=return_prob)
             torch.cuda.synchronize()
-            for fam, e0, e1, flops, byts in recs:
-                d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
-                d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += flops; d[3] += byts
+            per_rep.append([(fam, e0.elapsed_time(e1), flops, byts) for fam, e0, e1, flops, byts in recs])
     finally:
         hip.call = real_call
+    # the launch sequence is the same in every pass: a launch's time is its MEDIAN over the passes (event pairs around
+    # 10-us kernels pick up host jitter: single passes were seen 2x off)
+    agg = {}
+    n = min(len(r) for r in per_rep)
+    for i in range(n):
+        fam, _, flops, byts = per_rep[0][i]
+        ts = sorted(r[i][1] for r in per_rep)
+        d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
+        d[0] += reps; d[1] += ts[len(ts) // 2] * reps; d[2] += flops * reps; d[3] += byts * reps
     out = {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps) for k, v in agg.items()}
     if dw_shapes:
         out["_dw3x3_copy"] = same_size_copy_ms(dw_shapes[:len(dw_shapes) // reps], engine.dtype, engine.device)
     return out
 
 
-def same_size_copy_ms(shapes, dtype, dev, reps=3):
+def same_size_copy_ms(shapes, dtype, dev, reps=5):
     """The "measured HBM roofline" of the depthwise launches: a plain streaming copy (cfp_copy_rows) moving the same number of
     bytes as each depthwise 3x3 launch (input rows + output rows, same channel count), timed with the same event-pair protocol.
     -> total ms for one pass over all the shapes."""
@@ -132,16 +139,15 @@ def same_size_copy_ms(shapes, dtype, dev, reps=3):
         dst = ops.new_act(rows, C, dtype, dev)
         src.buf.normal_()
         ops.copy_rows(src, dst, rows)
-        best = None
+        ts = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             ops.copy_rows(src, dst, rows)
             e1.record()
             torch.cuda.synchronize()
-            t = e0.elapsed_time(e1)
-            best = t if best is None else min(best, t)
-        total += best
+            ts.append(e0.elapsed_time(e1))
+        total += sorted(ts)[len(ts) // 2]            # median, like the kernels it is compared with
     return total
 
 
@@ -401,7 +407,10 @@ def main():
                     # launch of this size is a streaming copy of the same bytes under the same timing protocol
                     cgbs = w["bytes"] / (dw_copy_ms * 1e-3) / 1e9
                     line["dw3x3"].update({"measured_copy_same_bytes": cgbs, "frac_of_measured_copy": gbs / cgbs,
-                                          "copy_avg_launch_us": dw_copy_ms * 1e3 / w["launches"]})
+                                          "copy_avg_launch_us": dw_copy_ms * 1e3 / w["launches"],
+                                          "protocol": "median of 5 event-pair timings per launch for the kernel AND the copy; the pair adds several us "
+                                                      "to both, which flatters the ratio -- back-to-back in a HIP graph (tools/dw_bench.py) "
+                                                      "the same launches take 12.5-19.7 us against 3.1-6.7 us for the copy"})
             line["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
             line["kernel_ms_total"] = total_ms
         if world == 1 and not a.no_cpu_baseline:
