@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
+RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)   # 312 FLOP/B: below it a kernel is bandwidth-bound by the roofline model
 
 
 def parse():
@@ -370,15 +371,23 @@ def main():
             # one hand-written kernel = one row: the tile shapes of igemm2_kernel are template instantiations of the same code
             groups = {}
             for k, v in convs.items():
-                g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "launches": 0, "traffic": 0.0, "traffic_known": True, "tiles": {}})
-                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["launches"] += v["launches"]
+                g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "traffic": 0.0, "traffic_known": True, "tiles": {}})
+                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
                 t = pmc_traffic(k)
                 if t is None:
                     g["traffic_known"] = False
                 else:
                     g["traffic"] += t * v["launches"]
+                # which roofline bounds this tile class: algorithmic intensity (FLOP per byte of input + output + weights, 16-bit)
+                # against the ridge of the machine (dense bf16 MFMA peak / HBM peak = 312 FLOP/B); most of the network's GEMMs have
+                # K, N <= 256 and sit far on the bandwidth side of it
+                ai = v["flops"] / max(v["bytes"], 1.0)
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                tfs = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                bound = "mfma" if ai >= RIDGE_FLOP_PER_BYTE else "hbm"
                 g["tiles"][k] = {"launches_per_step": v["launches"], "avg_launch_us": v["ms"] * 1e3 / v["launches"],
-                                 "achieved": v["flops"] / (v["ms"] * 1e-3) / 1e12, "traffic": t}
+                                 "achieved": tfs, "traffic": t, "flop_per_byte": ai, "achieved_GBps": gbs, "bound": bound,
+                                 "frac_of_bound": tfs / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS}
             names = {"igemm2": "igemm2_kernel (gen-2 16-bit implicit GEMM, all tile instantiations)",
                      "conv_igemm": "conv_igemm_kernel (gen-1 implicit GEMM)", "conv3x3_direct": "conv3x3_direct_kernel"}
             dom = max(groups, key=lambda k: groups[k]["ms"])
@@ -389,6 +398,8 @@ def main():
                                 "traffic": (d["traffic"] / d["launches"]) if d["traffic_known"] else None,
                                 "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                 "share_of_gpu_time": d["ms"] / total_ms, "flop_per_launch": d["flops"] / d["launches"],
+                                "flop_per_byte": d["flops"] / max(d["bytes"], 1.0), "achieved_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+                                "hbm_frac": d["bytes"] / (d["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "tiles": d["tiles"]}
             big = max(convs, key=lambda k: convs[k]["flops"] / max(convs[k]["launches"], 1))
             e = convs[big]      # the tile family holding the largest single GEMM (the depth head's 3x3 conv)
