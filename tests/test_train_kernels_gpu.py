@@ -24,6 +24,12 @@ CASES = [  # B, H, W, Cin, Cout, k, stride, pads (t, l, b, r)
     (1, 30, 40, 32, 32, 6, 6, (0, 0, 0, 0)),      # GSA sr conv: kernel = stride
     (2, 33, 47, 8, 16, 3, 1, (1, 1, 1, 1)),       # many rows, tiny channels
     (1, 1, 300, 64, 128, 1, 1, (0, 0, 0, 0)),     # Linear
+    (2, 128, 160, 16, 128, 3, 1, (1, 1, 1, 1)),   # 40 960 rows x 128 output channels (the decoder / head class of weight gradients)
+    (1, 200, 180, 24, 136, 1, 1, (0, 0, 0, 0)),   # ... pointwise, second channel tile 8 wide
+    (1, 192, 192, 8, 256, 3, 1, (1, 1, 1, 1)),    # ... two full channel tiles, K = 72 (ragged K tile)
+    (1, 192, 192, 32, 128, 3, 1, (1, 1, 1, 1)),   # K = 288
+    (1, 200, 180, 40, 136, 3, 2, (0, 0, 1, 1)),   # ... strided, ragged in both tile directions (Cout 136, K 360)
+    (1, 200, 184, 40, 136, 3, 1, (1, 1, 1, 1)),   # ... 36 800 rows, ragged tiles
 ]
 
 
