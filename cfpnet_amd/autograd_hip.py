@@ -59,6 +59,7 @@ class Tape:
         self.bw: List[Callable[[], None]] = []
         self._const: Dict[Tuple[str, int], torch.Tensor] = {}
         self.side, self._forked = side, False
+        self.marks: Dict[str, int] = {}          # name -> tape position: `backward(stop=...)` runs the closures recorded after it
 
     # ------------------------------------------------------------------ helpers
     def new(self, rows: int, C: int, dtype=None) -> torch.Tensor:
@@ -115,13 +116,20 @@ class Tape:
             fn()
         self._forked = True
 
-    def backward(self) -> None:
-        for f in reversed(self.bw):
+    def mark(self, name: str) -> None:
+        """Remember the current tape position (the trainer splits the backward there: everything recorded AFTER the mark is
+        differentiated first, e.g. head + decoder before the RGB encoder, so their gradient buckets can be reduced meanwhile)."""
+        self.marks[name] = len(self.bw)
+
+    def backward(self, stop: Optional[str] = None) -> None:
+        """Run the recorded closures in reverse; with `stop` only those recorded after that mark (call again to finish)."""
+        lo = self.marks[stop] if stop is not None else 0
+        for f in reversed(self.bw[lo:]):
             f()
         if self._forked:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
             self._forked = False
-        self.bw = []
+        self.bw = self.bw[:lo]
 
     # ------------------------------------------------------------------ dense conv / linear
     def conv(self, x: V, w: P, bias: Optional[P], B, H, W, k, stride, pt, pl, Ho, Wo) -> V:

@@ -23,11 +23,22 @@ constexpr int kTofThreads = 256;
 constexpr int kTofMaxBins = 1024;
 constexpr int kTofBatch = 8;         // pixels per thread in flight
 
+// Step 5 for one (zone, sample): both branches of sample_point_from_hist_parallel (dataloader.py:65-80) in float64, rounded to
+// float32.  UNIFORM: tensor_linspace(mu-3s, mu+3s) = w0*lo + w1*hi with the host's float32 linspace tables.  ICDF (the argparse
+// default, `--sample_uniform` absent): torch.distributions.Normal(mu, s).icdf(ppf) = mu + s * erfinv(2 ppf - 1) * sqrt(2), where
+// erfinv is evaluated in FLOAT32 on the 16 ppf points (the ppf tensor is float32, only the product is promoted) -- so that
+// table (`w0` here) is an input evaluated on the host like the linspace tables; product order as in Normal.icdf.
+__device__ __forceinline__ float tof_sample(double mu, double sg, float a, float b, int mode) {
+  if (mode == CFP_TOF_SAMPLE_ICDF) return (float)(mu + (sg * (double)a) * 1.4142135623730951);
+  const double lo = mu - 3.0 * sg, hi = mu + 3.0 * sg;
+  return (float)((double)a * lo + (double)b * hi);
+}
+
 struct TofP {
   const float* depth; long long img_stride; int H, W;
   int zone_num, zone_px, sy0, sx0; const int* offsets; int offset_bound;
   float max_d; int bins; double bin_width; int floor_count;
-  const float* w0; const float* w1; int nsamp;
+  const float* w0; const float* w1; int nsamp; int sample_mode;
   double* fh; float* rect; unsigned char* mask; float* pts; int* hist_out;
 };
 
@@ -142,8 +153,7 @@ __global__ __launch_bounds__(kTofThreads) void tof_hist_kernel(TofP p) {
   if (tid < p.nsamp) {
     float v = 0.f;
     if (key) {
-      const double lo = ms[0] - 3.0 * ms[1], hi = ms[0] + 3.0 * ms[1];
-      v = (float)((double)p.w0[tid] * lo + (double)p.w1[tid] * hi);
+      v = tof_sample(ms[0], ms[1], p.w0[tid], p.w1 ? p.w1[tid] : 0.f, p.sample_mode);
     }
     p.pts[o * p.nsamp + tid] = v;
   }
@@ -154,16 +164,14 @@ __global__ __launch_bounds__(kTofThreads) void tof_hist_kernel(TofP p) {
 
 // stand-alone step 5 for callers that keep the reference's two-call structure
 __global__ void tof_sample_kernel(const double* __restrict__ fh, const unsigned char* __restrict__ mask, const float* __restrict__ w0,
-                                  const float* __restrict__ w1, long long nz, int nsamp, float* __restrict__ pts) {
+                                  const float* __restrict__ w1, long long nz, int nsamp, int sample_mode, float* __restrict__ pts) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nz * nsamp) return;
   const long long z = i / nsamp;
   const int t = (int)(i - z * nsamp);
   float v = 0.f;
   if (mask[z]) {
-    const double mu = fh[z * 2], sg = fh[z * 2 + 1];
-    const double lo = mu - 3.0 * sg, hi = mu + 3.0 * sg;
-    v = (float)((double)w0[t] * lo + (double)w1[t] * hi);
+    v = tof_sample(fh[z * 2], fh[z * 2 + 1], w0[t], w1 ? w1[t] : 0.f, sample_mode);
   }
   pts[i] = v;
 }
@@ -171,21 +179,23 @@ __global__ void tof_sample_kernel(const double* __restrict__ fh, const unsigned 
 }  // namespace
 
 extern "C" int cfp_tof_sample_points(const double* fh, const unsigned char* mask, const float* w0, const float* w1, long long nzones,
-                                     int nsamp, float* pts, cfp_stream_t stream) {
-  CFP_REQUIRE(fh && mask && w0 && w1 && pts, CFP_EINVAL, "cfp_tof_sample_points: null pointer");
+                                     int nsamp, int sample_mode, float* pts, cfp_stream_t stream) {
+  CFP_REQUIRE(fh && mask && w0 && pts && (w1 || sample_mode == CFP_TOF_SAMPLE_ICDF), CFP_EINVAL, "cfp_tof_sample_points: null pointer");
   CFP_REQUIRE(nzones >= 0 && nsamp > 0, CFP_ESHAPE, "cfp_tof_sample_points: bad sizes");
+  CFP_REQUIRE(sample_mode == CFP_TOF_SAMPLE_UNIFORM || sample_mode == CFP_TOF_SAMPLE_ICDF, CFP_EINVAL, "cfp_tof_sample_points: bad sample_mode");
   if (nzones == 0) return CFP_OK;
   const long long total = nzones * nsamp;
   hipLaunchKernelGGL(tof_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fh, mask,
-                     w0, w1, nzones, nsamp, pts);
+                     w0, w1, nzones, nsamp, sample_mode, pts);
   return cfp_check_launch("cfp_tof_sample_points");
 }
 
 extern "C" int cfp_tof_hist_sim(const float* depth, long long img_stride, int B, int H, int W, int zone_num, int zone_px,
                                 int sy0, int sx0, const int* offsets, int offset_bound, float max_distance, int bins,
-                                double bin_width, int floor_count, const float* w0, const float* w1, int nsamp, double* fh,
-                                float* rect, unsigned char* mask, float* pts, int* hist_out, cfp_stream_t stream) {
-  CFP_REQUIRE(depth && w0 && w1 && fh && rect && mask && pts, CFP_EINVAL, "cfp_tof_hist_sim: null pointer");
+                                double bin_width, int floor_count, const float* w0, const float* w1, int nsamp, int sample_mode,
+                                double* fh, float* rect, unsigned char* mask, float* pts, int* hist_out, cfp_stream_t stream) {
+  CFP_REQUIRE(depth && w0 && (w1 || sample_mode == CFP_TOF_SAMPLE_ICDF) && fh && rect && mask && pts, CFP_EINVAL, "cfp_tof_hist_sim: null pointer");
+  CFP_REQUIRE(sample_mode == CFP_TOF_SAMPLE_UNIFORM || sample_mode == CFP_TOF_SAMPLE_ICDF, CFP_EINVAL, "cfp_tof_hist_sim: bad sample_mode");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && zone_num > 0 && zone_px > 0, CFP_ESHAPE, "cfp_tof_hist_sim: non-positive dimension");
   CFP_REQUIRE(img_stride >= (long long)H * W, CFP_ESHAPE, "cfp_tof_hist_sim: image stride smaller than H*W");
   CFP_REQUIRE(bins > 0 && bins <= kTofMaxBins, CFP_ESHAPE, "cfp_tof_hist_sim: bins must be in 1..1024");
@@ -203,7 +213,7 @@ extern "C" int cfp_tof_hist_sim(const float* depth, long long img_stride, int B,
   p.depth = depth; p.img_stride = img_stride; p.H = H; p.W = W;
   p.zone_num = zone_num; p.zone_px = zone_px; p.sy0 = sy0; p.sx0 = sx0; p.offsets = offsets; p.offset_bound = offset_bound;
   p.max_d = max_distance; p.bins = bins; p.bin_width = bin_width; p.floor_count = floor_count;
-  p.w0 = w0; p.w1 = w1; p.nsamp = nsamp;
+  p.w0 = w0; p.w1 = w1; p.nsamp = nsamp; p.sample_mode = sample_mode;
   p.fh = fh; p.rect = rect; p.mask = mask; p.pts = pts; p.hist_out = hist_out;
   hipLaunchKernelGGL(tof_hist_kernel, dim3(B * zone_num * zone_num), dim3(kTofThreads), 0, reinterpret_cast<hipStream_t>(stream), p);
   return cfp_check_launch("cfp_tof_hist_sim");

@@ -97,6 +97,10 @@ class NYUTrainFiles:
         """This rank's share of one epoch: the global permutation is cut into global batches of bs * world samples and every
         rank takes its slice of each (the reference's DataParallel splits each batch over the GPUs the same way)."""
         import threading, queue
+        if generator is None and self.world > 1:
+            # every rank must cut the SAME permutation: an unseeded per-process randperm would duplicate some samples across
+            # ranks and skip others in every epoch
+            raise ValueError("epoch_batches: with world > 1 pass a torch.Generator seeded identically on every rank (seed + epoch)")
         order = torch.randperm(len(self.samples), generator=generator).tolist()
         gb = bs * self.world
         chunks = [order[k * gb + self.rank * bs:k * gb + (self.rank + 1) * bs] for k in range(len(order) // gb)]

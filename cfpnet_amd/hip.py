@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcfpnet_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
+TOF_SAMPLE_UNIFORM, TOF_SAMPLE_ICDF = 0, 1
 
 _p, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
@@ -56,8 +57,8 @@ SIGNATURES = {
     "cfp_adamw_step": (_i, [_p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _i, _p, _p]),
     "cfp_grad_clip_ws_bytes": (_sz, []),
     "cfp_grad_clip_factor": (_i, [_p, C.c_longlong, _f, _p, _sz, _p, _p]),
-    "cfp_tof_hist_sim": (_i, [_p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _i, C.c_double, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
-    "cfp_tof_sample_points": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _p, _p]),
+    "cfp_tof_hist_sim": (_i, [_p, C.c_longlong, _i, _i, _i, _i, _i, _i, _i, _p, _i, _f, _i, C.c_double, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "cfp_tof_sample_points": (_i, [_p, _p, _p, _p, C.c_longlong, _i, _i, _p, _p]),
     "cfp_eval_metrics_ws_bytes": (_sz, [_i]),
     "cfp_eval_metrics": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p, _p]),
     "cfp_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i]),

@@ -25,6 +25,12 @@ def _cfg(config, name, default):
     return getattr(config, name, default)
 
 
+def icdf_ppf_points(nsamp: int) -> torch.Tensor:
+    """dataloader.py:70-71: `torch.Tensor(np.arange(delta, 1, (1 - 2 delta) / (S - 1)).tolist())`, float32."""
+    delta = 1e-3
+    return torch.Tensor(np.arange(delta, 1, (1 - 2 * delta) / (nsamp - 1)).tolist())
+
+
 def zone_layout(config, height: int, width: int) -> Tuple[int, int, int, int]:
     """(zone_num, zone_px, sy0, sx0) of the centred zone grid before the random offset (dataloader.py:94-103)."""
     train = _cfg(config, "mode", "online_eval") == "train"
@@ -36,22 +42,36 @@ def zone_layout(config, height: int, width: int) -> Tuple[int, int, int, int]:
 class TofSimulator:
     """Batched `get_hist_parallel` + `sample_point_from_hist_parallel` on one device.
 
-    The two float32 interpolation tables of `tensor_linspace` are evaluated by torch on the host, as the reference
-    does, and kept on the device."""
+    Both branches of `sample_point_from_hist_parallel` are built.  With `config.sample_uniform` the two float32
+    interpolation tables of `tensor_linspace` are evaluated by torch on the host, as the reference does, and kept on the
+    device.  Without it (the argparse default, dataloader.py:69-73) the samples are `Normal(mu, sigma).icdf` at
+    `zone_sample_num` ppf points; torch evaluates `erfinv(2 ppf - 1)` in float32 (the ppf tensor is float32) and only the
+    product with the float64 sigma is promoted, so that float32 table is evaluated on the host the same way."""
 
     def __init__(self, config, device="cuda:0"):
-        if not _cfg(config, "sample_uniform", True):
-            raise NotImplementedError("only --sample_uniform (every shipped config) is built on the device")
         self.config = config
         self.device = torch.device(device)
         self.nsamp = int(_cfg(config, "zone_sample_num", 16))
-        self.w0 = torch.linspace(1, 0, steps=self.nsamp).to(self.device)
-        self.w1 = torch.linspace(0, 1, steps=self.nsamp).to(self.device)
+        self.uniform = bool(_cfg(config, "sample_uniform", False))          # config.py:71: store_true, default False
+        if self.uniform:
+            self.w0 = torch.linspace(1, 0, steps=self.nsamp).to(self.device)
+            self.w1 = torch.linspace(0, 1, steps=self.nsamp).to(self.device)
+        else:
+            ppf = icdf_ppf_points(self.nsamp)
+            if ppf.numel() != self.nsamp:      # the reference's `fh[mask] = ...` assignment fails on the shape in that case
+                raise ValueError(f"arange(1e-3, 1, 0.998/{self.nsamp - 1}) has {ppf.numel()} points, not zone_sample_num")
+            self.w0 = torch.erfinv(2 * ppf - 1).to(self.device)
+            self.w1 = None
 
-    def set_weights(self, w0, w1) -> None:
-        """Install interpolation tables evaluated elsewhere (golden fixtures carry the generating host's)."""
+    @property
+    def sample_mode(self) -> int:
+        return hip.TOF_SAMPLE_UNIFORM if self.uniform else hip.TOF_SAMPLE_ICDF
+
+    def set_weights(self, w0, w1=None) -> None:
+        """Install tables evaluated elsewhere (golden fixtures carry the generating host's): the two linspace tables in
+        uniform mode, the erfinv table alone otherwise."""
         self.w0 = torch.as_tensor(np.asarray(w0), dtype=torch.float32).to(self.device).contiguous()
-        self.w1 = torch.as_tensor(np.asarray(w1), dtype=torch.float32).to(self.device).contiguous()
+        self.w1 = None if w1 is None else torch.as_tensor(np.asarray(w1), dtype=torch.float32).to(self.device).contiguous()
 
     def max_distance(self) -> float:
         c = self.config
@@ -91,19 +111,19 @@ class TofSimulator:
         hist = out.get("hist")
         hip.call("cfp_tof_hist_sim", depth.data_ptr(), depth.stride(0) if B > 1 else H * W, B, H, W, zn, zp, sy0, sx0,
                  offsets.data_ptr() if offsets is not None else None, bound, md, bins, BIN_WIDTH, AMBIENT_FLOOR,
-                 self.w0.data_ptr(), self.w1.data_ptr(), self.nsamp, out["fh"].data_ptr(), out["rect_data"].data_ptr(),
+                 self.w0.data_ptr(), hip.ptr(self.w1), self.nsamp, self.sample_mode, out["fh"].data_ptr(), out["rect_data"].data_ptr(),
                  out["mask"].data_ptr(), out["hist_data"].data_ptr(), hist.data_ptr() if hist is not None else None,
                  hip.current_stream())
         return out
 
     def sample_points(self, hist_data: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
-        """[.., 2] f64 (mu, sigma) + [..] bool -> [.., S] f32 (dataloader.py:65-80, uniform branch)."""
+        """[.., 2] f64 (mu, sigma) + [..] bool -> [.., S] f32 (dataloader.py:65-80, the branch `config.sample_uniform` selects)."""
         fh = hist_data.to(device=self.device, dtype=torch.float64).contiguous()
         mk = mask.to(device=self.device, dtype=torch.bool).contiguous()
         nz = mk.numel()
         pts = torch.empty(*mk.shape, self.nsamp, dtype=torch.float32, device=self.device)
-        hip.call("cfp_tof_sample_points", fh.data_ptr(), mk.data_ptr(), self.w0.data_ptr(), self.w1.data_ptr(), nz, self.nsamp,
-                 pts.data_ptr(), hip.current_stream())
+        hip.call("cfp_tof_sample_points", fh.data_ptr(), mk.data_ptr(), self.w0.data_ptr(), hip.ptr(self.w1), nz, self.nsamp,
+                 self.sample_mode, pts.data_ptr(), hip.current_stream())
         return pts
 
 

@@ -384,6 +384,7 @@ class TrainNet:
         x8 = ops.new_act(B * H * W, 8, self.dtype, dev)
         ops.rgb_to_nhwc8(rgb, x8, B, H, W)
         taps = self._encoder(t, V(x8.buf, needs_grad=False), B, H, W)
+        t.mark("encoder")             # backward of everything below runs before the encoder's (trainer: gradient buckets overlap it)
         (b0, h0, w0), (b1, h1, w1), (b2, h2, w2), (b3, h3, w3), (b4, h4, w4) = taps
         hist = add["hist_data"].to(dev, torch.float32).contiguous()
         Z, N = hist.shape[1], hist.shape[2]
@@ -423,9 +424,11 @@ class TrainNet:
         pred = t.softmax_expect(logits, centers, B, h0 * w0)
         return pred, edges, (B, h0, w0)
 
-    def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None):
+    def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None,
+                         stop_before_encoder: bool = False):
         """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
-        gradients are in `self.grads()`, running statistics in `self.buf`."""
+        gradients are in `self.grads()`, running statistics in `self.buf`.  `stop_before_encoder`: the backward stops where the
+        RGB encoder's begins (every non-encoder parameter gradient is final) and `finish_backward()` runs the rest."""
         dev = self.dev
         t = Tape(dev, self.dtype, side=self.side_stream)
         pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
@@ -434,5 +437,14 @@ class TrainNet:
         pred4 = pred.t.reshape(B, 1, h0, w0)
         loss = crit.forward(pred4, target.to(dev, torch.float32), loss_mask.to(dev) if loss_mask is not None else None, interpolate=True)
         pred.g = crit.backward(1.0).reshape(-1, 1).contiguous()
-        t.backward()
+        if stop_before_encoder:
+            t.backward(stop="encoder")
+            self._open_tape = t
+        else:
+            t.backward()
         return loss, pred4, edges
+
+    def finish_backward(self) -> None:
+        """Second half of `forward_backward(stop_before_encoder=True)`: the RGB encoder's backward."""
+        t, self._open_tape = self._open_tape, None
+        t.backward()

@@ -131,16 +131,54 @@ class FlatParams:
         for s in self.segments:
             self.view(s.name).copy_(state_dict[s.name].to(torch.float32))
 
-    def buckets(self, bucket_elems: int) -> List[Tuple[int, int]]:
-        """Contiguous [start, end) ranges covering the live gradients, walked from the END of the live range to its
-        beginning: the flat order is encoder -> ... -> head, backward produces gradients head first, so the first
-        bucket can be reduced while the encoder's backward is still running."""
-        out, end = [], self.live
-        while end > 0:
-            start = max(0, end - bucket_elems)
+    def buckets(self, bucket_elems: int, lo: int = 0, hi: Optional[int] = None) -> List[Tuple[int, int]]:
+        """Contiguous [start, end) ranges covering the live gradients in [lo, hi) (default: all of them), walked from the END
+        of the range to its beginning: the flat order is encoder -> ... -> head, backward produces gradients head first, so
+        the first bucket can be reduced while the encoder's backward is still running."""
+        out, end = [], self.live if hi is None else min(hi, self.live)
+        while end > lo:
+            start = max(lo, end - bucket_elems)
             out.append((start, end))
             end = start
         return out
+
+
+def _is_gloo(dist) -> bool:
+    try:
+        return dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
+def allreduce_range(flat: FlatParams, dist, world: int, lo: int, hi: int, bucket_elems: int = 8 * 1024 * 1024, async_op: bool = False):
+    """Average flat.grad[lo:hi) over the data-parallel ranks, one all-reduce per bucket on the CURRENT stream's timeline
+    (RCCL over xGMI with the "nccl" backend).  With the "gloo" backend (CPU tests, and the single-GPU 2-rank test) the bucket
+    is staged through host memory: gloo reduces host buffers.  `async_op` (RCCL only): returns [(work, chunk)] for `finish_allreduce`."""
+    if dist is None:
+        return []
+    handles = []
+    gloo = _is_gloo(dist)
+    for (a, b) in flat.buckets(bucket_elems, lo, hi):
+        chunk = flat.grad[a:b]
+        if gloo and chunk.is_cuda:
+            host = chunk.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            chunk.copy_(host.div_(world))
+            continue
+        h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=async_op)
+        handles.append((h, chunk))
+    if not async_op:
+        for _, chunk in handles:
+            chunk.div_(world)
+        return []
+    return handles
+
+
+def finish_allreduce(handles, world: int) -> None:
+    """Wait (stream-wise: the current stream waits for the collective's stream) and scale."""
+    for h, chunk in handles:
+        h.wait()
+        chunk.div_(world)
 
 
 def allreduce_gradients(flat: FlatParams, dist, world: int, bucket_elems: int = 8 * 1024 * 1024, async_op: bool = False):
@@ -149,15 +187,7 @@ def allreduce_gradients(flat: FlatParams, dist, world: int, bucket_elems: int = 
     21.4 M live f32 gradients = 86 MB = 3 buckets of 32 MB."""
     if dist is None or world <= 1:
         return []
-    handles = []
-    for (a, b) in flat.buckets(bucket_elems):
-        chunk = flat.grad[a:b]
-        h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=async_op)
-        handles.append((h, chunk))
-    if not async_op:
-        for _, chunk in handles:
-            chunk.div_(world)
-    return handles
+    return allreduce_range(flat, dist, world, 0, flat.live, bucket_elems, async_op)
 
 
 class FlatAdamW:

@@ -25,7 +25,7 @@ class Trainer:
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
                  change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True,
-                 base_resolution=spec.BASE_RESOLUTION, overlap_param_grads: bool = False):
+                 base_resolution=spec.BASE_RESOLUTION, overlap_param_grads: bool = False, comm: str = "overlap"):
         self.dev = torch.device(device)
         self.dtype, self.kernel_layout, self._hist10 = dtype, kernel_layout, hist_encoder_10x
         self._net_kw = dict(n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
@@ -34,8 +34,16 @@ class Trainer:
         self._opt_kw = dict(lr=lr, total_steps=total_steps, div_factor=div_factor, final_div_factor=final_div_factor, weight_decay=weight_decay,
                             clip_grad_norm=clip_grad_norm)
         self._shadow, self._to_torch = None, None
+        self._pending_opt = None         # optimizer state loaded before the first batch fixed the kernel layouts
         self._flip_jobs = None           # [(source buffer, flipped buffer, device descriptors, n, workgroups, dtype code)]
         self.dist, self.world = dist, world
+        # gradient averaging over the data-parallel ranks: "overlap" = the captured step is split where the RGB encoder's backward
+        # begins and the non-encoder bucket is reduced on a second stream while the encoder's backward runs;
+        # "sequential" = all buckets after the whole backward; "off" = skipped (measurement of the step without communication)
+        assert comm in ("overlap", "sequential", "off")
+        self.comm = comm
+        self._comm_stream = None
+        self._graph2 = None
         names = [(k, tuple(v.shape)) for k, v in state_dict.items()
                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
         self.flat = train_ops.FlatParams(names, train_ops.lr_group_of(hist_encoder_10x), device=self.dev)
@@ -74,6 +82,9 @@ class Trainer:
         assert self.opt.step_count == 0
         self.opt = train_ops.FlatAdamW(kflat, train_ops.OneCycle(k["lr"], k["total_steps"], k["div_factor"], k["final_div_factor"]),
                                        weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"])
+        if self._pending_opt is not None:
+            pending, self._pending_opt = self._pending_opt, None
+            self.load_optimizer_state_dict(pending)
 
     def _plan_weight_flips(self) -> None:
         """After the first bound step every convolution whose data gradient is needed has recorded its geometry: from now on
@@ -126,7 +137,7 @@ class Trainer:
             offs[name] = (oy, ox)
         return offs
 
-    def _grads_to_flat(self, input_data, target, offs):
+    def _grads_to_flat(self, input_data, target, offs, stop_before_encoder: bool = False):
         if self.kernel_layout and self._to_torch is None:
             self._bind_kernel_layout(input_data, offs)
         self.net.zero_grad()
@@ -135,7 +146,8 @@ class Trainer:
                 self._shadow.copy_(self.flat.param)                 # the one cast of the step
             if self._flip_jobs is not None:
                 self._refresh_weight_flips()
-            loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
+            loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs,
+                                                   stop_before_encoder=stop_before_encoder)
             if self._flip_jobs is None:
                 self._plan_weight_flips()
             return loss                                             # every gradient is already at its flat address
@@ -145,10 +157,19 @@ class Trainer:
             self.flat.view(name, "grad").copy_(g)
         return loss
 
-    def capture(self, input_data: dict, target: torch.Tensor):
+    def capture(self, input_data: dict, target: torch.Tensor, split: Optional[bool] = None):
         """Record forward + loss + backward + gradient gathering for this batch shape into ONE HIP graph (the eager step is
         ~5 600 launches and host-bound in 16-bit mode).  Inputs are copied into static buffers at every `step`; the random
-        positional-encoding windows are read by the kernels from a device buffer, so they still change per step."""
+        positional-encoding windows are read by the kernels from a device buffer, so they still change per step.
+
+        `split` (default: when there is a process group and comm == "overlap"): TWO graphs instead, cut where the backward of the
+        RGB encoder begins.  After the first one every non-encoder gradient (the "10x" group of the flat buffer, 2/3 of the bytes)
+        is final and its all-reduce runs on a communication stream beside the second graph; same kernels in the same order as
+        the single graph, so the results are bit-identical."""
+        if split is None:
+            split = self.dist is not None and self.comm == "overlap"
+        if split and not self.kernel_layout:
+            raise ValueError("the split step needs kernel_layout=True (gradients written at their final flat addresses)")
         dev = self.dev
         add = input_data["additional"]
         self._sin = {"rgb": input_data["rgb"].to(dev, torch.float32).contiguous().clone(),
@@ -160,14 +181,23 @@ class Trainer:
         self._offs_dev = {name: self._soffs[i] for i, name in enumerate(("cross_atten3", "cross_atten2", "cross_atten1"))}
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        saved = {k: v.clone() for k, v in self.net.buf.items()}       # the warm-up passes and the capture pass itself are real
+        with torch.cuda.stream(side):                                 # training forwards: they must not move the running statistics
             for _ in range(2):                                       # warm-up: builds the index maps, sets kernel attributes
                 self._grads_to_flat(self._sin, self._starget, self._offs_dev)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._sloss = self._grads_to_flat(self._sin, self._starget, self._offs_dev)
+            self._sloss = self._grads_to_flat(self._sin, self._starget, self._offs_dev, stop_before_encoder=split)
+        self._graph2 = None
+        if split:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):                # same memory pool: always replayed right after g
+                self.net.finish_backward()
+            self._graph2 = g2
+        for k, v in saved.items():
+            self.net.buf[k].copy_(v)
         self._graph = g
 
     def step(self, input_data: dict, target: torch.Tensor, pos_offsets: Optional[dict] = None):
@@ -183,11 +213,67 @@ class Trainer:
             self._soffs.copy_(torch.tensor([offs[n] for n in ("cross_atten3", "cross_atten2", "cross_atten1")], dtype=torch.int32), non_blocking=True)
             self._graph.replay()
             loss = self._sloss
+            if self._graph2 is not None and self.comm != "overlap":
+                self._graph2.replay()
+                self._reduce_group(None)
+            elif self._graph2 is not None:
+                self._reduce_group(1, beside=True)                   # head / decoder / fusion / ToF-encoder gradients: final now
+                self._graph2.replay()                                # RGB encoder backward, beside that all-reduce
+                self._reduce_group(0, beside=True)
+                torch.cuda.current_stream(self.dev).wait_stream(self._comm_stream)
+            else:
+                self._reduce_group(None)
         else:
             loss = self._grads_to_flat(input_data, target, offs)
-        train_ops.allreduce_gradients(self.flat, self.dist, self.world)
+            self._reduce_group(None)
         lr, beta1 = self.opt.step()
         return loss, lr, beta1
+
+    def _reduce_group(self, grp: Optional[int], beside: bool = False) -> None:
+        """Average the gradients of lr group `grp` (None: all live ones) over the ranks.  `beside`: on the communication stream,
+        ordered after everything issued so far on the current stream; the caller joins the stream before the optimizer."""
+        if self.dist is None or self.comm == "off":
+            if beside and self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.dev)
+            return
+        lo, hi = (0, self.flat.live) if grp is None else self.flat.group_range[grp]
+        if not beside:
+            train_ops.allreduce_range(self.flat, self.dist, self.world, lo, hi)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.dev)
+        cur = torch.cuda.current_stream(self.dev)
+        self._comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self._comm_stream):
+            handles = train_ops.allreduce_range(self.flat, self.dist, self.world, lo, hi, async_op=not train_ops._is_gloo(self.dist))
+            train_ops.finish_allreduce(handles, self.world)
+
+    # ------------------------------------------------------------------ optimizer state (checkpoint "optimizer" entry)
+    def _layout_signature(self):
+        return [(sg.name, sg.start, sg.numel) for sg in self.flat.segments]
+
+    def optimizer_state_dict(self) -> dict:
+        """AdamW moments + step counter for `model_io.save_checkpoint`'s "optimizer" entry (train.py:150).  The moments are
+        saved as the flat buffers they live in, with the (name, start, numel) table of that layout: a resumed run must lay its
+        parameters out the same way (same code, same attention_layer list), which `load_optimizer_state_dict` checks."""
+        if self.kernel_layout and self._to_torch is None:
+            raise RuntimeError("optimizer state exists only after the first training step fixed the kernel layouts")
+        return {"format": "cfpnet_amd.FlatAdamW/1", "kernel_layout": self._to_torch is not None, "step_count": self.opt.step_count,
+                "layout": self._layout_signature(), "exp_avg": self.opt.m.detach().cpu().clone(), "exp_avg_sq": self.opt.v.detach().cpu().clone()}
+
+    def load_optimizer_state_dict(self, state: dict) -> None:
+        if state.get("format") != "cfpnet_amd.FlatAdamW/1":
+            raise ValueError("not a cfpnet_amd optimizer state (the reference's torch AdamW state is not restored by train.py:83-84 either)")
+        if state["kernel_layout"] and self._to_torch is None:
+            if not self.kernel_layout:
+                raise ValueError("optimizer state was saved in kernel layout; this Trainer keeps the reference layout")
+            self._pending_opt = state                       # applied by _bind_kernel_layout on the first batch
+            return
+        if [tuple(x) for x in state["layout"]] != [tuple(x) for x in self._layout_signature()]:
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.opt.m.copy_(state["exp_avg"])
+        self.opt.v.copy_(state["exp_avg_sq"])
+        self.opt.step_count = int(state["step_count"])
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Parameters and running statistics in the reference's layout (for `model_io.save_checkpoint`)."""

@@ -32,6 +32,7 @@ typedef void* cfp_stream_t; /* hipStream_t */
 
 enum { CFP_OK = 0, CFP_EINVAL = -1, CFP_ESHAPE = -2, CFP_EHIP = -3 };
 enum { CFP_F32 = 0, CFP_BF16 = 1, CFP_F16 = 2 };
+enum { CFP_TOF_SAMPLE_UNIFORM = 0, CFP_TOF_SAMPLE_ICDF = 1 };   /* sample_point_from_hist_parallel: --sample_uniform / default */
 enum { CFP_ACT_NONE = 0, CFP_ACT_RELU = 1, CFP_ACT_LRELU = 2, CFP_ACT_SILU = 3, CFP_ACT_GELU = 4, CFP_ACT_SIGMOID = 5 };
 
 int cfp_version(void);
@@ -294,17 +295,22 @@ int cfp_grad_clip_factor(const float* grad, long long n, float max_norm, void* w
  *            subtracted (:108-109), strongest run of consecutive non-zero bins kept (:110-116), moments over bin
  *            centres built from multiples of bin_width (0.04) in f64 (:118,127-130).
  *   w0, w1   [nsamp] f32 (device): torch.linspace(1,0,nsamp) / torch.linspace(0,1,nsamp) as the HOST evaluates
- *            them (tensor_linspace, :42-57; ATen's vectorised linspace differs in the last bit between hosts).
+ *            them (tensor_linspace, :42-57; ATen's vectorised linspace differs in the last bit between hosts);
+ *            with sample_mode CFP_TOF_SAMPLE_ICDF w0 is the erfinv table of cfp_tof_sample_points and w1 may be NULL.
  * Outputs (device): fh [B,Z,2] f64 (mu, sigma); rect [B,Z,4] f32 (sy,sx,ey,ex); mask [B,Z] u8; pts [B,Z,nsamp] f32
  * (zero where mask is 0); hist_out [B,Z,bins] i32 (may be NULL): the counts that survive cluster selection. */
 int cfp_tof_hist_sim(const float* depth, long long img_stride, int B, int H, int W, int zone_num, int zone_px, int sy0,
                      int sx0, const int* offsets, int offset_bound, float max_distance, int bins, double bin_width,
-                     int floor_count, const float* w0, const float* w1, int nsamp, double* fh, float* rect,
+                     int floor_count, const float* w0, const float* w1, int nsamp, int sample_mode, double* fh, float* rect,
                      unsigned char* mask, float* pts, int* hist_out, cfp_stream_t stream);
-/* The sampling step alone (sample_point_from_hist_parallel with --sample_uniform, dataloader.py:65-80), for callers
- * that keep the reference's two calls: pts[z, t] = f32(w0[t]*(mu-3 sigma) + w1[t]*(mu+3 sigma)) in f64, 0 if !mask[z]. */
+/* The sampling step alone (sample_point_from_hist_parallel, dataloader.py:65-80), for callers that keep the reference's
+ * two calls.  sample_mode CFP_TOF_SAMPLE_UNIFORM (--sample_uniform, :74-79): pts[z, t] = f32(w0[t]*(mu-3 sigma) +
+ * w1[t]*(mu+3 sigma)) in f64.  CFP_TOF_SAMPLE_ICDF (the argparse default, :69-73): Normal(mu, sigma).icdf at the
+ * nsamp ppf points arange(1e-3, 1, 0.998/(nsamp-1)): pts[z, t] = f32(mu + (sigma * w0[t]) * sqrt(2)) in f64 with
+ * w0[t] = erfinv(2 ppf_t - 1) evaluated in FLOAT32 on the host, as torch does (the ppf tensor is f32); w1 is unused
+ * and may be NULL.  pts is 0 where !mask[z]. */
 int cfp_tof_sample_points(const double* fh, const unsigned char* mask, const float* w0, const float* w1, long long nzones,
-                          int nsamp, float* pts, cfp_stream_t stream);
+                          int nsamp, int sample_mode, float* pts, cfp_stream_t stream);
 
 /* Depth-evaluation metrics per image without leaving the device: compute_errors (src/utils/metrics.py:4-24 =
  * evaluate_all.py:15-35) fused with the protocol around it.

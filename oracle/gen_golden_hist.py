@@ -53,6 +53,25 @@ def main():
         print(name, "valid zones", int(mask.sum()), "/", mask.numel(), "mu[:3]", fh[:3, 0].tolist())
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hist_sim.npz"), **out)
+    # the non-uniform branch (argparse default: no --sample_uniform), dataloader.py:69-73: the reference's own samples for
+    # the (mu, sigma, mask) of every case above, with some valid zones masked out like drop_hist does (nyu.py:155-158)
+    icdf = {}
+    import math
+    for m in meta:
+        n = m["name"]
+        cfg = types.SimpleNamespace(zone_sample_num=16, sample_uniform=False)
+        fh, mask = torch.from_numpy(out[n + ".fh"]), torch.from_numpy(out[n + ".mask"].astype(bool))
+        mask[1::5] = False
+        pts = rdl.sample_point_from_hist_parallel(fh, mask, cfg)
+        assert pts.dtype == torch.float32 and pts.shape == (mask.numel(), 16)
+        icdf[n + ".mask"] = mask.numpy().astype(np.uint8)
+        icdf[n + ".pts"] = pts.numpy()
+    delta = 1e-3
+    ppf = torch.Tensor(np.arange(delta, 1, (1 - 2 * delta) / 15).tolist())
+    icdf["table"] = torch.erfinv(2 * ppf - 1).numpy()                         # float32 erfinv on THIS host
+    icdf["ppf"] = ppf.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hist_sim_icdf.npz"), **icdf)
+    print("icdf: table", icdf["table"][:3], "pts[0]", icdf[meta[0]["name"] + ".pts"][0, :4])
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 """CPU oracle for the ToF (L5 zone histogram) simulation -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-A numpy restatement of `get_hist_parallel` + the uniform branch of `sample_point_from_hist_parallel`
+A numpy restatement of `get_hist_parallel` + both branches of `sample_point_from_hist_parallel`
 (`/root/reference/src/utils/dataloader.py:83-134` and `:65-80`; call site `src/dataloader/nyu.py:154,179`).
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
 
@@ -20,10 +20,14 @@ What the reference computes per zone (one `zone_px` x `zone_px` patch of the gro
   4. n = sum(hist); mask = n > 0; with bin centres dist[i] = (float32(e[i+1]) + e[i]) / 2, e = arange(0, max_d+1e-9, 0.04)
      in float64:  mu = sum(dist*hist) / float32(n + 1e-9);  sigma = sqrt(sum(hist*(dist-mu)^2) / float32(n + 1e-9)) + 1e-9.
   5. samples: w0*(mu-3sigma) + w1*(mu+3sigma) in float64 with w0 = float32 linspace(1,0,S), w1 = float32 linspace(0,1,S),
-     rounded to float32; invalid zones are zero.
+     rounded to float32; invalid zones are zero.  Without `--sample_uniform` (the argparse default, dataloader.py:69-73):
+     Normal(mu, sigma).icdf(ppf) = mu + sigma * erfinv(2 ppf - 1) * sqrt(2) at ppf = float32(arange(1e-3, 1, 0.998/(S-1))),
+     where erfinv runs in float32 (ppf is a float32 tensor) and the products / sum in float64 (`sample_points_icdf`; pinned
+     by `tests/golden/hist_sim_icdf.npz` = the reference's own output, `oracle/gen_golden_hist.py`).
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional
 
 import numpy as np
@@ -39,6 +43,36 @@ def linspace_weights_f32(steps: int):
     HIP kernel), produced the way the reference produces them.  Golden fixtures carry the generating host's tables."""
     import torch
     return torch.linspace(1, 0, steps).numpy().copy(), torch.linspace(0, 1, steps).numpy().copy()
+
+
+def icdf_table_f32(steps: int) -> np.ndarray:
+    """erfinv(2 ppf - 1) in float32 at the reference's ppf points (dataloader.py:70-71), evaluated ON THIS HOST by torch like
+    the reference does; an input of the restatement for the same reason as the linspace tables."""
+    import torch
+    delta = 1e-3
+    ppf = torch.Tensor(np.arange(delta, 1, (1 - 2 * delta) / (steps - 1)).tolist())
+    return torch.erfinv(2 * ppf - 1).numpy().copy()
+
+
+def sample_points_icdf(fh: np.ndarray, mask: np.ndarray, table: np.ndarray) -> np.ndarray:
+    """Non-uniform branch (dataloader.py:69-73; torch.distributions.Normal.icdf: loc + scale * erfinv(2 v - 1) * sqrt(2)):
+    fh [Z,2] float64 (mu, sigma), mask [Z] bool, table [S] float32 -> [Z,S] float32, zero where masked out.
+    Order of operations as torch evaluates the expression: (sigma * t) * sqrt(2), then mu + that."""
+    fh = np.asarray(fh, dtype=np.float64)
+    t = np.asarray(table, dtype=np.float32).astype(np.float64)
+    out = (fh[:, 0:1] + (fh[:, 1:2] * t[None, :]) * np.float64(math.sqrt(2))).astype(np.float32)
+    out[~np.asarray(mask, dtype=bool)] = 0
+    return out
+
+
+def sample_points_uniform(fh: np.ndarray, mask: np.ndarray, w0: np.ndarray, w1: np.ndarray) -> np.ndarray:
+    """Uniform branch (dataloader.py:74-79) on given (mu, sigma): the step-5 arithmetic of `get_hist`."""
+    fh = np.asarray(fh, dtype=np.float64)
+    start, end = fh[:, 0] - 3.0 * fh[:, 1], fh[:, 0] + 3.0 * fh[:, 1]
+    out = (np.asarray(w0, np.float32).astype(np.float64)[None] * start[:, None]
+           + np.asarray(w1, np.float32).astype(np.float64)[None] * end[:, None]).astype(np.float32)
+    out[~np.asarray(mask, dtype=bool)] = 0
+    return out
 
 
 def zone_histogram(patch: np.ndarray, max_distance: float, bins: int) -> np.ndarray:

@@ -1,0 +1,121 @@
+"""Data-parallel training on the HIP path: one process per rank, per-rank shards, per-replica BatchNorm statistics,
+flat-gradient averaging -- the non-encoder bucket reduced on a communication stream while the RGB encoder's backward runs.
+Two ranks share cuda:0 under the gloo backend (buckets staged through host memory), so the real `Trainer` step with a real
+process group runs on a one-GPU box; RCCL replaces gloo on a multi-GPU node without touching this path."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(rank, B=2, H=256, W=320):
+    from cfpnet_amd import synthetic
+    inp = synthetic.make_inputs(B, H, W, 3, 64, seed=300 + rank, drop_hist=0.25)
+    target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=400 + 10 * rank + i, holes=0.1) for i in range(B)]))[:, None]
+    return inp, target
+
+
+OFFS = {"cross_atten3": (3, 5), "cross_atten2": (7, 2), "cross_atten1": (11, 30)}
+
+
+def _worker(rank, world, port, out, comm):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.trainer import Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    inp, target = _shard(rank)
+    dinp, dtgt = synthetic.to_device(inp, "cuda:0"), target.cuda()
+    tr = Trainer(sd, layers, lr=3e-4, total_steps=20, device="cuda:0", dist=dist, world=world, comm=comm)
+    tr.capture(dinp, dtgt)
+    assert (tr._graph2 is not None) == (comm == "overlap")
+    tr.step(dinp, dtgt, pos_offsets=OFFS)
+    torch.cuda.synchronize()
+    g1 = tr.flat.grad.detach().cpu().clone()
+    layout = [(sg.name, sg.start, sg.numel) for sg in tr.flat.segments]
+    tr.step(dinp, dtgt, pos_offsets=OFFS)
+    torch.cuda.synchronize()
+    res = {"grad_step1": g1, "layout": layout, "params": {k: v.clone() for k, v in tr.state_dict().items() if torch.is_tensor(v)}}
+    if rank == 0:
+        # what each rank's gradient is on its own (no process group), same initial parameters
+        singles = []
+        for r in range(world):
+            i2, t2 = _shard(r)
+            t1 = Trainer(sd, layers, lr=3e-4, total_steps=20, device="cuda:0")
+            t1._grads_to_flat(synthetic.to_device(i2, "cuda:0"), t2.cuda(), OFFS)
+            torch.cuda.synchronize()
+            singles.append(t1.flat.grad.detach().cpu().clone())
+            assert [(sg.name, sg.start, sg.numel) for sg in t1.flat.segments] == layout
+            del t1
+        res["singles"] = singles
+        res["initial"] = {k: v.clone() for k, v in sd.items() if torch.is_tensor(v)}
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm", ["overlap", "sequential"])
+def test_two_ranks_on_one_gpu_train_in_lockstep(tmp_path, comm):
+    from cfpnet_amd import spec
+    out = str(tmp_path / "ddp")
+    mp.spawn(_worker, args=(2, _free_port(), out, comm), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    # (1) the averaged gradient both ranks stepped with is the mean of the two single-rank gradients
+    mean = (r0["singles"][0] + r0["singles"][1]) / 2
+    assert torch.equal(r0["grad_step1"], r1["grad_step1"])
+    assert torch.equal(r0["grad_step1"], mean), float((r0["grad_step1"] - mean).abs().max())
+    assert float((r0["singles"][0] - r0["singles"][1]).abs().max()) > 0          # the shards really differ
+    # (2) after two steps every parameter is bit-identical on the two ranks; BatchNorm statistics are per replica
+    diff_params = [k for k in r0["params"] if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))
+                   and not torch.equal(r0["params"][k], r1["params"][k])]
+    assert not diff_params, diff_params[:5]
+    assert any(not torch.equal(r0["params"][k], r1["params"][k]) for k in r0["params"] if k.endswith("running_mean"))
+    # (3) the 48 dead tensors are neither reduced nor stepped; live ones moved
+    dead = [k for k in r0["initial"] if spec.is_dead_param(k)]
+    assert len(dead) == 48 and all(torch.equal(r0["params"][k], r0["initial"][k]) for k in dead)
+    assert not torch.equal(r0["params"]["decoder.conv0.weight"], r0["initial"]["decoder.conv0.weight"])
+    assert not torch.equal(r0["params"]["img_encoder.conv0.0.weight"], r0["initial"]["img_encoder.conv0.0.weight"])
+
+
+def test_split_step_graphs_equal_the_single_graph():
+    """Trainer.capture(split=True): the step as two HIP graphs cut where the RGB encoder's backward begins (the cut the
+    gradient all-reduce overlaps) leaves exactly the parameters of the one-graph step."""
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.trainer import Trainer
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    inp, target = _shard(0)
+    dinp, dtgt = synthetic.to_device(inp, "cuda:0"), target.cuda()
+    a = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=torch.bfloat16)
+    b = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=torch.bfloat16, comm="off")
+    a.capture(dinp, dtgt)
+    b.capture(dinp, dtgt, split=True)
+    assert a._graph2 is None and b._graph2 is not None
+    for _ in range(3):
+        la, _, _ = a.step(dinp, dtgt, pos_offsets=OFFS)
+        lb, _, _ = b.step(dinp, dtgt, pos_offsets=OFFS)
+    torch.cuda.synchronize()
+    assert float(la) == float(lb) and torch.equal(a.flat.param, b.flat.param)
+    for k in a.net.buf:
+        assert torch.equal(a.net.buf[k], b.net.buf[k]), k

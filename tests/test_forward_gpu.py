@@ -126,6 +126,47 @@ def test_full_model_16bit_error_is_bounded(dtype, bound):
     assert pr2 is None and torch.equal(p1, p2)
 
 
+_B8 = {}
+
+
+def _b8_case():
+    """BASELINE.json configs[1] exactly as bench.py runs it: batch 8, 480x640, 8x8 zones of 56 px, the bench's own seed;
+    the CPU oracle's forward of the 8 maps is computed once for the three dtype cases (8 x ~0.4 s on the GPU box)."""
+    if not _B8:
+        layers = spec.COMBINE1_LAYERS
+        sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+        inp = synthetic.make_inputs(8, 480, 640, 8, 56, seed=synthetic.SEED)
+        torch.set_num_threads(max(torch.get_num_threads(), 8))
+        e0, p0, pr0 = O.forward(sd, inp, layer_names=layers)
+        _B8.update(layers=layers, sd=sd, inp=inp, e0=e0, p0=p0, pr0=pr0[:, :, ::8, ::8].clone())
+    return _B8
+
+
+# measured on MI355X (profiles/r2_precision_taps.txt): f32 2e-6, fp16 and bf16 see TOL_* above
+@pytest.mark.parametrize("dtype,bound", [(torch.float32, TOL_F32), (torch.float16, TOL_F16), (torch.bfloat16, TOL_BF16)])
+def test_config1_batch8_as_benched_vs_oracle(dtype, bound):
+    """The benched configuration (BASELINE.json configs[1]: batch 8, 480x640) in every storage mode against the CPU oracle,
+    through the path bench.py times: the captured HIP graph (tile plans depend on M, so batch 8 picks other kernel variants
+    than the batch-1/2 cases above), eager and replayed results bit-identical, every image of the batch checked."""
+    c = _b8_case()
+    eng = Engine(c["sd"], layer_names=c["layers"], dtype=dtype)
+    dinp = synthetic.to_device(c["inp"], "cuda:0")
+    e1, p1, pr1 = eng.forward(dinp)
+    p1, e1, pr1 = p1.clone(), e1.clone(), pr1[:, :, ::8, ::8].float().cpu()
+    eng.capture(dinp)
+    e2, p2, pr2 = eng.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(e1, e2)
+    per_image = [rel_l1(p2[b].cpu().numpy(), c["p0"][b].numpy()) for b in range(8)]
+    r = rel_l1(p2.cpu().numpy(), c["p0"].numpy())
+    abs_rel = float(np.mean(np.abs(c["p0"].numpy() - p2.cpu().numpy()) / c["p0"].numpy()))
+    print(f"configs[1] B=8 {dtype}: pred relL1 {r:.3e} (per image max {max(per_image):.3e}), abs_rel {abs_rel:.3e}")
+    assert r < bound and max(per_image) < 1.5 * bound
+    assert torch.allclose(e2.cpu(), c["e0"], rtol=2e-3 if dtype != torch.float32 else 1e-4, atol=1e-3 if dtype != torch.float32 else 1e-4)
+    assert (pr1 - c["pr0"]).abs().max() < (5e-3 if dtype == torch.float32 else 6e-2)
+    assert p2.shape == (8, 1, 240, 320)
+
+
 def test_forward_is_deterministic_and_batch_independent():
     """Size-independent properties: same input -> identical bits; a sample's result does not depend
     on what else is in the batch (all-valid zones, so the batch-reduced geometry is shared) beyond

@@ -49,6 +49,36 @@ def test_oracle_matches_reference_golden(m):
     assert r["fh"].dtype == np.float64 and m["fh_dtype"] == "torch.float64"
 
 
+ZI = np.load(os.path.join(GOLDEN, "hist_sim_icdf.npz"))
+
+
+@pytest.mark.parametrize("m", META, ids=IDS)
+def test_oracle_icdf_branch_matches_reference_golden(m):
+    """dataloader.py:69-73 (no --sample_uniform, the argparse default): Normal(mu, sigma).icdf at 16 ppf points, with some
+    valid zones masked out by the caller.  Bit-equal to the reference's float32 samples."""
+    n = m["name"]
+    mask = ZI[n + ".mask"].astype(bool)
+    assert 0 < mask.sum() < Z[n + ".mask"].astype(bool).sum() or not Z[n + ".mask"].any()
+    pts = TO.sample_points_icdf(Z[n + ".fh"], mask, ZI["table"])
+    assert pts.dtype == np.float32 and np.array_equal(pts, ZI[n + ".pts"])
+    assert not pts[~mask].any()
+    # the table is float32 erfinv at the float32 ppf points; on this host it may differ from the fixture's in the last bit only
+    assert np.max(np.abs(TO.icdf_table_f32(16).astype(np.float64) - ZI["table"])) < 3e-7
+    assert np.array_equal(tof_ppf(), ZI["ppf"])
+
+
+def tof_ppf():
+    from cfpnet_amd.tof import icdf_ppf_points
+    return icdf_ppf_points(16).numpy()
+
+
+def test_oracle_uniform_sampling_alone_matches_get_hist():
+    m = META[0]
+    n = m["name"]
+    pts = TO.sample_points_uniform(Z[n + ".fh"], Z[n + ".mask"].astype(bool), Z[n + ".w0"], Z[n + ".w1"])
+    assert np.array_equal(pts, Z[n + ".pts"])
+
+
 def test_golden_cases_cover_invalid_zones_and_edge_hits():
     assert 0 < int(Z["eval480_sparse.mask"].sum()) < 64          # some zones without a signal
     d = _depth(META[IDS.index("eval480_mm")])
@@ -181,7 +211,32 @@ def test_reference_named_entry_points_and_errors():
     # a grid that cannot fit the image is refused on the host, before any launch
     with pytest.raises(RuntimeError, match="zone grid leaves the image"):
         tof.TofSimulator(_cfg(dict(mode="train", train_zone_num=8)), "cuda:0").simulate(dep)      # 8*64 = 512 > 416
-    with pytest.raises(NotImplementedError):
-        tof.TofSimulator(_cfg(m, sample_uniform=False), "cuda:0")
     with pytest.raises(ValueError):
         tof.TofSimulator(cfg, "cuda:0").simulate(dep.double())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", META, ids=IDS)
+def test_hip_icdf_sampling_matches_reference_golden(m):
+    """The non-uniform branch on the device (`cfp_tof_sample_points` / `cfp_tof_hist_sim` with CFP_TOF_SAMPLE_ICDF): bit-equal to
+    the reference's samples, both as the stand-alone sampling call and fused into the simulation launch."""
+    from cfpnet_amd import tof
+    n = m["name"]
+    cfg = _cfg(m, sample_uniform=False)
+    sim = tof.TofSimulator(cfg, "cuda:0")
+    assert sim.w1 is None and sim.sample_mode == 1
+    sim.set_weights(ZI["table"])
+    mask = torch.from_numpy(ZI[n + ".mask"].astype(bool))
+    pts = sim.sample_points(torch.from_numpy(Z[n + ".fh"]), mask).cpu().numpy()
+    assert np.array_equal(pts, ZI[n + ".pts"])
+    # fused: every valid zone of the simulation gets the icdf samples of ITS (mu, sigma)
+    dep = torch.from_numpy(_depth(m))[None].cuda()
+    r = sim.simulate(dep)
+    valid = Z[n + ".mask"].astype(bool)
+    want = TO.sample_points_icdf(r["fh"][0].cpu().numpy(), valid, ZI["table"])
+    assert np.array_equal(r["mask"][0].cpu().numpy(), valid)
+    assert np.array_equal(r["hist_data"][0].cpu().numpy(), want)
+    # the drop-in function of the data loader picks the branch from config.sample_uniform
+    p2 = tof.sample_point_from_hist_parallel(torch.from_numpy(Z[n + ".fh"]).cuda(), mask.cuda(), cfg)
+    tbl = TO.icdf_table_f32(16)
+    assert np.array_equal(p2.cpu().numpy(), TO.sample_points_icdf(Z[n + ".fh"], mask.numpy(), tbl))

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Batch-8 480x640 forward (prob output included) in the three storage modes, same protocol as bench.py:
+HIP-graph replay, single graph (latency) and the best in-flight mode (throughput)."""
+import os, sys, time, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfpnet_amd import spec, synthetic, weights
+from cfpnet_amd.engine import Engine
+
+layers = spec.COMBINE1_LAYERS
+sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+inp = synthetic.to_device(synthetic.make_inputs(B), "cuda:0")
+for dt in (torch.float32, torch.float16, torch.bfloat16):
+    eng = Engine(sd, layer_names=layers, dtype=dt)
+    (kind, n), times = eng.capture_best(inp, reps=12)
+    best = min(times.values())
+    print(json.dumps({"dtype": str(dt), "batch": B, "choice": f"{kind}:{n}", "ms_per_step": times,
+                      "maps_per_s_best": B / best * 1e3, "maps_per_s_single_graph": B / times["lanes:1"] * 1e3}))
+    del eng
+    torch.cuda.empty_cache()

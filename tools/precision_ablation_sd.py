@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Experiment: does error-diffusion ("sigma-delta") rounding of the 3x3 conv weights along the 9 taps reduce the weight-rounding
+error?  (Each weight still lands on one of its two neighbouring 16-bit values; the rounding errors of the 9 taps of one
+(cout, cin) pair sum to < 1 ulp instead of accumulating like a random walk, so the part of the error that multiplies the locally
+constant part of the input cancels.)  f32 engine, weights of ONE group rounded either way, rel-L1 of pred vs the exact f32 engine."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cfpnet_amd import spec, synthetic, weights
+from cfpnet_amd.engine import Engine
+
+SERP = [0, 1, 2, 5, 4, 3, 6, 7, 8]      # serpentine walk through the 3x3 taps: consecutive taps are spatial neighbours
+
+
+def rtn(w, dt):
+    return w.to(dt).float()
+
+
+def diffuse(w, dt):
+    """[Co,Ci,3,3] -> same, error diffusion along the serpentine tap order; other shapes: along the input-channel axis."""
+    w = w.float()
+    if w.dim() == 4 and w.shape[-1] == 3 and w.shape[-2] == 3:
+        flat = w.reshape(*w.shape[:2], 9)
+        out = torch.empty_like(flat)
+        e = torch.zeros_like(flat[..., 0])
+        for t in SERP:
+            v = flat[..., t] + e
+            q = v.to(dt).float()
+            e = v - q
+            out[..., t] = q
+        return out.reshape(w.shape)
+    return rtn(w, dt)
+
+
+GROUPS = {
+    "encoder.stem+stage0-2": lambda k: k.startswith(("img_encoder.conv0", "img_encoder.conv1", "img_encoder.conv2")),
+    "decoder.up1-4": lambda k: k.startswith("decoder.up"),
+    "fusion DAPM convs": lambda k: "transformer_path.conv" in k,
+    "decoder.conv0": lambda k: k.startswith("decoder.conv0"),
+    "depth_head.conv3x3": lambda k: k.startswith("depth_head.conv3x3"),
+    "all 3x3": lambda k: True,
+}
+
+
+def rel(a, b):
+    a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+    return float(np.abs(a - b).sum() / np.abs(a).sum())
+
+
+layers = spec.COMBINE1_LAYERS
+sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+e32 = Engine(sd, layer_names=layers, dtype=torch.float32)
+for seed in (synthetic.SEED, 7):
+    inp = synthetic.to_device(synthetic.make_inputs(1, seed=seed), "cuda:0")
+    e32.load_state_dict(sd)
+    p32 = e32.forward(inp)[1].clone()
+    for dt, name in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        for g, sel in GROUPS.items():
+            is33 = lambda k, v: torch.is_tensor(v) and v.dim() == 4 and v.shape[-1] == 3 and v.shape[-2] == 3 and v.shape[1] > 1 and sel(k)
+            res = []
+            for fn in (rtn, diffuse):
+                e32.load_state_dict({k: (fn(v, dt) if is33(k, v) else v) for k, v in sd.items()})
+                res.append(rel(p32, e32.forward(inp)[1]))
+            print(f"seed {seed} {name} {g:24s}: nearest {res[0]:.3e}   error-diffused {res[1]:.3e}   ratio {res[1] / res[0]:.2f}")

@@ -2,6 +2,7 @@
 """Training with the reference's CLI and loop (`/root/reference/train.py:41-209`):
 
     python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager] [--validate N]
+                    [--resume checkpoints/x.pt] [--weight_path weights/x.pt] [--backend nccl|gloo] [--local_gpu I]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py @configs/cfpnet_combine1.txt --synthetic 4096
 
 Per step: ToF simulation of the batch from its ground-truth depth (GPU), forward in training mode, SILog loss, backward of
@@ -93,6 +94,46 @@ def _prefetch(make, n, depth=3):
         yield item
 
 
+SHUFFLE_SEED = 117010053       # train.py:218 seeds everything with this number
+
+
+def load_model_file(path, manifest_sd):
+    """A `save_weights` file (bare state_dict) or a `save_checkpoint` file ({"model", "optimizer", "epoch"}), DataParallel's
+    "module." prefix stripped (model_io.py:47-52), checked STRICTLY against the model's keys and shapes like
+    `load_state_dict` does (model_io.py:16,54).  -> (state_dict, optimizer entry or None, epoch or None)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    opt, epoch = None, None
+    if isinstance(ckpt, dict) and "model" in ckpt and not torch.is_tensor(ckpt["model"]):
+        opt, epoch, ckpt = ckpt.get("optimizer"), ckpt.get("epoch"), ckpt["model"]
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt.items()}
+    want = {k: tuple(v.shape) for k, v in manifest_sd.items() if torch.is_tensor(v)}
+    missing, unexpected = sorted(set(want) - set(sd)), sorted(set(sd) - set(want))
+    bad = [k for k in want if k in sd and tuple(sd[k].shape) != want[k]]
+    if missing or unexpected or bad:
+        raise RuntimeError(f"{path}: state_dict does not match the model (missing {missing[:3]}{'...' if len(missing) > 3 else ''}, "
+                           f"unexpected {unexpected[:3]}{'...' if len(unexpected) > 3 else ''}, shape mismatch {bad[:3]})")
+    return sd, opt, epoch
+
+
+def save_training_checkpoint(path, weights_now, trainer, epoch):
+    """`save_checkpoint` of model_io.py:25-31: {"model", "optimizer", "epoch"}; the optimizer entry is the flat AdamW state."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save({"model": weights_now, "optimizer": trainer.optimizer_state_dict(), "epoch": int(epoch)}, path)
+
+
+def drop_zones(sim, s, drop, rng):
+    """nyu.py:155-158 then :179, in the reference's ORDER: int(len * drop_hist) of each sample's valid zones (drawn WITH
+    replacement) lose their validity BEFORE the sample points are computed, so a dropped zone enters the ToF encoder as an
+    all-zero row (`fh = zeros; fh[mask] = ...`, dataloader.py:67) exactly like a zone without signal does at evaluation time."""
+    m = s["mask"].cpu().numpy().copy()
+    for b in range(m.shape[0]):
+        idx = np.where(m[b])[0]
+        if idx.size:
+            m[b, rng.choice(idx, int(idx.size * drop))] = False
+    mask = torch.from_numpy(m).to(s["mask"].device)
+    return mask, sim.sample_points(s["fh"], mask)
+
+
 def main(argv=None):
     from cfpnet_amd import config, geometry, spec, weights
     from cfpnet_amd.tof import TofSimulator, zone_layout
@@ -105,6 +146,8 @@ def main(argv=None):
     log_every = _pop(argv, "--log_every", 10, int)
     n_val = _pop(argv, "--validate", 0, int)
     dtype = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[_pop(argv, "--dtype", "bf16")]
+    backend = _pop(argv, "--backend", "nccl")        # "gloo": ranks may share one GPU (tests), buckets staged through the host
+    local_gpu = _pop(argv, "--local_gpu", None, int)
     eager = "--eager" in argv
     no_augment = "--no_augment" in argv
     argv = [a for a in argv if a not in ("--eager", "--no_augment")]
@@ -116,10 +159,18 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29512")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world)
+        dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
+    if local_gpu is not None:
+        local = local_gpu
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # flags of the reference's CLI that this loop cannot honour are refused, not ignored
+    if int(getattr(args, "train_zone_random_offset", 0) or 0) > 0:
+        raise NotImplementedError("--train_zone_random_offset > 0 changes the zone geometry per step; the captured step has it fixed "
+                                  "(the ToF simulator itself supports per-sample offsets: cfpnet_amd.tof.TofSimulator.simulate(offsets=...))")
+    if float(getattr(args, "noise_prob", 0.0) or 0.0) > 1e-3 and rank == 0:
+        print("note: --noise_prob has no effect in the reference either (nyu.py:159-163 adds the noise to a copy); nothing is added here", flush=True)
 
     H, W = int(args.input_height), int(args.input_width)
     per_rank = max(1, int(args.bs) // world)
@@ -137,14 +188,24 @@ def main(argv=None):
         total_steps = min(total_steps, max_steps)
     layers = list(args.attention_layer)
     sd = weights.make_torch_state_dict(spec.model_manifest(layers, int(args.n_bins), int(args.zone_sample_num)))
-    wp = getattr(args, "weight_path", "") or ""
-    if wp:
-        sd.update(torch.load(wp, map_location="cpu"))
+    start_epoch, opt_state = 0, None
+    for path, is_resume in ((getattr(args, "weight_path", "") or "", False), (getattr(args, "resume", "") or "", True)):
+        if not path:
+            continue
+        loaded, opt, ep = load_model_file(path, sd)                 # strict: same keys, same shapes (model_io.py:14-17,34-54)
+        sd.update(loaded)
+        if is_resume and ep is not None:
+            # train.py:30-38 restores the weights only (its optimizer restore is commented out, :83-84); a checkpoint written by
+            # THIS loop also carries the flat AdamW moments + step counter and the run continues where it stopped
+            start_epoch = int(ep) + 1
+            opt_state = opt if isinstance(opt, dict) and opt.get("format", "").startswith("cfpnet_amd.") else None
     tr = Trainer(sd, layers, lr=float(args.lr), total_steps=max(total_steps, 2), weight_decay=float(args.wd), div_factor=float(args.div_factor),
                  final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
                  clip_grad_norm=None if args.disable_clip_grad else 0.1, device=dev, dist=dist, world=world, n_bins=int(args.n_bins),
                  min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding), dtype=dtype, no_skip_inside=bool(getattr(args, "no_skip_inside", False)),
                  norm=str(args.norm))
+    if opt_state is not None:
+        tr.load_optimizer_state_dict(opt_state)
     sim = TofSimulator(args, dev)
     zn, zp, _, _ = zone_layout(args, H, W)
     rects = geometry.centered_zone_rects(H, W, zn, zp)
@@ -177,8 +238,9 @@ def main(argv=None):
         if save_path:
             d = os.path.dirname(os.path.abspath(save_path))
             os.makedirs(d, exist_ok=True)
-            if epoch is not None:
+            if epoch is not None:                                    # train.py:150-155: checkpoint {model, optimizer, epoch} + bare weights
                 torch.save(weights_now, os.path.join(d, f"{epoch}_{m['rmse']:.3f}.pt"))
+                save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, epoch)
             if m["rmse"] < best_rmse:
                 torch.save(weights_now, os.path.join(d, "best.pt"))
         best_rmse = min(best_rmse, m["rmse"])
@@ -186,9 +248,11 @@ def main(argv=None):
         del eng
         return m
 
-    t0, seen, step = time.perf_counter(), 0, 0
-    for epoch in range(int(args.epochs)):
-        file_batches = files.epoch_batches(per_rank) if files is not None else None
+    t0, seen, step = time.perf_counter(), 0, start_epoch * steps_per_epoch
+    loss = torch.zeros(())
+    for epoch in range(start_epoch, int(args.epochs)):
+        # one global permutation per epoch, the same on every rank (each takes its slice of every global batch)
+        file_batches = files.epoch_batches(per_rank, generator=torch.Generator().manual_seed(SHUFFLE_SEED + epoch)) if files is not None else None
         if files is None and not no_augment:
             file_batches = _prefetch(lambda i, e=epoch: ds.raw_batch(e * steps_per_epoch + i, per_rank) + (None,), steps_per_epoch)
         for i in range(steps_per_epoch):
@@ -209,16 +273,11 @@ def main(argv=None):
                     raw_rgb, raw_dep = augment.rotate(raw_rgb, raw_dep, angles)
                 img, depd = augment.augment(raw_rgb, raw_dep, params, H, W)
             s = sim.simulate(depd)
-            mask = s["mask"]
-            if drop > 1e-3:                                   # nyu.py:155-158: drop int(len*drop_hist) valid zones, drawn WITH replacement
-                m = mask.cpu().numpy().copy()
-                for b in range(m.shape[0]):
-                    idx = np.where(m[b])[0]
-                    if idx.size:
-                        m[b, rng.choice(idx, int(idx.size * drop))] = False
-                mask = torch.from_numpy(m).to(dev)
-            inp = {"rgb": img, "additional": {"hist_data": s["hist_data"], "rect_data": s["rect_data"], "mask": mask, "patch_info": patch_info}}
-            if step == 0 and not eager:
+            mask, hist_data = s["mask"], s["hist_data"]
+            if drop > 1e-3:
+                mask, hist_data = drop_zones(sim, s, drop, rng)
+            inp = {"rgb": img, "additional": {"hist_data": hist_data, "rect_data": s["rect_data"], "mask": mask, "patch_info": patch_info}}
+            if not eager and tr._graph is None:
                 tr.capture(inp, depd)                         # the whole step as one HIP graph from here on
             loss, lr, beta1 = tr.step(inp, depd)
             step += 1
@@ -235,6 +294,8 @@ def main(argv=None):
     if rank == 0 and save_path:
         os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
         torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
+        if step > 0:
+            save_training_checkpoint(os.path.splitext(save_path)[0] + ".ckpt.pt", tr.state_dict(), tr, int(args.epochs) - 1)
     if dist:
         dist.barrier(); dist.destroy_process_group()
     return float(loss)
