@@ -109,6 +109,13 @@ class Engine:
         self.change_embedding, self.no_skip_inside, self.stem_act = change_embedding, no_skip_inside, stem_act
         self.dtype, self.device = dtype, torch.device(device)
         self.zone_sample_num = zone_sample_num
+        # depth head: conv3x3 -> conv_out -> softmax -> expectation as ONE kernel (csrc/head_fused.hip) in the 16-bit modes;
+        # head_hilo = (conv_out weights as hi + lo planes, ram fed to conv_out as hi + lo): the logits then carry neither the
+        # rounding of conv_out's weights nor that of ram -- measured +34 us / +200 us per batch of 8 for < 2 % of the error
+        # budget (profiles/r2_precision_budget.md), so both are OFF by default.  CFP_HEAD_FUSED=0 runs the separate kernels.
+        self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
+        hl = os.environ.get("CFP_HEAD_HILO", "00")
+        self.head_hilo = (hl[0] == "1", hl[1] == "1")
         self.half = dtype in (torch.bfloat16, torch.float16)     # 16-bit storage: the MFMA fast paths
         self.ve = 8 if self.half else 4
         self.P: Dict[str, torch.Tensor] = {}
@@ -142,6 +149,8 @@ class Engine:
         elif w.dim() == 3:
             w = w[:, :, :, None]
         co, ci, kh, kw = w.shape
+        if kh * kw > 1:
+            w = ops.round_taps(w, self.dtype)       # 16-bit storage: rounding error diffused over the taps (ops.round_taps)
         cip = (ci + 7) // 8 * 8
         if cip != ci:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cip - ci))
@@ -196,7 +205,7 @@ class Engine:
                 self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn2", eps=EPS)
             else:
                 self._conv(sd, q + ".pw", q + ".conv_pw.weight", bn=q + ".bn1", eps=EPS)
-                wd = sd[q + ".conv_dw.weight"].float()
+                wd = ops.round_taps(sd[q + ".conv_dw.weight"].float(), self.dtype)
                 self.P[q + ".dw.w"] = self._dev(wd.reshape(wd.shape[0], 9).t(), self.dtype)
                 self.P[q + ".dw.s"], self.P[q + ".dw.t"] = self._fold_bn(sd, q + ".bn2", None, wd.shape[0], EPS)
                 self.P[q + ".se.wr"] = self._dev(sd[q + ".se.conv_reduce.weight"].reshape(b.se_rd, b.mid))
@@ -252,6 +261,9 @@ class Engine:
         for i in (0, 2, 4):
             self.P[f"{h}.r{i}.w"], self.P[f"{h}.r{i}.b"] = self._dev(sd[f"{h}.regressor.{i}.weight"].t()), self._dev(sd[f"{h}.regressor.{i}.bias"])
         self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias")
+        if self.half and self.n_bins == 256:
+            # operand of the fused head kernel: K axis in the kernel's fragment order, hi + lo planes (ops.permute_wout)
+            self.P["conv_out.wp"] = ops.permute_wout(sd["conv_out.0.weight"], self.dtype, hilo=self.head_hilo[0]).to(self.device)
 
     # ------------------------------------------------------------------------------ buffers
     def _act(self, plan, key: str, rows: int, C: int, ld: Optional[int] = None, zero: bool = False) -> Act:
@@ -844,7 +856,8 @@ class Engine:
         HWh = hs[0] * wsz[0]
         unet = self._act(plan, "unet", Mh, 128)
         self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
-        ram = self._act(plan, "ram", Mh, 128)
+        fused_head = self.half and self.head_fused and self.n_bins == 256 and HWh % 16 == 0 and HWh >= 128 and "conv_out.wp" in self.P
+        ram = self._act(plan, "ram", Mh, 128) if (not fused_head or taps is not None) else None
         ns = max(1, min(256, HWh // 256))
         part = self._f32(plan, "head.sum", B * ns * 128)
         edges = out[0] if out is not None else torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
@@ -856,14 +869,19 @@ class Engine:
             ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
                               self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
                               edges, centers, B, 128, 256, self.n_bins)
-        self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
+        if not fused_head:
+            self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
         main.wait_stream(side)
         pred = out[1] if out is not None else torch.empty(B, 1, hs[0], wsz[0], dtype=torch.float32, device=dev)
         if out is not None:
             prob = out[2] if return_prob else None
         else:
             prob = torch.empty(B, self.n_bins, hs[0], wsz[0], dtype=self.dtype, device=dev) if return_prob else None
-        if self.half and self.n_bins == 256 and HWh % 8 == 0:
+        if fused_head:
+            # conv3x3 + conv_out + softmax + expectation in one kernel: neither ram nor the logits reach HBM
+            ops.depth_head_fused(unet, self.P[h + ".conv3x3.w"], self.P[h + ".conv3x3.s"], self.P[h + ".conv3x3.t"], self.P["conv_out.wp"],
+                                 self.P["conv_out.t"], centers, prob, pred, B, hs[0], wsz[0], ram_out=ram, ram_hilo=self.head_hilo[1])
+        elif self.half and self.n_bins == 256 and HWh % 8 == 0:
             # 1x1 conv + softmax + expectation in one kernel: the logits never reach HBM
             ops.bin_head_fused(ram, self.P["conv_out.w"], self.P["conv_out.t"], centers, prob, pred, B, HWh)
         else:

@@ -143,11 +143,59 @@ def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
              B, H, W, x.C, k, act, x.dt, _s())
 
 
+def _bracket16(w: torch.Tensor, dtype):
+    """(down, up): the largest value representable in `dtype` that is <= w and the smallest that is >= w, as float32."""
+    r16 = w.to(dtype)
+    r = r16.float()
+    bits = r16.view(torch.int16).to(torch.int32)
+    toward_inf = torch.where(r >= 0, bits + 1, bits - 1)          # next representable value away from zero ... for r < 0 towards zero
+    toward_ninf = torch.where(r > 0, bits - 1, bits + 1)
+    # r == +0: below it is the smallest negative subnormal (0x8001); r == -0 (bits -32768): above it is 0x0001
+    toward_ninf = torch.where(r16.view(torch.int16) == 0, torch.full_like(bits, -32767), toward_ninf)
+    toward_inf = torch.where(r16.view(torch.int16) == -32768, torch.ones_like(bits), toward_inf)
+    nxt_up = toward_inf.to(torch.int16).view(dtype).float()
+    nxt_dn = toward_ninf.to(torch.int16).view(dtype).float()
+    up = torch.where(r >= w, r, nxt_up)
+    down = torch.where(r <= w, r, nxt_dn)
+    return down, up
+
+
+def round_taps(w: torch.Tensor, dtype, bracket: bool = True) -> torch.Tensor:
+    """Round the weights of a k x k convolution ([..., kh, kw], float32) to the 16-bit storage format `dtype`, choosing the
+    rounding DIRECTION of every weight by error diffusion along the taps: walking the kh x kw window in serpentine order, a weight
+    goes to whichever of its two bracketing representable values is nearer to (weight + error left by its predecessors).  Every
+    weight stays within one unit in the last place of its float32 value, but the errors of the taps of one (cout, cin) pair cancel
+    instead of growing like a random walk, so the part of the layer's rounding error that multiplies the locally constant part of its
+    input (feature maps are smooth over a 3 x 3 neighbourhood, and after an activation their mean is not zero) disappears.
+    Measured on MI355X (tools/precision_ablation_sd.py, profiles/r2_precision_budget.md): the weight-rounding error of the depth
+    head's 3x3 conv drops ~6x in fp16 and ~3x in bf16; no kernel changes, no run-time cost.  Returns float32 holding exactly
+    representable values (the cast to `dtype` is then exact)."""
+    w = w.detach().float()
+    if dtype == torch.float32 or w.shape[-1] * w.shape[-2] == 1:
+        return w
+    kh, kw = w.shape[-2], w.shape[-1]
+    order = [r * kw + (c if r % 2 == 0 else kw - 1 - c) for r in range(kh) for c in range(kw)]
+    flat = w.reshape(*w.shape[:-2], kh * kw)
+    down, up = _bracket16(flat, dtype)
+    out = torch.empty_like(flat)
+    e = torch.zeros_like(flat[..., 0])
+    for t in order:
+        v = flat[..., t] + e
+        if bracket:
+            q = torch.where((v - down[..., t]).abs() <= (up[..., t] - v).abs(), down[..., t], up[..., t])
+        else:           # experiment only: plain error diffusion may move a small weight by the ulp of a large neighbour
+            q = v.to(dtype).float()
+        e = v - q
+        out[..., t] = q
+    return out.reshape(w.shape)
+
+
 def toeplitz_bands(w: torch.Tensor, dtype) -> torch.Tensor:
     """[C,1,k,k] or [C,k,k] depthwise weights (ky, kx) -> the banded-Toeplitz B-operand table of cfp_dwconv_large_mfma_nhwc."""
     w = w.detach().float().cpu()
     if w.dim() == 4:
         w = w[:, 0]
+    w = round_taps(w, dtype)
     C, k, _ = w.shape
     halo = (k - 1) // 2
     lm = (halo + 7) // 8 * 8
@@ -281,3 +329,29 @@ def bin_softmax(logits: Act, centers, prob, pred, B, HW, nbins):
 def bin_head_fused(x: Act, w, bias, centers, prob, pred, B, HW):
     hip.call("cfp_bin_head_fused", x.ptr, x.ld, w.data_ptr(), bias.data_ptr(), centers.data_ptr(), hip.ptr(prob),
              pred.data_ptr(), B, HW, x.C, x.dt, _s())
+
+
+def permute_wout(w: torch.Tensor, dtype, hilo: bool = True) -> torch.Tensor:
+    """conv_out weights [256, 128(, 1, 1)] float32 -> the operand of cfp_depth_head_fused: input-channel axis in the kernel's
+    fragment order, stored as [planes, 256, 128] in `dtype` (plane 0 = round(W), plane 1 = round(W - plane 0) when `hilo`)."""
+    w = w.detach().float().reshape(w.shape[0], -1)
+    assert w.shape == (256, 128)
+    pos = torch.arange(128)
+    kb, q, e = pos // 32, (pos % 32) // 8, pos % 8
+    src = 32 * kb + 16 * (e // 4) + 4 * q + (e % 4)
+    wp = w[:, src]
+    hi = wp.to(dtype)
+    planes = [hi]
+    if hilo:
+        planes.append((wp - hi.float()).to(dtype))
+    return torch.stack(planes).contiguous()
+
+
+def depth_head_fused(x: Act, w3, scale3, shift3, wout_perm: torch.Tensor, bias_out, centers, prob, pred, B, H, W, ram_out: Optional[Act] = None,
+                     ram_hilo: bool = True, probe: int = 0):
+    assert x.C == 128 and w3.shape == (128, 9 * 128) and wout_perm.shape[1:] == (256, 128) and wout_perm.dtype == x.buf.dtype
+    flags = (hip.HEAD_WOUT_HILO if wout_perm.shape[0] == 2 else 0) | (hip.HEAD_RAM_HILO if ram_hilo else 0) | (probe << 8)
+    if ram_out is not None:
+        assert ram_out.ld == 128 and ram_out.C == 128
+    hip.call("cfp_depth_head_fused", x.ptr, x.ld, w3.data_ptr(), hip.ptr(scale3), hip.ptr(shift3), wout_perm.data_ptr(), bias_out.data_ptr(),
+             centers.data_ptr(), hip.ptr(prob), pred.data_ptr(), ram_out.ptr if ram_out is not None else 0, B, H, W, flags, x.dt, _s())

@@ -249,6 +249,21 @@ int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw, const floa
 int cfp_bin_softmax(const void* logits, int ld, const float* centers, void* prob, float* pred,
                     int B, int HW, int nbins, int dtype, cfp_stream_t stream);
 
+/* The whole adaptive-bins head in one kernel (csrc/head_fused.hip):
+ *   ram = conv3x3(x) (128 -> 128, decoder.py:22-27 `self.conv3x3`), logits = conv_out(ram) (1x1, 128 -> 256,
+ *   deltar.py:18-19,51), prob = softmax over the 256 bins, pred = sum_n prob * centers (deltar.py:61).
+ * `ram` and the logits never reach HBM.  x [B*H*W, x_ld] NHWC 16-bit with 128 channels; w3 [128][3*3*128] as cfp_conv2d_nhwc
+ * lays weights out; scale3 / shift3 [128] f32 (may be NULL = 1 / 0; depth_head.conv3x3 has a bias and no activation);
+ * wout_perm [256][128] with the input-channel axis permuted for the kernel's fragment order: position 32 kb + 8 q + e holds
+ * channel 32 kb + 16 (e >> 2) + 4 q + (e & 3) (kb, q in 0..3, e in 0..7); with CFP_HEAD_WOUT_HILO a second [256][128] plane
+ * follows holding round16(W - hi) so conv_out's weights act with ~22 significant bits; CFP_HEAD_RAM_HILO feeds ram to the
+ * second GEMM as hi + lo (no 16-bit rounding of ram).  bias_out [256], centers [B,256] f32; prob [B,256,H*W] (NCHW, `dtype`,
+ * may be NULL); pred [B*H*W] f32; ram_out [B*H*W,128] (`dtype`, may be NULL: test hook).  bf16 / f16 only; H*W % 16 == 0 and H*W >= 128. */
+enum { CFP_HEAD_WOUT_HILO = 1, CFP_HEAD_RAM_HILO = 2 };
+int cfp_depth_head_fused(const void* x, int x_ld, const void* w3, const float* scale3, const float* shift3,
+                         const void* wout_perm, const float* bias_out, const float* centers, void* prob, float* pred,
+                         void* ram_out, int B, int H, int W, int flags, int dtype, cfp_stream_t stream);
+
 /* Fused bin head: logits = x @ w^T + bias never leave the chip:
  *   1x1 conv (Cin -> 256) on the matrix cores, row softmax, expectation, optional prob write.
  * Replaces conv_out (deltar.py:18-19,51) + deltar.py:61.  bf16 only; nbins == 256. */

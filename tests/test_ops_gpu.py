@@ -656,6 +656,55 @@ def test_bin_head_fused(HW, dtype):
     assert torch.equal(pred, pred2)
 
 
+def _head_ref(x, w3, b3, wo, bo, centers, B, H, W, ram_dtype):
+    """conv3x3 (+bias) -> [ram rounded to the storage type or not] -> conv_out -> softmax -> expectation, in float64."""
+    xi = x.double().reshape(B, H, W, 128).permute(0, 3, 1, 2)
+    ram = F.conv2d(xi, w3.double(), b3.double(), padding=1)
+    ram_s = ram.float().to(ram_dtype).double() if ram_dtype is not None else ram
+    logits = F.conv2d(ram_s, wo.double()[:, :, None, None], bo.double())
+    prob = torch.softmax(logits, dim=1)
+    pred = (prob * centers.double()[:, :, None, None]).sum(1)
+    return ram, prob.reshape(B, 256, H * W), pred.reshape(B, H * W)
+
+
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("B,H,W,ld", [(2, 12, 20, 128), (1, 16, 24, 136), (3, 8, 18, 128), (1, 40, 64, 128)])
+@pytest.mark.parametrize("hilo", [(True, True), (False, False), (True, False)])
+def test_depth_head_fused(B, H, W, ld, hilo, dtype):
+    """depth_head.conv3x3 -> conv_out -> softmax -> expectation as one kernel (csrc/head_fused.hip) against the float64 chain:
+    halo rows / columns, tiles that straddle rows and images, a ragged last tile (M % 128 != 0), an input pitch > 128, the ram
+    test hook, and the two exactness islands (hi + lo conv_out weights, hi + lo ram)."""
+    M = B * H * W
+    x = q(rnd(M, 128, seed=1), dtype)
+    w3 = rnd(128, 128, 3, 3, seed=2, scale=1.0 / math.sqrt(9 * 128))
+    b3 = rnd(128, seed=3, scale=0.5)
+    wo = rnd(256, 128, seed=4, scale=0.6)
+    bo = rnd(256, seed=5)
+    centers = torch.sort(torch.rand(B, 256, generator=torch.Generator().manual_seed(2)) * 10, dim=1)[0]
+    w3q = ops.round_taps(w3, dtype)                                             # what the engine packs
+    w3p = w3q.permute(0, 2, 3, 1).reshape(128, 9 * 128).to(dtype).to(DEV).contiguous()
+    wop = ops.permute_wout(wo, dtype, hilo=hilo[0]).to(DEV)
+    prob = torch.zeros(B, 256, H * W, dtype=dtype, device=DEV)
+    pred = torch.empty(M, device=DEV)
+    ram = ops.new_act(M, 128, dtype, DEV)
+    xa = to_act(x, dtype, ld=ld)
+    ops.depth_head_fused(xa, w3p, None, b3.to(DEV), wop, bo.to(DEV), centers.to(DEV), prob, pred, B, H, W, ram_out=ram, ram_hilo=hilo[1])
+    torch.cuda.synchronize()
+    wo_eff = wo if hilo[0] else q(wo, dtype)
+    ram_ref, p_ref, pred_ref = _head_ref(x, w3q, b3, wo_eff, bo, centers, B, H, W, None if hilo[1] else dtype)
+    close(ram.torch().float().cpu(), nhwc(ram_ref.float()), dtype, "ram")
+    # logits carry 1e-3-level noise only when ram is rounded; with both islands the probabilities are f32-accurate up to the 16-bit store
+    err = (prob.float().cpu() - p_ref.float()).abs().max()
+    assert float(err) < (2e-3 if dtype == torch.float16 else 1.2e-2), float(err)
+    # both islands on: what is left is the 16-bit input x itself (exact here) and the 2^-16 (bf16) / 2^-22 (fp16) residual of hi + lo
+    t = ({torch.bfloat16: 3e-4, torch.float16: 3e-5}[dtype]) if hilo == (True, True) else ({torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype])
+    assert torch.allclose(pred.cpu().reshape(B, H * W), pred_ref.float(), rtol=t, atol=t), \
+        float((pred.cpu().reshape(B, H * W) - pred_ref.float()).abs().max())
+    pred2 = torch.empty(M, device=DEV)
+    ops.depth_head_fused(xa, w3p, None, b3.to(DEV), wop, bo.to(DEV), centers.to(DEV), None, pred2, B, H, W, ram_hilo=hilo[1])
+    assert torch.equal(pred, pred2)
+
+
 # ---- bit-exact checks of the bf16 fast-path kernels ---------------------------------------------------------------
 # Small-integer inputs and weights make every product and every f32 partial sum exact, so the only rounding is the final
 # f32 -> bf16 store (round-to-nearest-even): the kernels must reproduce the integer convolution BIT FOR BIT, whatever their

@@ -30,7 +30,48 @@ def diffuse(w, dt):
             e = v - q
             out[..., t] = q
         return out.reshape(w.shape)
+    if w.dim() >= 2 and w.shape[1] > 1:          # 1x1 conv / Linear / Conv1d: along the input-channel axis
+        shp = w.shape
+        flat = w.reshape(shp[0], shp[1], -1)
+        out = torch.empty_like(flat)
+        e = torch.zeros_like(flat[:, 0])
+        for c in range(shp[1]):
+            v = flat[:, c] + e
+            q = v.to(dt).float()
+            e = v - q
+            out[:, c] = q
+        return out.reshape(shp)
     return rtn(w, dt)
+
+
+def diffuse2(w, dt):
+    """Depthwise / large kernels [C,1,k,k]: serpentine over the k x k taps; everything else as `diffuse`."""
+    w = w.float()
+    if w.dim() == 4 and w.shape[1] == 1 and w.shape[-1] > 1:
+        k = w.shape[-1]
+        order = [r * k + (c if r % 2 == 0 else k - 1 - c) for r in range(k) for c in range(k)]
+        flat = w.reshape(w.shape[0], k * k)
+        out = torch.empty_like(flat)
+        e = torch.zeros_like(flat[:, 0])
+        for t in order:
+            v = flat[:, t] + e
+            q = v.to(dt).float()
+            e = v - q
+            out[:, t] = q
+        return out.reshape(w.shape)
+    if w.dim() == 4 and w.shape[-1] > 3:          # sr convs (kernel = stride = window): serpentine over taps per (cout, cin)
+        k = w.shape[-1]
+        order = [r * k + (c if r % 2 == 0 else k - 1 - c) for r in range(k) for c in range(k)]
+        flat = w.reshape(w.shape[0], w.shape[1], k * k)
+        out = torch.empty_like(flat)
+        e = torch.zeros_like(flat[..., 0])
+        for t in order:
+            v = flat[..., t] + e
+            q = v.to(dt).float()
+            e = v - q
+            out[..., t] = q
+        return out.reshape(w.shape)
+    return diffuse(w, dt)
 
 
 GROUPS = {
@@ -51,7 +92,7 @@ def rel(a, b):
 layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
 e32 = Engine(sd, layer_names=layers, dtype=torch.float32)
-for seed in (synthetic.SEED, 7):
+for seed in (synthetic.SEED,):
     inp = synthetic.to_device(synthetic.make_inputs(1, seed=seed), "cuda:0")
     e32.load_state_dict(sd)
     p32 = e32.forward(inp)[1].clone()
@@ -61,5 +102,23 @@ for seed in (synthetic.SEED, 7):
             res = []
             for fn in (rtn, diffuse):
                 e32.load_state_dict({k: (fn(v, dt) if is33(k, v) else v) for k, v in sd.items()})
+                res.append(rel(p32, e32.forward(inp)[1]))
+            print(f"seed {seed} {name} {g:24s}: nearest {res[0]:.3e}   error-diffused {res[1]:.3e}   ratio {res[1] / res[0]:.2f}")
+        G2 = {"encoder IR 1x1 (pw, pwl)": lambda k: k.startswith(("img_encoder.conv3", "img_encoder.conv4")) and ("conv_pw" in k),
+              "encoder ER pwl 1x1": lambda k: k.startswith(("img_encoder.conv1", "img_encoder.conv2")) and "conv_pwl" in k,
+              "decoder 1x1 (conv1-4)": lambda k: k.startswith(("decoder.conv4", "decoder.conv3", "decoder.conv2", "decoder.conv1")),
+              "fusion linears": lambda k: k.startswith("decoder.cross_atten") and ("proj" in k or "merge" in k or "mlp" in k or "pwconv" in k),
+              "fusion sr convs": lambda k: ".gsa.sr." in k,
+              "fusion LKPM dw": lambda k: "dwconv2" in k,
+              "encoder dw3x3": lambda k: "conv_dw" in k,
+              "hist_encoder": lambda k: k.startswith("hist_encoder"),
+              "conv_out": lambda k: k.startswith("conv_out"),
+              "everything": lambda k: True}
+        for g, sel in G2.items():
+            ok = lambda k, v: (torch.is_tensor(v) and v.is_floating_point() and v.dim() >= 2 and "positional" not in k and ".se." not in k
+                               and "regressor" not in k and "conv1x1" not in k and sel(k))
+            res = []
+            for fn in (rtn, diffuse2):
+                e32.load_state_dict({k: (fn(v, dt) if ok(k, v) else v) for k, v in sd.items()})
                 res.append(rel(p32, e32.forward(inp)[1]))
             print(f"seed {seed} {name} {g:24s}: nearest {res[0]:.3e}   error-diffused {res[1]:.3e}   ratio {res[1] / res[0]:.2f}")
