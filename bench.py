@@ -65,6 +65,10 @@ def parse():
                     help="measure the TRAINING step instead (BASELINE.json configs[2..3]: per-GPU batch --train-batch at 416x544, bf16, "
                          "data parallel over --gpus ranks with the RCCL gradient all-reduce inside the timed region)")
     ap.add_argument("--train-batch", type=int, default=16, help="per-GPU batch of the training-step measurement (configs[2..3]: 16)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend of --train (nccl = RCCL over xGMI; gloo stages the gradient buckets through host memory: "
+                         "several ranks can then share one GPU, and with --force-dist a single rank exercises the whole DDP path)")
+    ap.add_argument("--force-dist", action="store_true", help="create the process group even for one rank (measures allreduce_ms / overlap_frac at N = 1)")
     return ap.parse_args()
 
 
@@ -75,7 +79,6 @@ def kernel_times(engine, inputs, return_prob, reps=5):
     dw_shapes = []
     real_call = hip.call
     stem_w = engine.P["stem.w"].data_ptr()
-    hist_w = engine.P["hist_encoder.hist_extractor1.pointnet_encoder.l1.w"].data_ptr()
 
     def timed_call(name, *a):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -86,7 +89,7 @@ def kernel_times(engine, inputs, return_prob, reps=5):
         if name in ("cfp_conv2d_nhwc", "cfp_conv2d_nhwc_ex"):
             B, H, W, Cin, Cout, KH, KW, stride, pt, pl, Ho, Wo = a[9:21]   # noqa
             M = B * Ho * Wo
-            cin_true = 3 if a[2] == stem_w else (1 if a[2] == hist_w else Cin)
+            cin_true = 3 if a[2] == stem_w else Cin
             flops = 2.0 * M * Cout * KH * KW * cin_true
             byts = 2.0 * (M * Cout + B * H * W * Cin + Cout * KH * KW * Cin)
             piw = a[26] if name.endswith("_ex") else 0
@@ -98,6 +101,12 @@ def kernel_times(engine, inputs, return_prob, reps=5):
             flops = 2.0 * 9 * B * Ho * Wo * C
             byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)
             dw_shapes.append((B * H * W, B * Ho * Wo, C))
+        elif name == "cfp_depth_head_fused":
+            B, H, W = a[11:14]
+            M = B * H * W
+            fam = "depth_head_fused_kernel (conv3x3 128->128 + conv_out 128->256 + softmax + expectation)"
+            flops = 2.0 * M * 128 * (9 * 128 + 256)
+            byts = 2.0 * (M * 128 + (M * 256 if a[8] else 0) + 128 * 9 * 128 + 256 * 128) + 4.0 * M
         elif name == "cfp_dwconv_large_nhwc":
             B, H, W, C, k = a[7:12]
             flops = 2.0 * k * k * B * H * W * C
@@ -167,7 +176,10 @@ def pmc_traffic(kernel_family: str):
     return None if e is None else e.get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(budget_s, layers, sd):
+def cpu_baseline(budget_s, layers, sd, batch_inputs=None):
+    """The CPU oracle timed on this box's host cores (B=1 forwards, bounded sample).  With `batch_inputs` (the bench's own batch,
+    host tensors) the oracle's prediction for EVERY map of that batch is also returned: the reference the 16-bit engines' rel-L1 /
+    abs_rel are measured against (one untimed batched forward)."""
     from cfpnet_amd import synthetic
     from oracle import cfpnet_oracle as O
     inp = synthetic.make_inputs(1, 480, 640, 8, 56, seed=synthetic.SEED)
@@ -191,17 +203,43 @@ def cpu_baseline(budget_s, layers, sd):
         times = [first]
     times.sort()
     med = times[len(times) // 2]
-    return inp, out, dict(value=1.0 / med, unit="maps/s", cores=torch.get_num_threads(), kind="port",
-                          sample=f"{len(times)} x B=1 480x640 full forward of the CPU oracle (PyTorch CPU fp32), median {med * 1e3:.0f} ms")
+    ref_batch = None
+    if batch_inputs is not None:
+        ref_batch = O.forward(sd, batch_inputs, layer_names=layers)[1]
+    return inp, out, ref_batch, dict(value=1.0 / med, unit="maps/s", cores=torch.get_num_threads(), kind="port",
+                                     sample=f"{len(times)} x B=1 480x640 full forward of the CPU oracle (PyTorch CPU fp32), median {med * 1e3:.0f} ms")
 
 
-def init_dist(backend: str = "nccl"):
+def reference_latency_ms(engine, inputs, warmup=100, iters=500):
+    """The reference's own latency protocol (evaluate_time.py:56-82): `warmup` forwards, then `iters` forwards each bracketed by
+    a device synchronize, sorted, the fastest one and the two slowest dropped, mean of the rest.  One HIP graph per forward."""
+    engine.capture(inputs, return_prob=True)
+    for _ in range(warmup):
+        engine.replay()
+    diff = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        engine.replay()
+        torch.cuda.synchronize()
+        diff.append((time.perf_counter() - t) * 1e3)
+    diff.sort()
+    return sum(diff[1:-2]) / (iters - 3), diff[len(diff) // 2]
+
+
+def err_vs(ref, got):
+    import numpy as np
+    ref, got = ref.double().cpu().numpy(), got.double().cpu().numpy()
+    return {"rel_l1": float(np.abs(ref - got).sum() / np.abs(ref).sum()), "abs_rel": float(np.mean(np.abs(ref - got) / ref))}
+
+
+def init_dist(backend: str = "nccl", force: bool = False):
     """One process per GPU (torch.distributed.run sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns
     (rank, world, local_rank, dist-module-or-None).  `backend="gloo"` is used by the CPU tests."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world <= 1:
+    if world <= 1 and not force:
         return rank, world, local, None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,7 +264,31 @@ def job_value(world: int, batch: int, steps: int, elapsed: float):
     return maps / elapsed, maps / elapsed / world
 
 
-def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2):
+def training_fidelity(sd, layers, inp, target, dev):
+    """bf16 / fp16 mixed-precision step against the float32 step on the SAME shard (the benched one): relative loss difference and
+    cosine of the whole parameter gradient (all live tensors concatenated)."""
+    from cfpnet_amd.train_model import TrainNet
+    offs = {"cross_atten3": (3, 5), "cross_atten2": (7, 2), "cross_atten1": (11, 20)}
+    out, ref = {}, None
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+        net = TrainNet(sd, layers, dev, dtype=dt)
+        loss, _, _ = net.forward_backward(inp, target, target > 1e-3, pos_offsets=offs)
+        torch.cuda.synchronize()
+        g = net.grads()
+        keys = sorted(g)
+        flat = torch.cat([g[k].reshape(-1).double() for k in keys])
+        if ref is None:
+            ref = (float(loss), flat, keys)
+        else:
+            assert keys == ref[2]
+            out[name] = {"loss_rel_diff": abs(float(loss) - ref[0]) / abs(ref[0]),
+                         "gradient_cosine": float((flat * ref[1]).sum() / (flat.norm() * ref[1].norm()))}
+        del net, g
+        torch.cuda.empty_cache()
+    return out
+
+
+def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2, fidelity: bool = False):
     """BASELINE.json configs[2..3] shape on ONE GPU: 416x544 crops, 6x6 zones of 64 px, `batch` samples, bf16 activations with
     float32 master parameters; one step = training forward + SILog + backward + AdamW/OneCycle, replayed as one HIP graph.
     (Single process: the RCCL gradient all-reduce of the multi-GPU run is not part of this number.)"""
@@ -255,7 +317,30 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
         dist.barrier()
     torch.cuda.synchronize()
     dt = max_over_ranks(time.perf_counter() - t0, dist, dev) / steps
-    return {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights",
+    extra = {}
+    if dist is not None:
+        # what the gradient averaging costs and how much of it the split step hides: the same steps with the buckets reduced after
+        # the whole backward ("sequential") and without any communication ("off")
+        def run_mode(mode):
+            tr.comm = mode
+            for _ in range(2):
+                tr.step(inp, target)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(inp, target)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            return max_over_ranks(time.perf_counter() - t1, dist, dev) / steps * 1e3
+        t_seq, t_off = run_mode("sequential"), run_mode("off")
+        tr.comm = "overlap"
+        ar = max(t_seq - t_off, 0.0)
+        extra = {"allreduce_ms": ar, "ms_per_step_sequential_allreduce": t_seq, "ms_per_step_no_allreduce": t_off,
+                 "overlap_frac": (min(max((t_seq - dt * 1e3) / ar, 0.0), 1.0) if ar > 1e-3 else None),
+                 "allreduce": "flat float32 gradient, 10x group (head/decoder/fusion/ToF encoder) reduced on a communication stream beside the "
+                              "RGB-encoder backward (second HIP graph of the split step), 1x group after it; backend " + str(dist.get_backend())}
+    elif fidelity:
+        extra = {"fidelity_vs_f32_same_batch": training_fidelity(sd, layers, inp, target, dev)}
+    return {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights", **extra,
             "config": {"workload": f"batch={batch} 416x544 crops + 6x6-zone ToF, training forward + SILog + backward + AdamW/OneCycle",
                        "launch": "one HIP graph per step" + (", flat-gradient RCCL all-reduce (3 x 32 MB buckets) + AdamW after it" if world > 1 else ""),
                        "n_gpus": world, "global_batch": world * batch},
@@ -264,7 +349,7 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
 
 def main():
     a = parse()
-    rank, world, local, dist = init_dist("nccl")
+    rank, world, local, dist = init_dist(a.backend, force=a.force_dist)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -275,7 +360,8 @@ def main():
                               "value": r["value"], "unit": "samples/s", "per_gpu": r["value"] / world, "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": r["config"],
-                              "loss_first_step": r["loss_first_step"]}))
+                              "loss_first_step": r["loss_first_step"],
+                              **{k: r[k] for k in ("allreduce_ms", "overlap_frac", "ms_per_step_sequential_allreduce", "ms_per_step_no_allreduce", "allreduce") if k in r}}))
         if dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -291,7 +377,8 @@ def main():
     sd = weights.make_torch_state_dict(spec.model_manifest(layers, base_resolution=base))
     TDT = {"bf16": torch.bfloat16, "f16": torch.float16}
     engine = Engine(sd, layer_names=layers, dtype=TDT[a.dtype], device=dev, base_resolution=base)
-    inputs = synthetic.to_device(synthetic.make_inputs(a.batch, a.height, a.width, zones, zone_px, seed=synthetic.SEED + rank, image_hw=base), dev)
+    host_inputs = synthetic.make_inputs(a.batch, a.height, a.width, zones, zone_px, seed=synthetic.SEED + rank, image_hw=base)
+    inputs = synthetic.to_device(host_inputs, dev)
     return_prob = not a.no_prob
 
     if dist:
@@ -325,29 +412,46 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
-
-    f16 = None
-    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_f16 and not a.no_cpu_baseline:
-        # same workload, same protocol, IEEE-half storage (the precision the 1e-3 relative-L1 gate needs); timed here,
-        # before the instrumented passes and the CPU baseline put load on the host
-        e16 = Engine(sd, layer_names=layers, dtype=torch.float16, device=dev)
-        if a.eager:
-            step16 = lambda: e16.forward_lanes(inputs, a.lanes, return_prob=return_prob)
-        else:
-            if a.inflight > 1:
-                e16.capture(inputs, return_prob=return_prob, inflight=a.inflight)
-                step16 = lambda: e16.replay_async()
-            else:
-                e16.capture(inputs, return_prob=return_prob, lanes=a.lanes)
-                step16 = lambda: e16.replay()
-        for _ in range(a.warmup):
-            step16()
+    # the line's own noise estimate: the same K-step region five more times (each synchronised), per-step time of each
+    repeats = []
+    for _ in range(5):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t1 = time.perf_counter()
         for _ in range(a.steps):
-            step16()
+            step()
         torch.cuda.synchronize()
-        f16 = (e16, time.perf_counter() - t0)
+        repeats.append((time.perf_counter() - t1) / a.steps * 1e3)
+    repeats.sort()
+
+    def timed_mode(dtype):
+        """Same workload, same launch mode, same protocol in another storage mode -> (engine, seconds for a.steps steps)."""
+        e2 = Engine(sd, layer_names=layers, dtype=dtype, device=dev, base_resolution=base)
+        if a.eager:
+            st = lambda: e2.forward_lanes(inputs, a.lanes, return_prob=return_prob)
+        elif a.inflight > 1:
+            e2.capture(inputs, return_prob=return_prob, inflight=a.inflight)
+            st = lambda: e2.replay_async()
+        else:
+            e2.capture(inputs, return_prob=return_prob, lanes=a.lanes)
+            st = lambda: e2.replay()
+        for _ in range(a.warmup):
+            st()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            st()
+        torch.cuda.synchronize()
+        return e2, time.perf_counter() - t2
+
+    f16 = f32 = None
+    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_f16 and not a.no_cpu_baseline:
+        # IEEE-half storage (same MFMA rate, the 16-bit mode that meets the 1e-3 relative-L1 gate) and the float32 parity mode
+        # (f32 MFMA, f32 storage: the mode the gate was defined for); timed here, before the instrumented passes and the CPU
+        # baseline put load on the host
+        f16 = timed_mode(torch.float16)
+        f32 = timed_mode(torch.float32)
+        f32[0]._graph = None; f32[0]._slots = None           # its in-flight slots hold ~9 GB: release before the rest
+        torch.cuda.empty_cache()
 
     if rank == 0:
         value, per_gpu = job_value(world, a.batch, a.steps, elapsed)
@@ -356,18 +460,21 @@ def main():
             "value": value, "unit": "maps/s", "per_gpu": per_gpu,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + {zones}x{zones}-zone ToF, eval forward incl. prob output"
+            "config": {"workload": f"batch={a.batch} {a.height}x{a.width} RGB + {zones}x{zones}-zone ToF, eval forward incl. the prob output "
+                                   f"[B,256,H/2,W/2] written in the storage dtype ({a.dtype}: 2 bytes/element; the reference returns it in float32)"
                                    if return_prob else f"batch={a.batch} {a.height}x{a.width} RGB + {zones}x{zones}-zone ToF, eval forward, prob output skipped",
                        "layers": "hist2image combine1 image x2 (CFPNet)", "launch": ("eager" if a.eager else "hipGraph replay") + (f", {a.lanes} concurrent batch lanes" if a.lanes > 1 else "")
                                  + (f", {a.inflight} batches in flight on concurrently scheduled HIP streams (one graph, buffer set and output set per slot)" if a.inflight > 1 else ""),
                        "parallelism": "replicas only" if world > 1 else "single GPU",
                        "lane_choice_ms_per_step": lane_ms},
+            "ms_per_step_repeats": {"min": repeats[0], "median": repeats[2], "max": repeats[-1],
+                                    "what": f"5 further repeats of the {a.steps}-step timed region, ms per step of each"},
         }
         if not a.no_kernel_times:
             kt = kernel_times(engine, inputs, return_prob)
             dw_copy_ms = kt.pop("_dw3x3_copy", None)
             total_ms = sum(v["ms"] for v in kt.values())
-            convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2", "conv3x3_direct"))}
+            convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2", "conv3x3_direct", "depth_head_fused"))}
             # one hand-written kernel = one row: the tile shapes of igemm2_kernel are template instantiations of the same code
             groups = {}
             for k, v in convs.items():
@@ -389,6 +496,7 @@ def main():
                                  "achieved": tfs, "traffic": t, "flop_per_byte": ai, "achieved_GBps": gbs, "bound": bound,
                                  "frac_of_bound": tfs / PEAK_BF16_TFLOPS if bound == "mfma" else gbs / PEAK_HBM_GBS}
             names = {"igemm2": "igemm2_kernel (gen-2 16-bit implicit GEMM, all tile instantiations)",
+                     "depth_head_fused_kernel (conv3x3 128->128 + conv_out 128->256 + softmax + expectation)": "depth_head_fused_kernel",
                      "conv_igemm": "conv_igemm_kernel (gen-1 implicit GEMM)", "conv3x3_direct": "conv3x3_direct_kernel"}
             dom = max(groups, key=lambda k: groups[k]["ms"])
             d = groups[dom]
@@ -426,21 +534,32 @@ def main():
             line["kernel_ms_total"] = total_ms
         if world == 1 and not a.no_cpu_baseline:
             import numpy as np
-            inp1, (e0, p0, pr0), cb = cpu_baseline(a.cpu_seconds, layers, sd)
+            inp1, (e0, p0, pr0), ref_batch, cb = cpu_baseline(a.cpu_seconds, layers, sd, host_inputs)
             line["cpu_baseline"] = cb
-            _, p1, _ = engine.forward(synthetic.to_device(inp1, dev), return_prob=False)
-            p1 = p1.float().cpu().numpy()
-            line["abs_rel"] = float(np.mean(np.abs(p0.numpy() - p1) / p0.numpy()))
-            line["rel_l1"] = float(np.abs(p0.numpy() - p1).sum() / np.abs(p0.numpy()).sum())
-            if f16 is not None:
-                e16, el16 = f16
-                _, q1, _ = e16.forward(synthetic.to_device(inp1, dev), return_prob=False)
-                q1 = q1.float().cpu().numpy()
-                line["f16"] = {"value": a.batch * a.steps / el16, "unit": "maps/s", "ms_per_step": el16 / a.steps * 1e3, "dtype": "f16",
-                               "abs_rel": float(np.mean(np.abs(p0.numpy() - q1) / p0.numpy())),
-                               "rel_l1": float(np.abs(p0.numpy() - q1).sum() / np.abs(p0.numpy()).sum())}
+            # parity figures on THE BENCHED BATCH (all `batch` maps), against the float32 CPU oracle
+            _, p1, _ = engine.forward(inputs, return_prob=False)
+            line.update(err_vs(ref_batch, p1))
+            line["parity_input"] = f"the benched batch itself: {a.batch} maps, every pixel of pred vs the CPU oracle (float32)"
+            for key, pair in (("f16", f16), ("f32", f32)):
+                if pair is None:
+                    continue
+                e2, el2 = pair
+                _, q1, _ = e2.forward(inputs, return_prob=False)
+                line[key] = {"value": a.batch * a.steps / el2, "unit": "maps/s", "ms_per_step": el2 / a.steps * 1e3, "dtype": key,
+                             "launch": "same as the headline line", **err_vs(ref_batch, q1)}
+            if f32 is not None:
+                line["f32"]["note"] = ("float32 parity mode: f32 storage, v_mfma_f32_16x16x4_f32 -- the mode that meets the north-star 1e-3 relative-L1 gate "
+                                       "by three orders of magnitude, timed under the same protocol")
+            # the reference's own latency protocol (evaluate_time.py:56-82: 100 warm-up, 500 timed, trimmed mean), one graph per forward
+            lat = {}
+            for bsz in (1, a.batch):
+                li = synthetic.to_device(synthetic.make_inputs(bsz, a.height, a.width, zones, zone_px, seed=synthetic.SEED, image_hw=base), dev)
+                mean_ms, med_ms = reference_latency_ms(engine, li)
+                lat[f"latency_b{bsz}"] = {"ms": mean_ms, "median_ms": med_ms, "maps_per_s": bsz / mean_ms * 1e3}
+            lat["protocol"] = "evaluate_time.py:56-82: 100 warm-up + 500 timed forwards, each synchronised, min 1 / max 2 dropped, mean; single HIP graph per forward"
+            line["latency"] = lat
         if world == 1 and not a.no_train and not a.no_cpu_baseline:
-            line["training"] = training_step_rate(a.train_batch, dev)
+            line["training"] = training_step_rate(a.train_batch, dev, fidelity=True)
         print(json.dumps(line))
     if dist:
         dist.barrier()

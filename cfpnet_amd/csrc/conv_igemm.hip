@@ -445,16 +445,22 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
   p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = dil;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && dil == 1) ? 1 : 0;
-  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
+  const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
+  per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
+  CFP_REQUIRE(!w2 || (p.pointwise && is16(dtype) && !per_image_weights && dil == 1 && !g_use_v1), CFP_EINVAL,
+              "cfp_conv2d_nhwc: two-term weights (CFP_CONV_W2) are for 16-bit pointwise layers with shared weights");
   const bool gen2 = dil == 1 && is16(dtype) && !g_use_v1 && p.K <= 16384 && KH < 256 && KW < 256 &&
-                    (long long)H * W * in_ld < (1ll << 30);
+                    ((long long)B * H * W + (long long)pad_t * W + pad_l) * in_ld * 2 < (1ll << 31) - 65536 &&      // 32-bit byte offsets into
+                    (long long)Cout * p.K * 2 < (1ll << 31) - 65536;                                                    // buffer descriptors
   if (gen2) {
     const int rpb = per_image_weights ? Ho * Wo : 0;
     int ln_variant = ln_gamma ? pick_ln_variant(Cout, p.M) : -1;
     const bool c33 = KH == 3 && KW == 3 && stride == 1 && !ln_gamma && rpb == 0 && (long long)Cout * p.K < (1ll << 31);
-    Plan2 pl = plan2(p.M, Cout, p.K, rpb, B, rpb == 0 && ln_variant < 0, c33);
+    Plan2 pl = plan2(p.M, Cout, w2 ? 2 * cdiv(p.K, 64) * 64 : p.K, rpb, B, rpb == 0 && ln_variant < 0, c33);
+    if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
     if (pl.direct >= 0) {
       int rc = conv3x3_launch(pl.direct, p, s);
       CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: direct 3x3 kernel launch failed");
@@ -481,6 +487,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   }
 
 gen1_path:
+  CFP_REQUIRE(!w2, CFP_ESHAPE, "cfp_conv2d_nhwc: two-term weights need the gen-2 kernel (tensor too large for 32-bit offsets)");
   // first-generation kernels (f32 parity mode, short-K bf16): per-image weights run image by image,
   // LayerNorm as a second kernel
   if (dtype == CFP_F32 && p.pointwise && p.M <= 64 && !per_image_weights && !ln_gamma && !g_use_v1) {

@@ -56,6 +56,9 @@ struct HeadP {
   int probe;        // timing probes (tools/head_bench.py --probe): 1 = descriptors with zero records (no fetch), 2 = stop after GEMM1, 4 = stop after GEMM2
 };
 
+#ifdef HF_GLDS
+__device__ __attribute__((aligned(16))) unsigned int g_hf_zero[4] = {0u, 0u, 0u, 0u};
+#endif
 template <int N> __device__ __forceinline__ void hf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename H, bool RAMLO>
@@ -105,6 +108,23 @@ __global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
     unsigned char* sB = sA + HF_BM * 128;                  // weight rows
     const int tap = ks >> 1;                               // Cin = 128 = two K-steps per tap: all scalar
     const int kh = tap / 3, kw = tap - kh * 3;
+#ifdef HF_GLDS
+    {   // A/B variant: global_load_lds with a 64-bit pointer select against a zero word (the gen-2 GEMM's loader)
+      using gptr_t = const __attribute__((address_space(1))) void*;
+      const unsigned char* xt = reinterpret_cast<const unsigned char*>(p.x) + (long long)(((kh - 1) * p.W + (kw - 1)) * p.x_ld * 2 + (ks & 1) * 128);
+      const unsigned char* wk = reinterpret_cast<const unsigned char*>(p.w3) + ks * 128;
+      const unsigned bit2 = 1u << tap;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned char* src = (a_mask[i] & bit2) ? xt + a_off[i] : reinterpret_cast<const unsigned char*>(g_hf_zero);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(sA + (i * 4 + wave) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wk + b_off[j]), (lds_ptr_t)(sB + (j * 4 + wave) * 1024), 16, 0, 0);
+      return;
+    }
+#endif
     const unsigned soff = (unsigned)((kh * p.W + kw) * p.x_ld * 2 + (ks & 1) * 128);   // + guard - (W + 1) * ld * 2 = tap (kh-1, kw-1)
     const unsigned bit = 1u << tap;
 #pragma unroll

@@ -22,6 +22,8 @@ struct ConvP {
   int rows_per_batch;      // > 0: M-tiles do not straddle images and image b uses weights w + b * w_bstride
   long long w_bstride;     // elements
   int f16;                 // 16-bit storage is IEEE half (CFP_F16) instead of bf16
+  int k2;                  // gen-2, pointwise only: > 0 = two-term weights.  Every weight row is [hi | lo], each half padded to k2 K-steps
+                           // (k2 * 64 elements); the kernel walks 2 * k2 K-steps and reads the SAME activations for both halves
   int dil;                 // input dilation (gen-1 kernels only): the input is read as if `dil - 1` zeros sat between its pixels --
                            // the data gradient of a stride-`dil` convolution; H / W stay the REAL input size
 };

@@ -113,6 +113,11 @@ class Engine:
         # head_hilo = (conv_out weights as hi + lo planes, ram fed to conv_out as hi + lo): the logits then carry neither the
         # rounding of conv_out's weights nor that of ram -- measured +34 us / +200 us per batch of 8 for < 2 % of the error
         # budget (profiles/r2_precision_budget.md), so both are OFF by default.  CFP_HEAD_FUSED=0 runs the separate kernels.
+        # two-term (hi + lo) 16-bit weights for the pointwise layers that run through the gen-2 GEMM with shared weights
+        # (ops.pack_w2 / CFP_CONV_W2).  Measured at batch 8 (gpurun_out/ mode_bench, precision_report): fp16 rel-L1 0.90e-3 -> 0.85e-3,
+        # bf16 6.7e-3 -> 5.9e-3 for +6.5 % step time -- the layers it cannot reach (per-image project weights, the fused LoFTR tail)
+        # keep most of the pointwise rounding error.  OFF by default (CFP_WEIGHTS2=1 turns it on).
+        self.weights2 = os.environ.get("CFP_WEIGHTS2", "0") == "1"
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -141,8 +146,9 @@ class Engine:
     def _dev(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
         return t.detach().to(device=self.device, dtype=dtype or torch.float32).contiguous()
 
-    def _pack_conv(self, w: torch.Tensor) -> torch.Tensor:
-        """[Co,Ci,kh,kw] or [Co,Ci] or [Co,Ci,1] -> [Co, kh*kw*Ci_padded] in the storage dtype."""
+    def _pack_conv(self, w: torch.Tensor, w2: bool = False) -> torch.Tensor:
+        """[Co,Ci,kh,kw] or [Co,Ci] or [Co,Ci,1] -> [Co, kh*kw*Ci_padded] in the storage dtype.  `w2` (pointwise layers, 16-bit
+        modes, self.weights2): two-term rows [hi | lo] instead (ops.pack_w2)."""
         w = w.detach().float()
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -154,7 +160,10 @@ class Engine:
         cip = (ci + 7) // 8 * 8
         if cip != ci:
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cip - ci))
-        return self._dev(w.permute(0, 2, 3, 1).reshape(co, kh * kw * cip), self.dtype)
+        flat = w.permute(0, 2, 3, 1).reshape(co, kh * kw * cip)
+        if w2 and self.weights2 and self.half and kh * kw == 1:
+            return ops.pack_w2(flat, self.dtype).to(self.device)
+        return self._dev(flat, self.dtype)
 
     def _fold_bn(self, sd, bn: Optional[str], bias: Optional[torch.Tensor], co: int, eps: float):
         """y = conv*scale + shift  ==  BN(conv + bias)"""
@@ -170,19 +179,19 @@ class Engine:
                 shift = shift + bias.detach().float() * scale
         return self._dev(scale), self._dev(shift)
 
-    def _conv(self, sd, name: str, wkey: str, bkey: Optional[str] = None, bn: Optional[str] = None, eps: float = _BN_EPS):
+    def _conv(self, sd, name: str, wkey: str, bkey: Optional[str] = None, bn: Optional[str] = None, eps: float = _BN_EPS, w2: bool = True):
         w = sd[wkey]
-        self.P[name + ".w"] = self._pack_conv(w)
+        self.P[name + ".w"] = self._pack_conv(w, w2)
         s, t = self._fold_bn(sd, bn, sd[bkey] if bkey else None, w.shape[0], eps)
         self.P[name + ".s"], self.P[name + ".t"] = s, t
 
     def _loftr_pack(self, sd, p: str, self_attn: bool):
         D = sd[p + ".q_proj.weight"].shape[0]
         if self_attn:
-            self.P[p + ".qkv"] = self._pack_conv(torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0))
+            self.P[p + ".qkv"] = self._pack_conv(torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0), True)
         else:
-            self.P[p + ".q"] = self._pack_conv(sd[p + ".q_proj.weight"])
-            self.P[p + ".kv"] = self._pack_conv(torch.cat([sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0))
+            self.P[p + ".q"] = self._pack_conv(sd[p + ".q_proj.weight"], True)
+            self.P[p + ".kv"] = self._pack_conv(torch.cat([sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0), True)
         self.P[p + ".merge"] = self._pack_conv(sd[p + ".merge.weight"])
         self.P[p + ".mlp0"] = self._pack_conv(sd[p + ".mlp.0.weight"])
         self.P[p + ".mlp2"] = self._pack_conv(sd[p + ".mlp.2.weight"])
@@ -212,11 +221,26 @@ class Engine:
                 self.P[q + ".se.br"] = self._dev(sd[q + ".se.conv_reduce.bias"])
                 self.P[q + ".se.we_t"] = self._dev(sd[q + ".se.conv_expand.weight"].reshape(b.mid, b.se_rd).t())
                 self.P[q + ".se.be"] = self._dev(sd[q + ".se.conv_expand.bias"])
-                self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn3", eps=EPS)
+                self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn3", eps=EPS, w2=False)   # folded per image by se_gate_fold
+        # ToF histogram encoder: one float32 parameter blob for the fused kernel (csrc/hist_encoder.hip): per layer W | scale | shift
+        parts, layout, off = [], [], 0
         for ex in (1, 2, 3):
             q = f"hist_encoder.hist_extractor{ex}.pointnet_encoder"
             for j in (1, 2, 3):
-                self._conv(sd, f"{q}.l{j}", f"{q}.conv{j}.weight", f"{q}.conv{j}.bias", bn=f"{q}.bn{j}")
+                w = sd[f"{q}.conv{j}.weight"].detach().float()
+                w = w.reshape(w.shape[0], -1)
+                co, ci = w.shape
+                sc, sh = self._fold_bn(sd, f"{q}.bn{j}", sd[f"{q}.conv{j}.bias"], co, _BN_EPS)
+                row = []
+                for t in (w.reshape(-1), sc.cpu(), sh.cpu()):
+                    row.append(off)
+                    parts.append(t.reshape(-1).cpu())
+                    off += (t.numel() + 3) // 4 * 4
+                    if t.numel() % 4:
+                        parts.append(torch.zeros(4 - t.numel() % 4))
+                layout.append((row[0], row[1], row[2], ci, co))
+        self.P["hist.blob"] = self._dev(torch.cat(parts))
+        self._hist_layout = layout
         d = "decoder"
         self._conv(sd, d + ".conv4", d + ".conv4.weight", d + ".conv4.bias")
         for i in (1, 2, 3, 4):
@@ -240,7 +264,7 @@ class Engine:
                     self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"] = self._dev(sd[l + ".gsa.norm.weight"]), self._dev(sd[l + ".gsa.norm.bias"])
                 elif ln == "combine1":
                     t = l + ".transformer_path"
-                    self.P[t + ".qkv"] = self._pack_conv(torch.cat([sd[t + ".q_proj.weight"], sd[t + ".k_proj.weight"], sd[t + ".v_proj.weight"]], 0))
+                    self.P[t + ".qkv"] = self._pack_conv(torch.cat([sd[t + ".q_proj.weight"], sd[t + ".k_proj.weight"], sd[t + ".v_proj.weight"]], 0), True)
                     self._conv(sd, t + ".conv1", t + ".conv1.weight", bn=t + ".bn1")
                     self._conv(sd, t + ".conv2", t + ".conv2.weight", bn=t + ".bn2")
                     k = l + ".large_kernel_path"
@@ -260,7 +284,7 @@ class Engine:
         self.P[h + ".w1x1"] = self._dev(sd[h + ".conv1x1.weight"].reshape(128, 128).t())      # [in][out]
         for i in (0, 2, 4):
             self.P[f"{h}.r{i}.w"], self.P[f"{h}.r{i}.b"] = self._dev(sd[f"{h}.regressor.{i}.weight"].t()), self._dev(sd[f"{h}.regressor.{i}.bias"])
-        self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias")
+        self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias", w2=False)
         if self.half and self.n_bins == 256:
             # operand of the fused head kernel: K axis in the kernel's fragment order, hi + lo planes (ops.permute_wout)
             self.P["conv_out.wp"] = ops.permute_wout(sd["conv_out.0.weight"], self.dtype, hilo=self.head_hilo[0]).to(self.device)
@@ -298,12 +322,12 @@ class Engine:
             (pt, pb), (pl, pr) = pads
             Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
         ops.conv2d(x, self.P[name + ".w"], self.P[name + ".s"], self.P[name + ".t"], out, B, H, W, k, k, stride, pt, pl,
-                   Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, k * k * x.C))
+                   Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, self.P[name + ".w"].shape[-1]))
         return Ho, Wo
 
     def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None, ln=None):
         ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual,
-                   None if ln is not None else self._ws(rows, out.C, x.C), ln)
+                   None if ln is not None else self._ws(rows, out.C, self.P[wname].shape[-1]), ln)
 
     def _ws(self, M: int, Cout: int, K: int) -> Optional[torch.Tensor]:
         """Split-K scratch shared by all layers (kernels on one stream run in order)."""
@@ -366,18 +390,13 @@ class Engine:
         return tap_acts
 
     def _hist_encoder(self, plan, hist: torch.Tensor, R: int, taps):
-        x = self._act(plan, "hist.in", R, 8)
-        ops.scalar_to_rows8(hist, x, R)
-        outs = []
-        for ex, c in zip((1, 2, 3), spec.HIST_CHANNELS):
-            q = f"hist_encoder.hist_extractor{ex}.pointnet_encoder"
-            for j in (1, 2, 3):
-                y = self._act(plan, f"hist.{ex}.{j}", R, c)
-                self._lin(f"{q}.l{j}.w", x, y, R, hip.ACT_RELU, None, f"{q}.l{j}")
-                x = y
-            outs.append(x)
-            if taps is not None:
-                taps[f"hist{ex - 1}"] = x.torch().float().cpu()
+        """encoder.py:45-50: nine pointwise layers in ONE launch, float32 arithmetic in every storage mode; only the three tapped
+        embeddings are stored (in the storage type)."""
+        outs = [self._act(plan, f"hist.{ex}", R, c) for ex, c in zip((1, 2, 3), spec.HIST_CHANNELS)]
+        ops.hist_encoder(hist.reshape(-1), self.P["hist.blob"], self._hist_layout, outs, R)
+        if taps is not None:
+            for ex, o in enumerate(outs):
+                taps[f"hist{ex}"] = o.torch().float().cpu()
         return outs
 
     # -- LoFTR encoder layer (transformer.py:41-71) on tokens living in xb[:, 0:D] of a [rows, 2D] buffer

@@ -66,13 +66,15 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
     """`ln = (gamma, beta, eps)` fuses a LayerNorm over the output channels (residual added after it);
     `per_image_weights`: w is [B, Cout, K] and image b uses w[b]."""
     assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
-    wshape = (B, out.C, KH * KW * x.C) if per_image_weights else (out.C, KH * KW * x.C)
-    assert w.dtype == x.buf.dtype and tuple(w.shape) == wshape and w.is_contiguous(), (w.shape, wshape)
+    K = KH * KW * x.C
+    wshape = (B, out.C, K) if per_image_weights else (out.C, K)
+    w2 = (not per_image_weights) and KH * KW == 1 and tuple(w.shape) == (out.C, 2 * ((K + 63) // 64) * 64)     # two-term rows [hi | lo]: pack_w2
+    assert w.dtype == x.buf.dtype and (w2 or tuple(w.shape) == wshape) and w.is_contiguous(), (w.shape, wshape)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     hip.call("cfp_conv2d_nhwc_ex", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
              B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
-             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights),
+             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights) | (hip.CONV_W2 if w2 else 0),
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 
@@ -158,6 +160,20 @@ def _bracket16(w: torch.Tensor, dtype):
     up = torch.where(r >= w, r, nxt_up)
     down = torch.where(r <= w, r, nxt_dn)
     return down, up
+
+
+def pack_w2(w2d: torch.Tensor, dtype) -> torch.Tensor:
+    """Pointwise weights [Cout, K] float32 -> two-term rows [Cout, 2 * Kp] in `dtype` (Kp = K rounded up to 64): hi = round(W),
+    lo = round(W - hi), zero padding behind each half (cfp_conv2d_nhwc_ex with CFP_CONV_W2)."""
+    w2d = w2d.detach().float()
+    co, k = w2d.shape
+    kp = (k + 63) // 64 * 64
+    hi = w2d.to(dtype)
+    lo = (w2d - hi.float()).to(dtype)
+    out = torch.zeros(co, 2 * kp, dtype=dtype)
+    out[:, :k] = hi
+    out[:, kp:kp + k] = lo
+    return out.contiguous()
 
 
 def round_taps(w: torch.Tensor, dtype, bracket: bool = True) -> torch.Tensor:
@@ -355,3 +371,14 @@ def depth_head_fused(x: Act, w3, scale3, shift3, wout_perm: torch.Tensor, bias_o
         assert ram_out.ld == 128 and ram_out.C == 128
     hip.call("cfp_depth_head_fused", x.ptr, x.ld, w3.data_ptr(), hip.ptr(scale3), hip.ptr(shift3), wout_perm.data_ptr(), bias_out.data_ptr(),
              centers.data_ptr(), hip.ptr(prob), pred.data_ptr(), ram_out.ptr if ram_out is not None else 0, B, H, W, flags, x.dt, _s())
+
+
+def hist_encoder(hist: torch.Tensor, blob: torch.Tensor, layout, outs, R: int):
+    """hist [R] f32, blob f32 parameters, layout = list of 9 (w_off, scale_off, shift_off, cin, cout); outs = three Acts [R, cout]."""
+    import ctypes
+    assert hist.dtype == torch.float32 and hist.is_contiguous() and hist.numel() >= R and blob.dtype == torch.float32 and len(layout) == 9
+    flat = [int(v) for row in layout for v in row]
+    arr = (ctypes.c_int * len(flat))(*flat)
+    for o, row in zip(outs, layout[2::3]):
+        assert o.C == row[4] and o.ld == o.C and o.c0 == 0 and o.rows >= R
+    hip.call("cfp_hist_encoder", hist.data_ptr(), blob.data_ptr(), ctypes.addressof(arr), outs[0].ptr, outs[1].ptr, outs[2].ptr, R, outs[0].dt, _s())

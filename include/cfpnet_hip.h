@@ -62,7 +62,13 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
  *     run as a second kernel on `out` in place.
  *   - per_image_weights != 0: `w` holds B weight matrices [B][Cout][K]; image b of the batch uses
  *     matrix b.  Used for the squeeze-excite gate folded into the project conv of the encoder's
- *     inverted-residual blocks (x * gate[b,:]) @ W^T == x @ (W * gate[b,:])^T, see cfp_se_fold. */
+ *     inverted-residual blocks (x * gate[b,:]) @ W^T == x @ (W * gate[b,:])^T, see cfp_se_fold.
+ *   - per_image_weights & CFP_CONV_W2 (16-bit pointwise layers with shared weights): TWO-TERM weights.  Every row of `w` is
+ *     [hi | lo] with hi = round16(W), lo = round16(W - hi), each half zero-padded to a multiple of 64 elements; the kernel runs
+ *     the K loop over both halves against the same activations, so the layer sees its weights with ~22 (fp16) / ~16 (bf16)
+ *     significant bits instead of 11 / 8.  Weight rounding of the pointwise layers is 0.8e-3 of the fp16 engine's 0.9e-3
+ *     relative-L1 error (profiles/r2_precision_budget.md). */
+enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument */
 int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                        const void* residual, int res_ld, void* out, int out_ld,
                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
@@ -231,6 +237,16 @@ int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, in
 int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream);
 /* f32 scalars [rows] -> [rows][8] with the value in column 0 (ToF sample depths, deltar.py:40). */
 int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_stream_t stream);
+
+/* ToF histogram encoder in one launch (csrc/hist_encoder.hip): HistogramEncoder.forward, encoder.py:45-50 = three HistExtractors
+ * (:31-35) of three [Conv1d k=1 -> BatchNorm1d -> ReLU] layers each (PointNetEncoder, :17-24), applied to every sample point
+ * independently.  hist [R] f32 (device): the R = B*Z*16 sample depths (deltar.py:40).  blob (device, f32): the parameters of the 9
+ * layers; layout (HOST, 45 ints): per layer (w_off, scale_off, shift_off, cin, cout), offsets in floats into blob: W [cout][cin]
+ * row-major, scale / shift [cout] = BatchNorm (+ conv bias) folded to y = relu(scale * (W x) + shift).  cin of layer 0 is 1, widths
+ * are multiples of 16 up to 128.  out0 / out1 / out2: the activations after layers 3, 6, 9, [R][cout] in `dtype` (all arithmetic
+ * is float32 whatever the storage type: v_mfma_f32_16x16x4_f32 on float32 activations held in LDS). */
+int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2, int R,
+                     int dtype, cfp_stream_t stream);
 
 /* Bin-width regressor + bin edges/centres, one workgroup per batch element, all f32:
  *   mean -> conv1x1 (no bias) -> Linear/LeakyReLU x2 -> Linear -> norm -> widths -> cumsum

@@ -656,6 +656,68 @@ def test_bin_head_fused(HW, dtype):
     assert torch.equal(pred, pred2)
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("rows,Cin,Cout", [(700, 136, 816), (9600, 56, 224), (70000, 32, 96), (300, 1392, 232), (5000, 64, 64)])
+def test_pointwise_two_term_weights(rows, Cin, Cout, dtype):
+    """CFP_CONV_W2: weight rows [hi | lo] (ops.pack_w2) walk the K loop twice over the same activations.  Against float64 with the
+    UNROUNDED weights the result must be as good as the 16-bit output store allows (inputs are exactly representable), i.e. far
+    better than the one-term layer; K tails (K % 64 != 0), split-K shapes and the short-K / many-row class (gen-1 in the plan)."""
+    x = q(rnd(rows, Cin, seed=1), dtype)
+    w = rnd(Cout, Cin, seed=2, scale=1.0 / math.sqrt(Cin))
+    sc, sh = 0.5 + torch.rand(Cout, generator=torch.Generator().manual_seed(3)), rnd(Cout, seed=4, scale=0.2)
+    ref = (x.double() @ w.double().t()) * sc.double() + sh.double()
+    outs = {}
+    for two in (False, True):
+        wp = (ops.pack_w2(w, dtype) if two else w.to(dtype)).to(DEV).contiguous()
+        out = ops.new_act(rows, Cout, torch.float32 if False else dtype, DEV)
+        ws_b = ops.conv2d_ws_bytes(rows, Cout, 2 * ((Cin + 63) // 64) * 64, ops.DT[dtype])
+        ws = torch.empty(max(ws_b // 4, 1), dtype=torch.float32, device=DEV) if ws_b else None
+        ops.linear(to_act(x, dtype), wp, sc.to(DEV), sh.to(DEV), out, rows, ws=ws)
+        outs[two] = out.torch().float().cpu().double()
+    e1 = float((outs[False] - ref).abs().sum() / ref.abs().sum())
+    e2 = float((outs[True] - ref).abs().sum() / ref.abs().sum())
+    store = float((ref.float().to(dtype).double() - ref).abs().sum() / ref.abs().sum())     # what the output rounding alone costs
+    print(f"{dtype} {rows}x{Cin}->{Cout}: rel-L1 one-term {e1:.2e}, two-term {e2:.2e}, output store alone {store:.2e}")
+    assert e2 < 1.15 * store + 1e-6 and e2 < e1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R", [32, 1000, 8192 + 5])
+def test_hist_encoder_fused(R, dtype):
+    """Nine pointwise Conv1d + BatchNorm1d + ReLU layers in one launch (csrc/hist_encoder.hip) against the float64 chain; float32
+    arithmetic in every storage mode, so only the final store rounds.  Ragged last workgroup (R % 32 != 0)."""
+    widths = [1, 32, 32, 32, 64, 64, 64, 128, 128, 128]
+    x = rnd(R, seed=1).abs() * 3
+    parts, layout, off, ref, taps = [], [], 0, x.double()[:, None], []
+    for l in range(9):
+        ci, co = widths[l], widths[l + 1]
+        w = rnd(co, ci, seed=10 + l, scale=1.5 / math.sqrt(ci))
+        sc = 0.5 + torch.rand(co, generator=torch.Generator().manual_seed(30 + l))
+        sh = rnd(co, seed=50 + l, scale=0.3)
+        row = []
+        for t in (w.reshape(-1), sc, sh):
+            row.append(off)
+            parts.append(t)
+            off += (t.numel() + 3) // 4 * 4
+            if t.numel() % 4:
+                parts.append(torch.zeros(4 - t.numel() % 4))
+        layout.append((row[0], row[1], row[2], ci, co))
+        ref = torch.relu((ref @ w.double().t()) * sc.double() + sh.double())
+        if l % 3 == 2:
+            taps.append(ref)
+    outs = [ops.new_act(R, c, dtype, DEV) for c in (32, 64, 128)]
+    ops.hist_encoder(x.to(DEV), torch.cat(parts).to(DEV), layout, outs, R)
+    torch.cuda.synchronize()
+    for o, t in zip(outs, taps):
+        got = o.torch().float().cpu()
+        if dtype == torch.float32:
+            assert torch.allclose(got, t.float(), rtol=2e-5, atol=2e-5)
+        else:
+            assert torch.equal(got, t.float().to(dtype).float()) or float((got - t.float()).abs().max() / t.abs().max()) < (2e-3 if dtype == torch.float16 else 1.6e-2)
+            # float32 arithmetic: all but a few elements are the correctly rounded float64 result
+            assert float((got != t.float().to(dtype).float()).float().mean()) < 0.02
+
+
 def _head_ref(x, w3, b3, wo, bo, centers, B, H, W, ram_dtype):
     """conv3x3 (+bias) -> [ram rounded to the storage type or not] -> conv_out -> softmax -> expectation, in float64."""
     xi = x.double().reshape(B, H, W, 128).permute(0, 3, 1, 2)
