@@ -24,6 +24,8 @@ struct HistEncP {
   const float* blob;              // all parameters, float32: per layer W [Cout][Cin] | scale [Cout] | shift [Cout]
   int w_off[HE_LAYERS], s_off[HE_LAYERS], t_off[HE_LAYERS], cin[HE_LAYERS], cout[HE_LAYERS];
   void* out[3];                   // taps after layers 3, 6, 9: [R][cout] in the storage type
+  const float* pe[3];             // optional [n_pe][cout] f32 table added to tap t on its way out (row = point index % n_pe): the
+  int n_pe;                       // fusion blocks' `feat1 + positional_encodings2` (fusion.py:123-125), saving three launches
   int R;
 };
 
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void hist_encoder_kernel(HistEncP p) {
     __syncthreads();
     cur ^= 1;
     if (l % 3 == 2) {                                               // layers 3, 6, 9 (l = 2, 5, 8): a tap leaves the chip
-      T* out = reinterpret_cast<T*>(p.out[tap++]);
+      T* out = reinterpret_cast<T*>(p.out[tap]);
+      const float* pe = p.pe[tap++];
       constexpr int VE = Vec<T>::N;
       const int cpr = Cout / VE;                                    // 16-byte vectors per row
       for (int q = tid; q < HE_P * cpr; q += 256) {
@@ -87,6 +90,11 @@ __global__ __launch_bounds__(256) void hist_encoder_kernel(HistEncP p) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < VE; ++e) v[e] = sX[cur][pt][cv * VE + e];
+        if (pe) {
+          const float* row = pe + (long long)((p0 + pt) % p.n_pe) * Cout + cv * VE;
+#pragma unroll
+          for (int e = 0; e < VE; ++e) v[e] += row[e];
+        }
         Vec<T>::store(out + (long long)(p0 + pt) * Cout + cv * VE, v);
       }
     }
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(256) void hist_encoder_kernel(HistEncP p) {
 
 }  // namespace
 
-extern "C" int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2, int R,
-                                int dtype, cfp_stream_t stream) {
+extern "C" int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2,
+                                const float* pe0, const float* pe1, const float* pe2, int n_pe, int R, int dtype, cfp_stream_t stream) {
   CFP_REQUIRE(hist && blob && layout && out0 && out1 && out2, CFP_EINVAL, "cfp_hist_encoder: null pointer");
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_hist_encoder: bad dtype");
   CFP_REQUIRE(R > 0, CFP_ESHAPE, "cfp_hist_encoder: no sample points");
@@ -104,6 +112,8 @@ extern "C" int cfp_hist_encoder(const float* hist, const float* blob, const int*
   HistEncP p;
   p.hist = hist; p.blob = blob; p.R = R;
   p.out[0] = out0; p.out[1] = out1; p.out[2] = out2;
+  p.pe[0] = pe0; p.pe[1] = pe1; p.pe[2] = pe2; p.n_pe = n_pe;
+  CFP_REQUIRE(!(pe0 || pe1 || pe2) || n_pe > 0, CFP_ESHAPE, "cfp_hist_encoder: positional tables need n_pe > 0");
   for (int l = 0; l < HE_LAYERS; ++l) {                            // layout: 5 host ints per layer (w_off, scale_off, shift_off, cin, cout), offsets in floats
     p.w_off[l] = layout[5 * l]; p.s_off[l] = layout[5 * l + 1]; p.t_off[l] = layout[5 * l + 2];
     p.cin[l] = layout[5 * l + 3]; p.cout[l] = layout[5 * l + 4];

@@ -118,6 +118,12 @@ class Engine:
         # bf16 6.7e-3 -> 5.9e-3 for +6.5 % step time -- the layers it cannot reach (per-image project weights, the fused LoFTR tail)
         # keep most of the pointwise rounding error.  OFF by default (CFP_WEIGHTS2=1 turns it on).
         self.weights2 = os.environ.get("CFP_WEIGHTS2", "0") == "1"
+        # fp16 only: pointwise (1x1 / Linear) weights are rounded with error diffusion along the INPUT-CHANNEL axis (ops.round_taps on
+        # [Cout, 1, Cin]): every row's rounding errors sum to < 1 ulp, so a layer's weight rounding no longer shifts its outputs'
+        # means -- the component that adds up coherently from layer to layer.  Measured on the benched batch: rel-L1 1.08e-3 ->
+        # 0.80e-3 (every image <= 0.86e-3), free.  In bf16 the same rounding measured worse (weights-only ablation 1.28x: the doubled
+        # per-weight variance of direction-only rounding outweighs the cancelled mean shift), so bf16 keeps round-to-nearest there.
+        self.diffuse_cin = os.environ.get("CFP_DIFFUSE_CIN", "1") == "1"
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -163,6 +169,8 @@ class Engine:
         flat = w.permute(0, 2, 3, 1).reshape(co, kh * kw * cip)
         if w2 and self.weights2 and self.half and kh * kw == 1:
             return ops.pack_w2(flat, self.dtype).to(self.device)
+        if kh * kw == 1 and self.diffuse_cin and self.dtype == torch.float16:
+            flat = ops.round_taps(flat.reshape(co, 1, kh * kw * cip), self.dtype).reshape(co, -1)     # error diffusion along the input channels
         return self._dev(flat, self.dtype)
 
     def _fold_bn(self, sd, bn: Optional[str], bias: Optional[torch.Tensor], co: int, eps: float):
@@ -287,7 +295,8 @@ class Engine:
         self._conv(sd, "conv_out", "conv_out.0.weight", "conv_out.0.bias", w2=False)
         if self.half and self.n_bins == 256:
             # operand of the fused head kernel: K axis in the kernel's fragment order, hi + lo planes (ops.permute_wout)
-            self.P["conv_out.wp"] = ops.permute_wout(sd["conv_out.0.weight"], self.dtype, hilo=self.head_hilo[0]).to(self.device)
+            self.P["conv_out.wp"] = ops.permute_wout(sd["conv_out.0.weight"], self.dtype, hilo=self.head_hilo[0],
+                                                   diffuse=self.diffuse_cin and self.dtype == torch.float16).to(self.device)
 
     # ------------------------------------------------------------------------------ buffers
     def _act(self, plan, key: str, rows: int, C: int, ld: Optional[int] = None, zero: bool = False) -> Act:
@@ -393,7 +402,11 @@ class Engine:
         """encoder.py:45-50: nine pointwise layers in ONE launch, float32 arithmetic in every storage mode; only the three tapped
         embeddings are stored (in the storage type)."""
         outs = [self._act(plan, f"hist.{ex}", R, c) for ex, c in zip((1, 2, 3), spec.HIST_CHANNELS)]
-        ops.hist_encoder(hist.reshape(-1), self.P["hist.blob"], self._hist_layout, outs, R)
+        # every tap feeds exactly one fusion block, as `feat1 + positional_encodings2` (fusion.py:123-125): added on the way out
+        # (tap ex -> cross_atten{ex}; with `taps` the raw embeddings are wanted, the engine then adds the table itself)
+        self._hist_pe_fused = taps is None
+        pe = [self.P[f"decoder.cross_atten{ex}.pe2"] for ex in (1, 2, 3)] if self._hist_pe_fused else (None, None, None)
+        ops.hist_encoder(hist.reshape(-1), self.P["hist.blob"], self._hist_layout, outs, R, pe, self.zone_sample_num)
         if taps is not None:
             for ex, o in enumerate(outs):
                 taps[f"hist{ex}"] = o.torch().float().cpu()
@@ -452,16 +465,22 @@ class Engine:
         if not self.change_embedding:
             emb0 = self._act(plan, f"{name}.emb0", M, D)
             ops.copy_rows(tok[0].slice(0, D), emb0, M)
-        src = self._act(plan, f"{name}.src", B * Z * N, D)
-        ops.add_rowtable(feat1, self.P[p + ".pe2"], src, B * Z * N, 1, N, N, 0, 0)
+        if self._hist_pe_fused:
+            src = feat1                     # the ToF encoder kernel already added positional_encodings2
+        else:
+            src = self._act(plan, f"{name}.src", B * Z * N, D)
+            ops.add_rowtable(feat1, self.P[p + ".pe2"], src, B * Z * N, 1, N, N, 0, 0)
         gh, gw = geo.grid_h, geo.grid_w
         Mz = B * gh * gw
         y0, y1, x0, x1 = geo.clipped(H, W)
         rect = (geo.sy_wo, geo.sx_wo, geo.tzh, geo.tzw)
 
+        last = len(self.layer_names) - 1
+        direct_out = False                  # the last layer's final kernel writes the block's output slice itself (no copy launch)
         for i, ln in enumerate(self.layer_names):
             l = f"{p}.layers.{i}"
             tag = f"{name}.L{i}"
+            final_dst = out if (i == last and taps is None) else None
             if ln == "hist2image":
                 zin = self._act(plan, f"{name}.zin", Mz, 2 * D)
                 zsrc = tok[cur].slice(0, D) if self.change_embedding else emb0
@@ -485,10 +504,12 @@ class Engine:
                 keys = self._act(plan, f"{name}.gsa.keys", B * hk * wk, D)
                 ops.layernorm(kraw, self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5, keys, B * hk * wk)
                 S = hk * wk
-                self._loftr(plan, f"{name}.gsa", l + ".gsa.encoder_layer", tok[cur], M, keys, B * S, spec.TWINS_HEADS, tok[cur ^ 1].slice(0, D),
+                self._loftr(plan, f"{name}.gsa", l + ".gsa.encoder_layer", tok[cur], M, keys, B * S, spec.TWINS_HEADS,
+                            final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D),
                             dict(groups=B, NB=B, Hk=1, Wk=S, th=1, tw=S, clip=(0, 1, 0, S), count_pad=False, v_length=float(S)),
                             dict(NB=B, Hq=H, Wq=W, qth=H, qtw=W))
                 cur ^= 1
+                direct_out = final_dst is not None
             elif ln == "combine1":
                 # DAPM (transformer.py:204-248)
                 t = l + ".transformer_path"
@@ -521,13 +542,15 @@ class Engine:
                 ops.layernorm(t1, self.P[k + ".norm.g"], self.P[k + ".norm.b"], 1e-6, t2, M)
                 h4 = self._act(plan, f"{name}.lk.h4", M, 4 * D)
                 self._lin(k + ".pw1.w", t2, h4, M, hip.ACT_GELU, None, k + ".pw1")
-                self._lin(k + ".pw2.w", h4, tok[cur ^ 1].slice(0, D), M, hip.ACT_NONE, xin.slice(0, D), k + ".pw2")
+                self._lin(k + ".pw2.w", h4, final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D), M, hip.ACT_NONE, xin.slice(0, D), k + ".pw2")
                 cur ^= 1
+                direct_out = final_dst is not None
             else:
                 raise NotImplementedError(ln)
             if taps is not None:
                 taps[f"{p}.layers.{i}"] = tok[cur].slice(0, D).torch().float().cpu().reshape(B, H * W, D)
-        ops.copy_rows(tok[cur].slice(0, D), out, M)
+        if not direct_out:
+            ops.copy_rows(tok[cur].slice(0, D), out, M)
 
     def _nchw(self, a: Act, B, H, W) -> torch.Tensor:
         return a.torch().float().cpu().reshape(B, H, W, a.C).permute(0, 3, 1, 2).contiguous()

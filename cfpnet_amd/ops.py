@@ -347,7 +347,7 @@ def bin_head_fused(x: Act, w, bias, centers, prob, pred, B, HW):
              pred.data_ptr(), B, HW, x.C, x.dt, _s())
 
 
-def permute_wout(w: torch.Tensor, dtype, hilo: bool = True) -> torch.Tensor:
+def permute_wout(w: torch.Tensor, dtype, hilo: bool = True, diffuse: bool = False) -> torch.Tensor:
     """conv_out weights [256, 128(, 1, 1)] float32 -> the operand of cfp_depth_head_fused: input-channel axis in the kernel's
     fragment order, stored as [planes, 256, 128] in `dtype` (plane 0 = round(W), plane 1 = round(W - plane 0) when `hilo`)."""
     w = w.detach().float().reshape(w.shape[0], -1)
@@ -356,7 +356,7 @@ def permute_wout(w: torch.Tensor, dtype, hilo: bool = True) -> torch.Tensor:
     kb, q, e = pos // 32, (pos % 32) // 8, pos % 8
     src = 32 * kb + 16 * (e // 4) + 4 * q + (e % 4)
     wp = w[:, src]
-    hi = wp.to(dtype)
+    hi = (round_taps(w.reshape(256, 1, 128), dtype).reshape(256, 128)[:, src] if diffuse else wp).to(dtype)
     planes = [hi]
     if hilo:
         planes.append((wp - hi.float()).to(dtype))
@@ -373,12 +373,16 @@ def depth_head_fused(x: Act, w3, scale3, shift3, wout_perm: torch.Tensor, bias_o
              centers.data_ptr(), hip.ptr(prob), pred.data_ptr(), ram_out.ptr if ram_out is not None else 0, B, H, W, flags, x.dt, _s())
 
 
-def hist_encoder(hist: torch.Tensor, blob: torch.Tensor, layout, outs, R: int):
-    """hist [R] f32, blob f32 parameters, layout = list of 9 (w_off, scale_off, shift_off, cin, cout); outs = three Acts [R, cout]."""
+def hist_encoder(hist: torch.Tensor, blob: torch.Tensor, layout, outs, R: int, pe=(None, None, None), n_pe: int = 0):
+    """hist [R] f32, blob f32 parameters, layout = list of 9 (w_off, scale_off, shift_off, cin, cout); outs = three Acts [R, cout];
+    pe = optional f32 tables [n_pe, cout] added to the taps (row = sample index % n_pe)."""
     import ctypes
     assert hist.dtype == torch.float32 and hist.is_contiguous() and hist.numel() >= R and blob.dtype == torch.float32 and len(layout) == 9
     flat = [int(v) for row in layout for v in row]
     arr = (ctypes.c_int * len(flat))(*flat)
     for o, row in zip(outs, layout[2::3]):
         assert o.C == row[4] and o.ld == o.C and o.c0 == 0 and o.rows >= R
-    hip.call("cfp_hist_encoder", hist.data_ptr(), blob.data_ptr(), ctypes.addressof(arr), outs[0].ptr, outs[1].ptr, outs[2].ptr, R, outs[0].dt, _s())
+    for t, o in zip(pe, outs):
+        assert t is None or (t.dtype == torch.float32 and tuple(t.shape) == (n_pe, o.C) and t.is_contiguous())
+    hip.call("cfp_hist_encoder", hist.data_ptr(), blob.data_ptr(), ctypes.addressof(arr), outs[0].ptr, outs[1].ptr, outs[2].ptr,
+             hip.ptr(pe[0]), hip.ptr(pe[1]), hip.ptr(pe[2]), n_pe, R, outs[0].dt, _s())

@@ -244,9 +244,11 @@ int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_str
  * layers; layout (HOST, 45 ints): per layer (w_off, scale_off, shift_off, cin, cout), offsets in floats into blob: W [cout][cin]
  * row-major, scale / shift [cout] = BatchNorm (+ conv bias) folded to y = relu(scale * (W x) + shift).  cin of layer 0 is 1, widths
  * are multiples of 16 up to 128.  out0 / out1 / out2: the activations after layers 3, 6, 9, [R][cout] in `dtype` (all arithmetic
- * is float32 whatever the storage type: v_mfma_f32_16x16x4_f32 on float32 activations held in LDS). */
-int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2, int R,
-                     int dtype, cfp_stream_t stream);
+ * is float32 whatever the storage type: v_mfma_f32_16x16x4_f32 on float32 activations held in LDS).  pe0 / pe1 / pe2 (device f32
+ * [n_pe][cout], each may be NULL): `positional_encodings2` of the fusion block that consumes the tap, added on the way out with
+ * row = sample index % n_pe (fusion.py:123-125: `feat1 + positional_encodings2`, n_pe = zone_sample_num). */
+int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2,
+                     const float* pe0, const float* pe1, const float* pe2, int n_pe, int R, int dtype, cfp_stream_t stream);
 
 /* Bin-width regressor + bin edges/centres, one workgroup per batch element, all f32:
  *   mean -> conv1x1 (no bias) -> Linear/LeakyReLU x2 -> Linear -> norm -> widths -> cumsum

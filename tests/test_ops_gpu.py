@@ -708,6 +708,13 @@ def test_hist_encoder_fused(R, dtype):
     outs = [ops.new_act(R, c, dtype, DEV) for c in (32, 64, 128)]
     ops.hist_encoder(x.to(DEV), torch.cat(parts).to(DEV), layout, outs, R)
     torch.cuda.synchronize()
+    # with the fusion blocks' positional tables added on the way out (row = sample index % 16)
+    pes = [rnd(16, c, seed=70 + c, scale=0.2) for c in (32, 64, 128)]
+    outs_pe = [ops.new_act(R, c, dtype, DEV) for c in (32, 64, 128)]
+    ops.hist_encoder(x.to(DEV), torch.cat(parts).to(DEV), layout, outs_pe, R, [t.to(DEV) for t in pes], 16)
+    for o, t, pe in zip(outs_pe, taps, pes):
+        want = (t + pe.double()[torch.arange(R) % 16]).float()
+        assert float((o.torch().float().cpu() - want).abs().max() / want.abs().max()) < {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
     for o, t in zip(outs, taps):
         got = o.torch().float().cpu()
         if dtype == torch.float32:

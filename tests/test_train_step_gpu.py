@@ -334,7 +334,7 @@ def _flat(gs, keys):
 
 
 # bounds = measured on MI355X with margin: (loss rel, pred rel-L1, full-gradient cosine, share of tensors whose rms is within 10 %)
-_SHARD_BOUNDS = {torch.float32: (2e-5, 2e-5, 0.9995, 0.99), torch.float16: (2e-3, 1e-2, 0.97, 0.9), torch.bfloat16: (1e-2, 6e-2, 0.80, 0.6)}
+_SHARD_BOUNDS = {torch.float32: (2e-5, 2e-5, 0.9995, 0.99), torch.float16: (2e-3, 1e-2, 0.97, 0.8), torch.bfloat16: (1e-2, 6e-2, 0.80, 0.6)}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
