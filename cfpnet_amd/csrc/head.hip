@@ -300,3 +300,97 @@ extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const 
                        centers, (bf16_t*)prob, pred, HW);
   return cfp_check_launch("cfp_bin_head_fused");
 }
+
+// ---- spatial mean of a 3x3 convolution's output WITHOUT running the convolution -----------------------------------------
+// The bin-width regressor starts with mean_HW(conv1x1(unet)) (decoder.py:28-29), and unet = decoder.conv0(t) is a LINEAR 3x3
+// convolution (bias, no BatchNorm, no activation, zero padding 1; decoder.py:126).  Its spatial sum is therefore a function of nine
+// shifted sums of its 32-channel INPUT t:   sum_px unet[m] = HW * b[m] + sum_{tap, c} W[m][tap][c] * S_tap[c],  where S_tap is the sum
+// of t over the image minus the border row / column the tap (dy, dx) never reads (plus the corner pixel subtracted twice):
+//     S(dy,dx) = T - [dy=+1] R_first - [dy=-1] R_last - [dx=+1] C_first - [dx=-1] C_last + corner.
+// T comes from cfp_channel_sum over t (39 MB instead of the 157 MB of unet); the kernel below adds up the four border lines itself,
+// uses the float32 master weights -- and the whole regressor branch now depends on t only, so it runs BESIDE conv0 instead of after
+// it: its latency chain (sums -> 4 dense layers -> bin centres) leaves the critical path conv0 -> head.
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(1024) void conv3x3_mean_kernel(const float* __restrict__ partial, int nsplit, const T* __restrict__ in, int in_ld,
+                                                            const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ msum,
+                                                            int H, int W, int C, int Cout) {
+  extern __shared__ float sm[];
+  float* q5 = sm;                  // [5][C]: all pixels, first row, last row, first column, last column
+  float* corner = sm + 5 * C;      // [4][C]: (0,0), (0,W-1), (H-1,0), (H-1,W-1)
+  float* S = corner + 4 * C;       // [9][C]
+  float* red = S + 9 * C;          // [1024]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const T* img = in + (long long)b * H * W * in_ld;
+  // five sums per channel, each by 1024 / C lanes in a fixed order: the channel sums of the splits, then the four border lines
+  const int L = 1024 / C;          // host: C divides 1024
+  const int c = tid % C, ln = tid / C;
+  for (int k = 0; k < 5; ++k) {
+    float s = 0.f;
+    if (k == 0) {
+      for (int j = ln; j < nsplit; j += L) s += partial[((long long)b * nsplit + j) * C + c];
+    } else {
+      const int n = k <= 2 ? W : H;
+      for (int j = ln; j < n; j += L) {
+        const int y = k == 1 ? 0 : k == 2 ? H - 1 : j, x = k == 3 ? 0 : k == 4 ? W - 1 : j;
+        s += to_f32<T>(img[((long long)y * W + x) * in_ld + c]);
+      }
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+      float t = 0.f;
+      for (int j = 0; j < L; ++j) t += red[j * C + tid];
+      q5[k * C + tid] = t;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 4 * C; i += 1024) {
+    const int k = i / C, cc = i - k * C;
+    const int y = (k >> 1) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
+    corner[i] = to_f32<T>(img[((long long)y * W + x) * in_ld + cc]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * C; i += 1024) {
+    const int tap = i / C, cc = i - tap * C;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    float s = q5[cc];
+    if (dy == 1) s -= q5[C + cc];
+    if (dy == -1) s -= q5[2 * C + cc];
+    if (dx == 1) s -= q5[3 * C + cc];
+    if (dx == -1) s -= q5[4 * C + cc];
+    if (dy != 0 && dx != 0) s += corner[((dy == -1 ? 2 : 0) + (dx == -1 ? 1 : 0)) * C + cc];
+    S[i] = s;
+  }
+  __syncthreads();
+  // out[m] = HW * bias[m] + W[m][0 .. 9C) . S: eight lanes per output, each a contiguous eighth of the row
+  const int K = 9 * C;
+  const int per = (K + 7) >> 3;
+  for (int m = tid >> 3; m < Cout; m += 128) {
+    const int part = tid & 7;
+    const int k0 = part * per, k1 = min(K, k0 + per);
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s = fmaf(w[(long long)m * K + k], S[k], s);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (part == 0) msum[(long long)b * Cout + m] = s + (float)(H * W) * (bias ? bias[m] : 0.f);
+  }
+}
+
+}  // namespace
+
+extern "C" int cfp_conv3x3_mean(const float* partial, int nsplit, const void* in, int in_ld, const float* w, const float* bias, float* msum,
+                                int B, int H, int W, int C, int Cout, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(partial && in && w && msum, CFP_EINVAL, "cfp_conv3x3_mean: null pointer");
+  CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv3x3_mean: bad dtype");
+  CFP_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C <= 512 && 1024 % C == 0 && Cout > 0 && nsplit > 0 && in_ld >= C, CFP_ESHAPE,
+              "cfp_conv3x3_mean: bad shape (C must divide 1024)");
+  const size_t lds = (size_t)(18 * C + 1024) * sizeof(float);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(conv3x3_mean_kernel<bf16_t>, dim3(B), dim3(1024), lds, s, partial, nsplit, (const bf16_t*)in, in_ld, w, bias, msum, H, W, C, Cout);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(conv3x3_mean_kernel<f16_t>, dim3(B), dim3(1024), lds, s, partial, nsplit, (const f16_t*)in, in_ld, w, bias, msum, H, W, C, Cout);
+  else hipLaunchKernelGGL(conv3x3_mean_kernel<float>, dim3(B), dim3(1024), lds, s, partial, nsplit, (const float*)in, in_ld, w, bias, msum, H, W, C, Cout);
+  return cfp_check_launch("cfp_conv3x3_mean");
+}

@@ -59,7 +59,18 @@ struct HeadP {
 #ifdef HF_GLDS
 __device__ __attribute__((aligned(16))) unsigned int g_hf_zero[4] = {0u, 0u, 0u, 0u};
 #endif
+// Stage hand-over: this wave's LDS-DMA loads have landed (vmcnt) AND its LDS-side operations have drained (lgkmcnt), then the
+// workgroup barrier.  With `s_waitcnt vmcnt(0)` + a raw s_barrier alone the kernel produced a wrong 32-pixel group (one wave's
+// pixels) about once per 640 forwards when three captured forwards ran concurrently -- never alone, never with same-input repeats
+// (tools/probes/inflight_race*.py, race_ab.sh: 5 / 3200 wrong results vs 0 / 3200 with this form): the zero words the hardware
+// writes for out-of-range lanes of a `buffer_load ... lds` are apparently not covered by vmcnt.  HF_RAW_BARRIER restores the old form.
+#ifdef HF_RAW_BARRIER
+#define HF_BARRIER() __builtin_amdgcn_s_barrier()
 template <int N> __device__ __forceinline__ void hf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#else
+#define HF_BARRIER() __syncthreads()
+template <int N> __device__ __forceinline__ void hf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+#endif
 
 template <typename H, bool RAMLO>
 __global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
   for (int ks = 0; ks < HF_STEPS; ++ks) {
     const int buf = ks & 1;
     hf_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                          // stage `buf` landed for every wave; stage buf^1 fully consumed
+    HF_BARRIER();                                          // stage `buf` landed for every wave; stage buf^1 fully consumed
     asm volatile("" ::: "memory");
     if (ks + 1 < HF_STEPS) issue(ks + 1, buf ^ 1);
     else issue_wout(0, buf ^ 1, 0);                        // the free stage receives Wout[:, first 64 channels]
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
   }
   // HF_STEPS is even: the last K-step used stage 1, Wout half 0 is (being) written to stage 0
   hf_wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();                            // stage 1 consumed by every wave; Wout half 0 landed
+  HF_BARRIER();                                            // stage 1 consumed by every wave; Wout half 0 landed
   asm volatile("" ::: "memory");
   issue_wout(1, 1, 0);                                     // lands while GEMM2 runs on half 0
   if (p.probe & 2) {
@@ -273,18 +284,18 @@ __global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
   constexpr bool ram_lo = RAMLO;
   gemm2_half(0, smem, ram_lo);
   hf_wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();                            // Wout half 1 landed; every wave is done with half 0 (stage 0)
+  HF_BARRIER();                                            // Wout half 1 landed; every wave is done with half 0 (stage 0)
   asm volatile("" ::: "memory");
   if (p.wout_lo) issue_wout(0, 0, 1);                      // lo plane of half 0 -> stage 0, during GEMM2 on half 1
   gemm2_half(1, smem + HF_STAGE, ram_lo);
   if (p.wout_lo) {                                         // Wout_lo * ram_hi: the lo plane only meets the hi fragments (lo * lo ~ 2^-22)
     hf_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    HF_BARRIER();
     asm volatile("" ::: "memory");
     issue_wout(1, 1, 1);
     gemm2_half(0, smem, false);
     hf_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    HF_BARRIER();
     asm volatile("" ::: "memory");
     gemm2_half(1, smem + HF_STAGE, false);
   }

@@ -288,6 +288,10 @@ class Engine:
                 else:
                     raise NotImplementedError(ln)
         h = "depth_head"
+        # float32 master weights of decoder.conv0 in (kh, kw, c) order: the regressor branch gets mean(unet) from sums of conv0's INPUT
+        w0 = sd[d + ".conv0.weight"].detach().float()
+        self.P[d + ".conv0.w32"] = self._dev(w0.permute(0, 2, 3, 1).reshape(w0.shape[0], -1))
+        self.P[d + ".conv0.b32"] = self._dev(sd[d + ".conv0.bias"])
         self._conv(sd, h + ".conv3x3", h + ".conv3x3.weight", h + ".conv3x3.bias")
         self.P[h + ".w1x1"] = self._dev(sd[h + ".conv1x1.weight"].reshape(128, 128).t())      # [in][out]
         for i in (0, 2, 4):
@@ -404,7 +408,7 @@ class Engine:
         outs = [self._act(plan, f"hist.{ex}", R, c) for ex, c in zip((1, 2, 3), spec.HIST_CHANNELS)]
         # every tap feeds exactly one fusion block, as `feat1 + positional_encodings2` (fusion.py:123-125): added on the way out
         # (tap ex -> cross_atten{ex}; with `taps` the raw embeddings are wanted, the engine then adds the table itself)
-        self._hist_pe_fused = taps is None
+        self._hist_pe_fused = taps is None and os.environ.get("CFP_NO_PE_FUSE", "0") != "1"
         pe = [self.P[f"decoder.cross_atten{ex}.pe2"] for ex in (1, 2, 3)] if self._hist_pe_fused else (None, None, None)
         ops.hist_encoder(hist.reshape(-1), self.P["hist.blob"], self._hist_layout, outs, R, pe, self.zone_sample_num)
         if taps is not None:
@@ -480,7 +484,7 @@ class Engine:
         for i, ln in enumerate(self.layer_names):
             l = f"{p}.layers.{i}"
             tag = f"{name}.L{i}"
-            final_dst = out if (i == last and taps is None) else None
+            final_dst = out if (i == last and taps is None and os.environ.get("CFP_NO_DIRECT_OUT", "0") != "1") else None
             if ln == "hist2image":
                 zin = self._act(plan, f"{name}.zin", Mz, 2 * D)
                 zsrc = tok[cur].slice(0, D) if self.change_embedding else emb0
@@ -897,20 +901,28 @@ class Engine:
         Mh = B * hs[0] * wsz[0]
         HWh = hs[0] * wsz[0]
         unet = self._act(plan, "unet", Mh, 128)
-        self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
         fused_head = self.half and self.head_fused and self.n_bins == 256 and HWh % 16 == 0 and HWh >= 128 and "conv_out.wp" in self.P
         ram = self._act(plan, "ram", Mh, 128) if (not fused_head or taps is not None) else None
-        ns = max(1, min(256, HWh // 256))
-        part = self._f32(plan, "head.sum", B * ns * 128)
         edges = out[0] if out is not None else torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
         centers = self._f32(plan, "head.centers", B * self.n_bins)
         h = "depth_head"
+        # bin-width regressor branch (decoder.py:28-36).  Its input mean_HW(conv1x1(unet)) is linear in unet = conv0(t), a linear
+        # 3x3 conv: the spatial sum of unet follows from nine shifted sums of the 32-channel t (cfp_channel_sum + cfp_conv3x3_mean),
+        # so the whole branch depends on t only and runs BESIDE conv0 on the side stream -- off the critical path conv0 -> head.
+        ns = max(1, min(64, HWh // 256))
+        bsum = self._f32(plan, "head.bsum", B * ns * t.C)
+        msum = self._f32(plan, "head.msum", B * 128)
+        if os.environ.get("CFP_OLD_SUMS", "0") == "1":      # probe switch: the round-1 order (sums of unet after conv0)
+            self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
         side.wait_stream(main)
-        with torch.cuda.stream(side):                # bin-width regressor branch beside the head's 3x3 conv
-            ops.channel_sum(unet, part, B, HWh, ns)
-            ops.bin_regressor(part, ns, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
+        with torch.cuda.stream(side):
+            ops.channel_sum(t, bsum, B, HWh, ns)
+            ops.conv3x3_mean(bsum, ns, t, self.P["decoder.conv0.w32"], self.P["decoder.conv0.b32"], msum, B, hs[0], wsz[0], 128)
+            ops.bin_regressor(msum, 1, 1.0 / HWh, self.P[h + ".w1x1"], self.P[h + ".r0.w"], self.P[h + ".r0.b"], self.P[h + ".r2.w"],
                               self.P[h + ".r2.b"], self.P[h + ".r4.w"], self.P[h + ".r4.b"], self.min_val, self.max_val, self.norm,
                               edges, centers, B, 128, 256, self.n_bins)
+        if os.environ.get("CFP_OLD_SUMS", "0") != "1":
+            self._cv("decoder.conv0", t, unet, B, hs[0], wsz[0], 3)
         if not fused_head:
             self._cv("depth_head.conv3x3", unet, ram, B, hs[0], wsz[0], 3)
         main.wait_stream(side)

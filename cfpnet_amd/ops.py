@@ -191,19 +191,29 @@ def round_taps(w: torch.Tensor, dtype, bracket: bool = True) -> torch.Tensor:
         return w
     kh, kw = w.shape[-2], w.shape[-1]
     order = [r * kw + (c if r % 2 == 0 else kw - 1 - c) for r in range(kh) for c in range(kw)]
-    flat = w.reshape(*w.shape[:-2], kh * kw)
-    down, up = _bracket16(flat, dtype)
-    out = torch.empty_like(flat)
-    e = torch.zeros_like(flat[..., 0])
-    for t in order:
-        v = flat[..., t] + e
-        if bracket:
-            q = torch.where((v - down[..., t]).abs() <= (up[..., t] - v).abs(), down[..., t], up[..., t])
-        else:           # experiment only: plain error diffusion may move a small weight by the ulp of a large neighbour
+    flat = w.reshape(-1, kh * kw)
+    if not bracket:           # experiment only: plain error diffusion may move a small weight by the ulp of a large neighbour
+        out = torch.empty_like(flat)
+        e = torch.zeros_like(flat[:, 0])
+        for t in order:
+            v = flat[:, t] + e
             q = v.to(dtype).float()
+            e = v - q
+            out[:, t] = q
+        return out.reshape(w.shape)
+    down, up = _bracket16(flat, dtype)
+    # the walk along the taps is sequential; numpy (float32, vectorised over all rows) keeps its per-step overhead at microseconds
+    import numpy as np
+    f, dn, upn = flat.numpy(), down.numpy(), up.numpy()
+    out = np.empty_like(f)
+    e = np.zeros(f.shape[0], dtype=np.float32)
+    for t in order:
+        v = f[:, t] + e
+        take_down = np.abs(v - dn[:, t]) <= np.abs(upn[:, t] - v)
+        q = np.where(take_down, dn[:, t], upn[:, t])
         e = v - q
-        out[..., t] = q
-    return out.reshape(w.shape)
+        out[:, t] = q
+    return torch.from_numpy(out).reshape(w.shape)
 
 
 def toeplitz_bands(w: torch.Tensor, dtype) -> torch.Tensor:
@@ -386,3 +396,10 @@ def hist_encoder(hist: torch.Tensor, blob: torch.Tensor, layout, outs, R: int, p
         assert t is None or (t.dtype == torch.float32 and tuple(t.shape) == (n_pe, o.C) and t.is_contiguous())
     hip.call("cfp_hist_encoder", hist.data_ptr(), blob.data_ptr(), ctypes.addressof(arr), outs[0].ptr, outs[1].ptr, outs[2].ptr,
              hip.ptr(pe[0]), hip.ptr(pe[1]), hip.ptr(pe[2]), n_pe, R, outs[0].dt, _s())
+
+
+def conv3x3_mean(partial: torch.Tensor, nsplit, x: Act, w32: torch.Tensor, bias, msum: torch.Tensor, B, H, W, Cout):
+    """partial [B, nsplit, C] = channel sums of x (channel_sum); w32 [Cout, 3*3*C] float32 in (kh, kw, c) order;
+    msum [B, Cout] f32 = spatial SUM of conv3x3(x) + bias."""
+    assert w32.dtype == torch.float32 and tuple(w32.shape) == (Cout, 9 * x.C) and msum.dtype == torch.float32 and msum.numel() >= B * Cout
+    hip.call("cfp_conv3x3_mean", partial.data_ptr(), nsplit, x.ptr, x.ld, w32.data_ptr(), hip.ptr(bias), msum.data_ptr(), B, H, W, x.C, Cout, x.dt, _s())

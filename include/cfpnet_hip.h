@@ -260,6 +260,15 @@ int cfp_bin_regressor(const float* partial, int nsplit, float inv_hw, const floa
                       const float* w2_t, const float* b2, float min_val, float max_val, int norm,
                       float* edges, float* centers, int B, int C, int hidden, int nbins, cfp_stream_t stream);
 
+/* Spatial SUM of a linear 3x3 convolution's output (stride 1, zero padding 1, bias, no activation) without running the convolution:
+ * from nine shifted sums of its INPUT (csrc/head.hip).  Used for DepthRegression's mean over conv1x1(unet) (decoder.py:28-29) where
+ * unet = decoder.conv0(t) (decoder.py:126): the regressor branch then depends on t only and runs beside conv0.
+ *   partial [B][nsplit][C] f32: channel sums of x over row splits (cfp_channel_sum); x [B,H,W,ld] (C channels, C divides 1024): the
+ *   kernel reads its four border lines and corner pixels itself; w [Cout][3][3][C] float32, bias [Cout] (may be NULL) ->
+ *   msum [B][Cout] = sum over all H*W output pixels (feed it to cfp_bin_regressor with nsplit = 1, inv_hw = 1/HW). */
+int cfp_conv3x3_mean(const float* partial, int nsplit, const void* in, int in_ld, const float* w, const float* bias, float* msum,
+                     int B, int H, int W, int C, int Cout, int dtype, cfp_stream_t stream);
+
 /* Per-pixel softmax over nbins logits + expectation over bin centres:
  *   prob[b, n, hw] = softmax_n(logits[b*HW + hw, n]);  pred[b, hw] = sum_n prob * centers[b, n]
  * prob (NCHW, `dtype`) may be NULL.  pred is f32.  Replaces nn.Softmax(dim=1) of deltar.py:19

@@ -725,6 +725,24 @@ def test_hist_encoder_fused(R, dtype):
             assert float((got != t.float().to(dtype).float()).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C,Cout,ns", [(2, 12, 20, 32, 128, 5), (1, 7, 9, 16, 40, 7), (3, 40, 64, 32, 128, 16)])
+def test_conv3x3_output_sum_from_input_sums(B, H, W, C, Cout, ns, dtype):
+    """cfp_channel_sum + cfp_conv3x3_mean: the spatial sum of a linear 3x3 convolution (zero padding 1, bias) from nine shifted sums of
+    its input, against the convolution itself (float64)."""
+    x = q(rnd(B * H * W, C, seed=1) + 0.3, dtype)
+    w = rnd(Cout, C, 3, 3, seed=2, scale=0.2)
+    bias = rnd(Cout, seed=3)
+    ref = F.conv2d(x.double().reshape(B, H, W, C).permute(0, 3, 1, 2), w.double(), bias.double(), padding=1).sum((2, 3))
+    xa = to_act(x, dtype, ld=C + (8 if dtype != torch.float32 else 4))
+    partial = torch.empty(B * ns * C, device=DEV)
+    msum = torch.empty(B, Cout, device=DEV)
+    ops.channel_sum(xa, partial, B, H * W, ns)
+    ops.conv3x3_mean(partial, ns, xa, w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV), bias.to(DEV), msum, B, H, W, Cout)
+    torch.cuda.synchronize()
+    assert float((msum.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 def _head_ref(x, w3, b3, wo, bo, centers, B, H, W, ram_dtype):
     """conv3x3 (+bias) -> [ram rounded to the storage type or not] -> conv_out -> softmax -> expectation, in float64."""
     xi = x.double().reshape(B, H, W, 128).permute(0, 3, 1, 2)

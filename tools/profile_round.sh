@@ -1,12 +1,19 @@
-# profiles of one round: kernel-trace stats, two PMC passes (FETCH_SIZE / WRITE_SIZE, each in its own run), SQ counters, a full bench line
-# usage on the GPU box:  bash tools/profile_round.sh r2x
+# profiles of one round on the GPU box: kernel-trace stats, two PMC passes (FETCH_SIZE / WRITE_SIZE, each in its own run), SQ counters.
+# The raw traces are tens of MB: they are summarised here and only the summaries stay under gpurun_out/ (copy them to profiles/).
+#   bash tools/profile_round.sh r2x
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r2}
+RAW=/tmp/prof_$TAG
+mkdir -p $RAW
 cd $R
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o $TAG --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-times --no-f16 --no-train > gpurun_out/prof_${TAG}_bench.json 2> gpurun_out/prof_$TAG.err
-ls -R gpurun_out/prof_$TAG | head -20
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch_$TAG -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-times --no-f16 --no-train --steps 3 --warmup 1 > /dev/null 2> gpurun_out/pmc_fetch_$TAG.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write_$TAG -o w --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-times --no-f16 --no-train --steps 3 --warmup 1 > /dev/null 2> gpurun_out/pmc_write_$TAG.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d gpurun_out/pmc_sq_$TAG -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-kernel-times --no-f16 --no-train --steps 3 --warmup 1 > /dev/null 2> gpurun_out/pmc_sq_$TAG.err
-find gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG -name "*.csv" | head -20
+BENCH="python3 bench.py --no-cpu-baseline --no-kernel-times --no-f16 --no-train"
+rocprofv3 --kernel-trace --stats -d $RAW/kt -o kt --output-format csv -- $BENCH > gpurun_out/${TAG}_prof_bench.json 2> $RAW/kt.err
+# forwards in that trace: 2 warm-up + 1 capture pass per candidate slot (lanes:1, inflight 2/3/4 = 1+2+3+4 slots) are eager, everything else replays
+python3 tools/prof_summary_csv.py $RAW/kt/kt_kernel_trace.csv --csv gpurun_out/${TAG}_bench_b8_kernel_stats.csv > gpurun_out/${TAG}_bench_b8_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/pf -o f --output-format csv -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/pf.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/pw -o w --output-format csv -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/pw.err
+python3 tools/pmc_traffic.py $RAW/pf/f_counter_collection.csv $RAW/pw/w_counter_collection.csv > gpurun_out/${TAG}_pmc_traffic.json
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $RAW/ps -o s --output-format csv -- $BENCH --steps 3 --warmup 1 > /dev/null 2> $RAW/ps.err
+python3 tools/pmc_sq_summary.py $RAW/ps/s_counter_collection.csv > gpurun_out/${TAG}_pmc_sq_inference.json
+head -n 30 gpurun_out/${TAG}_bench_b8_kernel_stats.txt
