@@ -163,16 +163,17 @@ def same_size_copy_ms(shapes, dtype, dev, reps=5):
 
 def pmc_traffic(kernel_family: str):
     """HBM bytes per launch of a kernel family from the last committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for 16-byte
-    streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        table = json.load(open(path))
-    except Exception:
-        return None
-    e = table.get(kernel_family)
+    (profiles/pmc_traffic.json and profiles/r2f_pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for
+    16-byte streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
+    table = {}
+    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                table.update(json.load(open(path)))
+            except Exception:
+                pass
+    e = table.get(kernel_family) or table.get(kernel_family.split(" ")[0])
     return None if e is None else e.get("hbm_bytes_per_launch")
 
 
