@@ -124,6 +124,10 @@ class Engine:
         # 0.80e-3 (every image <= 0.86e-3), free.  In bf16 the same rounding measured worse (weights-only ablation 1.28x: the doubled
         # per-weight variance of direction-only rounding outweighs the cancelled mean shift), so bf16 keeps round-to-nearest there.
         self.diffuse_cin = os.environ.get("CFP_DIFFUSE_CIN", "1") == "1"
+        # stride-1 inverted-residual blocks: expand GEMM + depthwise 3x3 (+ SE sums) as one kernel (csrc/mbconv.hip), 16-bit modes.
+        # Built, parity-tested and MEASURED SLOWER than the two kernels it replaces (40 vs 40 us alone at 30x40x816, 32 vs 23 us with
+        # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
+        self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -222,6 +226,9 @@ class Engine:
                 self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn2", eps=EPS)
             else:
                 self._conv(sd, q + ".pw", q + ".conv_pw.weight", bn=q + ".bn1", eps=EPS)
+                if self.half and self.mbconv_fused and b.stride == 1 and not self.weights2:
+                    # the same rounded expand weights in the LDS image layout of the fused expand -> depthwise kernel
+                    self.P[q + ".pw.wimg"] = ops.pack_mbconv_pw(self.P[q + ".pw.w"].float().cpu(), self.dtype).to(self.device)
                 wd = ops.round_taps(sd[q + ".conv_dw.weight"].float(), self.dtype)
                 self.P[q + ".dw.w"] = self._dev(wd.reshape(wd.shape[0], 9).t(), self.dtype)
                 self.P[q + ".dw.s"], self.P[q + ".dw.t"] = self._fold_bn(sd, q + ".bn2", None, wd.shape[0], EPS)
@@ -380,14 +387,22 @@ class Engine:
                 self._cv(q + ".exp", x, mid, B, h, w, 3, b.stride, pads, hip.ACT_SILU)
                 self._cv(q + ".pwl", mid, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
             else:
-                mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
-                self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
                 mid2 = self._act(plan, f"enc{bi}.dw", B * ho * wo, b.mid)
-                # depthwise + BN + SiLU, emitting the per-strip channel sums squeeze-excite needs
-                ns = ops.dwconv3x3_strips(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype])
-                part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
-                ops.dwconv3x3_sum(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w, b.stride,
-                                  pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
+                mbp = ops.mbconv_plan(B, h, w, x.C, b.mid) if (q + ".pw.wimg") in self.P else None
+                if mbp is not None:
+                    # expand GEMM + BN + SiLU + depthwise 3x3 + BN + SiLU + SE sums in one launch: the expanded tensor stays in LDS
+                    ns = mbp[0]
+                    part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
+                    ops.mbconv_expand_dw(x, self.P[q + ".pw.wimg"], self.P[q + ".pw.s"], self.P[q + ".pw.t"], self.P[q + ".dw.w"],
+                                         self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w)
+                else:
+                    mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
+                    self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
+                    # depthwise + BN + SiLU, emitting the per-strip channel sums squeeze-excite needs
+                    ns = ops.dwconv3x3_strips(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype])
+                    part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
+                    ops.dwconv3x3_sum(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w, b.stride,
+                                      pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
                 # SE tail (mean -> FC -> SiLU -> FC -> sigmoid) in one launch; the gate multiplies the project conv's
                 # input channels, so it is folded into per-image project weights instead of a pass over mid2
                 wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)

@@ -403,3 +403,28 @@ def conv3x3_mean(partial: torch.Tensor, nsplit, x: Act, w32: torch.Tensor, bias,
     msum [B, Cout] f32 = spatial SUM of conv3x3(x) + bias."""
     assert w32.dtype == torch.float32 and tuple(w32.shape) == (Cout, 9 * x.C) and msum.dtype == torch.float32 and msum.numel() >= B * Cout
     hip.call("cfp_conv3x3_mean", partial.data_ptr(), nsplit, x.ptr, x.ld, w32.data_ptr(), hip.ptr(bias), msum.data_ptr(), B, H, W, x.C, Cout, x.dt, _s())
+
+
+def mbconv_plan(B, H, W, Cin, mid):
+    """-> (tiles per image, KP) of cfp_mbconv_expand_dw, or None if the shape does not fit its LDS tile."""
+    import ctypes
+    t, kp = ctypes.c_int(0), ctypes.c_int(0)
+    rc = hip.load().cfp_mbconv_plan(B, H, W, Cin, mid, ctypes.byref(t), ctypes.byref(kp))
+    return (t.value, kp.value) if rc == 0 else None
+
+
+def pack_mbconv_pw(w2d: torch.Tensor, dtype) -> torch.Tensor:
+    """Expand weights [mid, Cin] (values already on the 16-bit grid or float32) -> [mid, KP + 8] in `dtype`, zero padded: the LDS image
+    layout cfp_mbconv_expand_dw copies linearly (KP = Cin rounded up to 32)."""
+    mid, cin = w2d.shape
+    kp = (cin + 31) // 32 * 32
+    out = torch.zeros(mid, kp + 8, dtype=dtype)
+    out[:, :cin] = w2d.to(dtype)
+    return out.contiguous()
+
+
+def mbconv_expand_dw(x: Act, wpw: torch.Tensor, s1, t1, wdw: torch.Tensor, s2, t2, out: Act, partial: Optional[torch.Tensor], B, H, W):
+    mid = out.C
+    assert wpw.dtype == x.buf.dtype and wpw.shape[0] == mid and wdw.shape == (9, mid) and wdw.dtype == x.buf.dtype
+    hip.call("cfp_mbconv_expand_dw", x.ptr, x.ld, wpw.data_ptr(), s1.data_ptr(), t1.data_ptr(), wdw.data_ptr(), s2.data_ptr(), t2.data_ptr(),
+             out.ptr, out.ld, hip.ptr(partial), B, H, W, x.C, mid, x.dt, _s())

@@ -158,6 +158,20 @@ int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, 
 int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden, const float* w_expand_t, const float* b_expand,
                 int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
+/* Front half of a stride-1 inverted-residual block in one launch (csrc/mbconv.hip): conv_pw 1x1 (Cin -> mid) + BN1 + SiLU ->
+ * conv_dw 3x3 (depthwise, padding 1) + BN2 + SiLU (timm InvertedResidual as the reference builds it, encoder.py:66-69) + the
+ * per-tile channel sums squeeze-excite needs.  The expanded tensor never reaches HBM.
+ *   x [B,H,W,x_ld] (Cin channels); wpw [mid][KP + 8] 16-bit with KP = Cin rounded up to 32 (cfp_mbconv_plan), zero padding behind
+ *   the Cin real columns: the LDS image layout of the weights; s1 / t1, s2 / t2 [mid] f32: BatchNorm folded to scale / shift;
+ *   wdw [9][mid] 16-bit (tap-major, like cfp_dwconv3x3_nhwc); out [B,H,W,out_ld] (mid channels); partial (may be NULL)
+ *   [B][tiles_per_image][mid] f32 channel sums per spatial tile (tiles_per_image from cfp_mbconv_plan; feed cfp_se_gate_fold with
+ *   nsplit = tiles_per_image).  bf16 / f16 only; Cin % 8 == 0, mid % 16 == 0.  cfp_mbconv_plan returns CFP_ESHAPE if the shape
+ *   does not fit (the engine then runs cfp_conv2d_nhwc + cfp_dwconv3x3_sum_nhwc). */
+int cfp_mbconv_plan(int B, int H, int W, int Cin, int mid, int* tiles_per_image, int* KP);
+int cfp_mbconv_expand_dw(const void* x, int x_ld, const void* wpw, const float* s1, const float* t1, const void* wdw,
+                         const float* s2, const float* t2, void* out, int out_ld, float* partial, int B, int H, int W, int Cin,
+                         int mid, int dtype, cfp_stream_t stream);
+
 /* cfp_se_hidden + cfp_se_fold in one launch (mean -> FC -> SiLU -> FC -> sigmoid -> per-image project weights),
  * structured for latency: this is what the engine calls between the depthwise conv and the project conv of every
  * inverted-residual block.  Same arguments as the two calls it replaces; C <= 2048, R <= 64. */

@@ -167,6 +167,23 @@ def test_config1_batch8_as_benched_vs_oracle(dtype, bound):
     assert p2.shape == (8, 1, 240, 320)
 
 
+@pytest.mark.parametrize("env", [{"CFP_MBCONV_FUSED": "1"}, {"CFP_WEIGHTS2": "1"}, {"CFP_HEAD_FUSED": "0"}, {"CFP_HEAD_HILO": "10"}],
+                         ids=["mbconv_fused", "two_term_weights", "separate_head_kernels", "wout_hilo"])
+def test_optional_kernel_paths_keep_parity(env, monkeypatch):
+    """The paths that are measured-and-not-default (fused expand->depthwise kernel, two-term pointwise weights, hi+lo conv_out
+    weights) and the round-1 head kernels stay correct: fp16 engine against the CPU oracle at the gate, on the B=2 case."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    layers, sd, inp = _full_case(2, 480, 640, 8, 56, 21, 0.2)
+    e0, p0, pr0 = O.forward(sd, inp, layer_names=layers)
+    eng = Engine(sd, layer_names=layers, dtype=torch.float16)
+    e1, p1, pr1 = eng.forward(inp)
+    torch.cuda.synchronize()
+    r = rel_l1(p1.cpu().numpy(), p0.numpy())
+    print(f"{env}: fp16 pred relL1 {r:.3e}")
+    assert r < TOL_F16
+
+
 def test_forward_is_deterministic_and_batch_independent():
     """Size-independent properties: same input -> identical bits; a sample's result does not depend
     on what else is in the batch (all-valid zones, so the batch-reduced geometry is shared) beyond

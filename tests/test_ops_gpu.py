@@ -743,6 +743,37 @@ def test_conv3x3_output_sum_from_input_sums(B, H, W, C, Cout, ns, dtype):
     assert float((msum.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("B,H,W,Cin,mid", [(2, 30, 40, 136, 816), (1, 15, 20, 232, 1392), (2, 30, 40, 112, 448), (1, 13, 17, 56, 224), (3, 7, 5, 112, 672)])
+def test_mbconv_expand_dw_fused(B, H, W, Cin, mid, dtype):
+    """conv_pw 1x1 + BN + SiLU -> conv_dw 3x3 + BN + SiLU + squeeze-excite channel sums in one kernel (csrc/mbconv.hip) against
+    the float64 chain with the expanded tensor rounded to the storage type where the unfused path stores it.  Ragged tiles
+    (13x17, 7x5), Cin that needs K padding (136, 232, 56), channel groups with a short last chunk (816 = 51 x 16)."""
+    plan = ops.mbconv_plan(B, H, W, Cin, mid)
+    assert plan is not None
+    ntile, kp = plan
+    x = q(rnd(B * H * W, Cin, seed=1), dtype)
+    wpw = q(rnd(mid, Cin, seed=2, scale=1.0 / math.sqrt(Cin)), dtype)
+    wdw = q(rnd(mid, 3, 3, seed=3, scale=0.4), dtype)
+    g = torch.Generator().manual_seed(4)
+    s1, t1 = 0.7 + 0.6 * torch.rand(mid, generator=g), rnd(mid, seed=5, scale=0.3)
+    s2, t2 = 0.7 + 0.6 * torch.rand(mid, generator=g), rnd(mid, seed=6, scale=0.3)
+    xi = x.double().reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    m1 = F.silu(F.conv2d(xi, wpw.double()[:, :, None, None]) * s1.double()[None, :, None, None] + t1.double()[None, :, None, None])
+    m1 = m1.float().to(dtype).double()                                            # the expanded tensor is a 16-bit tile
+    m2 = F.silu(F.conv2d(m1, wdw.double()[:, None], padding=1, groups=mid) * s2.double()[None, :, None, None] + t2.double()[None, :, None, None])
+    out = ops.new_act(B * H * W, mid, dtype, DEV)
+    out.buf.fill_(float("nan"))
+    part = torch.full((B * ntile * mid,), float("nan"), device=DEV)
+    ops.mbconv_expand_dw(to_act(x, dtype, ld=Cin + 8), ops.pack_mbconv_pw(wpw, dtype).to(DEV), s1.to(DEV), t1.to(DEV),
+                         wdw.reshape(mid, 9).t().contiguous().to(dtype).to(DEV), s2.to(DEV), t2.to(DEV), out, part, B, H, W)
+    torch.cuda.synchronize()
+    close(from_nhwc(out.torch(), B, H, W), m2.float(), dtype, "mid2")
+    sums = part.reshape(B, ntile, mid).sum(1).cpu().double()
+    ref = m2.sum((2, 3))
+    assert float((sums - ref).abs().max() / ref.abs().max()) < (2e-3 if dtype == torch.float16 else 1.2e-2)
+
+
 def _head_ref(x, w3, b3, wo, bo, centers, B, H, W, ram_dtype):
     """conv3x3 (+bias) -> [ram rounded to the storage type or not] -> conv_out -> softmax -> expectation, in float64."""
     xi = x.double().reshape(B, H, W, 128).permute(0, 3, 1, 2)
