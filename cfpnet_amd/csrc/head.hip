@@ -15,12 +15,12 @@ __device__ __forceinline__ void fc_layer(const float* __restrict__ in, const flo
   const int c0 = g * per, c1 = min(n_in, c0 + per);
   for (int o = o0; o < n_out; o += 256) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int c = c0; c < c1; c += 16) {
-      float w[16];
+    for (int c = c0; c < c1; c += 32) {          // 32 weight loads in flight per thread: a layer is 1-2 memory round trips
+      float w[32];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) w[j] = (c + j < c1) ? wt[(long long)(c + j) * n_out + o] : 0.f;
+      for (int j = 0; j < 32; ++j) w[j] = (c + j < c1) ? wt[(long long)(c + j) * n_out + o] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; j += 4) {
+      for (int j = 0; j < 32; j += 4) {
         s0 = fmaf((c + j < c1) ? in[c + j] : 0.f, w[j], s0);
         s1 = fmaf((c + j + 1 < c1) ? in[c + j + 1] : 0.f, w[j + 1], s1);
         s2 = fmaf((c + j + 2 < c1) ? in[c + j + 2] : 0.f, w[j + 2], s2);
@@ -320,32 +320,50 @@ __global__ __launch_bounds__(1024) void conv3x3_mean_kernel(const float* __restr
   float* q5 = sm;                  // [5][C]: all pixels, first row, last row, first column, last column
   float* corner = sm + 5 * C;      // [4][C]: (0,0), (0,W-1), (H-1,0), (H-1,W-1)
   float* S = corner + 4 * C;       // [9][C]
-  float* red = S + 9 * C;          // [1024]
+  float* red = S + 9 * C;          // [5][1024]
   const int b = blockIdx.x, tid = threadIdx.x;
   const T* img = in + (long long)b * H * W * in_ld;
-  // five sums per channel, each by 1024 / C lanes in a fixed order: the channel sums of the splits, then the four border lines
+  // five sums per channel, each by 1024 / C lanes in a fixed order: the channel sums of the splits, then the four border lines.
+  // All loads of a thread are independent (four accumulators per line, everything requested before it is used) and the five
+  // reductions share one pair of barriers: as a chain of dependent loads this kernel took 57 us for 8 workgroups.
   const int L = 1024 / C;          // host: C divides 1024
   const int c = tid % C, ln = tid / C;
-  for (int k = 0; k < 5; ++k) {
-    float s = 0.f;
-    if (k == 0) {
-      for (int j = ln; j < nsplit; j += L) s += partial[((long long)b * nsplit + j) * C + c];
-    } else {
-      const int n = k <= 2 ? W : H;
-      for (int j = ln; j < n; j += L) {
-        const int y = k == 1 ? 0 : k == 2 ? H - 1 : j, x = k == 3 ? 0 : k == 4 ? W - 1 : j;
-        s += to_f32<T>(img[((long long)y * W + x) * in_ld + c]);
-      }
+  float s5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = ln;
+    for (; j + 3 * L < nsplit; j += 4 * L) {
+      const float v0 = partial[((long long)b * nsplit + j) * C + c], v1 = partial[((long long)b * nsplit + j + L) * C + c];
+      const float v2 = partial[((long long)b * nsplit + j + 2 * L) * C + c], v3 = partial[((long long)b * nsplit + j + 3 * L) * C + c];
+      a0 += v0; a1 += v1; a2 += v2; a3 += v3;
     }
-    red[tid] = s;
-    __syncthreads();
-    if (tid < C) {
-      float t = 0.f;
-      for (int j = 0; j < L; ++j) t += red[j * C + tid];
-      q5[k * C + tid] = t;
-    }
-    __syncthreads();
+    for (; j < nsplit; j += L) a0 += partial[((long long)b * nsplit + j) * C + c];
+    s5[0] = (a0 + a1) + (a2 + a3);
   }
+#pragma unroll
+  for (int k = 1; k < 5; ++k) {
+    const int n = k <= 2 ? W : H;
+    const long long stride = (k <= 2 ? 1ll : (long long)W) * in_ld;                       // along the row (k = 1, 2) or down the column (k = 3, 4)
+    const T* line = img + (k == 2 ? (long long)(H - 1) * W * in_ld : 0) + (k == 4 ? (long long)(W - 1) * in_ld : 0) + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = ln;
+    for (; j + 3 * L < n; j += 4 * L) {
+      const T v0 = line[j * stride], v1 = line[(j + L) * stride], v2 = line[(j + 2 * L) * stride], v3 = line[(j + 3 * L) * stride];
+      a0 += to_f32<T>(v0); a1 += to_f32<T>(v1); a2 += to_f32<T>(v2); a3 += to_f32<T>(v3);
+    }
+    for (; j < n; j += L) a0 += to_f32<T>(line[j * stride]);
+    s5[k] = (a0 + a1) + (a2 + a3);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) red[k * 1024 + tid] = s5[k];
+  __syncthreads();
+  for (int i = tid; i < 5 * C; i += 1024) {
+    const int k = i / C, cc = i - k * C;
+    float t = 0.f;
+    for (int j = 0; j < L; ++j) t += red[k * 1024 + j * C + cc];
+    q5[i] = t;
+  }
+  __syncthreads();
   for (int i = tid; i < 4 * C; i += 1024) {
     const int k = i / C, cc = i - k * C;
     const int y = (k >> 1) ? H - 1 : 0, x = (k & 1) ? W - 1 : 0;
@@ -364,14 +382,31 @@ __global__ __launch_bounds__(1024) void conv3x3_mean_kernel(const float* __restr
     S[i] = s;
   }
   __syncthreads();
-  // out[m] = HW * bias[m] + W[m][0 .. 9C) . S: eight lanes per output, each a contiguous eighth of the row
+  // out[m] = HW * bias[m] + W[m][0 .. 9C) . S: eight lanes per output, each a contiguous eighth of the row, its weights fetched as
+  // 16-byte vectors that are all in flight before the first multiply
   const int K = 9 * C;
   const int per = (K + 7) >> 3;
   for (int m = tid >> 3; m < Cout; m += 128) {
     const int part = tid & 7;
     const int k0 = part * per, k1 = min(K, k0 + per);
     float s = 0.f;
-    for (int k = k0; k < k1; ++k) s = fmaf(w[(long long)m * K + k], S[k], s);
+    if ((per & 3) == 0 && per <= 64 && k1 - k0 == per) {
+      const f32x4* wv = reinterpret_cast<const f32x4*>(w + (long long)m * K + k0);
+      f32x4 buf[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) buf[q4] = (q4 * 4 < per) ? wv[q4] : f32x4{0.f, 0.f, 0.f, 0.f};
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int q4 = 0; q4 < 16; ++q4) {
+        if (q4 * 4 < per) {
+          a0 = fmaf(buf[q4][0], S[k0 + q4 * 4], a0); a1 = fmaf(buf[q4][1], S[k0 + q4 * 4 + 1], a1);
+          a2 = fmaf(buf[q4][2], S[k0 + q4 * 4 + 2], a2); a3 = fmaf(buf[q4][3], S[k0 + q4 * 4 + 3], a3);
+        }
+      }
+      s = (a0 + a1) + (a2 + a3);
+    } else {
+      for (int k = k0; k < k1; ++k) s = fmaf(w[(long long)m * K + k], S[k], s);
+    }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
@@ -387,7 +422,7 @@ extern "C" int cfp_conv3x3_mean(const float* partial, int nsplit, const void* in
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv3x3_mean: bad dtype");
   CFP_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C <= 512 && 1024 % C == 0 && Cout > 0 && nsplit > 0 && in_ld >= C, CFP_ESHAPE,
               "cfp_conv3x3_mean: bad shape (C must divide 1024)");
-  const size_t lds = (size_t)(18 * C + 1024) * sizeof(float);
+  const size_t lds = (size_t)(18 * C + 5 * 1024) * sizeof(float);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(conv3x3_mean_kernel<bf16_t>, dim3(B), dim3(1024), lds, s, partial, nsplit, (const bf16_t*)in, in_ld, w, bias, msum, H, W, C, Cout);
   else if (dtype == CFP_F16) hipLaunchKernelGGL(conv3x3_mean_kernel<f16_t>, dim3(B), dim3(1024), lds, s, partial, nsplit, (const f16_t*)in, in_ld, w, bias, msum, H, W, C, Cout);

@@ -244,6 +244,127 @@ int launch_tail(const TailP<H>& p, hipStream_t s) {
   return 0;
 }
 
+// ---- LKPM tail (Block14.forward after the depthwise conv, convnext.py:48-58): LayerNorm(1e-6) -> pwconv1 (D -> 4D) -> GELU ->
+// pwconv2 (4D -> D) -> + input, for the 16 token rows of a wave, with the same machinery as the LoFTR tail: the 4D-wide hidden tile
+// lives in the wave's LDS region and never reaches HBM (unfused: a LayerNorm launch, two GEMM launches and 2 x 4D x 2 bytes per
+// token of traffic -- 79 MB at the 1/4 scale of a batch of 8).  pwconv1 runs in two halves of 2D output channels so that its weight
+// slabs ([2D][64], double buffered) and the four waves' tiles fit the LDS at D = 128.
+template <typename H> struct LkpmP {
+  const H* t; const H* xin; H* out;
+  const H* w1; const H* w2;
+  const float* lg; const float* lb; const float* b1; const float* b2;
+  int t_ld, x_ld, out_ld, rows;
+  float ln_eps;
+};
+
+template <typename H, int D>
+__global__ __launch_bounds__(256) void lkpm_tail_kernel(LkpmP<H> p) {
+  constexpr int PA = D + 8, PH = 4 * D + 8;               // row pitches (elements): +16 bytes
+  constexpr int WAVE_LDS = (PA + PH) * 16 * 2;            // normalised-input / output tile | hidden tile of one wave
+  constexpr int BSTAGE = 2 * D * 128;                     // largest weight slab: [2D rows][64 k]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  unsigned char* sB = smem;
+  H* tA = reinterpret_cast<H*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  H* tH = tA + 16 * PA;
+  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+  constexpr int XCH = D / 8;                               // 16-byte chunks per row
+
+  // ---- t tile -> LDS, LayerNorm over the D channels of each row (lane = row fr, quarter fq of the channels) -------------------------
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < p.rows) v = *reinterpret_cast<const u32x4*>(p.t + m * p.t_ld + ch * 8);
+    *reinterpret_cast<u32x4*>(tA + r * PA + ch * 8) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {
+    constexpr int Q = D / 4;                               // channels per lane
+    float v[Q];
+#pragma unroll
+    for (int c = 0; c < Q; c += 8) Vec<H>::load(tA + fr * PA + fq * Q + c, v + c);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) s += v[c];
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / (float)D);
+    float qq = 0.f;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) { const float dl = v[c] - mean; qq = fmaf(dl, dl, qq); }
+    qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+    const float rstd = rsqrtf(qq * (1.f / (float)D) + p.ln_eps);
+#pragma unroll
+    for (int c = 0; c < Q; c += 8) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[c + e] - mean) * rstd * p.lg[fq * Q + c + e] + p.lb[fq * Q + c + e];
+      Vec<H>::store(tA + fr * PA + fq * Q + c, o);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- pwconv1 + GELU: two halves of 2D hidden channels ------------------------------------------------------------------------------
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 acc[2 * D / 16];
+    tail_gemm<H, 2 * D / 16, BSTAGE>(acc, p.w1 + (long long)half * 2 * D * D, D,
+                                     [&](int k) { return *reinterpret_cast<const s16x8*>(tA + fr * PA + k + fq * 8); }, sB, wave, lane);
+#pragma unroll
+    for (int j = 0; j < 2 * D / 16; ++j) {
+      const float bj = p.b1[half * 2 * D + j * 16 + fr];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        tH[(fq * 4 + r) * PH + half * 2 * D + j * 16 + fr] = from_f32<H>(act_c<CFP_ACT_GELU>(acc[j][r] + bj));
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- pwconv2 (K = 4D) + bias, staged in FLOAT32 over the (consumed) hidden tile; the residual is added on the way out, so the
+  // output is rounded once, like the unfused GEMM epilogue does -----------------------------------------------------------------------
+  constexpr int PF = D + 4;                                // floats per staged row (16 x PF x 4 <= 16 x PH x 2)
+  float* tF = reinterpret_cast<float*>(tH);
+  {
+    f32x4 acc[D / 16];
+    tail_gemm<H, D / 16, BSTAGE>(acc, p.w2, 4 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tH are complete (tail_gemm consumed them)
+#pragma unroll
+    for (int j = 0; j < D / 16; ++j) {
+      const float bj = p.b2[j * 16 + fr];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tF[(fq * 4 + r) * PF + j * 16 + fr] = acc[j][r] + bj;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    if (m < p.rows) {
+      float a[8], b[8];
+      Vec<float>::load(tF + r * PF + ch * 8, a);
+      Vec<float>::load(tF + r * PF + ch * 8 + 4, a + 4);
+      Vec<H>::load(p.xin + m * p.x_ld + ch * 8, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+      Vec<H>::store(p.out + m * p.out_ld + ch * 8, a);
+    }
+  }
+}
+
+template <typename H, int D>
+int launch_lkpm(const LkpmP<H>& p, hipStream_t s) {
+  constexpr size_t lds = 2 * (2 * D * 128) + 4 * (((D + 8) + (4 * D + 8)) * 16 * 2);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = lkpm_tail_kernel<H, D>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
@@ -283,4 +404,29 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
   if (dtype == CFP_F16) run(f16_t{}); else run(bf16_t{});
   CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_loftr_tail: launch failed");
   return cfp_check_launch("cfp_loftr_tail");
+}
+
+extern "C" int cfp_lkpm_tail(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1,
+                             const void* w2, const float* b2, const float* ln_g, const float* ln_b, float ln_eps, int rows, int D, int dtype,
+                             cfp_stream_t stream) {
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_lkpm_tail: bf16/f16 only (the f32 parity mode uses the unfused kernels)");
+  CFP_REQUIRE(t && xin && out && w1 && b1 && w2 && b2 && ln_g && ln_b, CFP_EINVAL, "cfp_lkpm_tail: null pointer");
+  CFP_REQUIRE(rows > 0 && (D == 32 || D == 64 || D == 128), CFP_ESHAPE, "cfp_lkpm_tail: D must be 32/64/128");
+  CFP_REQUIRE(t_ld >= D && x_ld >= D && out_ld >= D && t_ld % 8 == 0 && x_ld % 8 == 0 && out_ld % 8 == 0, CFP_ESHAPE,
+              "cfp_lkpm_tail: pitches must be >= D and multiples of 8");
+  CFP_REQUIRE(aligned16(t) && aligned16(xin) && aligned16(out) && aligned16(w1) && aligned16(w2), CFP_EINVAL, "cfp_lkpm_tail: pointers must be 16-byte aligned");
+  int rc = -2;
+  auto run = [&](auto tag) {
+    using H = decltype(tag);
+    LkpmP<H> p;
+    p.t = (const H*)t; p.xin = (const H*)xin; p.out = (H*)out; p.w1 = (const H*)w1; p.w2 = (const H*)w2;
+    p.lg = ln_g; p.lb = ln_b; p.b1 = b1; p.b2 = b2; p.t_ld = t_ld; p.x_ld = x_ld; p.out_ld = out_ld; p.rows = rows; p.ln_eps = ln_eps;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (D == 32) rc = launch_lkpm<H, 32>(p, s);
+    else if (D == 64) rc = launch_lkpm<H, 64>(p, s);
+    else rc = launch_lkpm<H, 128>(p, s);
+  };
+  if (dtype == CFP_F16) run(f16_t{}); else run(bf16_t{});
+  CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_lkpm_tail: launch failed");
+  return cfp_check_launch("cfp_lkpm_tail");
 }

@@ -128,6 +128,7 @@ class Engine:
         # Built, parity-tested and MEASURED SLOWER than the two kernels it replaces (40 vs 40 us alone at 30x40x816, 32 vs 23 us with
         # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
         self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
+        self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -557,11 +558,19 @@ class Engine:
                                           hip.ACT_RELU)
                 else:
                     ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
-                t2 = self._act(plan, f"{name}.lk.t2", M, D)
-                ops.layernorm(t1, self.P[k + ".norm.g"], self.P[k + ".norm.b"], 1e-6, t2, M)
-                h4 = self._act(plan, f"{name}.lk.h4", M, 4 * D)
-                self._lin(k + ".pw1.w", t2, h4, M, hip.ACT_GELU, None, k + ".pw1")
-                self._lin(k + ".pw2.w", h4, final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D), M, hip.ACT_NONE, xin.slice(0, D), k + ".pw2")
+                lk_dst = final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D)
+                if self.half and self.lkpm_fused and not self.weights2 and D in (32, 64, 128) and M >= 30000:
+                    # LayerNorm -> pwconv1 -> GELU -> pwconv2 -> + input in one kernel: the 4D-wide hidden tensor stays in LDS.
+                    # Measured at batch 8 (tools/small_kernel_bench.py): 24 vs 49 us at the 1/4 scale, 29 vs 34 us at 1/8, 30 vs 25 us at
+                    # 1/16 (9 600 rows = 150 workgroups: too few to hide the chain's latency) -> only the many-row scales take it
+                    ops.lkpm_tail(t1, xin.slice(0, D), lk_dst, self.P[k + ".pw1.w"], self.P[k + ".pw1.t"], self.P[k + ".pw2.w"], self.P[k + ".pw2.t"],
+                                  self.P[k + ".norm.g"], self.P[k + ".norm.b"], M)
+                else:
+                    t2 = self._act(plan, f"{name}.lk.t2", M, D)
+                    ops.layernorm(t1, self.P[k + ".norm.g"], self.P[k + ".norm.b"], 1e-6, t2, M)
+                    h4 = self._act(plan, f"{name}.lk.h4", M, 4 * D)
+                    self._lin(k + ".pw1.w", t2, h4, M, hip.ACT_GELU, None, k + ".pw1")
+                    self._lin(k + ".pw2.w", h4, lk_dst, M, hip.ACT_NONE, xin.slice(0, D), k + ".pw2")
                 cur ^= 1
                 direct_out = final_dst is not None
             else:

@@ -104,6 +104,7 @@ SIGNATURES = {
     "cfp_bin_regressor": (_i, [_p, _i, _f] + [_p] * 7 + [_f, _f, _i, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_bin_softmax": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p]),
     "cfp_conv3x3_mean": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "cfp_lkpm_tail": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _p]),
     "cfp_mbconv_plan": (_i, [_i, _i, _i, _i, _i, _p, _p]),
     "cfp_mbconv_expand_dw": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
     "cfp_hist_encoder": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -428,3 +428,10 @@ def mbconv_expand_dw(x: Act, wpw: torch.Tensor, s1, t1, wdw: torch.Tensor, s2, t
     assert wpw.dtype == x.buf.dtype and wpw.shape[0] == mid and wdw.shape == (9, mid) and wdw.dtype == x.buf.dtype
     hip.call("cfp_mbconv_expand_dw", x.ptr, x.ld, wpw.data_ptr(), s1.data_ptr(), t1.data_ptr(), wdw.data_ptr(), s2.data_ptr(), t2.data_ptr(),
              out.ptr, out.ld, hip.ptr(partial), B, H, W, x.C, mid, x.dt, _s())
+
+
+def lkpm_tail(t: Act, xin: Act, out: Act, w1, b1, w2, b2, ln_g, ln_b, rows, ln_eps=1e-6):
+    D = t.C
+    assert xin.C == D and out.C == D and tuple(w1.shape) == (4 * D, D) and tuple(w2.shape) == (D, 4 * D) and w1.dtype == t.buf.dtype
+    hip.call("cfp_lkpm_tail", t.ptr, t.ld, xin.ptr, xin.ld, out.ptr, out.ld, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+             ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps), rows, D, t.dt, _s())

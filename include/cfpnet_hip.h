@@ -264,6 +264,14 @@ int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_str
 int cfp_hist_encoder(const float* hist, const float* blob, const int* layout, void* out0, void* out1, void* out2,
                      const float* pe0, const float* pe1, const float* pe2, int n_pe, int R, int dtype, cfp_stream_t stream);
 
+/* LKPM tail in one launch (csrc/loftr_tail.hip): Block14.forward after its depthwise conv + BatchNorm + ReLU (convnext.py:48-58):
+ *   out = xin + pwconv2(GELU(pwconv1(LayerNorm(t))))      LayerNorm over the D channels, eps = ln_eps (1e-6), exact-erf GELU
+ * t [rows, t_ld] = the depthwise stage's output, xin [rows, x_ld] = the block's input (residual), w1 [4D][D], b1 [4D], w2 [D][4D],
+ * b2 [D], ln_g / ln_b [D].  The 4D-wide hidden tensor never reaches HBM.  bf16 / f16 only; D in {32, 64, 128}. */
+int cfp_lkpm_tail(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1,
+                  const void* w2, const float* b2, const float* ln_g, const float* ln_b, float ln_eps, int rows, int D, int dtype,
+                  cfp_stream_t stream);
+
 /* Bin-width regressor + bin edges/centres, one workgroup per batch element, all f32:
  *   mean -> conv1x1 (no bias) -> Linear/LeakyReLU x2 -> Linear -> norm -> widths -> cumsum
  * Every weight matrix is passed TRANSPOSED, [n_in][n_out] (coalesced across output threads).

@@ -774,6 +774,28 @@ def test_mbconv_expand_dw_fused(B, H, W, Cin, mid, dtype):
     assert float((sums - ref).abs().max() / ref.abs().max()) < (2e-3 if dtype == torch.float16 else 1.2e-2)
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("rows,D,ld", [(1200 * 2 + 7, 128, 256), (4800, 64, 128), (19200 + 33, 32, 64)])
+def test_lkpm_tail_fused(rows, D, ld, dtype):
+    """LayerNorm(1e-6) -> pwconv1 -> GELU(erf) -> pwconv2 -> + input in one kernel (cfp_lkpm_tail) against the float64 chain with
+    the unfused path's rounding points (normalised input and hidden tensor stored in the 16-bit type, one rounding of the output).
+    Ragged last workgroup, inputs living in slices of wider buffers."""
+    t = q(rnd(rows, D, seed=1).abs() * 1.5, dtype)                      # post-ReLU input
+    xin = q(rnd(rows, D, seed=2), dtype)
+    w1 = q(rnd(4 * D, D, seed=3, scale=1.0 / math.sqrt(D)), dtype)
+    w2 = q(rnd(D, 4 * D, seed=4, scale=1.0 / math.sqrt(4 * D)), dtype)
+    b1, b2 = rnd(4 * D, seed=5, scale=0.2), rnd(D, seed=6, scale=0.2)
+    g, bt = 1.0 + 0.2 * rnd(D, seed=7), rnd(D, seed=8, scale=0.1)
+    ln = F.layer_norm(t.double(), (D,), g.double(), bt.double(), 1e-6).float().to(dtype).double()
+    h = F.gelu(ln @ w1.double().t() + b1.double()).float().to(dtype).double()
+    ref = (h @ w2.double().t() + b2.double() + xin.double()).float()
+    out = ops.new_act(rows, D, dtype, DEV, ld)
+    ops.lkpm_tail(to_act(t, dtype), to_act(xin, dtype, ld=ld), out.slice(0, D) if ld != D else out, w1.to(dtype).to(DEV), b1.to(DEV),
+                  w2.to(dtype).to(DEV), b2.to(DEV), g.to(DEV), bt.to(DEV), rows)
+    torch.cuda.synchronize()
+    close(out.torch().float().cpu(), ref, dtype, "lkpm out")
+
+
 def _head_ref(x, w3, b3, wo, bo, centers, B, H, W, ram_dtype):
     """conv3x3 (+bias) -> [ram rounded to the storage type or not] -> conv_out -> softmax -> expectation, in float64."""
     xi = x.double().reshape(B, H, W, 128).permute(0, 3, 1, 2)
