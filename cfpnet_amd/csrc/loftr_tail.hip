@@ -27,6 +27,7 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 
 template <typename H> struct TailP {
   const H* q; const float* kv; const float* ksum; const H* x; H* out;
+  const H* wq;                   // optional: q_proj weights [D][D]; the kernel then computes q = x @ wq^T for its own rows and `q` is unused
   const H* wm; const H* w0; const H* w2;
   const float* g1; const float* b1; const float* g2; const float* b2;
   int q_ld, x_ld, out_ld;
@@ -139,6 +140,20 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
     *reinterpret_cast<u32x4*>(tX + r * PA + ch * 8) = v;
   }
 
+  // ---- optional q projection for this wave's rows (transformer.py:45: q = q_proj(x)): one more GEMM of the chain instead of a separate
+  // launch that writes [rows, D] and is read back here; q is rounded to the storage type like the unfused GEMM's output ----------------
+  const bool own_q = p.wq != nullptr;
+  if (own_q) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x4 acc[D / 16];
+    tail_gemm<H, D / 16, BSTAGE>(acc, p.wq, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tX + fr * PA + k + fq * 8); }, sB, wave, lane);
+#pragma unroll
+    for (int j = 0; j < D / 16; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PH + j * 16 + fr] = from_f32<H>(acc[j][r]);     // the hidden tile is free until mlp.0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
   // ---- linear-attention apply: lane = (row, head slot) --------------------------------------------
   {
     const int r = fr;
@@ -155,14 +170,25 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
       const int h = fq + 4 * hs;
       const float* __restrict__ kv = p.kv + (g * HEADS + h) * d * d;
       const float* __restrict__ ks = p.ksum + (g * HEADS + h) * d;
-      const H* qp = p.q + mm * p.q_ld + h * d;
       float qv[d];
-      if constexpr (d >= 8) {
+      if (own_q) {                                           // uniform
+        const H* qp = tH + r * PH + h * d;
+        if constexpr (d >= 8) {
 #pragma unroll
-        for (int c = 0; c < d; c += 8) Vec<H>::load(qp + c, qv + c);
+          for (int c = 0; c < d; c += 8) Vec<H>::load(qp + c, qv + c);
+        } else {
+#pragma unroll
+          for (int c = 0; c < d; ++c) qv[c] = to_f32<H>(qp[c]);
+        }
       } else {
+        const H* qp = p.q + mm * p.q_ld + h * d;
+        if constexpr (d >= 8) {
 #pragma unroll
-        for (int c = 0; c < d; ++c) qv[c] = to_f32<H>(qp[c]);
+          for (int c = 0; c < d; c += 8) Vec<H>::load(qp + c, qv + c);
+        } else {
+#pragma unroll
+          for (int c = 0; c < d; ++c) qv[c] = to_f32<H>(qp[c]);
+        }
       }
       float o[d];
 #pragma unroll
@@ -368,19 +394,19 @@ int launch_lkpm(const LkpmP<H>& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
-                              void* out, int out_ld, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
+                              void* out, int out_ld, const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
                               const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
                               int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
                               int dtype, cfp_stream_t stream) {
   CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_loftr_tail: bf16/f16 only (the f32 parity mode uses the unfused kernels)");
-  CFP_REQUIRE(q && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
-              "cfp_loftr_tail: null pointer");
+  CFP_REQUIRE((q || w_q) && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
+              "cfp_loftr_tail: null pointer (q or w_q must be given)");
   CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && v_length > 0.f, CFP_ESHAPE, "cfp_loftr_tail: bad grid");
   CFP_REQUIRE((D == 32 || D == 64 || D == 128) && (heads == 4 || heads == 8), CFP_ESHAPE,
               "cfp_loftr_tail: D must be 32/64/128 and heads 4/8");
-  CFP_REQUIRE(q_ld >= D && x_ld >= D && out_ld >= D && q_ld % 8 == 0 && x_ld % 8 == 0 && out_ld % 8 == 0, CFP_ESHAPE,
+  CFP_REQUIRE((w_q || (q_ld >= D && q_ld % 8 == 0)) && x_ld >= D && out_ld >= D && x_ld % 8 == 0 && out_ld % 8 == 0, CFP_ESHAPE,
               "cfp_loftr_tail: pitches must be >= D and multiples of 8");
-  CFP_REQUIRE(aligned16(q) && aligned16(x) && aligned16(out) && aligned16(w_merge) && aligned16(w_mlp0) && aligned16(w_mlp2) &&
+  CFP_REQUIRE(aligned16(q) && aligned16(w_q) && aligned16(x) && aligned16(out) && aligned16(w_merge) && aligned16(w_mlp0) && aligned16(w_mlp2) &&
                   aligned16(kv), CFP_EINVAL, "cfp_loftr_tail: pointers must be 16-byte aligned");
   CFP_REQUIRE((long long)NB * Hq * Wq < (1ll << 31), CFP_ESHAPE, "cfp_loftr_tail: too many rows");
   int rc = -2;
@@ -388,7 +414,7 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
     using H = decltype(tag);
     TailP<H> p;
     p.q = (const H*)q; p.kv = kv; p.ksum = ksum; p.x = (const H*)x; p.out = (H*)out;
-    p.wm = (const H*)w_merge; p.w0 = (const H*)w_mlp0; p.w2 = (const H*)w_mlp2;
+    p.wq = (const H*)w_q; p.wm = (const H*)w_merge; p.w0 = (const H*)w_mlp0; p.w2 = (const H*)w_mlp2;
     p.g1 = ln1_g; p.b1 = ln1_b; p.g2 = ln2_g; p.b2 = ln2_b;
     p.q_ld = q_ld; p.x_ld = x_ld; p.out_ld = out_ld;
     p.rows = NB * Hq * Wq; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);

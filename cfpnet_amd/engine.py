@@ -129,6 +129,7 @@ class Engine:
         # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
         self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
+        self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -204,7 +205,8 @@ class Engine:
             self.P[p + ".qkv"] = self._pack_conv(torch.cat([sd[p + ".q_proj.weight"], sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0), True)
         else:
             self.P[p + ".q"] = self._pack_conv(sd[p + ".q_proj.weight"], True)
-            self.P[p + ".kv"] = self._pack_conv(torch.cat([sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0), True)
+        self.P[p + ".kv"] = self._pack_conv(torch.cat([sd[p + ".k_proj.weight"], sd[p + ".v_proj.weight"]], 0), True)
+        self.P[p + ".q1"] = self._pack_conv(sd[p + ".q_proj.weight"])      # single-term copy for the fused tail's own q projection
         self.P[p + ".merge"] = self._pack_conv(sd[p + ".merge.weight"])
         self.P[p + ".mlp0"] = self._pack_conv(sd[p + ".mlp.0.weight"])
         self.P[p + ".mlp2"] = self._pack_conv(sd[p + ".mlp.2.weight"])
@@ -438,11 +440,16 @@ class Engine:
         d = D // heads
         x = xb.slice(0, D)
         qb = self._act(plan, f"{tag}.qkv", rows_q, 3 * D)
-        if src is None:       # self attention: one GEMM for q|k|v
+        tail_q = self.half and self.tail_q        # the fused tail projects q for its own rows: no q GEMM, no q tensor
+        if src is None and tail_q:
+            self._lin(p + ".kv", x, qb.slice(D, 2 * D), rows_q)
+            kA, vA = qb.slice(D, D), qb.slice(2 * D, D)
+        elif src is None:     # self attention: one GEMM for q|k|v
             self._lin(p + ".qkv", x, qb, rows_q)
             kA, vA = qb.slice(D, D), qb.slice(2 * D, D)
         else:
-            self._lin(p + ".q", x, qb.slice(0, D), rows_q)
+            if not tail_q:
+                self._lin(p + ".q", x, qb.slice(0, D), rows_q)
             kvb = self._act(plan, f"{tag}.kvsrc", rows_s, 2 * D)
             self._lin(p + ".kv", src, kvb, rows_s)
             kA, vA = kvb.slice(0, D), kvb.slice(D, D)
@@ -455,7 +462,8 @@ class Engine:
                            kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
         if self.half:
             # apply + merge + norm1 + mlp + norm2 + residual in one kernel: the intermediates stay in LDS
-            ops.loftr_tail(qb.slice(0, D), kv, ks, x, out, self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
+            ops.loftr_tail(None if tail_q else qb.slice(0, D), kv, ks, x, out, self.P[p + ".q1"] if tail_q else None,
+                           self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
                            (self.P[p + ".norm1.g"], self.P[p + ".norm1.b"]), (self.P[p + ".norm2.g"], self.P[p + ".norm2.b"]),
                            apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"], kvmode["v_length"], heads)
             return

@@ -47,7 +47,7 @@ SIGNATURES = {
     "cfp_attn_kv_ws_floats": (_sz, [_i] * 7),
     "cfp_attn_kv_reduce": (_i, [_p, _i, _p, _i, _p, _p, _p] + [_i] * 10 + [_f, _i, _i, _i, _p]),
     "cfp_attn_apply": (_i, [_p, _i, _p, _p, _p, _i] + [_i] * 9 + [_f, _f, _i, _i, _i, _p]),
-    "cfp_loftr_tail": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 5 + [_f, _f, _i, _i, _i, _p]),
+    "cfp_loftr_tail": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 5 + [_f, _f, _i, _i, _i, _p]),
     "cfp_resize_bilinear": (_i, [_p, _i] + [_i] * 6 + [_p, _i] + [_i] * 6 + [_p] + [_i] * 7 + [_p]),
     "cfp_add_rowtable": (_i, [_p, _i, _p, _p, _i] + [_i] * 8 + [_p]),
     "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),

@@ -303,11 +303,16 @@ def attn_apply(q: Act, kv, ksum, out: Act, NB, Hq, Wq, qth, qtw, excl, v_length,
              NB, Hq, Wq, qth, qtw, ey0, ey1, ex0, ex1, float(v_length), float(eps), heads, d, q.dt, _s())
 
 
-def loftr_tail(q: Act, kv, ksum, x: Act, out: Act, w_merge, w_mlp0, w_mlp2, ln1, ln2, NB, Hq, Wq, qth, qtw, v_length, heads,
-               eps=1e-6, ln_eps=1e-5):
+def loftr_tail(q: Optional[Act], kv, ksum, x: Act, out: Act, w_q, w_merge, w_mlp0, w_mlp2, ln1, ln2, NB, Hq, Wq, qth, qtw, v_length,
+               heads, eps=1e-6, ln_eps=1e-5):
+    """`q` given: the projected queries; `q` None and `w_q` [D, D] given: the kernel projects q = x @ w_q^T for its own rows."""
     D = x.C
-    assert q.C == D and out.C == D and w_merge.shape == (D, D) and w_mlp0.shape == (2 * D, 2 * D) and w_mlp2.shape == (D, 2 * D)
-    hip.call("cfp_loftr_tail", q.ptr, q.ld, kv.data_ptr(), ksum.data_ptr(), x.ptr, x.ld, out.ptr, out.ld, w_merge.data_ptr(),
+    assert (q is None) != (w_q is None), "loftr_tail: give either q or w_q"
+    assert out.C == D and w_merge.shape == (D, D) and w_mlp0.shape == (2 * D, 2 * D) and w_mlp2.shape == (D, 2 * D)
+    assert q is None or q.C == D
+    assert w_q is None or w_q.shape == (D, D)
+    hip.call("cfp_loftr_tail", q.ptr if q is not None else None, q.ld if q is not None else 0, kv.data_ptr(), ksum.data_ptr(), x.ptr, x.ld,
+             out.ptr, out.ld, w_q.data_ptr() if w_q is not None else None, w_merge.data_ptr(),
              w_mlp0.data_ptr(), w_mlp2.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr(),
              float(ln_eps), NB, Hq, Wq, qth, qtw, float(v_length), float(eps), heads, D, x.dt, _s())
 

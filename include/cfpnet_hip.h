@@ -217,10 +217,11 @@ int cfp_attn_apply(const void* q, int q_ld, const float* kv, const float* ksum, 
  *   out = LayerNorm(h @ w_mlp2^T; ln2) + x                              transformer.py:67-71
  * q, x, out: [NB*Hq*Wq rows] with pitches q_ld / x_ld / out_ld; the query -> key-group map is that of
  * cfp_attn_apply (g = (b, y / qth, x / qtw)); no exclusion rectangle.  w_merge [D][D], w_mlp0 [2D][2D],
- * w_mlp2 [D][2D], all K-contiguous bf16.  Intermediates stay in LDS; rounding points (bf16 after the
+ * w_mlp2 [D][2D], all K-contiguous bf16.  w_q (optional, [D][D]): when given, q may be NULL and the kernel computes
+ * q = x @ w_q^T (transformer.py:45) for its own rows, rounded to the storage type like a stored q.  Intermediates stay in LDS; rounding points (bf16 after the
  * apply, before each LayerNorm and after the ReLU) are those of the unfused sequence. */
 int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
-                   void* out, int out_ld, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
+                   void* out, int out_ld, const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
                    const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
                    int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
                    int dtype, cfp_stream_t stream);

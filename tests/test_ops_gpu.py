@@ -512,11 +512,21 @@ def test_loftr_tail_fused_vs_reference(D, heads, NB, Hq, Wq, qth, qtw, dtype):
     kvd, ksd = kvf.contiguous().to(DEV), ksf.contiguous().to(DEV)
     wmd, w0d, w2d = (t.to(dtype).to(DEV) for t in (wm, w0, w2))
     ln1, ln2 = (g1.to(DEV), b1.to(DEV)), (g2.to(DEV), b2.to(DEV))
-    ops.loftr_tail(qa, kvd, ksd, xa, out, wmd, w0d, w2d, ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
+    ops.loftr_tail(qa, kvd, ksd, xa, out, None, wmd, w0d, w2d, ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
     torch.cuda.synchronize()
     got = out.torch().float().cpu()
     close(got, ref, dtype, f"loftr tail D={D} heads={heads}")
     assert float(out.buf[:, :D].abs().max()) == 0
+    # the kernel projecting q itself (q = x @ wq^T, transformer.py:45) == the same kernel fed the stored projection
+    wq = q(rnd(D, D, seed=12, scale=1.0 / math.sqrt(D)), dtype)
+    wqd = wq.to(dtype).to(DEV)
+    qp = ops.new_act(rows, D, dtype, DEV)
+    ops.linear(xa, wqd, None, None, qp, rows)
+    o_a, o_b = ops.new_act(rows, D, dtype, DEV), ops.new_act(rows, D, dtype, DEV)
+    ops.loftr_tail(qp, kvd, ksd, xa, o_a, None, wmd, w0d, w2d, ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
+    ops.loftr_tail(None, kvd, ksd, xa, o_b, wqd, wmd, w0d, w2d, ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
+    torch.cuda.synchronize()
+    close(o_b.torch().float().cpu(), o_a.torch().float().cpu(), dtype, f"loftr tail own q D={D} heads={heads}")
     # unfused HIP chain
     msg_a = ops.new_act(rows, D, dtype, DEV)
     ops.attn_apply(qa, kvd, ksd, msg_a, NB, Hq, Wq, qth, qtw, (0, 0, 0, 0), S, heads, d)
