@@ -11,9 +11,10 @@ layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 inp = synthetic.to_device(synthetic.make_inputs(B), "cuda:0")
-for dt in (torch.float32, torch.float16, torch.bfloat16):
+for dt in ((torch.bfloat16,) if os.environ.get('MODE_BENCH_BF16_ONLY') else (torch.float32, torch.float16, torch.bfloat16)):
     eng = Engine(sd, layer_names=layers, dtype=dt)
-    (kind, n), times = eng.capture_best(inp, reps=12)
+    mx = int(os.environ.get("MODE_BENCH_MAX_INFLIGHT", "4"))
+    (kind, n), times = eng.capture_best(inp, reps=12, candidates=(("lanes", 1),) + tuple(("inflight", k) for k in range(2, mx + 1)))
     best = min(times.values())
     print(json.dumps({"dtype": str(dt), "batch": B, "choice": f"{kind}:{n}", "ms_per_step": times,
                       "maps_per_s_best": B / best * 1e3, "maps_per_s_single_graph": B / times["lanes:1"] * 1e3}))
