@@ -56,21 +56,34 @@ __global__ __launch_bounds__(64) void kv_reduce_kernel(KvP p) {
 #pragma unroll
     for (int j = 0; j < D; ++j) acc[i][j] = 0.f;
   }
-  for (int s = s_begin + kl; s < s_end; s += KL) {
-    const int yy = y0 + s / rw, xx = x0 + s % rw;
-    const long long row = ((long long)b * p.Hk + yy) * p.Wk + xx;
-    const T* kp = K + row * p.k_ld + h * D + ip * IC;
-    const T* vp = V + row * p.v_ld + h * D;
-    float kf[IC], vf[D];
+  // KU keys per iteration, their loads issued together: the loop is a chain of memory round trips (one per key before), not FMAs
+  constexpr int KU = 4;
+  for (int s0 = s_begin + kl; s0 < s_end; s0 += KL * KU) {
+    float kf[KU][IC], vf[KU][D];
 #pragma unroll
-    for (int i = 0; i < IC; ++i) kf[i] = elu1(to_f32<T>(kp[i]));
+    for (int u = 0; u < KU; ++u) {
+      const int s = min(s0 + u * KL, s_end - 1);
+      const int yy = y0 + s / rw, xx = x0 + s % rw;
+      const long long row = ((long long)b * p.Hk + yy) * p.Wk + xx;
+      const T* kp = K + row * p.k_ld + h * D + ip * IC;
+      const T* vp = V + row * p.v_ld + h * D;
 #pragma unroll
-    for (int j = 0; j < D; ++j) vf[j] = to_f32<T>(vp[j]) * p.inv_len;
+      for (int i = 0; i < IC; ++i) kf[u][i] = to_f32<T>(kp[i]);
 #pragma unroll
-    for (int i = 0; i < IC; ++i) {
-      ks[i] += kf[i];
+      for (int j = 0; j < D; ++j) vf[u][j] = to_f32<T>(vp[j]);
+    }
 #pragma unroll
-      for (int j = 0; j < D; ++j) acc[i][j] = fmaf(kf[i], vf[j], acc[i][j]);
+    for (int u = 0; u < KU; ++u) {
+      if (s0 + u * KL >= s_end) continue;              // same order of accumulation per lane as the one-key loop
+#pragma unroll
+      for (int j = 0; j < D; ++j) vf[u][j] *= p.inv_len;
+#pragma unroll
+      for (int i = 0; i < IC; ++i) {
+        const float kk = elu1(kf[u][i]);
+        ks[i] += kk;
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc[i][j] = fmaf(kk, vf[u][j], acc[i][j]);
+      }
     }
   }
   // butterfly over the key lanes (lanes with equal ip)

@@ -253,6 +253,10 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
       u32x4 v = *reinterpret_cast<const u32x4*>(in + ((long long)(b * H + hic) * W + wic) * in_ld + c0);
       *reinterpret_cast<u32x4*>(tile + px * PP + cvl * 16) = ok ? v : zero4;
     }
+    // (This loop compiles to load -> s_waitcnt vmcnt(0) -> ds_write per iteration, ~11 serial round trips per thread.  Issuing eight
+    // loads before the first wait, with add-and-wrap indices instead of the divisions, was measured in round 2: the load phase stays at
+    // 5.9-6.1 us (in-kernel stamps) and the kernel at 13-22 us -- the phase is bound by the 2.3x fetch amplification of 128-byte pieces at
+    // a 1.3-2.8 KB stride, not by the number of loads a thread has in flight.  Not adopted.)
   }
   {
     const int nmain_ = Wo >> 4, tw_ = Wo & 15;

@@ -26,7 +26,17 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
     if (rr < rl) {
-      for (int r = r_begin + rr; r < r_end; r += rl) {
+      int r = r_begin + rr;
+      for (; r + 3 * rl < r_end; r += 4 * rl) {          // four rows in flight (one per iteration = one memory round trip per row)
+        float v[4][VE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec<T>::load(in + ((long long)b * HW + r + u * rl) * in_ld + (cv0 + cv) * VE, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < VE; ++e) acc[e] += v[u][e];
+      }
+      for (; r < r_end; r += rl) {
         float v[VE];
         Vec<T>::load(in + ((long long)b * HW + r) * in_ld + (cv0 + cv) * VE, v);
 #pragma unroll
@@ -425,21 +435,30 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeP p) {
     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
     float tap[4][VE];
     const int ys[2] = {y0, y1}, xs[2] = {x0, x1};
+    // validity first (the four zone flags are requested together), then four UNCONDITIONAL loads from clamped addresses and a select on
+    // the values: `if (ok) load` compiled to one branch + memory round trip per tap, up to eight in a row with the zone flags
+    bool ok[4]; unsigned char zv[4]; const T* sp[4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int ry = ys[a], rx = xs[c];              // rectangle coordinates
         const int gy = p.sy0 + ry, gx = p.sx0 + rx;    // source-map coordinates
-        float* tp = tap[a * 2 + c];
-        bool ok = gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws;
-        if (ok && p.zone_valid) ok = p.zone_valid[(long long)b * p.zn * p.zn + (ry / p.p1) * p.zn + rx / p.p2] != 0;
-        if (ok) Vec<T>::load(src + ((long long)(b * p.Hs + gy) * p.Ws + gx) * p.src_ld + cv * VE, tp);
-        else {
-#pragma unroll
-          for (int e = 0; e < VE; ++e) tp[e] = 0.f;
-        }
+        ok[a * 2 + c] = gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws;
+        const int gyc = min(max(gy, 0), p.Hs - 1), gxc = min(max(gx, 0), p.Ws - 1);
+        sp[a * 2 + c] = src + ((long long)(b * p.Hs + gyc) * p.Ws + gxc) * p.src_ld + cv * VE;
+        zv[a * 2 + c] = 1;
+        if (p.zone_valid)                              // uniform
+          zv[a * 2 + c] = p.zone_valid[(long long)b * p.zn * p.zn + min(max(ry / p.p1, 0), p.zn - 1) * p.zn + min(max(rx / p.p2, 0), p.zn - 1)];
       }
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) Vec<T>::load(sp[t4], tap[t4]);
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const bool keep = ok[t4] && zv[t4] != 0;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) tap[t4][e] = keep ? tap[t4][e] : 0.f;
+    }
     float o[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e)

@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfpnet_hip.so")
+LIB_PATH = os.environ.get("CFP_HIP_LIB") or os.path.join(_HERE, "libcfpnet_hip.so")      # CFP_HIP_LIB: A/B runs against another build
 
 F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
