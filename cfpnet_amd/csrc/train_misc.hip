@@ -99,12 +99,21 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ 
   float s[VE];
 #pragma unroll
   for (int e = 0; e < VE; ++e) s[e] = 0.f;
-  for (int r = rl; r < HW; r += lanes) {
-    float a[VE], b[VE];
-    Vec<T>::load(x + (base + r) * x_ld + cc, a);
-    Vec<T>::load(y + (base + r) * y_ld + cc, b);
+  constexpr int U = 4;                       // four rows in flight per thread (one per iteration was a chain of ~HW / 8 round trips)
+  for (int r = rl; r < HW; r += lanes * U) {
+    float a[U][VE], b[U][VE];
 #pragma unroll
-    for (int e = 0; e < VE; ++e) s[e] = fmaf(a[e], b[e], s[e]);
+    for (int u = 0; u < U; ++u) {
+      const int rr = min(r + u * lanes, HW - 1);
+      Vec<T>::load(x + (base + rr) * x_ld + cc, a[u]);
+      Vec<T>::load(y + (base + rr) * y_ld + cc, b[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r + u * lanes >= HW) continue;
+#pragma unroll
+      for (int e = 0; e < VE; ++e) s[e] = fmaf(a[u][e], b[u][e], s[e]);
+    }
   }
 #pragma unroll
   for (int e = 0; e < VE; ++e) red[tid][e] = s[e];
