@@ -414,6 +414,36 @@ class Tape:
         self.bw.append(bw)
         return y
 
+    def se_block(self, x: V, w1: P, b1: P, w2: P, b2: P, B, HW) -> V:
+        """y = x * sigmoid(W2 silu(W1 mean_HW(x) + b1) + b2)  (timm SqueezeExcite) as 3 launches forward and 4 backward: channel sums,
+        the gate kernel (cfp_se_train_fwd), the broadcast multiply; backward: channel dot, the two kernels of cfp_se_train_bwd, one
+        broadcast multiply-add.  Same arithmetic as channel_mean -> linear -> act -> linear -> act -> mul_bcast on this tape."""
+        assert w1.t.dtype == torch.float32 and w2.t.dtype == torch.float32
+        ns = max(1, min(64, HW // 16, -(-1024 // B)))
+        part = torch.empty(B * ns, x.C, dtype=torch.float32, device=self.dev)
+        ops.channel_sum(_act(x.t), part, B, HW, ns)
+        mean, z1, gate = train_ops.se_train_fwd(part, ns, 1.0 / HW, w1.t, b1.t, w2.t, b2.t, B)
+        y = V(train_ops.bcast_fma(x.t, gate, None, B, HW))
+
+        def bw():
+            if y.g is None:
+                return
+            dgate = train_ops.channel_dot(x.t, y.g, B, HW)
+            ps = (w1, b1, w2, b2)
+            direct = [self._direct(p) for p in ps]
+            if all(d is not None for d in direct):
+                res = train_ops.se_train_bwd(dgate, gate, z1, mean, w1.t, w2.t, 1.0 / HW,
+                                             outs=(direct[0].view(w1.t.shape), direct[1][:b1.t.numel()], direct[2].view(w2.t.shape), direct[3][:b2.t.numel()]))
+                for p, d in zip(ps, direct):
+                    p.g = d
+            else:
+                res = train_ops.se_train_bwd(dgate, gate, z1, mean, w1.t, w2.t, 1.0 / HW)
+                for p, g in zip(ps, res[:4]):
+                    self.pgrad(p, lambda out, beta, g=g: train_ops.into(g, out, beta))
+            self.acc(x, train_ops.bcast_fma(y.g, gate, res[4], B, HW))
+        self.bw.append(bw)
+        return y
+
     def row_normalize(self, x: V) -> V:
         y = V(torch.empty_like(x.t))
         hip.call("cfp_row_normalize", x.t.data_ptr(), None, y.t.data_ptr(), x.rows, x.C, hip.current_stream())

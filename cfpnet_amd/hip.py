@@ -79,6 +79,9 @@ SIGNATURES = {
     "cfp_layernorm_bwd": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _i, _p, _p, C.c_longlong, _i, _i, _p, _sz, _p]),
     "cfp_axpby": (_i, [_p, _i, _p, _i, _f, _f, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_rowtable_grad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "cfp_se_train_ws_floats": (_sz, [_i, _i, _i]),
+    "cfp_se_train_fwd": (_i, [_p, _i, _f] + [_p] * 7 + [_i, _i, _i, _p]),
+    "cfp_se_train_bwd": (_i, [_p] * 12 + [_f, _f, _i, _i, _i, _p]),
     "cfp_channel_dot": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_bcast_fma": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv3x3_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 11 + [_p]),

@@ -7,6 +7,8 @@ list.  Float32 storage (the parity mode); there is no CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -62,6 +64,7 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self.se_fused = os.environ.get("CFP_SE_FUSED_TRAIN", "1") != "0"      # squeeze-excite gate + its backward as three kernels (csrc/se_train.hip)
         self.side_stream: Optional[torch.cuda.Stream] = None      # set by the trainer: parameter gradients beside the dY -> dX chain
         self.flipped: Dict[str, torch.Tensor] = {}        # bound mode: name -> flipped conv weight, refreshed by the trainer every step
         self._bound = None                                # (FlatParams in kernel layouts, 16-bit shadow) once `bind` was called
@@ -194,12 +197,17 @@ class TrainNet:
                     x = t.dw3x3(x, self._dw3(q + ".conv_dw.weight"), B, H, W, s, same_pad(H, 3, s)[0], same_pad(W, 3, s)[0], Ho, Wo)
                     H, W = Ho, Wo
                     x = self._bn(t, x, q + ".bn2", hip.ACT_SILU, ENC_EPS, ENC_MOM)
-                    g = t.channel_mean(x, B, H * W)
                     R = self.sd[q + ".se.conv_reduce.weight"].shape[0]
                     Rp = -(-R // 4) * 4                               # zero-padded hidden units: SiLU(0) = 0 feeds zero columns
-                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_reduce.weight", cout_pad=Rp, f32=True), self._vec(q + ".se.conv_reduce.bias", Rp)), hip.ACT_SILU)
-                    g = t.act(t.linear(g, self._conv_w(q + ".se.conv_expand.weight", cin_pad=Rp, f32=True), self._vec(q + ".se.conv_expand.bias")), hip.ACT_SIGMOID)
-                    x = t.mul_bcast(x, g, B, H * W)
+                    w1, b1 = self._conv_w(q + ".se.conv_reduce.weight", cout_pad=Rp, f32=True), self._vec(q + ".se.conv_reduce.bias", Rp)
+                    w2, b2 = self._conv_w(q + ".se.conv_expand.weight", cin_pad=Rp, f32=True), self._vec(q + ".se.conv_expand.bias")
+                    if self.se_fused and Rp <= 64 and x.C <= 2048 and x.C % 4 == 0 and B <= 64:
+                        x = t.se_block(x, w1, b1, w2, b2, B, H * W)    # 3 + 4 launches instead of ~8 + ~16
+                    else:
+                        g = t.channel_mean(x, B, H * W)
+                        g = t.act(t.linear(g, w1, b1), hip.ACT_SILU)
+                        g = t.act(t.linear(g, w2, b2), hip.ACT_SIGMOID)
+                        x = t.mul_bcast(x, g, B, H * W)
                     x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
                     x = self._bn(t, x, q + ".bn3", hip.ACT_NONE, ENC_EPS, ENC_MOM)
                 if s == 1 and inp.C == x.C:

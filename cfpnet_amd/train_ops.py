@@ -385,6 +385,34 @@ def channel_dot(x2d, y2d, B, HW):
     return out
 
 
+def se_train_fwd(part, ns, inv_hw, w1, b1, w2, b2, B):
+    """-> (mean [B, C], z1 [B, Rp], gate [B, C]) float32 from the channel-sum partials [B * ns, C] (cfp_se_train_fwd)."""
+    from . import hip
+    C, Rp = w1.shape[1], w1.shape[0]
+    f = lambda n: torch.empty(B, n, dtype=torch.float32, device=part.device)
+    mean, z1, gate = f(C), f(Rp), f(C)
+    hip.call("cfp_se_train_fwd", part.data_ptr(), ns, float(inv_hw), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), mean.data_ptr(),
+             z1.data_ptr(), gate.data_ptr(), B, C, Rp, hip.current_stream())
+    return mean, z1, gate
+
+
+def se_train_bwd(dgate, gate, z1, mean, w1, w2, inv_hw, outs=None):
+    """-> (dW1, db1, dW2, db2, add [B, C]); `outs`: four float32 tensors the parameter gradients are written into (beta = 0)."""
+    from . import hip
+    B, C = gate.shape
+    Rp = w1.shape[0]
+    dev = gate.device
+    if outs is None:
+        outs = (torch.empty(Rp, C, dtype=torch.float32, device=dev), torch.empty(Rp, dtype=torch.float32, device=dev),
+                torch.empty(C, Rp, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev))
+    add = torch.empty(B, C, dtype=torch.float32, device=dev)
+    ws = torch.empty(int(hip.load().cfp_se_train_ws_floats(B, C, Rp)), dtype=torch.float32, device=dev)
+    hip.call("cfp_se_train_bwd", dgate.data_ptr(), gate.data_ptr(), z1.data_ptr(), mean.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+             outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), add.data_ptr(), ws.data_ptr(), float(inv_hw), 0.0,
+             B, C, Rp, hip.current_stream())
+    return outs + (add,)
+
+
 def bcast_fma(dy2d, gate, add, B, HW, dx=None):
     from . import hip, ops
     dx = torch.empty_like(dy2d) if dx is None else dx

@@ -449,6 +449,19 @@ int cfp_axpby(const void* x, int x_ld, const void* y, int y_ld, float a, float b
 /* Gradient of `x + PE[oy:oy+H, ox:ox+W]` (fusion.py:87-97) w.r.t. the learned table: dtable[...] = beta*dtable + sum_b dx. */
 int cfp_rowtable_grad(const void* dx, int ld, float* dtable, int B, int H, int W, int C, int Wt, int oy, int ox, float beta,
                       int dtype, cfp_stream_t stream);
+/* Squeeze-excite gate in the training step (timm SqueezeExcite of the encoder's inverted-residual blocks, encoder.py:57-69), float32:
+ *   forward : mean[b,c] = sum_s partial[b,s,c] * inv_hw;  z1 = W1 mean + b1;  gate = sigmoid(W2 silu(z1) + b2)      (one launch)
+ *   backward: from dgate[b,c] = sum_hw dy * x (cfp_channel_dot): dW1, db1, dW2, db2 (out = beta * out + grad) and
+ *             add[b,c] = d(loss)/d(mean) * inv_hw, the term cfp_bcast_fma adds to dy * gate                          (two launches)
+ * W1 [Rp][C], b1 [Rp], W2 [C][Rp], b2 [C]; Rp = hidden width padded to a multiple of 4 with zero rows / columns, <= 64; C <= 2048;
+ * B <= 64 in the backward.  mean [B][C], z1 [B][Rp], gate [B][C] are kept by the caller between the two calls;
+ * ws: cfp_se_train_ws_floats(B, C, Rp) floats. */
+size_t cfp_se_train_ws_floats(int B, int C, int Rp);
+int cfp_se_train_fwd(const float* partial, int nsplit, float inv_hw, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* mean, float* z1, float* gate, int B, int C, int Rp, cfp_stream_t stream);
+int cfp_se_train_bwd(const float* dgate, const float* gate, const float* z1, const float* mean, const float* w1, const float* w2,
+                     float* dw1, float* db1, float* dw2, float* db2, float* add, float* ws, float inv_hw, float beta, int B, int C,
+                     int Rp, cfp_stream_t stream);
 /* out[b][c] = sum over the HW rows of image b of x*y: gradient of the squeeze-excite gate (sum dy * x). */
 int cfp_channel_dot(const void* x, int x_ld, const void* y, int y_ld, float* out, int B, int HW, int C, int dtype, cfp_stream_t stream);
 /* dx = dy * gate[b][c] + add[b][c] (add may be NULL): squeeze-excite backward w.r.t. the gated activation. */

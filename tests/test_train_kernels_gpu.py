@@ -393,3 +393,42 @@ def test_tape_conv_with_kernel_equal_stride(B, H, W, Cin, Cout, k, dtype):
     want_dw = w.grad.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin)
     assert float((wp.g.cpu() - want_dw).abs().max()) <= (3e-5 + (2e-2 if dtype != torch.float32 else 0)) * float(want_dw.abs().max())
     assert float((bp.g.cpu() - b.grad).abs().max()) <= 3e-5 * float(b.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C,R", [(16, 26 * 34, 816, 34), (16, 13 * 17, 1392, 58), (3, 50, 96, 4), (2, 17, 2048, 64), (5, 300, 384, 16)])
+def test_tape_squeeze_excite_block_fused(B, HW, C, R, dtype):
+    """Tape.se_block (channel sums + cfp_se_train_fwd + broadcast multiply; backward: channel dot + cfp_se_train_bwd + one multiply-add)
+    against torch autograd of timm's SqueezeExcite, x * sigmoid(W2 silu(W1 mean(x) + b1) + b2), with the hidden width padded to a
+    multiple of 4 the way train_model does (zero rows / columns: their gradients must come out zero)."""
+    from cfpnet_amd.autograd_hip import P, Tape, V
+    Rp = -(-R // 4) * 4
+    x = (rnd(B, HW, C, seed=1) * 1.3 + 0.2).to(dtype).float().requires_grad_(True)
+    w1 = rnd(R, C, seed=2, scale=1.0 / math.sqrt(C)).requires_grad_(True)
+    b1 = rnd(R, seed=3, scale=0.3).requires_grad_(True)
+    w2 = rnd(C, R, seed=4, scale=1.0 / math.sqrt(R)).requires_grad_(True)
+    b2 = rnd(C, seed=5, scale=0.3).requires_grad_(True)
+    gate = torch.sigmoid(F.silu(x.mean(1) @ w1.t() + b1) @ w2.t() + b2)
+    y = x * gate[:, None, :]
+    dy = rnd(B, HW, C, seed=6).to(dtype).float()
+    y.backward(dy)
+
+    t = Tape(DEV, dtype)
+    w1p = torch.zeros(Rp, C); w1p[:R] = w1.detach()
+    b1p = torch.zeros(Rp); b1p[:R] = b1.detach()
+    w2p = torch.zeros(C, Rp); w2p[:, :R] = w2.detach()
+    ps = [P("w1", w1p.to(DEV), lambda g: g), P("b1", b1p.to(DEV), lambda g: g), P("w2", w2p.to(DEV), lambda g: g), P("b2", b2.detach().to(DEV), lambda g: g)]
+    xv = V(x.detach().reshape(B * HW, C).to(dtype).to(DEV))
+    yv = t.se_block(xv, *ps, B, HW)
+    yv.g = dy.reshape(B * HW, C).to(dtype).to(DEV)
+    t.backward()
+    torch.cuda.synchronize()
+    tol = OUT_TOL[dtype]
+    assert float((yv.t.float().cpu().reshape(B, HW, C) - y.detach()).abs().max()) <= tol * float(y.detach().abs().max())
+    assert float((xv.g.float().cpu().reshape(B, HW, C) - x.grad).abs().max()) <= (tol + 2e-5) * float(x.grad.abs().max())
+    # parameter gradients: float32 sums of products of 16-bit-rounded inputs -> tight bounds in every mode
+    pt = 2e-4 if dtype == torch.float32 else 2e-2
+    for got, want in ((ps[0].g.cpu()[:R], w1.grad), (ps[1].g.cpu()[:R], b1.grad), (ps[2].g.cpu()[:, :R], w2.grad), (ps[3].g.cpu(), b2.grad)):
+        assert float((got - want).abs().max()) <= pt * float(want.abs().max()) + 1e-6
+    if Rp > R:
+        assert float(ps[0].g[R:].abs().max()) == 0 and float(ps[1].g[R:].abs().max()) == 0 and float(ps[2].g[:, R:].abs().max()) == 0
