@@ -305,13 +305,17 @@ class Tape:
         Ca, Cb = a.C, b.C
         y = V(self.new(a.rows, Ca + Cb, a.t.dtype))
         full = ops.Act(y.t, 0, Ca + Cb)
-        ops.copy_rows(_act(a.t), full.slice(0, Ca), a.rows)
-        ops.copy_rows(_act(b.t), full.slice(Ca, Cb), a.rows)
+        ops.copy_rows2(_act(a.t), full.slice(0, Ca), _act(b.t), full.slice(Ca, Cb), a.rows)
 
         def bw():
             if y.g is None:
                 return
             gf = ops.Act(y.g, 0, Ca + Cb)
+            if a.needs_grad and b.needs_grad:       # both halves in one launch
+                ga, gb = self.new(a.rows, Ca, y.g.dtype), self.new(b.rows, Cb, y.g.dtype)
+                ops.copy_rows2(gf.slice(0, Ca), _act(ga), gf.slice(Ca, Cb), _act(gb), a.rows)
+                self.acc(a, ga); self.acc(b, gb)
+                return
             for v, c0, c in ((a, 0, Ca), (b, Ca, Cb)):
                 if v.needs_grad:
                     g = self.new(v.rows, c, y.g.dtype)

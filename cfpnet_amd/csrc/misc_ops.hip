@@ -512,6 +512,24 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ in
   }
 }
 
+// two independent strided row copies in one launch (blockIdx.y picks one): a channel concatenation, or its backward split
+struct Copy2P { const void* in[2]; void* out[2]; int in_ld[2], out_ld[2]; FastDiv fcv[2]; };
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows2_kernel(Copy2P p, long long rows) {
+  constexpr int VE = Vec<T>::N;
+  const int k = blockIdx.y;
+  const T* __restrict__ in = reinterpret_cast<const T*>(p.in[k]);
+  T* __restrict__ out = reinterpret_cast<T*>(p.out[k]);
+  const int in_ld = p.in_ld[k], out_ld = p.out_ld[k];
+  const FastDiv fcv = p.fcv[k];
+  const unsigned total = (unsigned)(rows * fcv.d);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned ru, cvu;
+    fd_rowcol(i, fcv, ru, cvu);
+    *reinterpret_cast<u32x4*>(out + (long long)ru * out_ld + cvu * VE) = *reinterpret_cast<const u32x4*>(in + (long long)ru * in_ld + cvu * VE);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restrict__ rgb, T* __restrict__ out, int HW, long long total) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -758,6 +776,28 @@ extern "C" int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, i
   else
     hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, (long long)rows, C, fcv);
   return cfp_check_launch("cfp_copy_rows");
+}
+
+extern "C" int cfp_copy_rows2(const void* in0, int in0_ld, void* out0, int out0_ld, int C0, const void* in1, int in1_ld, void* out1, int out1_ld,
+                              int C1, int rows, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_copy_rows2");
+  const int ve = vec_elems(dtype);
+  CFP_REQUIRE(in0 && out0 && in1 && out1 && aligned16(in0) && aligned16(out0) && aligned16(in1) && aligned16(out1), CFP_EINVAL,
+              "cfp_copy_rows2: bad pointer");
+  CFP_REQUIRE(rows > 0 && C0 > 0 && C1 > 0 && C0 % ve == 0 && C1 % ve == 0 && in0_ld % ve == 0 && out0_ld % ve == 0 && in1_ld % ve == 0 &&
+                  out1_ld % ve == 0 && in0_ld >= C0 && out0_ld >= C0 && in1_ld >= C1 && out1_ld >= C1, CFP_ESHAPE, "cfp_copy_rows2: bad shape");
+  const long long total = (long long)rows * (std::max(C0, C1) / ve);
+  CFP_REQUIRE(total < (1ll << 31), CFP_ESHAPE, "cfp_copy_rows2: too many elements");
+  Copy2P p;
+  p.in[0] = in0; p.in[1] = in1; p.out[0] = out0; p.out[1] = out1;
+  p.in_ld[0] = in0_ld; p.in_ld[1] = in1_ld; p.out_ld[0] = out0_ld; p.out_ld[1] = out1_ld;
+  p.fcv[0] = make_fastdiv((unsigned)(C0 / ve)); p.fcv[1] = make_fastdiv((unsigned)(C1 / ve));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(ew_blocks(total), 2);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(copy_rows2_kernel<bf16_t>, grid, dim3(256), 0, s, p, (long long)rows);
+  else if (dtype == CFP_F16) hipLaunchKernelGGL(copy_rows2_kernel<f16_t>, grid, dim3(256), 0, s, p, (long long)rows);
+  else hipLaunchKernelGGL(copy_rows2_kernel<float>, grid, dim3(256), 0, s, p, (long long)rows);
+  return cfp_check_launch("cfp_copy_rows2");
 }
 
 extern "C" int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream) {

@@ -51,6 +51,7 @@ SIGNATURES = {
     "cfp_resize_bilinear": (_i, [_p, _i] + [_i] * 6 + [_p, _i] + [_i] * 6 + [_p] + [_i] * 7 + [_p]),
     "cfp_add_rowtable": (_i, [_p, _i, _p, _p, _i] + [_i] * 8 + [_p]),
     "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "cfp_copy_rows2": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_rgb_to_nhwc8": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "cfp_scalar_to_rows8": (_i, [_p, _p, _i, _i, _p]),
     "cfp_silog_ws_bytes": (_sz, [_i, _i, _i]),

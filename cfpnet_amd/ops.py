@@ -335,6 +335,12 @@ def copy_rows(x: Act, out: Act, rows):
     hip.call("cfp_copy_rows", x.ptr, x.ld, out.ptr, out.ld, rows, x.C, x.dt, _s())
 
 
+def copy_rows2(x0: Act, out0: Act, x1: Act, out1: Act, rows):
+    """Two strided row copies in one launch (concatenation / split)."""
+    assert x0.dt == x1.dt == out0.dt == out1.dt and out0.C == x0.C and out1.C == x1.C
+    hip.call("cfp_copy_rows2", x0.ptr, x0.ld, out0.ptr, out0.ld, x0.C, x1.ptr, x1.ld, out1.ptr, out1.ld, x1.C, rows, x0.dt, _s())
+
+
 def rgb_to_nhwc8(rgb: torch.Tensor, out: Act, B, H, W):
     assert rgb.dtype == torch.float32 and rgb.is_contiguous() and out.C == 8 and out.ld == 8
     hip.call("cfp_rgb_to_nhwc8", rgb.data_ptr(), out.ptr, B, H, W, out.dt, _s())

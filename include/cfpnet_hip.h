@@ -247,6 +247,9 @@ int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, i
 
 /* Strided row copy out[r, 0:C] = in[r, 0:C]. */
 int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, int C, int dtype, cfp_stream_t stream);
+/* Two such copies in one launch (a channel concatenation [a | b] -> out, or its backward split): copy k moves `rows` rows of Ck channels. */
+int cfp_copy_rows2(const void* in0, int in0_ld, void* out0, int out0_ld, int C0, const void* in1, int in1_ld, void* out1, int out1_ld,
+                   int C1, int rows, int dtype, cfp_stream_t stream);
 
 /* rgb f32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] (channels 3..7 zero) in `dtype`. */
 int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream);

@@ -432,3 +432,21 @@ def test_tape_squeeze_excite_block_fused(B, HW, C, R, dtype):
         assert float((got - want).abs().max()) <= pt * float(want.abs().max()) + 1e-6
     if Rp > R:
         assert float(ps[0].g[R:].abs().max()) == 0 and float(ps[1].g[R:].abs().max()) == 0 and float(ps[2].g[:, R:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,Ca,Cb", [(1000, 64, 40), (37, 256, 232), (5000, 8, 128)])
+def test_tape_concat_and_split(rows, Ca, Cb, dtype):
+    """Tape.concat: [a | b] in one launch (cfp_copy_rows2), its backward the two slices in one launch; exact copies."""
+    from cfpnet_amd.autograd_hip import Tape, V
+    a, b = rnd(rows, Ca, seed=1).to(dtype).to(DEV), rnd(rows, Cb, seed=2).to(dtype).to(DEV)
+    for need_b in (True, False):
+        t = Tape(DEV, dtype)
+        av, bv = V(a), V(b, needs_grad=need_b)
+        y = t.concat(av, bv)
+        g = rnd(rows, Ca + Cb, seed=3).to(dtype).to(DEV)
+        y.g = g
+        t.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(y.t, torch.cat([a, b], 1))
+        assert torch.equal(av.g, g[:, :Ca]) and (bv.g is None if not need_b else torch.equal(bv.g, g[:, Ca:]))
