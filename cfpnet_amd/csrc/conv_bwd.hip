@@ -158,46 +158,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgP p) {
 // 16-bit inputs on the 16-bit matrix cores (v_mfma_f32_16x16x32_bf16/_f16): the tiles are staged as they lie in memory
 // ([pixel row][channel]) and the operands -- which want the pixel axis along k -- are read with the hardware transpose
 // read ds_read_b64_tr_b16 (a 16-lane group fetches 4 rows x 16 columns and every lane receives one column of it).
-constexpr int W16M = 128;           // pixel rows per staging step (four k = 32 MFMA steps per barrier pair)
-constexpr int W16P = WB + 8;        // LDS row pitch in elements (144 B: 16-byte aligned rows, 2-way bank conflicts at worst)
+constexpr int W16M = 128;           // pixel rows per staging step of the 64 x 64 tile (four k = 32 MFMA steps per barrier pair)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // PW: pointwise stride-1 convolution / Linear (the majority of the layers): im2col row m IS input row m, no (b, ho, wo) split.
-template <typename H, bool PW>
+// TCO x TK: output tile (64 or 128 each).  With 64 x 64 tiles the big launches (the 3x3 convolutions at 1/2 and 1/4 scale: 2 - 9 * 10^5
+// pixel rows) are bound by L2 -> LDS traffic -- dY is re-read once per K tile, the im2col operand once per Cout tile: 8.4 GB for the
+// head's 128 -> 128 conv, 717 us = 15 % of the MFMA peak -- so those run 128-wide tiles (4x less operand traffic per FLOP, 16
+// accumulator tiles per wave); the ~200 small layers keep the 64 x 64 tile for its parallelism.
+template <typename H, bool PW, int TCO, int TK>
 __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
-  __shared__ __attribute__((aligned(16))) unsigned short sD[W16M * W16P];    // dY tile  [m][co]
-  __shared__ __attribute__((aligned(16))) unsigned short sX[W16M * W16P];    // im2col tile [m][k']
+  constexpr int MS = (TCO == 64 && TK == 64) ? W16M : 64;     // pixel rows per staging step
+  constexpr int PD = TCO + 8, PX = TK + 8;                    // LDS row pitches in elements (16-byte aligned rows, 2-way bank conflicts at worst)
+  __shared__ __attribute__((aligned(16))) unsigned short sD[MS * PD];    // dY tile  [m][co]
+  __shared__ __attribute__((aligned(16))) unsigned short sX[MS * PX];    // im2col tile [m][k']
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_k = (p.K + WB - 1) / WB;
+  const int tiles_k = (p.K + TK - 1) / TK;
   const int tile_co = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_co * tiles_k;
-  const int co0 = tile_co * WB, k0 = tile_k * WB;
+  const int co0 = tile_co * TCO, k0 = tile_k * TK;
   const int m_begin = blockIdx.y * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(p.x);
   const unsigned short* __restrict__ DY = reinterpret_cast<const unsigned short*>(p.dy);
-  constexpr int NV = W16M * (WB / 8) / 256;        // 16-byte vectors per thread and operand per step (2)
-  int s_row[NV], s_col[NV], x_kh[NV], x_kw[NV], x_ci[NV];
-  bool k_ok[NV], co_ok[NV];
+  constexpr int NVD = MS * (TCO / 8) / 256, NVX = MS * (TK / 8) / 256;      // 16-byte vectors per thread and step of each operand
+  int d_row[NVD], d_col[NVD], x_row[NVX], x_col[NVX], x_kh[NVX], x_kw[NVX], x_ci[NVX];
+  bool k_ok[NVX], co_ok[NVD];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
+  for (int i = 0; i < NVD; ++i) {
     const int q = tid + i * 256;
-    s_row[i] = q / (WB / 8);
-    s_col[i] = (q - s_row[i] * (WB / 8)) * 8;
-    const int kk = k0 + s_col[i];
+    d_row[i] = q / (TCO / 8);
+    d_col[i] = (q - d_row[i] * (TCO / 8)) * 8;
+    co_ok[i] = co0 + d_col[i] < p.Cout;
+  }
+#pragma unroll
+  for (int i = 0; i < NVX; ++i) {
+    const int q = tid + i * 256;
+    x_row[i] = q / (TK / 8);
+    x_col[i] = (q - x_row[i] * (TK / 8)) * 8;
+    const int kk = k0 + x_col[i];
     k_ok[i] = kk < p.K;
     const int tap = kk / p.Cin;
     x_ci[i] = kk - tap * p.Cin;
     x_kh[i] = tap / p.KW;
     x_kw[i] = tap - x_kh[i] * p.KW;
-    co_ok[i] = co0 + s_col[i] < p.Cout;
   }
   const int HoWo = p.Ho * p.Wo;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 rD[NV], rX[NV];
+  u32x4 rD[NVD], rX[NVX];
   auto fetch = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int m = m0 + s_row[i];
+    for (int i = 0; i < NVX; ++i) {
+      const int m = m0 + x_row[i];
       const bool m_ok = m < m_end;
       const int mm = m_ok ? m : m_begin;
       bool in_ok;
@@ -214,63 +225,69 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
         xrow = (long long)(b * p.H + hic) * p.W + wic;
       }
       const u32x4 vx = *reinterpret_cast<const u32x4*>(X + xrow * p.x_ld + (k_ok[i] ? x_ci[i] : 0));
-      const u32x4 vd = *reinterpret_cast<const u32x4*>(DY + (long long)mm * p.dy_ld + (co_ok[i] ? co0 + s_col[i] : 0));
       rX[i] = in_ok ? vx : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+      const int m = m0 + d_row[i];
+      const bool m_ok = m < m_end;
+      const int mm = m_ok ? m : m_begin;
+      const u32x4 vd = *reinterpret_cast<const u32x4*>(DY + (long long)mm * p.dy_ld + (co_ok[i] ? co0 + d_col[i] : 0));
       rD[i] = (m_ok && co_ok[i]) ? vd : zero4;
     }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      *reinterpret_cast<u32x4*>(&sX[s_row[i] * W16P + s_col[i]]) = rX[i];
-      *reinterpret_cast<u32x4*>(&sD[s_row[i] * W16P + s_col[i]]) = rD[i];
-    }
+    for (int i = 0; i < NVX; ++i) *reinterpret_cast<u32x4*>(&sX[x_row[i] * PX + x_col[i]]) = rX[i];
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) *reinterpret_cast<u32x4*>(&sD[d_row[i] * PD + d_col[i]]) = rD[i];
   };
-  const int qa = (wave >> 1) * 32, qb = (wave & 1) * 32;
+  constexpr int TI = TCO / 32, TJ = TK / 32;          // 16 x 16 accumulator tiles per wave along Cout / K'
+  const int qa = (wave >> 1) * (TCO / 2), qb = (wave & 1) * (TK / 2);
   const int g = lane >> 4, idx = lane & 15, tq = idx >> 2, tp = idx & 3;
   // this lane's address inside a 4-row x 16-column block (rows 8g .. of a k = 32 step): row tq, columns 4 tp .. 4 tp + 3
-  const int blk = (8 * g + tq) * W16P + 4 * tp;
+  const int blkD = (8 * g + tq) * PD + 4 * tp, blkX = (8 * g + tq) * PX + 4 * tp;
   auto tr = [&](const unsigned short* base) -> s16x4 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
   };
-  f32x4 acc[2][2];
+  f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (m_begin < m_end) fetch(m_begin);
-  for (int m0 = m_begin; m0 < m_end; m0 += W16M) {
+  for (int m0 = m_begin; m0 < m_end; m0 += MS) {
     __syncthreads();
     stash();
     __syncthreads();
-    if (m0 + W16M < m_end) fetch(m0 + W16M);
+    if (m0 + MS < m_end) fetch(m0 + MS);
 #pragma unroll
-    for (int ks = 0; ks < W16M / 32; ++ks) {
-      s16x8 a[2], bb[2];
+    for (int ks = 0; ks < MS / 32; ++ks) {
+      s16x8 a[TI], bb[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned short* base = sD + ks * 32 * W16P + blk + qa + i * 16;
-        const s16x4 lo = tr(base), hi = tr(base + 4 * W16P);
+      for (int i = 0; i < TI; ++i) {
+        const unsigned short* base = sD + ks * 32 * PD + blkD + qa + i * 16;
+        const s16x4 lo = tr(base), hi = tr(base + 4 * PD);
         a[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned short* base = sX + ks * 32 * W16P + blk + qb + j * 16;
-        const s16x4 lo = tr(base), hi = tr(base + 4 * W16P);
+      for (int j = 0; j < TJ; ++j) {
+        const unsigned short* base = sX + ks * 32 * PX + blkX + qb + j * 16;
+        const s16x4 lo = tr(base), hi = tr(base + 4 * PX);
         bb[j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<H>(a[i], bb[j], acc[i][j]);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = mfma16<H>(a[i], bb[j], acc[i][j]);
     }
   }
   const int fr = lane & 15, fk = lane >> 4;
   float* __restrict__ slab = p.slabs + (long long)blockIdx.y * p.Cout * p.K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + qa + i * 16 + fk * 4 + r, kk = k0 + qb + j * 16 + fr;
@@ -365,11 +382,33 @@ inline int wgrad_nsplit(int Cout, int K, int M) {
   return (int)ns;
 }
 
+// 16-bit launches with many pixel rows: 128-wide tiles along every axis that has them (see conv_wgrad16_kernel)
+struct WgPlan { int tco, tk, mstep, nsplit; };
+inline WgPlan wgrad_plan16(int Cout, int K, int M) {
+  static const bool big_off = [] { const char* e = getenv("CFP_WGRAD_BIG"); return e && e[0] == '0'; }();      // A/B switch
+  WgPlan pl{WB, WB, W16M, 0};
+  if (M >= 100000 && !big_off) {
+    if (Cout > 64) pl.tco = 128;
+    if (K > 64) pl.tk = 128;
+  }
+  if (pl.tco == WB && pl.tk == WB) { pl.nsplit = wgrad_nsplit(Cout, K, M); return pl; }
+  pl.mstep = 64;
+  const long long tiles = (long long)cdiv(Cout, pl.tco) * cdiv(K, pl.tk);
+  long long ns = (768 + tiles - 1) / tiles;
+  const long long max_ns = cdiv(M, 8 * pl.mstep);            // at least 512 rows per chunk
+  if (ns > max_ns) ns = max_ns;
+  if (ns > 1024) ns = 1024;
+  if (ns < 1) ns = 1;
+  pl.nsplit = (int)ns;
+  return pl;
+}
+
 }  // namespace
 
 extern "C" size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M) {
   if (Cout <= 0 || K <= 0 || M <= 0) return 0;
-  return (size_t)wgrad_nsplit(Cout, K, M) * Cout * K * sizeof(float);
+  const int ns = std::max(wgrad_nsplit(Cout, K, M), wgrad_plan16(Cout, K, M).nsplit);      // the dtype is not known here: the larger plan
+  return (size_t)ns * Cout * K * sizeof(float);
 }
 
 extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int Cin, int Cout,
@@ -393,19 +432,25 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.Ho = Ho; p.Wo = Wo; p.M = (int)M; p.K = (int)K;
   fastdiv_make((unsigned)(Ho * Wo), &p.mg_hw, &p.sh_hw);
   fastdiv_make((unsigned)Wo, &p.mg_w, &p.sh_w);
-  p.nsplit = wgrad_nsplit(Cout, (int)K, (int)M);
-  const int mstep = is16(dtype) ? W16M : WM;
+  const WgPlan pl = is16(dtype) ? wgrad_plan16(Cout, (int)K, (int)M) : WgPlan{WB, WB, WM, wgrad_nsplit(Cout, (int)K, (int)M)};
+  p.nsplit = pl.nsplit;
+  const int mstep = pl.mstep;
   p.rows_per_split = cdiv(cdiv(M, p.nsplit), mstep) * mstep;
   p.nsplit = cdiv(M, p.rows_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.nsplit == 1 && beta == 0.f) p.slabs = dw;            // a single slab IS the result: written in place, no second kernel
-  const dim3 grid(cdiv(Cout, WB) * cdiv(K, WB), p.nsplit);
+  const dim3 grid(cdiv(Cout, pl.tco) * cdiv(K, pl.tk), p.nsplit);
   const bool pw = KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W;
-  if (dtype == CFP_BF16 && pw) hipLaunchKernelGGL((conv_wgrad16_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
-  else if (dtype == CFP_BF16) hipLaunchKernelGGL((conv_wgrad16_kernel<bf16_t, false>), grid, dim3(256), 0, s, p);
-  else if (dtype == CFP_F16 && pw) hipLaunchKernelGGL((conv_wgrad16_kernel<f16_t, true>), grid, dim3(256), 0, s, p);
-  else if (dtype == CFP_F16) hipLaunchKernelGGL((conv_wgrad16_kernel<f16_t, false>), grid, dim3(256), 0, s, p);
+#define WG16(H, PWV, A, Bk) hipLaunchKernelGGL((conv_wgrad16_kernel<H, PWV, A, Bk>), grid, dim3(256), 0, s, p)
+#define WG16_T(H, PWV) do { if (pl.tco == 128 && pl.tk == 128) WG16(H, PWV, 128, 128); else if (pl.tco == 128) WG16(H, PWV, 128, 64); \
+                            else if (pl.tk == 128) WG16(H, PWV, 64, 128); else WG16(H, PWV, 64, 64); } while (0)
+  if (dtype == CFP_BF16 && pw) WG16_T(bf16_t, true);
+  else if (dtype == CFP_BF16) WG16_T(bf16_t, false);
+  else if (dtype == CFP_F16 && pw) WG16_T(f16_t, true);
+  else if (dtype == CFP_F16) WG16_T(f16_t, false);
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
+#undef WG16_T
+#undef WG16
   const long long n = (long long)Cout * K;
   if (p.nsplit > 1 || beta != 0.f) {
     // enough workgroups first, then as few split lanes as that allows

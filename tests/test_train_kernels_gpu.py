@@ -450,3 +450,27 @@ def test_tape_concat_and_split(rows, Ca, Cb, dtype):
         torch.cuda.synchronize()
         assert torch.equal(y.t, torch.cat([a, b], 1))
         assert torch.equal(av.g, g[:, :Ca]) and (bv.g is None if not need_b else torch.equal(bv.g, g[:, Ca:]))
+
+
+# launches with >= 1e5 pixel rows take the 128-wide weight-gradient tiles (conv_bwd.hip wgrad_plan16): one case per tile shape,
+# ragged Cout / K, the im2col path with padding and the pointwise path
+BIG_WGRAD = [(2, 224, 232, 32, 128, 3, 1, (1, 1, 1, 1)),      # 128 x 128 tiles, K = 288
+             (1, 320, 328, 80, 32, 3, 1, (1, 1, 1, 1)),       # 64 x 128 (Cout = 32: half a Cout tile), K = 720
+             (1, 330, 310, 128, 200, 1, 1, (0, 0, 0, 0)),     # pointwise, 128 x 128, ragged Cout
+             (1, 330, 310, 64, 136, 1, 1, (0, 0, 0, 0)),      # 128 x 64 (K = 64)
+             (2, 230, 226, 24, 72, 3, 2, (0, 0, 1, 1))]       # stride 2: 25 k rows only -> the 64 x 64 tile; control
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", BIG_WGRAD)
+def test_conv_weight_gradient_many_rows(case, dtype):
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x, w, dy, dx_ref, dw_ref, Ho, Wo = _ref(case, dtype)
+    xd, dyd = nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV)
+    dw = train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo)
+    dw3 = train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    got = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    err = float((got - dw_ref).abs().max()) / float(dw_ref.abs().max())
+    assert err < 1e-4, (case, dtype, err)                      # f32 sums of ~1e5 exact products
+    assert torch.equal(dw3, dw)
