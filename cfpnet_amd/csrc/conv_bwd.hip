@@ -28,7 +28,7 @@ struct WgP {
   const void* x; const void* dy; float* slabs;
   int x_ld, dy_ld;
   int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
-  int M, K, rows_per_split, nsplit;
+  int M, K, rows_per_split, nsplit, ntiles, xcd_order;
   unsigned mg_hw, sh_hw, mg_w, sh_w;           // floor(m / (Ho*Wo)) and floor(r / Wo) as multiply-high + shift (m < 2^31)
 };
 
@@ -174,9 +174,21 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
   __shared__ __attribute__((aligned(16))) unsigned short sX[MS * PX];    // im2col tile [m][k']
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_k = (p.K + TK - 1) / TK;
-  const int tile_co = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_co * tiles_k;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), and all output tiles of one pixel chunk read
+  // the same dY rows and (shifted) x rows.  With (tile, chunk) = (blockIdx.x, blockIdx.y) the tiles of a chunk landed on 8 different
+  // XCDs and each fetched the chunk itself: 9x the compulsory HBM traffic for a 3x3 conv (712 us for the head's weight gradient).
+  // Here XCD x owns the chunks x, x + 8, ... and walks all tiles of a chunk back to back, so they meet in ONE L2.
+  int tile, split;
+  if (p.xcd_order) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    tile = slot % p.ntiles; split = (slot / p.ntiles) * 8 + xcd;
+  } else {                                                    // many tiles per chunk: plain (tile fastest) order
+    tile = blockIdx.x % p.ntiles; split = blockIdx.x / p.ntiles;
+  }
+  if (split >= p.nsplit) return;                              // padding of the chunk count to a multiple of 8 (uniform: before any barrier)
+  const int tile_co = tile / tiles_k, tile_k = tile - tile_co * tiles_k;
   const int co0 = tile_co * TCO, k0 = tile_k * TK;
-  const int m_begin = blockIdx.y * p.rows_per_split;
+  const int m_begin = split * p.rows_per_split;
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const unsigned short* __restrict__ X = reinterpret_cast<const unsigned short*>(p.x);
   const unsigned short* __restrict__ DY = reinterpret_cast<const unsigned short*>(p.dy);
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
     }
   }
   const int fr = lane & 15, fk = lane >> 4;
-  float* __restrict__ slab = p.slabs + (long long)blockIdx.y * p.Cout * p.K;
+  float* __restrict__ slab = p.slabs + (long long)split * p.Cout * p.K;
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -394,7 +406,9 @@ inline WgPlan wgrad_plan16(int Cout, int K, int M) {
   if (pl.tco == WB && pl.tk == WB) { pl.nsplit = wgrad_nsplit(Cout, K, M); return pl; }
   pl.mstep = 64;
   const long long tiles = (long long)cdiv(Cout, pl.tco) * cdiv(K, pl.tk);
-  long long ns = (768 + tiles - 1) / tiles;
+  // every workgroup of the launch resident at once, XCD by XCD: these kernels hold 3 workgroups per CU (152 VGPRs), an XCD has 32 CUs and
+  // owns the chunks x, x + 8, ...  One workgroup too many per XCD costs a whole extra round (the head's 774 workgroups on 768 slots: 627 us)
+  long long ns = 8 * std::max<long long>(1, 96 / tiles);
   const long long max_ns = cdiv(M, 8 * pl.mstep);            // at least 512 rows per chunk
   if (ns > max_ns) ns = max_ns;
   if (ns > 1024) ns = 1024;
@@ -439,9 +453,12 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.nsplit = cdiv(M, p.rows_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (p.nsplit == 1 && beta == 0.f) p.slabs = dw;            // a single slab IS the result: written in place, no second kernel
-  const dim3 grid(cdiv(Cout, pl.tco) * cdiv(K, pl.tk), p.nsplit);
+  p.ntiles = cdiv(Cout, pl.tco) * cdiv(K, pl.tk);
+  p.xcd_order = p.ntiles <= 24 ? 1 : 0;
+  const dim3 grid(p.ntiles, p.nsplit);                        // float32 kernel: (tile, chunk)
+  const dim3 grid16((unsigned)p.ntiles * (unsigned)(cdiv(p.nsplit, 8) * 8));      // 16-bit kernels: one axis, XCD-aware order inside
   const bool pw = KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W;
-#define WG16(H, PWV, A, Bk) hipLaunchKernelGGL((conv_wgrad16_kernel<H, PWV, A, Bk>), grid, dim3(256), 0, s, p)
+#define WG16(H, PWV, A, Bk) hipLaunchKernelGGL((conv_wgrad16_kernel<H, PWV, A, Bk>), grid16, dim3(256), 0, s, p)
 #define WG16_T(H, PWV) do { if (pl.tco == 128 && pl.tk == 128) WG16(H, PWV, 128, 128); else if (pl.tco == 128) WG16(H, PWV, 128, 64); \
                             else if (pl.tk == 128) WG16(H, PWV, 64, 128); else WG16(H, PWV, 64, 64); } while (0)
   if (dtype == CFP_BF16 && pw) WG16_T(bf16_t, true);
