@@ -199,8 +199,12 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
   constexpr int PP = CVB * 16 + 16;               // pixel pitch in bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char tile[];
   const int CV = C / 8;
-  const int strip = blockIdx.y % nstrips, b = blockIdx.y / nstrips;
-  const int cv0 = blockIdx.x * CVB;
+  // XCD-aware order: the channel blocks of one strip straddle each other's 128-byte lines and neighbouring strips share halo rows; dealt
+  // round-robin over the 8 XCDs every one of them fetched those lines into its own L2 (the 2.3x fetch amplification of DESIGN 4.2)
+  const int lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bx = lin % (int)gridDim.x, by = lin / (int)gridDim.x;
+  const int strip = by % nstrips, b = by / nstrips;
+  const int cv0 = bx * CVB;
   const int ho_begin = strip * R;
   const int rows = min(R, Ho - ho_begin);
   const int rows_in = (rows - 1) * STRIDE + 3, cols_in = (Wo - 1) * STRIDE + 3;
