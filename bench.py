@@ -163,10 +163,10 @@ def same_size_copy_ms(shapes, dtype, dev, reps=5):
 
 def pmc_traffic(kernel_family: str):
     """HBM bytes per launch of a kernel family from the last committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, profiles/r2f_pmc_traffic.json and profiles/r2k_pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for
+    (profiles/pmc_traffic.json, profiles/r2f_pmc_traffic.json, profiles/r2k_pmc_traffic.json and profiles/r2n_pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for
     16-byte streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
     table = {}
-    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
+    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json", "r2n_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
