@@ -281,7 +281,7 @@ class Tape:
             self.off_path(param_grads)
             dx = torch.empty_like(x.t)                                                   # data gradient = correlation with the flipped kernel
             if mfma:
-                ops.dwconv_large_mfma(_act(y.g), ops.toeplitz_bands_dev(w.t.flip(1, 2), x.t.dtype), self.const("ones", C), self.const("zeros", C),
+                ops.dwconv_large_mfma(_act(y.g), ops.toeplitz_bands_dev(w.t, x.t.dtype, flip=True), self.const("ones", C), self.const("zeros", C),
                                       _act(dx), B, H, W, k, hip.ACT_NONE)
             else:
                 wf = w.t.flip(1, 2).transpose(1, 2).contiguous().reshape(C, k * k)

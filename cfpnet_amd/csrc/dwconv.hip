@@ -897,6 +897,40 @@ extern "C" size_t cfp_dwconv_large_toeplitz_elems(int C, int k) {
   return (size_t)C * k * nh * 64 * 8;
 }
 
+namespace {
+// band table of cfp_dwconv_large_mfma_nhwc from float32 weights [C][k][k] (ky, kx) that live on the device (training: they change every
+// step): out[c][ky][h][lane][e] = w[c][ky'][kx'] for kx = 32 h + 8 (lane / 16) + e - (LM - halo) - lane % 16 inside [0, k), else 0;
+// flip: (ky', kx') = (k - 1 - ky, k - 1 - kx), the data gradient's kernel.  One launch instead of five torch ones.
+template <typename T>
+__global__ __launch_bounds__(256) void toeplitz_bands_kernel(const float* __restrict__ w, T* __restrict__ out, int k, int nh, int lm_minus_halo,
+                                                             int flip, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    long long t = i >> 9;
+    const int h = (int)(t % nh); t /= nh;
+    const int ky = (int)(t % k);
+    const long long c = t / k;
+    const int kx = 32 * h + 8 * (lane >> 4) + e - lm_minus_halo - (lane & 15);
+    float v = 0.f;
+    if (kx >= 0 && kx < k) v = w[(c * k + (flip ? k - 1 - ky : ky)) * k + (flip ? k - 1 - kx : kx)];
+    out[i] = from_f32<T>(v);
+  }
+}
+}  // namespace
+
+extern "C" int cfp_dwconv_large_toeplitz(const float* w, void* out, int C, int k, int flip, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(w && out, CFP_EINVAL, "cfp_dwconv_large_toeplitz: null pointer");
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_dwconv_large_toeplitz: the band table is a 16-bit operand");
+  CFP_REQUIRE(C > 0 && (k == 7 || k == 15 || k == 31), CFP_ESHAPE, "cfp_dwconv_large_toeplitz: k must be 7, 15 or 31");
+  const int halo = (k - 1) / 2, lm = (halo + 7) / 8 * 8, nh = (16 + lm + halo + 31) / 32;
+  const long long total = (long long)C * k * nh * 512;
+  const int blocks = (int)std::min<long long>(2048, (total + 255) / 256);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(toeplitz_bands_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, w, (bf16_t*)out, k, nh, lm - halo, flip, total);
+  else hipLaunchKernelGGL(toeplitz_bands_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, w, (f16_t*)out, k, nh, lm - halo, flip, total);
+  return cfp_check_launch("cfp_dwconv_large_toeplitz");
+}
+
 extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void* toeplitz, const float* scale, const float* shift,
                                           void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                                           cfp_stream_t stream) {

@@ -38,6 +38,7 @@ SIGNATURES = {
     "cfp_se_gate_fold": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_dwconv_large_toeplitz_elems": (_sz, [_i, _i]),
+    "cfp_dwconv_large_toeplitz": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_mfma_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_channel_sum": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_hidden": (_i, [_p, _i, _f, _p, _p, _p, _i, _i, _i, _p]),

@@ -237,25 +237,14 @@ def toeplitz_bands(w: torch.Tensor, dtype) -> torch.Tensor:
     return g.contiguous().to(dtype)
 
 
-_TOEPLITZ_IDX = {}
-
-
-def toeplitz_bands_dev(w: torch.Tensor, dtype) -> torch.Tensor:
+def toeplitz_bands_dev(w: torch.Tensor, dtype, flip: bool = False) -> torch.Tensor:
     """`toeplitz_bands` for weights that live (and change every step) on the device: [C,k,k] (ky, kx) float32 -> the band table in
-    `dtype`, by one gather with a cached index table -- no host round trip, capturable in a HIP graph."""
+    `dtype` (of the 180-degree-rotated kernel when `flip`), one launch (cfp_dwconv_large_toeplitz), capturable in a HIP graph."""
     C, k, _ = w.shape
-    key = (k, str(w.device))
-    if key not in _TOEPLITZ_IDX:
-        halo = (k - 1) // 2
-        lm = (halo + 7) // 8 * 8
-        nh = (16 + lm + halo + 31) // 32
-        lane, h, e = torch.arange(64), torch.arange(nh), torch.arange(8)
-        kx = 32 * h[:, None, None] + 8 * (lane[None, :, None] // 16) + e[None, None, :] - (lm - halo) - (lane[None, :, None] % 16)
-        ok = (kx >= 0) & (kx < k)
-        _TOEPLITZ_IDX[key] = (kx.clamp(0, k - 1).reshape(-1).to(w.device), ok.reshape(1, 1, -1).to(w.device), (nh, 64, 8))
-    idx, ok, tail = _TOEPLITZ_IDX[key]
-    g = torch.where(ok, w.index_select(2, idx), torch.zeros((), dtype=w.dtype, device=w.device))
-    return g.reshape(C, k, *tail).to(dtype).contiguous()
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    out = torch.empty(int(hip.load().cfp_dwconv_large_toeplitz_elems(C, k)), dtype=dtype, device=w.device)
+    hip.call("cfp_dwconv_large_toeplitz", w.data_ptr(), out.data_ptr(), C, k, int(flip), DT[dtype], _s())
+    return out
 
 
 def dwconv_large_mfma(x: Act, tb: torch.Tensor, scale, shift, out: Act, B, H, W, k, act):

@@ -129,6 +129,9 @@ int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float
  * with halo = (k-1)/2, LM = halo rounded up to 8, h < NH = ceil((16 + LM + halo) / 32); cfp_dwconv_large_toeplitz_elems
  * gives its size in elements.  It is built once per weight tensor on the host (cfpnet_amd/engine.py). */
 size_t cfp_dwconv_large_toeplitz_elems(int C, int k);
+/* The same table built on the device from float32 weights [C][k][k] (training: the master weights change every step); flip != 0
+ * gives the table of the 180-degree-rotated kernel (the data gradient).  out: cfp_dwconv_large_toeplitz_elems(C, k) 16-bit elements. */
+int cfp_dwconv_large_toeplitz(const float* w, void* out, int C, int k, int flip, int dtype, cfp_stream_t stream);
 int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void* toeplitz, const float* scale, const float* shift,
                                void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                                cfp_stream_t stream);

@@ -474,3 +474,23 @@ def test_conv_weight_gradient_many_rows(case, dtype):
     err = float((got - dw_ref).abs().max()) / float(dw_ref.abs().max())
     assert err < 1e-4, (case, dtype, err)                      # f32 sums of ~1e5 exact products
     assert torch.equal(dw3, dw)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,k", [(32, 31), (64, 15), (128, 7), (16, 31)])
+def test_toeplitz_band_table_on_device(C, k, dtype):
+    """cfp_dwconv_large_toeplitz (the band table of the matrix-core large-kernel depthwise conv, rebuilt from the float32 master weights
+    every training step) == the same gather written with torch, for the kernel and for its 180-degree rotation (data gradient)."""
+    w = rnd(C, k, k, seed=1)
+    halo = (k - 1) // 2
+    lm = (halo + 7) // 8 * 8
+    nh = (16 + lm + halo + 31) // 32
+    lane, h, e = torch.arange(64), torch.arange(nh), torch.arange(8)
+    kx = 32 * h[:, None, None] + 8 * (lane[None, :, None] // 16) + e[None, None, :] - (lm - halo) - (lane[None, :, None] % 16)
+    ok = (kx >= 0) & (kx < k)
+    for flip in (False, True):
+        src = w.flip(1, 2) if flip else w
+        want = torch.where(ok[None, None], src[:, :, kx.clamp(0, k - 1)], torch.zeros(())).to(dtype).reshape(-1)
+        got = ops.toeplitz_bands_dev(w.to(DEV), dtype, flip=flip)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want)
