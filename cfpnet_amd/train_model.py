@@ -433,10 +433,11 @@ class TrainNet:
         return pred, edges, (B, h0, w0)
 
     def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None,
-                         stop_before_encoder: bool = False):
+                         stop_before_encoder: bool = False, loss_sync=None):
         """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
         gradients are in `self.grads()`, running statistics in `self.buf`.  `stop_before_encoder`: the backward stops where the
-        RGB encoder's begins (every non-encoder parameter gradient is final) and `finish_backward()` runs the rest."""
+        RGB encoder's begins (every non-encoder parameter gradient is final) and `finish_backward()` runs the rest.
+        `loss_sync` = (torch.distributed module, world size): the loss is the global-batch SILog over the ranks (SILogLoss.sync_moments)."""
         dev = self.dev
         t = Tape(dev, self.dtype, side=self.side_stream)
         pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
@@ -444,7 +445,11 @@ class TrainNet:
         crit = train_ops.SILogLoss()
         pred4 = pred.t.reshape(B, 1, h0, w0)
         loss = crit.forward(pred4, target.to(dev, torch.float32), loss_mask.to(dev) if loss_mask is not None else None, interpolate=True)
-        pred.g = crit.backward(1.0).reshape(-1, 1).contiguous()
+        gl = 1.0
+        if loss_sync is not None:
+            loss = crit.sync_moments(loss_sync[0])
+            gl = float(loss_sync[1])                                            # the gradient average over the ranks divides by it again
+        pred.g = crit.backward(gl).reshape(-1, 1).contiguous()
         if stop_before_encoder:
             t.backward(stop="encoder")
             self._open_tape = t

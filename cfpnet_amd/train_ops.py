@@ -46,6 +46,29 @@ class SILogLoss:
 
     __call__ = forward
 
+    def sync_moments(self, dist, group=None) -> torch.Tensor:
+        """Make the loss the GLOBAL-batch SILog over all data-parallel ranks: all-reduce the three moments (sum g, sum g^2, n) and
+        recompute mean / variance / loss from the totals -- what the reference gets from nn.DataParallel, which gathers the predictions
+        and evaluates ONE loss on the whole batch (train.py:119-123); per-rank losses (the default of this trainer) are a slightly
+        different objective.  Call between `forward` and `backward`, then pass `backward(grad_loss=world_size)`: the gradient averaging
+        over the ranks divides by it again.  Returns the global loss (device scalar).  Three tiny torch kernels + one collective."""
+        st = self._stats.double()
+        mean, n, dg = st[1], st[2], st[3]
+        s = mean * n
+        s2 = (dg - 0.15 * mean * mean) * (n - 1.0) + s * s / n                  # var_unbiased = (s2 - s^2 / n) / (n - 1)
+        m = torch.stack([s, s2, n])
+        if dist.get_backend(group) == "gloo":                                  # host-staged, like the gradient buckets under gloo
+            h = m.cpu()
+            dist.all_reduce(h, group=group)
+            m = h.to(self._stats.device)
+        else:
+            dist.all_reduce(m, group=group)
+        S, S2, N = m[0], m[1], m[2]
+        gmean = S / N
+        gdg = (S2 - S * S / N) / (N - 1.0) + 0.15 * gmean * gmean
+        self._stats.copy_(torch.stack([10.0 * torch.sqrt(gdg), gmean, N, gdg]).float())
+        return self._stats[0]
+
     def backward(self, grad_loss: float = 1.0) -> torch.Tensor:
         B, Hp, Wp, Ht, Wt, interp = self._shape
         grad = torch.empty(B, 1, Hp, Wp, dtype=torch.float32, device=self._stats.device)

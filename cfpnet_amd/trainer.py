@@ -25,7 +25,7 @@ class Trainer:
                  div_factor: float = 25.0, final_div_factor: float = 100.0, hist_encoder_10x: bool = True, clip_grad_norm: Optional[float] = None,
                  device="cuda:0", dist=None, world: int = 1, n_bins: int = 256, min_val: float = 1e-3, max_val: float = 10.0,
                  change_embedding: bool = True, dtype=torch.float32, no_skip_inside: bool = False, norm: str = "linear", kernel_layout: bool = True,
-                 base_resolution=spec.BASE_RESOLUTION, overlap_param_grads: bool = False, comm: str = "overlap"):
+                 base_resolution=spec.BASE_RESOLUTION, overlap_param_grads: bool = False, comm: str = "overlap", sync_loss: bool = False):
         self.dev = torch.device(device)
         self.dtype, self.kernel_layout, self._hist10 = dtype, kernel_layout, hist_encoder_10x
         self._net_kw = dict(n_bins=n_bins, min_val=min_val, max_val=max_val, change_embedding=change_embedding, dtype=dtype,
@@ -37,6 +37,9 @@ class Trainer:
         self._pending_opt = None         # optimizer state loaded before the first batch fixed the kernel layouts
         self._flip_jobs = None           # [(source buffer, flipped buffer, device descriptors, n, workgroups, dtype code)]
         self.dist, self.world = dist, world
+        # sync_loss: the SILog loss over the GLOBAL batch (its three moments all-reduced), as the reference's nn.DataParallel loop
+        # computes it; default is the per-rank loss of DistributedDataParallel-style training (SURVEY 8e documents the difference)
+        self.sync_loss = bool(sync_loss) and dist is not None and world > 1
         # gradient averaging over the data-parallel ranks: "overlap" = the captured step is split where the RGB encoder's backward
         # begins and the non-encoder bucket is reduced on a second stream while the encoder's backward runs;
         # "sequential" = all buckets after the whole backward; "off" = skipped (measurement of the step without communication)
@@ -137,6 +140,9 @@ class Trainer:
             offs[name] = (oy, ox)
         return offs
 
+    def _loss_sync(self):
+        return (self.dist, self.world) if self.sync_loss else None
+
     def _grads_to_flat(self, input_data, target, offs, stop_before_encoder: bool = False):
         if self.kernel_layout and self._to_torch is None:
             self._bind_kernel_layout(input_data, offs)
@@ -147,11 +153,11 @@ class Trainer:
             if self._flip_jobs is not None:
                 self._refresh_weight_flips()
             loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs,
-                                                   stop_before_encoder=stop_before_encoder)
+                                                   stop_before_encoder=stop_before_encoder, loss_sync=self._loss_sync())
             if self._flip_jobs is None:
                 self._plan_weight_flips()
             return loss                                             # every gradient is already at its flat address
-        loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs)
+        loss, pred, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs, loss_sync=self._loss_sync())
         self.flat.grad.zero_()
         for name, g in self.net.grads().items():
             self.flat.view(name, "grad").copy_(g)
@@ -170,6 +176,10 @@ class Trainer:
             split = self.dist is not None and self.comm == "overlap"
         if split and not self.kernel_layout:
             raise ValueError("the split step needs kernel_layout=True (gradients written at their final flat addresses)")
+        if self.sync_loss and self.dist.get_backend() != "nccl":
+            # the moments' all-reduce sits between the loss forward and backward, inside the captured region: RCCL collectives can be
+            # captured, gloo's host-staged ones cannot (untested on a multi-GPU node from this single-GPU box: eager is the tested path)
+            raise ValueError("sync_loss with a captured step needs the nccl (RCCL) backend; use the eager Trainer.step under gloo")
         dev = self.dev
         add = input_data["additional"]
         self._sin = {"rgb": input_data["rgb"].to(dev, torch.float32).contiguous().clone(),

@@ -119,3 +119,44 @@ def test_split_step_graphs_equal_the_single_graph():
     assert float(la) == float(lb) and torch.equal(a.flat.param, b.flat.param)
     for k in a.net.buf:
         assert torch.equal(a.net.buf[k], b.net.buf[k]), k
+
+
+def _silog_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from cfpnet_amd import synthetic, train_ops
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    g = torch.Generator().manual_seed(11)
+    B, Hp, Wp, Ht, Wt = 4, 60, 80, 120, 160
+    pred = (torch.rand(B, 1, Hp, Wp, generator=g) * 5 + 0.5).cuda()
+    tgt = torch.from_numpy(np.stack([synthetic.make_depth(Ht, Wt, seed=70 + i, holes=0.15) for i in range(B)]))[:, None].float().cuda()
+    mask = tgt > 1e-3
+    half = slice(rank * (B // world), (rank + 1) * (B // world))
+    crit = train_ops.SILogLoss()
+    crit.forward(pred[half].contiguous(), tgt[half].contiguous(), mask[half].contiguous(), interpolate=True)
+    loss = crit.sync_moments(dist)
+    grad = crit.backward(float(world))
+    torch.cuda.synchronize()
+    res = {"loss": float(loss), "grad": grad.cpu()}
+    if rank == 0:
+        full = train_ops.SILogLoss()
+        res["full_loss"] = float(full.forward(pred, tgt, mask, interpolate=True))
+        res["full_grad"] = full.backward(1.0).cpu()
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_batch_silog_over_two_ranks(tmp_path):
+    """SILogLoss.sync_moments: two ranks hold half a batch each; after the all-reduce of (sum g, sum g^2, n) both report the loss of the
+    WHOLE batch, and `backward(world)` gives world x the whole-batch gradient on the rank's own pixels (the gradient averaging over the
+    ranks divides by world again) -- the reference's nn.DataParallel semantics (one loss on the gathered batch, train.py:119-123)."""
+    world, out = 2, str(tmp_path / "silog")
+    mp.spawn(_silog_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(f"{out}.{k}") for k in range(world)]
+    full_loss, full_grad = r[0]["full_loss"], r[0]["full_grad"]
+    for k in range(world):
+        assert abs(r[k]["loss"] - full_loss) <= 2e-6 * abs(full_loss)
+        want = world * full_grad[k * 2:(k + 1) * 2]
+        assert float((r[k]["grad"] - want).abs().max()) <= 1e-5 * float(want.abs().max())

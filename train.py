@@ -150,7 +150,8 @@ def main(argv=None):
     local_gpu = _pop(argv, "--local_gpu", None, int)
     eager = "--eager" in argv
     no_augment = "--no_augment" in argv
-    argv = [a for a in argv if a not in ("--eager", "--no_augment")]
+    sync_loss = "--sync_loss" in argv                # global-batch SILog (three moments all-reduced), the reference's DataParallel semantics
+    argv = [a for a in argv if a not in ("--eager", "--no_augment", "--sync_loss")]
     args = config.parse_args(argv) if argv else config.defaults()
     args.mode = "train"
 
@@ -203,7 +204,7 @@ def main(argv=None):
                  final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
                  clip_grad_norm=None if args.disable_clip_grad else 0.1, device=dev, dist=dist, world=world, n_bins=int(args.n_bins),
                  min_val=float(args.min_depth), max_val=float(args.max_depth), change_embedding=bool(args.change_embedding), dtype=dtype, no_skip_inside=bool(getattr(args, "no_skip_inside", False)),
-                 norm=str(args.norm))
+                 norm=str(args.norm), sync_loss=sync_loss)
     if opt_state is not None:
         tr.load_optimizer_state_dict(opt_state)
     sim = TofSimulator(args, dev)
