@@ -146,6 +146,12 @@ class Tape:
             if g is None:
                 return
             def param_grads():
+                if bias is not None and g.dtype != torch.float32 and bias.gview is not None and w.gview is not None:
+                    # 16-bit modes: the bias gradient comes out of the weight-gradient launch (one more matrix-core product per step)
+                    bw_, bb_ = (0.0 if w.g is None else 1.0), (0.0 if bias.g is None else 1.0)
+                    train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=w.gview, beta=bw_, db=bias.gview, beta_b=bb_)
+                    w.g, bias.g = w.gview, bias.gview
+                    return
                 if bias is not None:
                     self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
                 self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))

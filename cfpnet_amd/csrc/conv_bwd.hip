@@ -17,6 +17,7 @@
 //                    Wt[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci], after which dX is a plain cfp_conv2d_nhwc call
 //                    (stride 1, padding K-1-pad, input dilation = the forward stride).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -26,6 +27,7 @@ constexpr int WP = WB + 16;     // LDS row pitch in floats: 80 = 16 mod 32 -> th
 
 struct WgP {
   const void* x; const void* dy; float* slabs;
+  int bias;                                    // != 0: slab = [dW (Cout x K) | db (Cout)], db = column sums of dY (16-bit kernels)
   int x_ld, dy_ld;
   int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
   int M, K, rows_per_split, nsplit, ntiles, xcd_order;
@@ -267,6 +269,14 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
   for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient db[co] = sum_m dY[m][co] for free: one more B fragment of ones against the dY fragments that are already in registers
+  // (all 16 columns of the result are that sum); only the first K tile's left waves do it.  Replaces a column-reduction + finaliser pair.
+  const bool do_bias = p.bias && tile_k == 0 && (wave & 1) == 0;
+  const short one16 = std::is_same<H, bf16_t>::value ? (short)0x3F80 : (short)0x3C00;      // 1.0 in bf16 / fp16
+  const s16x8 ones = {one16, one16, one16, one16, one16, one16, one16, one16};
+  f32x4 accb[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (m_begin < m_end) fetch(m_begin);
   for (int m0 = m_begin; m0 < m_end; m0 += MS) {
     __syncthreads();
@@ -292,10 +302,24 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = mfma16<H>(a[i], bb[j], acc[i][j]);
+      if (do_bias) {                            // wave-uniform
+#pragma unroll
+        for (int i = 0; i < TI; ++i) accb[i] = mfma16<H>(a[i], ones, accb[i]);
+      }
     }
   }
   const int fr = lane & 15, fk = lane >> 4;
-  float* __restrict__ slab = p.slabs + (long long)split * p.Cout * p.K;
+  const long long slab_elems = (long long)p.Cout * p.K + (p.bias ? p.Cout : 0);
+  float* __restrict__ slab = p.slabs + (long long)split * slab_elems;
+  if (do_bias && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + qa + i * 16 + fk * 4 + r;
+        if (co < p.Cout) slab[(long long)p.Cout * p.K + co] = accb[i][r];
+      }
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -310,9 +334,10 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgP p) {
 // dw = beta * dw + sum over the splits, in a fixed order.  EW consecutive elements per workgroup, 256 / EW lanes over the splits:
 // a small weight tensor split 768 ways (32x32 Linear over 2*10^5 rows) is a long dependent chain per element, so the splits are
 // walked by up to 8 lanes with 4 loads in flight each, and the lanes meet in LDS in lane order.
+// (`n_dw` < n: the slab is [dW | db]; elements from n_dw on go to db with their own beta.)
 template <int EW>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
-                                                           float beta) {
+                                                           float beta, long long n_dw, float* __restrict__ db, float beta_b) {
   constexpr int LANES = 256 / EW;
   __shared__ float red[LANES][EW];
   const int e = threadIdx.x % EW, sl = threadIdx.x / EW;
@@ -337,7 +362,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int l = 0; l < LANES; ++l) s += red[l][e];
       }
     }
-    if (sl == 0 && i < n) dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+    if (sl == 0 && i < n) {
+      if (i < n_dw) dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+      else db[i - n_dw] = beta_b != 0.f ? beta_b * db[i - n_dw] + s : s;
+    }
     if (LANES > 1) __syncthreads();
   }
 }
@@ -422,13 +450,25 @@ inline WgPlan wgrad_plan16(int Cout, int K, int M) {
 extern "C" size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M) {
   if (Cout <= 0 || K <= 0 || M <= 0) return 0;
   const int ns = std::max(wgrad_nsplit(Cout, K, M), wgrad_plan16(Cout, K, M).nsplit);      // the dtype is not known here: the larger plan
-  return (size_t)ns * Cout * K * sizeof(float);
+  return (size_t)ns * ((size_t)Cout * K + Cout) * sizeof(float);            // + the bias-gradient column of cfp_conv2d_wgrad_bias
 }
+
+extern "C" int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                                     int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 
 extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int Cin, int Cout,
                                 int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws,
                                 size_t ws_bytes, cfp_stream_t stream) {
+  return cfp_conv2d_wgrad_bias(x, x_ld, dy, dy_ld, dw, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, 0.f, dtype, ws,
+                               ws_bytes, stream);
+}
+
+extern "C" int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                                     int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   CFP_REQUIRE(x && dy && dw && ws, CFP_EINVAL, "cfp_conv2d_wgrad: null pointer");
+  CFP_REQUIRE(!db || is16(dtype), CFP_EINVAL, "cfp_conv2d_wgrad_bias: the fused bias gradient is a 16-bit path (float32: cfp_colsum)");
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_wgrad: bad dtype");
   const int ve = vec_elems(dtype);
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0, CFP_ESHAPE,
@@ -452,7 +492,8 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   p.rows_per_split = cdiv(cdiv(M, p.nsplit), mstep) * mstep;
   p.nsplit = cdiv(M, p.rows_per_split);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (p.nsplit == 1 && beta == 0.f) p.slabs = dw;            // a single slab IS the result: written in place, no second kernel
+  p.bias = db ? 1 : 0;
+  if (p.nsplit == 1 && beta == 0.f && !db) p.slabs = dw;     // a single slab IS the result: written in place, no second kernel
   p.ntiles = cdiv(Cout, pl.tco) * cdiv(K, pl.tk);
   p.xcd_order = p.ntiles <= 24 ? 1 : 0;
   const dim3 grid(p.ntiles, p.nsplit);                        // float32 kernel: (tile, chunk)
@@ -468,14 +509,14 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
   else hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, s, p);
 #undef WG16_T
 #undef WG16
-  const long long n = (long long)Cout * K;
-  if (p.nsplit > 1 || beta != 0.f) {
+  const long long n_dw = (long long)Cout * K, n = n_dw + (db ? Cout : 0);
+  if (p.nsplit > 1 || beta != 0.f || db) {
     // enough workgroups first, then as few split lanes as that allows
     const int ew = (n >= 256 * 512 || p.nsplit < 8) ? 256 : (n >= 64 * 512 || p.nsplit < 32) ? 64 : 32;
     const int blocks = (int)std::min<long long>(2048, (n + ew - 1) / ew);
-    if (ew == 256) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
-    else if (ew == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta);
+    if (ew == 256) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
+    else if (ew == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
   }
   return cfp_check_launch("cfp_conv2d_wgrad");
 }

@@ -67,6 +67,7 @@ SIGNATURES = {
     "cfp_eval_metrics": (_i, [_p, _i, _i, _p, _i, _i, _i, _i, _i, _f, _f, _p, _sz, _p, _p]),
     "cfp_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "cfp_conv2d_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 12 + [_f, _i, _p, _sz, _p]),
+    "cfp_conv2d_wgrad_bias": (_i, [_p, _i, _p, _i, _p, _p] + [_i] * 12 + [_f, _f, _i, _p, _sz, _p]),
     "cfp_conv2d_weight_flip": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_weight_flip_blocks": (_i, [_ll]),
     "cfp_conv2d_weight_flip_batch": (_i, [_p, _p, _p, _i, _i, _i, _p]),

@@ -267,8 +267,9 @@ def lr_group_of(hist_encoder_10x: bool):
 # the C ABI on NHWC row tensors [rows, C]; `autograd_hip.Tape` chains them into the backward of the whole network.
 # ------------------------------------------------------------------------------------------------------------------
 def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, dw: Optional[torch.Tensor] = None,
-                 beta: float = 0.0) -> torch.Tensor:
-    """x2d [B*H*W, Cin], dy2d [B*Ho*Wo, Cout] (same dtype: f32 / bf16 / f16) -> dw [Cout, KH*KW*Cin] f32 (= beta*dw + grad)."""
+                 beta: float = 0.0, db: Optional[torch.Tensor] = None, beta_b: float = 0.0) -> torch.Tensor:
+    """x2d [B*H*W, Cin], dy2d [B*Ho*Wo, Cout] (same dtype: f32 / bf16 / f16) -> dw [Cout, KH*KW*Cin] f32 (= beta*dw + grad).
+    `db` (16-bit dtypes): float32 [>= Cout], receives beta_b*db + the bias gradient (column sums of dy) from the same launch."""
     from . import hip, ops
     Cin, Cout = x2d.shape[1], dy2d.shape[1]
     K, M = KH * KW * Cin, B * Ho * Wo
@@ -277,6 +278,11 @@ def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride,
         beta = 0.0
     nbytes = hip.load().cfp_conv2d_wgrad_ws_bytes(Cout, K, M)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2d.device)
+    if db is not None:
+        assert x2d.dtype != torch.float32 and db.dtype == torch.float32 and db.numel() >= Cout
+        hip.call("cfp_conv2d_wgrad_bias", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), db.data_ptr(), B, H, W,
+                 Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, beta_b, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
+        return dw
     hip.call("cfp_conv2d_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, Cin, Cout, KH, KW,
              stride, pad_t, pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
     return dw

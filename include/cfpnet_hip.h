@@ -407,6 +407,11 @@ size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M);
 int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws,
                      size_t ws_bytes, cfp_stream_t stream);
+/* The same, plus the bias gradient db[co] = beta_b * db + sum over output pixels of dY[m][co] from the SAME launch (16-bit dtypes only:
+ * one more matrix-core product against a fragment of ones; float32 callers use cfp_colsum).  db may be NULL (= cfp_conv2d_wgrad). */
+int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                          int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: the weights the data gradient convolves with. */
 int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream);
 /* The same for n weight tensors in one launch (a training step flips every convolution's weights once).  `desc` is a DEVICE

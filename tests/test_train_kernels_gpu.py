@@ -494,3 +494,22 @@ def test_toeplitz_band_table_on_device(C, k, dtype):
         got = ops.toeplitz_bands_dev(w.to(DEV), dtype, flip=flip)
         torch.cuda.synchronize()
         assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", CASES[:6] + BIG_WGRAD[:4])
+def test_conv_weight_gradient_with_fused_bias_gradient(case, dtype):
+    """cfp_conv2d_wgrad_bias: db = column sums of dY from the weight-gradient launch itself (a fragment of ones on the matrix cores),
+    with its own beta; dW unchanged (bit for bit) by the extra product."""
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x, w, dy, dx_ref, dw_ref, Ho, Wo = _ref(case, dtype)
+    xd, dyd = nhwc(x).to(dtype).to(DEV), nhwc(dy).to(dtype).to(DEV)
+    dw0 = train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo)
+    db = torch.full((Cout + 3,), 2.0, device=DEV)
+    dw1 = train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, db=db, beta_b=0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(dw1, dw0)
+    want = nhwc(dy).to(dtype).float().sum(0)
+    got = db.cpu()
+    assert float((got[:Cout] - (1.0 + want)).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-4
+    assert float((got[Cout:] - 2.0).abs().max()) == 0
