@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Which torch (at::native) kernels run INSIDE the captured training step, and between which of our kernels: from the rocprofv3
+--kernel-trace database of `tools/train_bench.py --graph` (last replayed step).  Found the five-launch torch construction of the
+Toeplitz band tables (now cfp_dwconv_large_toeplitz).
+
+    rocprofv3 --kernel-trace --stats -d /tmp/tp -o tp -- python3 tools/train_bench.py --dtype bf16 --graph --steps 8
+    python3 tools/torch_kernels_in_step.py /tmp/tp/*.db
+"""
 import sqlite3, sys, re, collections
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 t = [r[0] for r in cur.execute("select name from sqlite_master where type='table'") if 'kernel_dispatch' in r[0]][0]
