@@ -201,13 +201,16 @@ class Tape:
         return self.conv(x, w, bias, 1, 1, x.rows, 1, 1, 0, 0, 1, x.rows)
 
     # ------------------------------------------------------------------ normalisation / activation
-    def bn_act(self, x: V, gamma: P, beta: P, running_mean, running_var, eps, momentum, act) -> V:
+    def bn_act(self, x: V, gamma: P, beta: P, running_mean, running_var, eps, momentum, act, residual: Optional[V] = None) -> V:
+        """act(BatchNorm(x)) [+ residual]: the skip connection of a residual block rides on the apply pass instead of a separate add."""
         bn = train_ops.BatchNormTrain(x.C, self.dev, eps=eps, momentum=momentum)
-        y = V(bn.forward(x.t, gamma.t, beta.t, running_mean, running_var, act))
+        y = V(bn.forward(x.t, gamma.t, beta.t, running_mean, running_var, act, residual.t if residual is not None else None))
 
         def bw():
             if y.g is None:
                 return
+            if residual is not None:
+                self.acc(residual, y.g, own=False)
             go, bo = self._direct(gamma), self._direct(beta)
             dx, dg, db = bn.backward(x.t, y.g, act, dgamma_out=go, dbeta_out=bo)
             self._pvec(gamma, dg, go); self._pvec(beta, db, bo); self.acc(x, dx)
@@ -237,13 +240,16 @@ class Tape:
         self.bw.append(bw)
         return y
 
-    def layernorm(self, x: V, gamma: P, beta: P, eps) -> V:
+    def layernorm(self, x: V, gamma: P, beta: P, eps, residual: Optional[V] = None) -> V:
+        """LayerNorm(x) [+ residual] (the kernel's own residual input: transformer.py:71 `x + message`)."""
         y = V(torch.empty_like(x.t))
-        ops.layernorm(_act(x.t), gamma.t, beta.t, eps, _act(y.t), x.rows)
+        ops.layernorm(_act(x.t), gamma.t, beta.t, eps, _act(y.t), x.rows, residual=_act(residual.t) if residual is not None else None)
 
         def bw():
             if y.g is None:
                 return
+            if residual is not None:
+                self.acc(residual, y.g, own=False)
             go, bo = self._direct(gamma), self._direct(beta)
             dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps, dgamma_out=go, dbeta_out=bo)
             self._pvec(gamma, dg, go); self._pvec(beta, db, bo); self.acc(x, dx)

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void colfinal_kernel(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, int ld, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int act, T* __restrict__ out, int out_ld,
-                                                              long long rows, int C, long long rows_per_chunk, int colbits) {
+                                                              long long rows, int C, long long rows_per_chunk, int colbits,
+                                                              const T* __restrict__ res, int res_ld) {
   constexpr int VE = Vec<T>::N;
   const int cols = 1 << colbits, lanes = 256 >> colbits;       // narrow tensors: fewer column lanes, more row lanes
   const int cl = threadIdx.x & (cols - 1), rl = threadIdx.x >> colbits;
@@ -248,15 +249,22 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
   with_act(act, [&](auto A) {
     constexpr int U = 4;
     for (long long r = r0 + rl; r < r1; r += lanes * U) {
-      float v[U][VE];
+      float v[U][VE], rs[U][VE];
 #pragma unroll
-      for (int u = 0; u < U; ++u) Vec<T>::load(x + min(r + (long long)u * lanes, r1 - 1) * ld + c, v[u]);
+      for (int u = 0; u < U; ++u) {
+        const long long rr = min(r + (long long)u * lanes, r1 - 1);
+        Vec<T>::load(x + rr * ld + c, v[u]);
+        if (res) Vec<T>::load(res + rr * res_ld + c, rs[u]);        // uniform: the skip connection added after the activation
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long long rr = r + (long long)u * lanes;
         if (rr >= r1) continue;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) v[u][e] = act_precise<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
+        for (int e = 0; e < VE; ++e) {
+          v[u][e] = act_precise<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
+          if (res) v[u][e] = to_f32<T>(from_f32<T>(v[u][e])) + rs[u][e];      // same rounding as the separate add of a stored tensor
+        }
         Vec<T>::store(out + rr * out_ld + c, v[u]);
       }
     }
@@ -464,13 +472,19 @@ extern "C" int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, 
 
 extern "C" int cfp_scale_shift_act(const void* x, int ld, const float* scale, const float* shift, int act, void* out, int out_ld,
                                    long long rows, int C, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(x && scale && shift && out && aligned16(x) && aligned16(out), CFP_EINVAL, "cfp_scale_shift_act: bad pointer");
+  return cfp_scale_shift_act_res(x, ld, scale, shift, act, nullptr, 0, out, out_ld, rows, C, dtype, stream);
+}
+
+extern "C" int cfp_scale_shift_act_res(const void* x, int ld, const float* scale, const float* shift, int act, const void* res, int res_ld,
+                                       void* out, int out_ld, long long rows, int C, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(x && scale && shift && out && aligned16(x) && aligned16(out) && aligned16(res), CFP_EINVAL, "cfp_scale_shift_act: bad pointer");
   BN_COMMON("cfp_scale_shift_act");
-  CFP_REQUIRE(out_ld % ve == 0 && out_ld >= C, CFP_ESHAPE, "cfp_scale_shift_act: bad out_ld");
+  CFP_REQUIRE(out_ld % ve == 0 && out_ld >= C && (!res || (res_ld % ve == 0 && res_ld >= C)), CFP_ESHAPE, "cfp_scale_shift_act: bad pitch");
   const EwGrid eg = ew_cols(rows, C, ve);
   const long long rpc = eg.rpc;
   const dim3 grid(eg.gx, eg.gy);
-#define SL(T) hipLaunchKernelGGL(scale_shift_act_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, scale, shift, act, (T*)out, out_ld, rows, C, rpc, eg.colbits)
+#define SL(T) hipLaunchKernelGGL(scale_shift_act_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, scale, shift, act, (T*)out, out_ld, rows, C, rpc, eg.colbits, \
+                                 (const T*)res, res_ld)
   if (dtype == CFP_BF16) SL(bf16_t); else if (dtype == CFP_F16) SL(f16_t); else SL(float);
 #undef SL
   return cfp_check_launch("cfp_scale_shift_act");

@@ -75,6 +75,7 @@ SIGNATURES = {
     "cfp_bn_ws_bytes": (_sz, [_i]),
     "cfp_bn_train_stats": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _f, _f] + [_p] * 7 + [_p, _sz, _p]),
     "cfp_scale_shift_act": (_i, [_p, _i, _p, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
+    "cfp_scale_shift_act_res": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_bn_train_bwd": (_i, [_p, _i, _p, _i, C.c_longlong, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),
     "cfp_colsum": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _sz, _p]),
     "cfp_act_bwd": (_i, [_p, _i, _p, _i, _i, _p, _i, C.c_longlong, _i, _i, _p]),

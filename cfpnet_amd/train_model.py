@@ -64,6 +64,7 @@ class TrainNet:
             if k.endswith(("running_mean", "running_var")):
                 self.buf[k] = v if share_buffers else v.clone()       # share_buffers: update the caller's running statistics in place
         self._idx_cache: Dict = {}
+        self.res_fused = os.environ.get("CFP_RES_FUSED_TRAIN", "1") != "0"    # skip connections added inside the BatchNorm-apply / LayerNorm pass
         self.se_fused = os.environ.get("CFP_SE_FUSED_TRAIN", "1") != "0"      # squeeze-excite gate + its backward as three kernels (csrc/se_train.hip)
         self.side_stream: Optional[torch.cuda.Stream] = None      # set by the trainer: parameter gradients beside the dY -> dX chain
         self.flipped: Dict[str, torch.Tensor] = {}        # bound mode: name -> flipped conv weight, refreshed by the trainer every step
@@ -156,9 +157,9 @@ class TrainNet:
         self.P = {}
 
     # ------------------------------------------------------------------ building blocks
-    def _bn(self, t: Tape, x: V, prefix: str, act: int, eps=1e-5, mom=0.1) -> V:
+    def _bn(self, t: Tape, x: V, prefix: str, act: int, eps=1e-5, mom=0.1, residual: Optional[V] = None) -> V:
         return t.bn_act(x, self._vec(prefix + ".weight"), self._vec(prefix + ".bias"), self.buf[prefix + ".running_mean"],
-                        self.buf[prefix + ".running_var"], eps, mom, act)
+                        self.buf[prefix + ".running_var"], eps, mom, act, residual=residual)
 
     def _conv_same(self, t: Tape, x: V, wname: str, B, H, W, stride, cin_pad=None, bias: Optional[str] = None):
         w = self._conv_w(wname, cin_pad)
@@ -189,7 +190,10 @@ class TrainNet:
                     x, H, W = self._conv_same(t, x, q + ".conv_exp.weight", B, H, W, s)
                     x = self._bn(t, x, q + ".bn1", hip.ACT_SILU, ENC_EPS, ENC_MOM)
                     x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
-                    x = self._bn(t, x, q + ".bn2", hip.ACT_NONE, ENC_EPS, ENC_MOM)
+                    skip = inp if (self.res_fused and s == 1 and inp.C == x.C) else None       # the skip connection rides on the last BatchNorm's apply pass
+                    x = self._bn(t, x, q + ".bn2", hip.ACT_NONE, ENC_EPS, ENC_MOM, residual=skip)
+                    if skip is not None:
+                        inp = None
                 else:
                     x = t.conv(x, self._conv_w(q + ".conv_pw.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
                     x = self._bn(t, x, q + ".bn1", hip.ACT_SILU, ENC_EPS, ENC_MOM)
@@ -209,8 +213,11 @@ class TrainNet:
                         g = t.act(t.linear(g, w2, b2), hip.ACT_SIGMOID)
                         x = t.mul_bcast(x, g, B, H * W)
                     x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
-                    x = self._bn(t, x, q + ".bn3", hip.ACT_NONE, ENC_EPS, ENC_MOM)
-                if s == 1 and inp.C == x.C:
+                    skip = inp if (self.res_fused and s == 1 and inp.C == x.C) else None
+                    x = self._bn(t, x, q + ".bn3", hip.ACT_NONE, ENC_EPS, ENC_MOM, residual=skip)
+                    if skip is not None:
+                        inp = None
+                if inp is not None and s == 1 and inp.C == x.C:
                     x = t.add(x, inp)
                 i += 1
             if stage != "conv3.0":
@@ -242,8 +249,9 @@ class TrainNet:
         msg = t.layernorm(msg, self._vec(p + ".norm1.weight"), self._vec(p + ".norm1.bias"), 1e-5)
         h = t.linear(t.concat(x, msg), self._conv_w(p + ".mlp.0.weight"))
         h = t.linear(t.act(h, hip.ACT_RELU), self._conv_w(p + ".mlp.2.weight"))
-        h = t.layernorm(h, self._vec(p + ".norm2.weight"), self._vec(p + ".norm2.bias"), 1e-5)
-        return t.add(h, x)
+        if self.res_fused:
+            return t.layernorm(h, self._vec(p + ".norm2.weight"), self._vec(p + ".norm2.bias"), 1e-5, residual=x)      # norm2(mlp) + x
+        return t.add(t.layernorm(h, self._vec(p + ".norm2.weight"), self._vec(p + ".norm2.bias"), 1e-5), x)
 
     def _maps(self, key, build):
         if key not in self._idx_cache:
@@ -296,8 +304,9 @@ class TrainNet:
         msg = t.gather(msg, idx_out, inv_out)                              # only outside tokens receive a message
         f = t.concat(tok, msg)
         f = self._bn(t, self._conv3(t, f, p + ".conv1.weight", None, B, H, W), p + ".bn1", hip.ACT_NONE)
-        f = self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W), p + ".bn2", hip.ACT_NONE)
-        return t.add(f, tok)
+        if self.res_fused:
+            return self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W), p + ".bn2", hip.ACT_NONE, residual=tok)     # bn2(conv2) + feat
+        return t.add(self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W), p + ".bn2", hip.ACT_NONE), tok)
 
     def _lkpm(self, t: Tape, p: str, tok: V, B, H, W) -> V:
         k = self.sd[p + ".dwconv2.weight"].shape[-1]

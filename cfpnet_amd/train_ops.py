@@ -319,15 +319,17 @@ class BatchNormTrain:
         self.nbytes = hip.load().cfp_bn_ws_bytes(C)
         self.ws = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
 
-    def forward(self, x2d, gamma, beta, running_mean, running_var, act: int):
+    def forward(self, x2d, gamma, beta, running_mean, running_var, act: int, residual: Optional[torch.Tensor] = None):
+        """`residual` [rows, C]: added after the activation in the apply pass (the block's skip connection)."""
         from . import hip, ops
         rows = x2d.shape[0]
         hip.call("cfp_bn_train_stats", x2d.data_ptr(), x2d.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.ptr(gamma), hip.ptr(beta), self.eps,
                  self.momentum, hip.ptr(running_mean), hip.ptr(running_var), self.mean.data_ptr(), self.var.data_ptr(), self.invstd.data_ptr(),
                  self.scale.data_ptr(), self.shift.data_ptr(), self.ws.data_ptr(), self.nbytes, hip.current_stream())
         y = torch.empty_like(x2d)
-        hip.call("cfp_scale_shift_act", x2d.data_ptr(), x2d.stride(0), self.scale.data_ptr(), self.shift.data_ptr(), act, y.data_ptr(),
-                 y.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.current_stream())
+        hip.call("cfp_scale_shift_act_res", x2d.data_ptr(), x2d.stride(0), self.scale.data_ptr(), self.shift.data_ptr(), act,
+                 hip.ptr(residual), residual.stride(0) if residual is not None else 0, y.data_ptr(), y.stride(0), rows, self.C,
+                 ops.DT[x2d.dtype], hip.current_stream())
         return y
 
     def backward(self, x2d, dy2d, act: int, dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None):

@@ -437,6 +437,10 @@ int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, int dtype, 
 /* out = act(x * scale[c] + shift[c]) (BatchNorm apply + SiLU / LeakyReLU / ReLU / GELU / sigmoid / none). */
 int cfp_scale_shift_act(const void* x, int ld, const float* scale, const float* shift, int act, void* out, int out_ld,
                         long long rows, int C, int dtype, cfp_stream_t stream);
+/* out = act(x * scale[c] + shift[c]) + res  (res may be NULL): the block's skip connection added in the same pass (the sum is rounded
+ * like the separate add of the stored activation). */
+int cfp_scale_shift_act_res(const void* x, int ld, const float* scale, const float* shift, int act, const void* res, int res_ld,
+                            void* out, int out_ld, long long rows, int C, int dtype, cfp_stream_t stream);
 /* Backward of act(BatchNorm(x)) in training mode: dgamma, dbeta (f32) and dx from the pre-BN input x and dy. */
 int cfp_bn_train_bwd(const void* x, int ld, const void* dy, int dy_ld, long long rows, int C, int dtype, const float* mean,
                      const float* invstd, const float* scale, const float* shift, int act, float* dgamma, float* dbeta,
