@@ -456,6 +456,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
                     ((long long)B * H * W + (long long)pad_t * W + pad_l) * in_ld * 2 < (1ll << 31) - 65536 &&      // 32-bit byte offsets into
                     (long long)Cout * p.K * 2 < (1ll << 31) - 65536;                                                    // buffer descriptors
   if (gen2) {
+    CFP_REQUIRE(aligned16(scale) && aligned16(shift), CFP_EINVAL, "cfp_conv2d_nhwc: scale / shift must be 16-byte aligned (read as 4-float vectors)");
     const int rpb = per_image_weights ? Ho * Wo : 0;
     int ln_variant = ln_gamma ? pick_ln_variant(Cout, p.M) : -1;
     const bool c33 = KH == 3 && KW == 3 && stride == 1 && !ln_gamma && rpb == 0 && (long long)Cout * p.K < (1ll << 31);

@@ -213,48 +213,52 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = mfma16<H>(af[i], bfr[j], acc[i][j]);
+          acc[i][j] = mfma16<H>(bfr[j], af[i], acc[i][j]);      // transposed: acc[r] = 4 CONSECUTIVE CHANNELS (n = 4 fq + r) of pixel row fr
     }
   }
   wait_vmcnt<0>();
   __syncthreads();   // every wave is done with the operand stages: LDS becomes the C tile
 
+  // The accumulators are held transposed (weights as the MFMA's row operand): a lane owns four consecutive output channels of one
+  // pixel, so the epilogue moves 8-byte (16-bit) / 16-byte (float32 slab) vectors instead of sixteen 2-byte LDS writes per thread.
   if constexpr (SPLITK) {
     float* slab = slabs + (long long)sp * p.M * p.Cout;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + a_row0 + i * 16 + fq * 4 + r;
-          const int n = n0 + b_row0 + j * 16 + fr;
-          if (m < m_end && n < p.Cout) slab[(long long)m * p.Cout + n] = acc[i][j][r];
-        }
+      for (int j = 0; j < TN; ++j) {
+        const int m = m0 + a_row0 + i * 16 + fr;
+        const int n = n0 + b_row0 + j * 16 + fq * 4;
+        if (m < m_end && n < p.Cout) *reinterpret_cast<f32x4*>(slab + (long long)m * p.Cout + n) = acc[i][j];      // Cout % 8 == 0, n % 4 == 0
+      }
     return;
   } else {
     constexpr int CP = BN + 8;   // C-tile pitch in elements (one 16-byte chunk of padding)
     static_assert(BM * CP * 2 <= STAGES * STAGE_BYTES, "C tile must fit in the operand LDS");
     H* sC = reinterpret_cast<H*>(smem);
-    float sc[TN], sh[TN];
+    f32x4 sc[TN], sh[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + b_row0 + j * 16 + fr;
+      const int n = n0 + b_row0 + j * 16 + fq * 4;
       const bool ok = n < p.Cout;
-      sc[j] = (ok && p.scale) ? p.scale[n] : 1.f;
-      sh[j] = (ok && p.shift) ? p.shift[n] : 0.f;
+      sc[j] = (ok && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      sh[j] = (ok && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     with_act(p.act, [&](auto A) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+          const int row = a_row0 + i * 16 + fr;
+          const int col = b_row0 + j * 16 + fq * 4;
+          float y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = a_row0 + i * 16 + fq * 4 + r;
-            const int col = b_row0 + j * 16 + fr;
-            sC[row * CP + col] = from_f32<H>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
-          }
+          for (int r = 0; r < 4; ++r) y[r] = act_c<decltype(A)::value>(acc[i][j][r] * sc[j][r] + sh[j][r]);
+          uint2 pk;
+          pk.x = pack2<H>(y[0], y[1]);
+          pk.y = pack2<H>(y[2], y[3]);
+          *reinterpret_cast<uint2*>(sC + row * CP + col) = pk;
+        }
     });
     __syncthreads();
     constexpr int CH = BN / 8;   // 16-byte chunks per tile row (a power of two <= 16)
