@@ -228,10 +228,19 @@ def reference_latency_ms(engine, inputs, warmup=100, iters=500):
     return sum(diff[1:-2]) / (iters - 3), diff[len(diff) // 2]
 
 
+PARITY_GATE = 1e-3          # BASELINE.json north_star: "within 1e-3 relative L1 on the predicted depth map"
+
+
 def err_vs(ref, got):
+    """Parity of `got` against the float32 CPU oracle on the same inputs; `gate_met` says whether THIS storage mode is inside the
+    north-star tolerance.  (bf16 storage is not and cannot be: 8-bit mantissas of weights and activations put a floor of ~6e-3 under
+    it, profiles/r2_precision_budget.md; fp16 storage and the float32 mode are inside.)"""
     import numpy as np
     ref, got = ref.double().cpu().numpy(), got.double().cpu().numpy()
-    return {"rel_l1": float(np.abs(ref - got).sum() / np.abs(ref).sum()), "abs_rel": float(np.mean(np.abs(ref - got) / ref))}
+    rel = float(np.abs(ref - got).sum() / np.abs(ref).sum())
+    per_image = [float(np.abs(r - g).sum() / np.abs(r).sum()) for r, g in zip(ref, got)]
+    return {"rel_l1": rel, "abs_rel": float(np.mean(np.abs(ref - got) / ref)), "rel_l1_worst_image": max(per_image),
+            "gate": PARITY_GATE, "gate_met": bool(rel <= PARITY_GATE and max(per_image) <= PARITY_GATE)}
 
 
 def init_dist(backend: str = "nccl", force: bool = False):
@@ -529,8 +538,7 @@ def main():
                     line["dw3x3"].update({"measured_copy_same_bytes": cgbs, "frac_of_measured_copy": gbs / cgbs,
                                           "copy_avg_launch_us": dw_copy_ms * 1e3 / w["launches"],
                                           "protocol": "median of 5 event-pair timings per launch for the kernel AND the copy; the pair adds several us "
-                                                      "to both, which flatters the ratio -- back-to-back in a HIP graph (tools/dw_bench.py) "
-                                                      "the same launches take 12.5-19.7 us against 3.1-6.7 us for the copy"})
+                                                      "to both, which flatters the ratio -- see in_graph for the back-to-back figure"})
             line["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
             line["kernel_ms_total"] = total_ms
         if world == 1 and not a.no_cpu_baseline:
@@ -561,6 +569,19 @@ def main():
             line["latency"] = lat
         if world == 1 and not a.no_train and not a.no_cpu_baseline:
             line["training"] = training_step_rate(a.train_batch, dev, fidelity=True)
+    train_multi = None
+    if world > 1 and not a.no_train and not a.config5:
+        # the data-parallel TRAINING step on all ranks (BASELINE.json configs[2..3]: per-GPU batch 16, RCCL all-reduce of the flat
+        # gradient inside the timed region): inference is replicas only, so this object is where the 1 -> N scaling of the north star
+        # ("linear 1->8 GPU DDP scaling >= 0.9x") is measured.  Every rank takes part; rank 0 reports.
+        engine._graph = None; engine._slots = None; engine._plans.clear()
+        engine = None
+        torch.cuda.empty_cache()
+        train_multi = training_step_rate(a.train_batch, dev, dist=dist, world=world)
+        train_multi["per_gpu"] = train_multi["value"] / world
+    if rank == 0:
+        if train_multi is not None:
+            line["training"] = train_multi
         print(json.dumps(line))
     if dist:
         dist.barrier()

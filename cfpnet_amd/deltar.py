@@ -54,7 +54,7 @@ class _Store(nn.Module):
 class Deltar(_Store):
     def __init__(self, n_bins: int = 100, min_val: float = 0.1, max_val: float = 10, norm: str = "linear", *,
                  args=None, dtype=torch.bfloat16, stem_act: bool = False, init: str = "deterministic",
-                 base_resolution=spec.BASE_RESOLUTION):
+                 base_resolution=spec.BASE_RESOLUTION, prob_dtype=torch.float32):
         super().__init__()
         a = args if args is not None else _global_args
         self.num_classes = n_bins
@@ -70,6 +70,10 @@ class Deltar(_Store):
             if ln not in ("hist2image", "image", "combine1"):
                 raise NotImplementedError(ln)      # fusion.py:37
         self.compute_dtype = dtype
+        # the reference returns `prob` in float32 (deltar.py:51,64-67); the engine writes it in its storage type (2 bytes per element at
+        # batch 8 = 315 MB instead of 630 MB).  At THIS boundary the reference's type is the default (one cast); prob_dtype=None hands
+        # out the engine's tensor as it is
+        self.prob_dtype = prob_dtype
         self.stem_act = stem_act
         self.base_resolution = tuple(base_resolution)     # decoder.py:82-88 hard-codes 480x640; larger tables are a generalisation
         self._manifest = spec.model_manifest(self.layer_names, n_bins, self.zone_sample_num, self.base_resolution)
@@ -146,6 +150,8 @@ class Deltar(_Store):
         if pos_offsets is None:
             pos_offsets = self.draw_pos_offsets(input_data["rgb"].shape[-2], input_data["rgb"].shape[-1])
         edges, pred, prob = eng.forward(input_data, return_prob=kwargs.get("return_prob", True), pos_offsets=pos_offsets)
+        if prob is not None and self.prob_dtype is not None and prob.dtype != self.prob_dtype:
+            prob = prob.to(self.prob_dtype)
         return edges, pred, prob, None
 
 

@@ -54,9 +54,12 @@ class SILogLoss:
         over the ranks divides by it again.  Returns the global loss (device scalar).  Three tiny torch kernels + one collective."""
         st = self._stats.double()
         mean, n, dg = st[1], st[2], st[3]
-        s = mean * n
-        s2 = (dg - 0.15 * mean * mean) * (n - 1.0) + s * s / n                  # var_unbiased = (s2 - s^2 / n) / (n - 1)
-        m = torch.stack([s, s2, n])
+        # a rank whose shard has no valid pixel (n = 0; n = 1: no variance term) contributes ZERO moments instead of the NaN its local
+        # mean / variance are -- the all-reduce would otherwise spread that NaN into every rank's loss and gradients
+        zero = torch.zeros((), dtype=torch.float64, device=st.device)
+        s = torch.where(n > 0, mean * n, zero)
+        s2 = torch.where(n > 1, (dg - 0.15 * mean * mean) * (n - 1.0) + s * s / n.clamp(min=1.0), torch.where(n > 0, s * s, zero))   # var_unbiased = (s2 - s^2 / n) / (n - 1)
+        m = torch.stack([s, s2, torch.where(n > 0, n, zero)])
         if dist.get_backend(group) == "gloo":                                  # host-staged, like the gradient buckets under gloo
             h = m.cpu()
             dist.all_reduce(h, group=group)
@@ -64,8 +67,9 @@ class SILogLoss:
         else:
             dist.all_reduce(m, group=group)
         S, S2, N = m[0], m[1], m[2]
-        gmean = S / N
-        gdg = (S2 - S * S / N) / (N - 1.0) + 0.15 * gmean * gmean
+        Nc = N.clamp(min=2.0)                                                  # N <= 1 over ALL ranks: no variance; loss 10 * sqrt(0.15) |mean|, finite
+        gmean = S / N.clamp(min=1.0)
+        gdg = torch.where(N > 1, (S2 - S * S / Nc) / (Nc - 1.0), torch.zeros_like(S)) + 0.15 * gmean * gmean
         self._stats.copy_(torch.stack([10.0 * torch.sqrt(gdg), gmean, N, gdg]).float())
         return self._stats[0]
 

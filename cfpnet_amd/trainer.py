@@ -82,9 +82,13 @@ class Trainer:
         self._shadow = torch.empty(kflat.total, dtype=self.dtype, device=self.dev) if self.dtype != torch.float32 else None
         self.net.bind(kflat, self._shadow)
         k = self._opt_kw
-        assert self.opt.step_count == 0
+        # the pre-bind optimizer never stepped (its moments are zero); a schedule position set before the first batch (train.py's
+        # resume without optimizer state) carries over
+        assert not bool(self.opt.m.any()) and not bool(self.opt.v.any()), "optimizer moments exist before the kernel layout was bound"
+        resumed_at = self.opt.step_count
         self.opt = train_ops.FlatAdamW(kflat, train_ops.OneCycle(k["lr"], k["total_steps"], k["div_factor"], k["final_div_factor"]),
                                        weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"])
+        self.opt.step_count = resumed_at
         if self._pending_opt is not None:
             pending, self._pending_opt = self._pending_opt, None
             self.load_optimizer_state_dict(pending)
@@ -279,6 +283,11 @@ class Trainer:
                 raise ValueError("optimizer state was saved in kernel layout; this Trainer keeps the reference layout")
             self._pending_opt = state                       # applied by _bind_kernel_layout on the first batch
             return
+        if not state["kernel_layout"] and self.kernel_layout:
+            # a reference-layout state into a Trainer that will re-lay its parameters on the first batch: the moments would be written
+            # into the pre-bind optimizer and dropped by the bind -- refuse instead of losing them silently
+            raise ValueError("optimizer state was saved in the reference layout (kernel_layout=False); this Trainer keeps kernel layouts -- "
+                             "resume it with Trainer(kernel_layout=False)")
         if [tuple(x) for x in state["layout"]] != [tuple(x) for x in self._layout_signature()]:
             raise ValueError("optimizer state was saved for a different parameter layout")
         self.opt.m.copy_(state["exp_avg"])

@@ -83,6 +83,38 @@ def gain_for(key: str, kind: str) -> float:
     return _GAIN[kind]
 
 
+def normal(key: str, shape, std: float, salt: int = 0) -> np.ndarray:
+    """Key-addressed N(0, std^2): Box-Muller on two splitmix64 streams of the key."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    u1 = splitmix64_uniform((fnv1a64(key) + 2 * salt + 1) & _M64, n)
+    u2 = splitmix64_uniform((fnv1a64(key) + 2 * salt + 2) & _M64, n)
+    z = np.sqrt(-2.0 * np.log1p(-u1)) * np.cos(2.0 * math.pi * u2)
+    return (std * z).astype(np.float32).reshape(shape)
+
+
+def make_tensor_kaiming(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
+    """The reference's OWN initialisation family (`Deltar._reset_parameters`, deltar.py:23-32; fusion.py:22-23): every Conv / Linear
+    outside the RGB encoder is kaiming-normal with fan_out / relu gain (std = sqrt(2 / (Cout * kh * kw))), biases keep PyTorch's default
+    U(+-1/sqrt(fan_in)), BatchNorm / LayerNorm affine parameters are (1, 0), the positional tables trunc_normal(std 0.2).  The encoder
+    is not re-initialised by the reference (timm's pretrained weights, unavailable offline): it keeps the key-addressed uniform
+    tensors.  BatchNorm RUNNING statistics are placeholders here; the tests calibrate them to the network's own batch statistics
+    (what training leaves in them), tests/helpers.calibrate_bn."""
+    if key.startswith("img_encoder."):
+        return make_tensor(key, shape, kind)
+    if kind in _GAIN:
+        fan_out = int(shape[0] * np.prod(shape[2:])) if len(shape) > 2 else int(shape[0])
+        return normal(key, shape, math.sqrt(2.0 / fan_out))
+    if kind == "bias":
+        return uniform(key, shape, -0.05, 0.05)
+    if kind in ("bn_weight", "ln_weight"):
+        return np.ones(shape, dtype=np.float32)
+    if kind in ("bn_bias", "ln_bias"):
+        return np.zeros(shape, dtype=np.float32)
+    if kind == "posenc":
+        return np.clip(normal(key, shape, 0.2), -2.0, 2.0)
+    return make_tensor(key, shape, kind)
+
+
 def make_tensor(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
     if kind in _GAIN:
         fan_in = int(np.prod(shape[1:]))
@@ -109,10 +141,21 @@ def make_tensor(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
     raise KeyError(kind)
 
 
-def make_state_dict(manifest: Iterable[Tuple[str, Tuple[int, ...], str]]) -> Dict[str, "np.ndarray"]:
-    return {k: make_tensor(k, s, kind) for k, s, kind in manifest}
+def make_tensor_kaiming_peaked(key: str, shape: Tuple[int, ...], kind: str) -> np.ndarray:
+    """The kaiming family with a CONFIDENT head: conv_out's weights x 6, so the 256-way softmax is peaked like a trained model's
+    (the plain family's is nearly flat -- max prob 0.03 -- which hides logit errors in the expectation)."""
+    t = make_tensor_kaiming(key, shape, kind)
+    return t * np.float32(6.0) if key == "conv_out.0.weight" else t
 
 
-def make_torch_state_dict(manifest):
+FAMILIES = {"uniform": make_tensor, "kaiming": make_tensor_kaiming, "kaiming_peaked": make_tensor_kaiming_peaked}
+
+
+def make_state_dict(manifest: Iterable[Tuple[str, Tuple[int, ...], str]], family: str = "uniform") -> Dict[str, "np.ndarray"]:
+    f = FAMILIES[family]
+    return {k: f(k, s, kind) for k, s, kind in manifest}
+
+
+def make_torch_state_dict(manifest, family: str = "uniform"):
     import torch
-    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in make_state_dict(manifest).items()}
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in make_state_dict(manifest, family).items()}

@@ -160,3 +160,52 @@ def test_global_batch_silog_over_two_ranks(tmp_path):
         assert abs(r[k]["loss"] - full_loss) <= 2e-6 * abs(full_loss)
         want = world * full_grad[k * 2:(k + 1) * 2]
         assert float((r[k]["grad"] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def _nccl_worker(rank, world, port, out):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.trainer import Trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    inp, target = _shard(0)
+    dinp, dtgt = synthetic.to_device(inp, "cuda:0"), target.cuda()
+    res = {"backend": dist.get_backend()}
+    for name, kw in (("nccl_overlap", dict(dist=dist, world=1, comm="overlap")), ("nccl_sequential", dict(dist=dist, world=1, comm="sequential")),
+                     ("no_dist", {})):
+        tr = Trainer(sd, layers, lr=3e-4, total_steps=20, device="cuda:0", dtype=torch.bfloat16, **kw)
+        tr.capture(dinp, dtgt)
+        if name == "nccl_overlap":
+            assert tr._graph2 is not None                    # the split step: bucket of the 10x group reduced beside the encoder's backward
+        losses = []
+        for _ in range(2):
+            loss, _, _ = tr.step(dinp, dtgt, pos_offsets=OFFS)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        res[name] = {"param": tr.flat.param.detach().cpu().clone(), "grad": tr.flat.grad.detach().cpu().clone(), "loss": losses}
+        del tr
+        torch.cuda.empty_cache()
+    torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_process_group_runs_the_overlapped_step(tmp_path):
+    """First execution of the RCCL branch of the gradient averaging (`train_ops.allreduce_range` with `async_op=True` on the
+    communication stream, `finish_allreduce`) on the one GPU this box has: a 1-rank "nccl" process group.  Averaging over one rank is
+    the identity, so two captured steps with comm = "overlap" (split graphs, buckets reduced beside the RGB encoder's backward) and
+    comm = "sequential" must leave bit for bit the parameters and gradients of the trainer without a process group.  The child is
+    SPAWNED (never a re-exec of a process that has touched the GPU)."""
+    out = str(tmp_path / "nccl1.pt")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["backend"] == "nccl"
+    for mode in ("nccl_overlap", "nccl_sequential"):
+        assert r[mode]["loss"] == r["no_dist"]["loss"], mode
+        assert torch.equal(r[mode]["grad"], r["no_dist"]["grad"]), mode
+        assert torch.equal(r[mode]["param"], r["no_dist"]["param"]), mode
+    assert float(r["no_dist"]["grad"].abs().max()) > 0

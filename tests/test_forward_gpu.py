@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import DECODER_CASES, case_inputs, load_case, rel_l1  # noqa: E402
+from helpers import DECODER_CASES, calibrate_bn, case_inputs, load_case, rel_l1  # noqa: E402
 from cfpnet_amd import spec, synthetic, weights  # noqa: E402
 from cfpnet_amd.engine import Engine  # noqa: E402
 from oracle import cfpnet_oracle as O  # noqa: E402
@@ -167,6 +167,37 @@ def test_config1_batch8_as_benched_vs_oracle(dtype, bound):
     assert p2.shape == (8, 1, 240, 320)
 
 
+@pytest.mark.parametrize("family", ["uniform", "kaiming", "kaiming_peaked"])
+def test_fp16_meets_the_gate_on_three_seeds_of_every_weight_family(family):
+    """The one 16-bit mode that is inside the north-star tolerance must be inside it ROBUSTLY, not on one batch and one weight
+    distribution: configs[1] (batch 8, 480x640) through the captured graph, three input seeds x three weight families -- the
+    key-addressed uniform one the other tests use; the reference's own initialisation (kaiming-normal fan_out for every Conv / Linear
+    outside the encoder, trunc_normal(0.2) positional tables, deltar.py:23-32, fusion.py:22-23) with BatchNorm running statistics
+    calibrated to the network's batch statistics (variances 25-30, means far from 0: what training leaves there); and the same
+    with a confident head (peaked softmax).  fp16 relative L1 <= 1e-3 on EVERY image."""
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers), family=family)
+    if family != "uniform":
+        sd = calibrate_bn(sd, layers)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    eng = Engine(sd, layer_names=layers, dtype=torch.float16)
+    worst = 0.0
+    for si, seed in enumerate((synthetic.SEED, 4242, 97)):
+        inp = synthetic.make_inputs(8, 480, 640, 8, 56, seed=seed, drop_hist=(0.0, 0.34, 0.1)[si])
+        _, p0, _ = O.forward(sd, inp, layer_names=layers)
+        dinp = synthetic.to_device(inp, "cuda:0")
+        if si == 0:
+            eng.capture(dinp)
+        _, p1, _ = eng.replay(dinp)
+        torch.cuda.synchronize()
+        per_image = [rel_l1(p1[b].cpu().numpy(), p0[b].numpy()) for b in range(8)]
+        print(f"fp16 {family} seed {seed}: rel-L1 {rel_l1(p1.cpu().numpy(), p0.numpy()):.3e}, worst image {max(per_image):.3e}, "
+              f"pred std {float(p0.std()):.3f}")
+        worst = max(worst, max(per_image))
+        assert max(per_image) <= TOL_F16, (family, seed, per_image)
+    print(f"fp16 {family}: worst image of 24 = {worst:.3e}")
+
+
 @pytest.mark.parametrize("env", [{"CFP_MBCONV_FUSED": "1"}, {"CFP_WEIGHTS2": "1"}, {"CFP_HEAD_FUSED": "0"}, {"CFP_HEAD_HILO": "10"}],
                          ids=["mbconv_fused", "two_term_weights", "separate_head_kernels", "wout_hilo"])
 def test_optional_kernel_paths_keep_parity(env, monkeypatch):
@@ -218,6 +249,7 @@ def test_deltar_module_boundary():
     edges, pred, prob, _ = out
     assert edges.shape == (1, 257) and pred.shape == (1, 1, 240, 320) and prob.shape == (1, 256, 240, 320)
     assert pred.is_cuda and float(pred.min()) > 1e-3 and float(pred.max()) < 10
+    assert prob.dtype == torch.float32 and pred.dtype == torch.float32 and edges.dtype == torch.float32     # the reference's types (deltar.py:64-67)
     model.train()
     with pytest.raises(RuntimeError, match="no CPU path"):      # parameters still on the host: the training step refuses, it does not fall back
         model(inp)
@@ -277,3 +309,32 @@ def test_batches_in_flight_match_forward(dtype, tol):
     e, p, pr = eng.replay(inps[3])
     torch.cuda.synchronize()
     assert rel_l1(p.cpu().numpy(), want[3][1].cpu().numpy()) <= tol
+
+
+def test_in_flight_stress_is_bit_exact():
+    """Regression guard for the stage hand-over race round 2 found in the fused head (one wave's 32 pixels wrong about once per 640
+    forwards, ONLY with several captured forwards in flight and DIFFERENT inputs per slot; profiles/r2_inflight_race.txt): 300 rounds
+    of 8 different inputs through 4 in-flight slots = 2 400 forwards, every result bit-compared with the eager forward of the
+    same input.  The kernels that stage through LDS-DMA (gen-2 GEMM, LoFTR / LKPM tails, fused head) all run in it."""
+    layers, sd, _ = _full_case(2, 256, 320, 3, 64, 21, 0.0)
+    eng = Engine(sd, layer_names=layers, dtype=torch.float16)
+    inps = [synthetic.to_device(synthetic.make_inputs(2, 256, 320, 3, 64, seed=40 + i, drop_hist=0.2 * (i % 2)), "cuda:0") for i in range(8)]
+    want = [tuple(t.clone() for t in eng.forward(x)) for x in inps]
+    torch.cuda.synchronize()
+    eng.capture(inps[0], inflight=4)
+    n = len(eng._slots)
+    bad = []
+    for r in range(300):
+        got = []
+        for i, x in enumerate(inps):
+            (e, p, pr), ev = eng.replay_async(x)
+            got.append((p, pr, ev))
+            if len(got) >= n:                      # consume the oldest before its slot comes round again
+                j = len(got) - n
+                got[j][2].synchronize()
+                got[j] = (got[j][0].clone(), got[j][1].clone(), None)
+        torch.cuda.synchronize()
+        for i, (p, pr, _) in enumerate(got):
+            if not (torch.equal(p, want[i][1]) and torch.equal(pr, want[i][2])):
+                bad.append((r, i))
+    assert not bad, f"{len(bad)} of 2400 in-flight forwards differ from the eager result: {bad[:8]}"

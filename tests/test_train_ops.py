@@ -94,6 +94,38 @@ def test_two_rank_gloo_gradient_allreduce(tmp_path):
     assert torch.all(r["grad"][r["dead"][0]: r["dead"][1]] == -7.0)       # dead tail is not reduced
 
 
+class _FakeGroup:
+    """all_reduce(sum) against a second rank whose three moments are given: enough of torch.distributed for sync_moments."""
+
+    def __init__(self, other):
+        self.other = other
+
+    def get_backend(self, group=None):
+        return "gloo"
+
+    def all_reduce(self, t, group=None):
+        t.add_(self.other.to(t.dtype))
+
+
+@pytest.mark.parametrize("n_local", [0, 1])
+def test_silog_sync_moments_survives_a_rank_without_valid_pixels(n_local):
+    """A rank whose shard has no valid pixel reports mean = variance = NaN locally; its moments enter the global-batch loss as
+    zeros, so the other ranks' loss stays finite and equals the loss over their pixels alone."""
+    g = torch.tensor([0.3, -0.2, 0.5, 0.1, 0.9], dtype=torch.float64)
+    other = torch.stack([g.sum(), (g * g).sum(), torch.tensor(float(len(g)), dtype=torch.float64)])
+    crit = train_ops.SILogLoss()
+    if n_local == 0:
+        crit._stats = torch.tensor([float("nan"), float("nan"), 0.0, float("nan")])
+        want_g = g
+    else:
+        crit._stats = torch.tensor([float("nan"), 0.7, 1.0, float("nan")])        # one pixel: a mean, no variance
+        want_g = torch.cat([g, torch.tensor([0.7], dtype=torch.float64)])
+    loss = crit.sync_moments(_FakeGroup(other))
+    want = 10.0 * torch.sqrt(want_g.var(unbiased=True) + 0.15 * want_g.mean() ** 2)
+    assert torch.isfinite(loss) and abs(float(loss) - float(want)) < 1e-5 * float(want)
+    assert float(crit._stats[2]) == len(want_g)
+
+
 # ------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("masked,interp", [(True, True), (False, False)])

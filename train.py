@@ -100,11 +100,14 @@ SHUFFLE_SEED = 117010053       # train.py:218 seeds everything with this number
 def load_model_file(path, manifest_sd):
     """A `save_weights` file (bare state_dict) or a `save_checkpoint` file ({"model", "optimizer", "epoch"}), DataParallel's
     "module." prefix stripped (model_io.py:47-52), checked STRICTLY against the model's keys and shapes like
-    `load_state_dict` does (model_io.py:16,54).  -> (state_dict, optimizer entry or None, epoch or None)."""
+    `load_state_dict` does (model_io.py:16,54).  -> (state_dict, optimizer entry or None, epoch or None); for a checkpoint of
+    this loop `epoch` is (last fully completed epoch, global step)."""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     opt, epoch = None, None
     if isinstance(ckpt, dict) and "model" in ckpt and not torch.is_tensor(ckpt["model"]):
-        opt, epoch, ckpt = ckpt.get("optimizer"), ckpt.get("epoch"), ckpt["model"]
+        opt, epoch, gstep, ckpt = ckpt.get("optimizer"), ckpt.get("epoch"), ckpt.get("global_step"), ckpt["model"]
+        if gstep is not None:                    # written by THIS loop: the real progress, also of a run cut short by --max_steps
+            epoch = (epoch, int(gstep))
     sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in ckpt.items()}
     want = {k: tuple(v.shape) for k, v in manifest_sd.items() if torch.is_tensor(v)}
     missing, unexpected = sorted(set(want) - set(sd)), sorted(set(sd) - set(want))
@@ -115,10 +118,13 @@ def load_model_file(path, manifest_sd):
     return sd, opt, epoch
 
 
-def save_training_checkpoint(path, weights_now, trainer, epoch):
-    """`save_checkpoint` of model_io.py:25-31: {"model", "optimizer", "epoch"}; the optimizer entry is the flat AdamW state."""
+def save_training_checkpoint(path, weights_now, trainer, epoch, global_step):
+    """`save_checkpoint` of model_io.py:25-31: {"model", "optimizer", "epoch"}; the optimizer entry is the flat AdamW state.
+    `epoch` is the last FULLY completed epoch (-1: none yet) -- the reference's meaning, `--resume` continues at epoch + 1 -- and
+    `global_step` the number of optimizer steps taken so far, so a run that stopped inside an epoch (--max_steps) resumes where it
+    stopped instead of being taken for finished."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save({"model": weights_now, "optimizer": trainer.optimizer_state_dict(), "epoch": int(epoch)}, path)
+    torch.save({"model": weights_now, "optimizer": trainer.optimizer_state_dict(), "epoch": int(epoch), "global_step": int(global_step)}, path)
 
 
 def drop_zones(sim, s, drop, rng):
@@ -189,7 +195,7 @@ def main(argv=None):
         total_steps = min(total_steps, max_steps)
     layers = list(args.attention_layer)
     sd = weights.make_torch_state_dict(spec.model_manifest(layers, int(args.n_bins), int(args.zone_sample_num)))
-    start_epoch, opt_state = 0, None
+    start_epoch, start_step, opt_state = 0, 0, None
     for path, is_resume in ((getattr(args, "weight_path", "") or "", False), (getattr(args, "resume", "") or "", True)):
         if not path:
             continue
@@ -198,7 +204,12 @@ def main(argv=None):
         if is_resume and ep is not None:
             # train.py:30-38 restores the weights only (its optimizer restore is commented out, :83-84); a checkpoint written by
             # THIS loop also carries the flat AdamW moments + step counter and the run continues where it stopped
-            start_epoch = int(ep) + 1
+            if isinstance(ep, tuple):                              # this loop's checkpoint: real progress
+                start_step = min(int(ep[1]), total_steps)
+                start_epoch = start_step // steps_per_epoch
+            else:                                                  # the reference's: epoch = last finished epoch
+                start_epoch = int(ep) + 1
+                start_step = min(start_epoch * steps_per_epoch, total_steps)
             opt_state = opt if isinstance(opt, dict) and opt.get("format", "").startswith("cfpnet_amd.") else None
     tr = Trainer(sd, layers, lr=float(args.lr), total_steps=max(total_steps, 2), weight_decay=float(args.wd), div_factor=float(args.div_factor),
                  final_div_factor=float(args.final_div_factor), hist_encoder_10x=bool(args.hist_encoder_10x),
@@ -207,6 +218,17 @@ def main(argv=None):
                  norm=str(args.norm), sync_loss=sync_loss)
     if opt_state is not None:
         tr.load_optimizer_state_dict(opt_state)
+    elif start_step > 0:
+        # a reference-format checkpoint has no AdamW state to restore (train.py:83-84 is commented out there too): the moments restart
+        # at zero, but the OneCycle schedule continues at the resumed step (what the reference means by `last_epoch`), so the
+        # logged step and the learning rate stay consistent and the final anneal still happens
+        tr.opt.step_count = start_step
+        if rank == 0:
+            print(f"resume without optimizer state: AdamW moments restart, OneCycle continues at step {start_step}/{total_steps}", flush=True)
+    if sync_loss and dist is not None and backend != "nccl" and not eager:
+        eager = True            # the moments' all-reduce sits inside the captured region; only RCCL collectives can be captured
+        if rank == 0:
+            print("note: --sync_loss under the gloo backend runs the eager step (a captured step needs RCCL)", flush=True)
     sim = TofSimulator(args, dev)
     zn, zp, _, _ = zone_layout(args, H, W)
     rects = geometry.centered_zone_rects(H, W, zn, zp)
@@ -241,7 +263,8 @@ def main(argv=None):
             os.makedirs(d, exist_ok=True)
             if epoch is not None:                                    # train.py:150-155: checkpoint {model, optimizer, epoch} + bare weights
                 torch.save(weights_now, os.path.join(d, f"{epoch}_{m['rmse']:.3f}.pt"))
-                save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, epoch)
+                if steps_here > 0:                                   # the optimizer state exists once a step ran in this process
+                    save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, epoch, at_step)
             if m["rmse"] < best_rmse:
                 torch.save(weights_now, os.path.join(d, "best.pt"))
         best_rmse = min(best_rmse, m["rmse"])
@@ -249,8 +272,10 @@ def main(argv=None):
         del eng
         return m
 
-    t0, seen, step = time.perf_counter(), 0, start_epoch * steps_per_epoch
+    t0, seen, step, steps_here = time.perf_counter(), 0, start_step, 0
     loss = torch.zeros(())
+    if start_step >= total_steps and rank == 0:
+        print(f"nothing left to train: the checkpoint is at step {start_step} of {total_steps}", flush=True)
     for epoch in range(start_epoch, int(args.epochs)):
         # one global permutation per epoch, the same on every rank (each takes its slice of every global batch)
         file_batches = files.epoch_batches(per_rank, generator=torch.Generator().manual_seed(SHUFFLE_SEED + epoch)) if files is not None else None
@@ -259,6 +284,10 @@ def main(argv=None):
         for i in range(steps_per_epoch):
             if step >= total_steps:
                 break
+            if epoch * steps_per_epoch + i < start_step:          # resumed inside this epoch: these batches were consumed before
+                if file_batches is not None:
+                    next(file_batches)
+                continue
             if no_augment and files is None:
                 img, dep = ds.batch(epoch * steps_per_epoch + i, per_rank)
                 depd = dep.to(dev)
@@ -282,6 +311,7 @@ def main(argv=None):
                 tr.capture(inp, depd)                         # the whole step as one HIP graph from here on
             loss, lr, beta1 = tr.step(inp, depd)
             step += 1
+            steps_here += 1
             seen += per_rank * world
             if rank == 0 and (step % log_every == 0 or step == 1 or step == total_steps):
                 torch.cuda.synchronize()
@@ -295,8 +325,8 @@ def main(argv=None):
     if rank == 0 and save_path:
         os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
         torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
-        if step > 0:
-            save_training_checkpoint(os.path.splitext(save_path)[0] + ".ckpt.pt", tr.state_dict(), tr, int(args.epochs) - 1)
+        if steps_here > 0:            # the last FULLY completed epoch (-1: none) + the global step: a cut-short run resumes, not "finished"
+            save_training_checkpoint(os.path.splitext(save_path)[0] + ".ckpt.pt", tr.state_dict(), tr, step // steps_per_epoch - 1, step)
     if dist:
         dist.barrier(); dist.destroy_process_group()
     return float(loss)
