@@ -755,12 +755,20 @@ hipError_t launch_dwlarge_any(const void* in, int in_ld, const float* w, const f
 
 }  // namespace
 
+// dw3x3_stream.hip
+int cfp_dws_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld, float* partial,
+                   int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream,
+                   const char* who);
+int cfp_dws_strips(int B, int Ho, int Wo, int C, int stride);
+void cfp_dws_debug_set(int key, int value);
+
 namespace {
 // Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
 // Among the configurations whose input strip fits 64 KB of LDS, take the one with the lowest
 // (halo read amplification) x (penalty for leaving CUs idle).
 struct DwPlan { int cvb, R, nstrips; size_t lds; };
 int g_dw_force_cvb = 0, g_dw_force_R = 0, g_dw_valu = 0;   // cfp_debug_set keys 3 / 4 / 5 (tools/dw_bench.py)
+int g_dw_no_stream = 0;                                    // key 6: 1 = keep dw3x3_mfma_kernel instead of the pipelined dw3x3_stream_kernel (A/B)
 inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out_tile = false) {
   DwPlan best{8, 1, Ho, 0};
   double bc = 1e30;
@@ -806,6 +814,11 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
               std::string(who) + ": pointers must be 16-byte aligned");
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
+  if (mfma && !g_dw_no_stream) {
+    // the software-pipelined kernel (dw3x3_stream.hip): same arithmetic, load / compute / store overlapped inside a workgroup
+    const int rc = cfp_dws_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype, stream, who);
+    if (rc != 1) return rc;
+  }
   const DwPlan d = dw_plan(B, Ho, Wo, C, stride, ve, mfma);
   CFP_REQUIRE((long long)B * d.nstrips <= 65535, CFP_ESHAPE, std::string(who) + ": grid too large");
   CFP_REQUIRE(d.lds <= 64 * 1024, CFP_ESHAPE, std::string(who) + ": map too wide for the LDS strip");
@@ -848,7 +861,10 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
 }
 }  // namespace
 
-void cfp_dw_debug_set(int key, int value) { if (key == 3) g_dw_force_cvb = value; else if (key == 4) g_dw_force_R = value; else g_dw_valu = value; }
+void cfp_dw_debug_set(int key, int value) {
+  if (key == 3) g_dw_force_cvb = value; else if (key == 4) g_dw_force_R = value; else if (key == 5) g_dw_valu = value;
+  else if (key == 6) g_dw_no_stream = value; else cfp_dws_debug_set(key, value);
+}
 
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                                   void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
@@ -859,6 +875,10 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (is16(dtype) && C % 16 == 0 && !g_dw_valu && !g_dw_no_stream) {
+    const int n = cfp_dws_strips(B, Ho, Wo, C, stride);
+    if (n > 0) return n;
+  }
   return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype), is16(dtype) && C % 16 == 0 && !g_dw_valu).nstrips;
 }
 

@@ -335,6 +335,98 @@ __global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restr
   }
 }
 
+// se_gate_fold2 (round 3): the squeeze-excite tail when the depthwise kernel has already taken the reduce FC's dot products.
+// The reduce layer is linear in the channel sums, so every workgroup of dw3x3_stream_kernel (image b, 64-channel block, row
+// range) contributes  hpart[b][k][r] = sum_{c in block} w_reduce[r][c] * (sum of its output pixels of channel c)  and what is
+// left here is
+//   phase A  hidden[r] = silu(inv_hw * sum_k hpart[b][k][r] + b_reduce[r])        K = blocks x ranges partials, added in k order
+//   phase B  gate[c]   = sigmoid(hidden . w_expand_t[:, c] + b_expand[c])          the 128 channels of this slab
+//   phase C  wout[b][n][c] = w[n][c] * gate[c]                                     this workgroup's share of the project rows
+// grid (ceil(C/128), B, Z): Z splits the project rows so that the launch fills the chip; every load batch of a phase is in flight
+// together.  se_gate_fold_kernel above needed the R x C reduce weights (323 KB at C = 1392) in EVERY workgroup and ran 48 workgroups
+// of 1024 threads: 15.8 us per launch, 24 launches per forward (profiles/r2n_bench_b8_kernel_stats.txt).
+template <typename T>
+__global__ __launch_bounds__(256) void se_gate_fold2_kernel(const float* __restrict__ hpart, int K, float inv_hw, const float* __restrict__ br,
+                                                            const float* __restrict__ we_t, const float* __restrict__ be,
+                                                            const float* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R, int rows_per_z) {
+  constexpr int VE = Vec<T>::N;
+  __shared__ float hsum[4][64];
+  __shared__ float hid[64];
+  __shared__ float gpart[2][128];
+  __shared__ float gate[128];
+  const int b = blockIdx.y, slab = blockIdx.x, z = blockIdx.z;
+  const int tid = threadIdx.x;
+  // ---- phase A: thread (r = tid & 63, quarter kq = tid >> 6) adds its partials k = kq, kq + 4, ... in order (16 loads in flight)
+  {
+    const int r = tid & 63, kq = tid >> 6;
+    float s = 0.f;
+    if (r < R) {
+      const float* hp = hpart + (long long)b * K * R + r;
+      for (int k0 = kq; k0 < K; k0 += 64) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = (k0 + 4 * u < K) ? hp[(long long)(k0 + 4 * u) * R] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u];
+      }
+    }
+    hsum[kq][r] = s;
+  }
+  __syncthreads();
+  if (tid < 64) hid[tid] = tid < R ? act_c<CFP_ACT_SILU>(((hsum[0][tid] + hsum[1][tid]) + (hsum[2][tid] + hsum[3][tid])) * inv_hw + br[tid]) : 0.f;
+  __syncthreads();
+  // ---- phase B: channel cl = tid & 127, half of the hidden units rh = tid >> 7 (up to 32 loads in flight)
+  {
+    const int cl = tid & 127, rh = tid >> 7;
+    const int c = slab * 128 + cl;
+    float s = 0.f;
+    if (c < C) {
+      float t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = (rh * 32 + u < R) ? we_t[(long long)(rh * 32 + u) * C + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) s = fmaf(hid[rh * 32 + u], t[u], s);
+    }
+    gpart[rh][cl] = s;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int c = slab * 128 + tid;
+    gate[tid] = act_c<CFP_ACT_SIGMOID>(gpart[0][tid] + gpart[1][tid] + (c < C ? be[c] : 0.f));
+  }
+  __syncthreads();
+  // ---- phase C: vector lane vl (128 / VE per row), row lane rl; 4 rows in flight per thread
+  {
+    constexpr int VPS = 128 / VE;
+    constexpr int NRL = 256 / VPS;
+    const int vl = tid % VPS, rl = tid / VPS;
+    const int cv = slab * VPS + vl;
+    if (cv * VE < C) {
+      float g[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) g[e] = gate[vl * VE + e];
+      const int n1 = min(Cout, (z + 1) * rows_per_z);
+      for (int n = z * rows_per_z + rl; n < n1; n += 4 * NRL) {
+        float v[4][VE];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (n + k * NRL < n1) {      // FLOAT32 project weights: the folded weight is rounded to the storage type once, not twice
+#pragma unroll
+            for (int e = 0; e < VE; e += 4) Vec<float>::load(w + (long long)(n + k * NRL) * C + cv * VE + e, v[k] + e);
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (n + k * NRL < n1) {
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[k][e] *= g[e];
+            Vec<T>::store(wout + ((long long)b * Cout + n + k * NRL) * C + cv * VE, v[k]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scale_channels_kernel(T* __restrict__ x, int ld, const float* __restrict__ gate,
                                                              int HW, int C, long long total) {
@@ -541,6 +633,28 @@ __global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restri
   }
 }
 
+// 16-bit storage only: channels 0-2 = the image rounded to the storage type, channels 3-5 = what that rounding lost (x - hi, itself
+// rounded), 6-7 = 0.  A stem whose weight rows repeat the three real channels in slots 3-5 then sums w * (hi + lo) in its float32
+// accumulators: the network sees the float32 input the reference sees (src/models/encoder.py:71-73 feeds float32 RGB) for free --
+// the K axis of the stem GEMM is padded to 8 channel slots per tap anyway.
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_to_nhwc8_hilo_kernel(const float* __restrict__ rgb, T* __restrict__ out, int HW, long long total) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long b = i / HW, hw = i % HW;
+    const float* p = rgb + b * 3 * HW + hw;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = p[c * (long long)HW];
+      const float hi = to_f32<T>(from_f32<T>(x));
+      v[c] = hi;
+      v[3 + c] = x - hi;
+    }
+    v[6] = 0.f; v[7] = 0.f;
+    Vec<T>::store(out + i * 8, v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scalar_to_rows8_kernel(const float* __restrict__ in, T* __restrict__ out, long long rows) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long long)gridDim.x * 256) {
@@ -635,6 +749,33 @@ extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, 
     hipLaunchKernelGGL(se_gate_fold_kernel<float>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
                        b_expand, (const float*)w_proj, (float*)w_out, Cout, C, R);
   return cfp_check_launch("cfp_se_gate_fold");
+}
+
+extern "C" int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const float* b_reduce, const float* w_expand_t, const float* b_expand,
+                                 const float* w_proj, void* w_out, int B, int Cout, int C, int R, int dtype, cfp_stream_t stream) {
+  CHECK_DTYPE("cfp_se_gate_fold2");
+  CFP_REQUIRE(hpart && b_reduce && w_expand_t && b_expand && w_proj && w_out, CFP_EINVAL, "cfp_se_gate_fold2: null pointer");
+  CFP_REQUIRE(aligned16(w_proj) && aligned16(w_out), CFP_EINVAL, "cfp_se_gate_fold2: pointers must be 16-byte aligned");
+  CFP_REQUIRE(B > 0 && B <= 65535 && K > 0 && Cout > 0 && C > 0 && C % 8 == 0 && R > 0 && R <= 64, CFP_ESHAPE,
+              "cfp_se_gate_fold2: need C % 8 == 0, R <= 64");
+  const int slabs = cdiv(C, 128);
+  int Z = cdiv(384, slabs * B);                       // enough workgroups to fill 256 CUs; each recomputes the (cheap) phases A and B
+  if (Z > 8) Z = 8;
+  if (Z > Cout) Z = Cout;
+  if (Z < 1) Z = 1;
+  const int rows_per_z = cdiv(Cout, Z);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(slabs, B, cdiv(Cout, rows_per_z));
+  if (dtype == CFP_BF16)
+    hipLaunchKernelGGL(se_gate_fold2_kernel<bf16_t>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
+                       (bf16_t*)w_out, Cout, C, R, rows_per_z);
+  else if (dtype == CFP_F16)
+    hipLaunchKernelGGL(se_gate_fold2_kernel<f16_t>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
+                       (f16_t*)w_out, Cout, C, R, rows_per_z);
+  else
+    hipLaunchKernelGGL(se_gate_fold2_kernel<float>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
+                       (float*)w_out, Cout, C, R, rows_per_z);
+  return cfp_check_launch("cfp_se_gate_fold2");
 }
 
 extern "C" int cfp_se_scale(void* x, int ld, const float* hidden, const float* w_expand_t, const float* b_expand, int B, int HW,
@@ -810,6 +951,17 @@ extern "C" int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W
   else if (dtype == CFP_F16) hipLaunchKernelGGL(rgb_to_nhwc8_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (f16_t*)out, H * W, total);
   else hipLaunchKernelGGL(rgb_to_nhwc8_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (float*)out, H * W, total);
   return cfp_check_launch("cfp_rgb_to_nhwc8");
+}
+
+extern "C" int cfp_rgb_to_nhwc8_hilo(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_rgb_to_nhwc8_hilo: 16-bit storage types only");
+  CFP_REQUIRE(rgb && out && aligned16(out), CFP_EINVAL, "cfp_rgb_to_nhwc8_hilo: bad pointer");
+  CFP_REQUIRE(B > 0 && H > 0 && W > 0, CFP_ESHAPE, "cfp_rgb_to_nhwc8_hilo: bad shape");
+  long long total = (long long)B * H * W;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == CFP_BF16) hipLaunchKernelGGL(rgb_to_nhwc8_hilo_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (bf16_t*)out, H * W, total);
+  else hipLaunchKernelGGL(rgb_to_nhwc8_hilo_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, rgb, (f16_t*)out, H * W, total);
+  return cfp_check_launch("cfp_rgb_to_nhwc8_hilo");
 }
 
 extern "C" int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_stream_t stream) {

@@ -922,6 +922,51 @@ def test_dwconv3x3_mfma_bit_exact_on_integers(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(8, 30, 40, 816, 1), (8, 15, 20, 1392, 1), (8, 60, 80, 224, 2), (8, 30, 40, 816, 2), (8, 30, 40, 448, 1),
+                                  (2, 26, 34, 672, 1), (2, 13, 17, 1392, 1), (2, 40, 60, 208, 1), (1, 20, 30, 1392, 1), (2, 52, 68, 224, 2),
+                                  (1, 7, 5, 16, 1), (3, 16, 16, 80, 1), (1, 33, 130, 48, 2)])
+def test_dwconv3x3_stream_kernel_equals_the_single_phase_kernel(case, dtype):
+    """dw3x3_stream_kernel (round 3: whole input image requested by LDS-DMA at kernel start, consumed in row steps behind counted
+    vmcnt waits, results stored beside the next step's compute) against dw3x3_mfma_kernel (load -> compute -> store), same
+    arithmetic: outputs BIT-identical on the encoder's shapes at the benched batch, the training / config-5 / smoke shapes
+    (row tails of 1 ... 14 pixels, ragged last row range, last channel block partly empty, stride 2 with TF-SAME padding), with
+    the tensors embedded in wider buffers (pitch > C); channel sums equal up to the order of the per-range partial sums."""
+    B, H, W, Cc, s = case
+    lib = hip.load()
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = max((Ho - 1) * s + 3 - H, 0) // 2, max((Wo - 1) * s + 3 - W, 0) // 2
+    x = q(rnd(B, Cc, H, W, seed=11), dtype)
+    w = q(rnd(Cc, 1, 3, 3, seed=12, scale=0.4), dtype)
+    scale, shift = (rnd(Cc, seed=13).abs() + 0.5).to(DEV), rnd(Cc, seed=14).to(DEV)
+    wa = w.reshape(Cc, 9).t().contiguous().to(dtype).to(DEV)
+    xin = to_act(nhwc(x), dtype, ld=Cc + 24, c0=8)
+    res = []
+    try:
+        for old in (1, 0):
+            lib.cfp_debug_set(6, old)
+            buf = ops.new_act(B * Ho * Wo, Cc, dtype, DEV, ld=Cc + 16, zero=True)
+            out = ops.Act(buf.buf, 8, Cc)
+            ns = ops.dwconv3x3_strips(B, Ho, Wo, Cc, s, ops.DT[dtype])
+            part = torch.full((B, ns, Cc), float("nan"), device=DEV)
+            ops.dwconv3x3_sum(xin, wa, scale, shift, out, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+            torch.cuda.synchronize()
+            res.append((buf.buf.clone(), part.sum(1).cpu(), ns))
+    finally:
+        lib.cfp_debug_set(6, 0)
+    (o_old, s_old, _), (o_new, s_new, ns_new) = res
+    ref = F.silu(F.conv2d(F.pad(x, (pl, (Wo - 1) * s + 3 - W - pl, pt, (Ho - 1) * s + 3 - H - pt)), w, None, s, 0, 1, Cc)
+                 * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None])
+    close(from_nhwc(ops.Act(o_new, 8, Cc).torch(), B, Ho, Wo), ref, dtype, f"dw3x3 stream {case}")
+    close(from_nhwc(ops.Act(o_old, 8, Cc).torch(), B, Ho, Wo), ref, dtype, f"dw3x3 single-phase {case}")
+    if not torch.equal(o_old.view(torch.int16), o_new.view(torch.int16)):
+        d = (o_old.float() - o_new.float()).abs().reshape(B, Ho, Wo, -1)
+        idx = torch.nonzero(d > 0)
+        raise AssertionError(f"stream kernel output differs {case}: {idx.shape[0]} elements, first {idx[:6].tolist()}, max {float(d.max()):.3e}")
+    assert float(o_new[:, :8].float().abs().max()) == 0 and float(o_new[:, 8 + Cc:].float().abs().max()) == 0     # nothing outside the slice
+    assert torch.isfinite(s_new).all() and torch.allclose(s_new, s_old, rtol=2e-5, atol=2e-5 * float(s_old.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (1, 64, 32, 8, 31)])
 def test_dwconv_large_toeplitz_bit_exact_on_integers(case, dtype):
     B, H, W, Cc, k = case

@@ -10,6 +10,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8);
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the MFMA kernel (diagnostic build path, act + 100)")
 ap.add_argument("--phases", action="store_true", help="also time the kernel with its compute phase skipped (act=99)")
+ap.add_argument("--ab", action="store_true", help="also time the round-2 single-phase kernel (cfp_debug_set(6, 1)) beside the pipelined one")
+ap.add_argument("--sweep-stream", action="store_true", help="sweep the pipelined kernel's rows per step S and rows per workgroup RT")
 a = ap.parse_args()
 lib = hip.load()
 DEV = "cuda:0"
@@ -33,7 +35,7 @@ for (H, W, C, s) in shapes:
     xs = [ops.Act(torch.randn(B * H * W, C, device=DEV).to(torch.bfloat16), 0, C) for _ in range(NB)]
     outs = [ops.new_act(B * Ho * Wo, C, torch.bfloat16, DEV) for _ in range(NB)]
     w = torch.randn(9, C, device=DEV).to(torch.bfloat16); sc = torch.ones(C, device=DEV); sh = torch.zeros(C, device=DEV)
-    part = torch.zeros(B * 64 * C + 6 * 65536, device=DEV)
+    part = torch.zeros(B * 64 * C + 16 * 65536, device=DEV)
     k = [0]
     def run():
         i = k[0] % NB; k[0] += 1
@@ -47,17 +49,44 @@ for (H, W, C, s) in shapes:
     mb = 2.0 * (B * H * W * C + B * Ho * Wo * C) / 1e6
     t = timeit(run, a.reps); tc = timeit(cp, a.reps)
     line = f"{B}x{H}x{W}x{C} s{s}: {mb:6.1f} MB  auto {t:6.1f} us = {mb / t:5.2f} TB/s   copy_rows(out-sized) {tc:6.1f} us = {2.0 * 2 * B * Ho * Wo * C / 1e6 / tc:5.2f} TB/s"
+    if a.ab:
+        lib.cfp_debug_set(6, 1)
+        told = timeit(run, a.reps)
+        lib.cfp_debug_set(6, 0)
+        line += f"   round-2 kernel {told:6.1f} us   pipelined/copy {t / tc:4.2f}x (target <= 1.7x)   old/copy {told / tc:4.2f}x"
+    if a.sweep_stream:
+        best = (t, "auto")
+        for S in (1, 2, 3, 4):
+            for k in (1, 2, 3, 4, 5, 6, 8):
+                lib.cfp_debug_set(7, S); lib.cfp_debug_set(8, S * k)
+                try:
+                    tt = timeit(run, max(5, a.reps // 3))
+                except RuntimeError:
+                    continue
+                line += f"\n      S{S} RT{S * k}: {tt:6.1f}"
+                if tt < best[0]: best = (tt, f"S{S} RT{S * k}")
+        lib.cfp_debug_set(7, 0); lib.cfp_debug_set(8, 0)
+        line += f"\n   best {best[1]} {best[0]:.1f} us"
     if a.stamps:
         ns = ops.dwconv3x3_strips(B, Ho, Wo, C, s, hip.BF16)
         part.zero_()
         torch.cuda.synchronize()
         ops.dwconv3x3_sum(xs[0], w, sc, sh, outs[0], part, B, H, W, s, pt, pl, Ho, Wo, 100 + hip.ACT_SILU)
         torch.cuda.synchronize()
-        dbg = part[B * ns * C: B * ns * C + 6 * 60000].reshape(-1, 6).cpu()
+        raw = part[B * ns * C: B * ns * C + 16 * 20000]
+        if float(raw[5]) == 2.0:        # the pipelined kernel: 16 floats per workgroup, per-step stamps
+            d16 = raw.reshape(-1, 16).cpu()
+            d16 = d16[d16[:, 5] == 2.0]
+            med = lambda c: float(d16[:, c][d16[:, c] > 0].median()) if bool((d16[:, c] > 0).any()) else 0.0
+            line += ("\n      per-step stamps (median cycles since workgroup start): rows landed " + " / ".join(f"{med(6 + k):.0f}" for k in range(4))
+                     + "; step done " + " / ".join(f"{med(10 + k):.0f}" for k in range(4)))
+            dbg = d16[:, :6].clone(); dbg[:, 5] = 1.0
+        else:
+            dbg = part[B * ns * C: B * ns * C + 6 * 60000].reshape(-1, 6).cpu()
         dbg = dbg[dbg[:, 5] == 1.0]
         t0, t1 = dbg[:, 3], dbg[:, 4]
         span = float((t1.max() - t0.min())) * 10.0      # 100 MHz ticks -> ns
-        line += (f"\n      stamps: {dbg.shape[0]} workgroups; cycles load {dbg[:,0].median():.0f} compute {dbg[:,1].median():.0f} "
+        line += (f"\n      stamps: {dbg.shape[0]} workgroups; cycles until the first step's rows landed {dbg[:,0].median():.0f}, rest {dbg[:,1].median():.0f}, "
                  f"copy-out {dbg[:,2].median():.0f} (max {dbg[:,0].max():.0f}/{dbg[:,1].max():.0f}/{dbg[:,2].max():.0f}); "
                  f"first start -> last end {span / 1e3:.1f} us; start spread {float(t0.max() - t0.min()) * 10 / 1e3:.1f} us; "
                  f"median wg lifetime {float((t1 - t0).median()) * 10 / 1e3:.1f} us")
