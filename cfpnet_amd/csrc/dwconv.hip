@@ -782,7 +782,12 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out
       if (g_dw_force_R && R != g_dw_force_R) continue;
       const int rows_in = (R - 1) * stride + 3;
       size_t lds = (size_t)rows_in * cols_in * (out_tile ? cvb * 16 + 16 : cvb * 16);   // out_tile: the MFMA kernel's padded pixel pitch
-      if (out_tile) lds += 16 + (size_t)(R * (cdiv(Wo, 16) + 1) + 16) * 64;              // + its unit table
+      if (out_tile) {                                                                    // + its unit table, sized as the kernel fills it:
+        const int nmain = Wo >> 4, tw = Wo & 15;                                          // row tails narrower than 16 are gathered from RB rows,
+        const int RB = tw == 0 ? 1 : (16 % tw == 0 ? 16 / tw : 1);                        // and a row block has RB * nmain + 1 units even when the
+        const int upb = RB * nmain + (tw ? 1 : 0);                                        // strip holds fewer than RB rows (round 3: the old bound
+        lds += 16 + (size_t)cdiv(R, RB) * upb * 64;                                       // R * (ceil(Wo/16) + 1) overflowed LDS for Wo = 65, R = 1)
+      }
       const size_t red = (size_t)(256 / cvb) * cvb * ve * sizeof(float);
       if (lds < red) lds = red;
       if (lds > 64 * 1024) break;

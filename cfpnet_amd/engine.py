@@ -220,6 +220,13 @@ class Engine:
         e = "img_encoder"
         EPS = spec.ENC_BN_EPS
         self._conv(sd, "stem", f"{e}.conv0.0.weight", bn=f"{e}.conv0.1", eps=EPS)
+        # 16-bit modes: the stem reads the image as hi + lo pairs (cfp_rgb_to_nhwc8_hilo), i.e. exactly; its weight rows repeat the three
+        # real input channels in the channel slots 3-5 of every tap (slots the K padding to 8 per tap left empty)
+        self.rgb_hilo = self.half and os.environ.get("CFP_RGB_HILO", "1") == "1"
+        if self.rgb_hilo:
+            w = self.P["stem.w"].reshape(-1, 9, 8).clone()
+            w[:, :, 3:6] = w[:, :, 0:3]
+            self.P["stem.w"] = w.reshape(w.shape[0], 72).contiguous()
         for b in spec.ENC_BLOCKS:
             q = f"{e}.{b.prefix}"
             if b.kind == "cn":
@@ -368,7 +375,7 @@ class Engine:
         """encoder.py:71-79 over timm tf_efficientnetv2_b3 blocks; returns the five tap Acts."""
         e = "img_encoder"
         x8 = self._act(plan, "rgb8", B * H * W, 8)
-        ops.rgb_to_nhwc8(rgb, x8, B, H, W)
+        (ops.rgb_to_nhwc8_hilo if self.rgb_hilo else ops.rgb_to_nhwc8)(rgb, x8, B, H, W)
         pads = (_same_pad(H, 3, 2), _same_pad(W, 3, 2))
         h, w = math.ceil(H / 2), math.ceil(W / 2)
         x = self._act(plan, "stem", B * h * w, spec.ENC_STEM_OUT)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "cfp_dwconv3x3_sum_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p] + [_i] * 11 + [_p]),
     "cfp_se_fold": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_gate_fold": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_se_gate_fold2": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_dwconv_large_toeplitz_elems": (_sz, [_i, _i]),
     "cfp_dwconv_large_toeplitz": (_i, [_p, _p, _i, _i, _i, _i, _p]),
@@ -54,6 +55,7 @@ SIGNATURES = {
     "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_copy_rows2": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_rgb_to_nhwc8": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "cfp_rgb_to_nhwc8_hilo": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "cfp_scalar_to_rows8": (_i, [_p, _p, _i, _i, _p]),
     "cfp_silog_ws_bytes": (_sz, [_i, _i, _i]),
     "cfp_silog_loss_fwd": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _sz, _p, _p]),

@@ -140,6 +140,13 @@ def se_gate_fold(partial, nsplit, inv_hw, wr, br, we_t, be, w_proj: torch.Tensor
              w_proj.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_proj.dtype], _s())
 
 
+def se_gate_fold2(hpart, K, inv_hw, br, we_t, be, w_proj32: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R):
+    assert w_proj32.shape == (Cout, C) and w_proj32.dtype == torch.float32 and w_out.shape == (B, Cout, C)
+    assert we_t.shape == (R, C) and hpart.dtype == torch.float32 and hpart.numel() >= B * K * R
+    hip.call("cfp_se_gate_fold2", hpart.data_ptr(), K, float(inv_hw), br.data_ptr(), we_t.data_ptr(), be.data_ptr(),
+             w_proj32.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_out.dtype], _s())
+
+
 def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
     hip.call("cfp_dwconv_large_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
              B, H, W, x.C, k, act, x.dt, _s())
@@ -333,6 +340,12 @@ def copy_rows2(x0: Act, out0: Act, x1: Act, out1: Act, rows):
 def rgb_to_nhwc8(rgb: torch.Tensor, out: Act, B, H, W):
     assert rgb.dtype == torch.float32 and rgb.is_contiguous() and out.C == 8 and out.ld == 8
     hip.call("cfp_rgb_to_nhwc8", rgb.data_ptr(), out.ptr, B, H, W, out.dt, _s())
+
+
+def rgb_to_nhwc8_hilo(rgb: torch.Tensor, out: Act, B, H, W):
+    """16-bit storage: [hi(3) | lo(3) | 0 0] per pixel -- the stem then sees the float32 image (its weight rows repeat the real channels)."""
+    assert rgb.dtype == torch.float32 and rgb.is_contiguous() and out.C == 8 and out.ld == 8
+    hip.call("cfp_rgb_to_nhwc8_hilo", rgb.data_ptr(), out.ptr, B, H, W, out.dt, _s())
 
 
 def scalar_to_rows8(x: torch.Tensor, out: Act, rows):

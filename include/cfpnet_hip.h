@@ -182,6 +182,14 @@ int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float
                      const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out,
                      int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
+/* The squeeze-excite tail when the depthwise kernel has already applied the reduce FC to its channel sums (the reduce layer is
+ * linear in them): hpart [B][K][R] f32 partial dot products (cfp_dwconv3x3_se_nhwc), added in k order;
+ *   hidden = silu(inv_hw * sum_k hpart + b_reduce);  gate = sigmoid(hidden . w_expand_t + b_expand);  w_out[b][n][c] = w_proj[n][c] * gate[c]
+ * with w_proj the FLOAT32 project weights [Cout][C] (the folded weights are rounded to `dtype` once) and w_out [B][Cout][C] in `dtype`.
+ * Replaces timm SqueezeExcite + the gate multiply as cfp_se_gate_fold does; one full-chip launch.  C % 8 == 0, R <= 64. */
+int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const float* b_reduce, const float* w_expand_t, const float* b_expand,
+                      const float* w_proj, void* w_out, int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
+
 /* x[b, hw, c] *= gate[b, c] in place. */
 int cfp_scale_channels(void* x, int ld, const float* gate, int B, int HW, int C, int dtype, cfp_stream_t stream);
 
@@ -256,6 +264,11 @@ int cfp_copy_rows2(const void* in0, int in0_ld, void* out0, int out0_ld, int C0,
 
 /* rgb f32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] (channels 3..7 zero) in `dtype`. */
 int cfp_rgb_to_nhwc8(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream);
+/* The same for the 16-bit storage types with the input kept EXACT: channels 0-2 = rgb rounded to `dtype`, channels 3-5 = what the
+ * rounding lost (rgb - hi, rounded), 6-7 = 0.  With the stem's weight rows repeating the three real channels in slots 3-5 the
+ * float32 accumulators see w * (hi + lo): the float32 image the reference feeds its encoder (encoder.py:71-73), at no extra cost
+ * (the stem GEMM pads every tap to 8 channel slots anyway).  bf16 / f16 only. */
+int cfp_rgb_to_nhwc8_hilo(const float* rgb, void* out, int B, int H, int W, int dtype, cfp_stream_t stream);
 /* f32 scalars [rows] -> [rows][8] with the value in column 0 (ToF sample depths, deltar.py:40). */
 int cfp_scalar_to_rows8(const float* in, void* out, int rows, int dtype, cfp_stream_t stream);
 

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=8);
 ap.add_argument("--sweep", action="store_true")
 ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of the MFMA kernel (diagnostic build path, act + 100)")
 ap.add_argument("--phases", action="store_true", help="also time the kernel with its compute phase skipped (act=99)")
+ap.add_argument("--ld-align", type=int, default=0, help="pad the row pitch of input and output to a multiple of this many elements (64 = whole 128-byte lines per channel block)")
 ap.add_argument("--ab", action="store_true", help="also time the round-2 single-phase kernel (cfp_debug_set(6, 1)) beside the pipelined one")
 ap.add_argument("--sweep-stream", action="store_true", help="sweep the pipelined kernel's rows per step S and rows per workgroup RT")
 a = ap.parse_args()
@@ -32,10 +33,11 @@ for (H, W, C, s) in shapes:
     pt = max((Ho - 1) * s + 3 - H, 0) // 2; pl = max((Wo - 1) * s + 3 - W, 0) // 2
     # rotate over several buffers so that back-to-back launches do not just hit in L2
     NB = 6
-    xs = [ops.Act(torch.randn(B * H * W, C, device=DEV).to(torch.bfloat16), 0, C) for _ in range(NB)]
-    outs = [ops.new_act(B * Ho * Wo, C, torch.bfloat16, DEV) for _ in range(NB)]
+    ld = -(-C // a.ld_align) * a.ld_align if a.ld_align else C
+    xs = [ops.Act(torch.randn(B * H * W, ld, device=DEV).to(torch.bfloat16), 0, C) for _ in range(NB)]
+    outs = [ops.new_act(B * Ho * Wo, C, torch.bfloat16, DEV, ld=ld) for _ in range(NB)]
     w = torch.randn(9, C, device=DEV).to(torch.bfloat16); sc = torch.ones(C, device=DEV); sh = torch.zeros(C, device=DEV)
-    part = torch.zeros(B * 64 * C + 16 * 65536, device=DEV)
+    part = torch.zeros(B * 64 * C + 24 * 65536, device=DEV)
     k = [0]
     def run():
         i = k[0] % NB; k[0] += 1
@@ -56,15 +58,15 @@ for (H, W, C, s) in shapes:
         line += f"   round-2 kernel {told:6.1f} us   pipelined/copy {t / tc:4.2f}x (target <= 1.7x)   old/copy {told / tc:4.2f}x"
     if a.sweep_stream:
         best = (t, "auto")
-        for S in (1, 2, 3, 4):
-            for k in (1, 2, 3, 4, 5, 6, 8):
-                lib.cfp_debug_set(7, S); lib.cfp_debug_set(8, S * k)
+        for S in (1, 2, 4):
+            for NW in (0, 512):
+                lib.cfp_debug_set(7, S); lib.cfp_debug_set(8, NW)
                 try:
                     tt = timeit(run, max(5, a.reps // 3))
                 except RuntimeError:
                     continue
-                line += f"\n      S{S} RT{S * k}: {tt:6.1f}"
-                if tt < best[0]: best = (tt, f"S{S} RT{S * k}")
+                line += f"\n      S{S} NW{NW or 'auto'}: {tt:6.1f}"
+                if tt < best[0]: best = (tt, f"S{S} NW{NW or 'auto'}")
         lib.cfp_debug_set(7, 0); lib.cfp_debug_set(8, 0)
         line += f"\n   best {best[1]} {best[0]:.1f} us"
     if a.stamps:
@@ -73,14 +75,15 @@ for (H, W, C, s) in shapes:
         torch.cuda.synchronize()
         ops.dwconv3x3_sum(xs[0], w, sc, sh, outs[0], part, B, H, W, s, pt, pl, Ho, Wo, 100 + hip.ACT_SILU)
         torch.cuda.synchronize()
-        raw = part[B * ns * C: B * ns * C + 16 * 20000]
-        if float(raw[5]) == 2.0:        # the pipelined kernel: 16 floats per workgroup, per-step stamps
-            d16 = raw.reshape(-1, 16).cpu()
-            d16 = d16[d16[:, 5] == 2.0]
-            med = lambda c: float(d16[:, c][d16[:, c] > 0].median()) if bool((d16[:, c] > 0).any()) else 0.0
-            line += ("\n      per-step stamps (median cycles since workgroup start): rows landed " + " / ".join(f"{med(6 + k):.0f}" for k in range(4))
-                     + "; step done " + " / ".join(f"{med(10 + k):.0f}" for k in range(4)))
-            dbg = d16[:, :6].clone(); dbg[:, 5] = 1.0
+        raw = part[B * ns * C: B * ns * C + 24 * 20000]
+        if float(raw[5]) == 3.0:        # the persistent pipelined kernel: 24 floats per workgroup, per-step stamps
+            d24 = raw.reshape(-1, 24).cpu()
+            d24 = d24[d24[:, 5] == 3.0]
+            med = lambda c: float(d24[:, c][d24[:, c] > 0].median()) if bool((d24[:, c] > 0).any()) else 0.0
+            line += ("\n      per-step stamps (median cycles since workgroup start): rows landed " + " / ".join(f"{med(6 + k):.0f}" for k in range(6))
+                     + "; step done " + " / ".join(f"{med(12 + k):.0f}" for k in range(6))
+                     + f"; all DMA issued {med(18):.0f}, unit table built {med(19):.0f}")
+            dbg = d24[:, :6].clone(); dbg[:, 5] = 1.0
         else:
             dbg = part[B * ns * C: B * ns * C + 6 * 60000].reshape(-1, 6).cpu()
         dbg = dbg[dbg[:, 5] == 1.0]
