@@ -152,7 +152,10 @@ __global__ __launch_bounds__(512) void dw3x3_stream_kernel(DwsP p) {
       int off = ty * rowb + tx * pixb + ch * 16;
       for (; il < sg.ni; il += 8) {
         const bool ok = ch < chv && ty >= ty_lo && ty < ty_hi && tx >= tx_lo && tx < tx_hi;
-        glds16(ok ? img + off : zsrc, base + il * 1024);
+        // pad chunks are never read: their lanes stay OFF (an LDS-DMA lane with EXEC = 0 moves nothing).  Only real halo pixels
+        // fetch the zero word -- with every lane 8 of every instruction of every CU reading that one 16-byte address the DMA
+        // stream ran at ~300 cycles per instruction (one L2 channel serving 25 000 requests per launch)
+        if (ch < 8) glds16(ok ? img + off : zsrc, base + il * 1024);
         // this wave's next instruction: slot += 512 = 56 pixels + 8 chunks
         ch += 8; tx += 56; off += 56 * pixb + 128;
         if (ch >= 9) { ch -= 9; tx += 1; off += pixb - 144; }

@@ -768,7 +768,10 @@ namespace {
 // (halo read amplification) x (penalty for leaving CUs idle).
 struct DwPlan { int cvb, R, nstrips; size_t lds; };
 int g_dw_force_cvb = 0, g_dw_force_R = 0, g_dw_valu = 0;   // cfp_debug_set keys 3 / 4 / 5 (tools/dw_bench.py)
-int g_dw_no_stream = 0;                                    // key 6: 1 = keep dw3x3_mfma_kernel instead of the pipelined dw3x3_stream_kernel (A/B)
+// key 6: 0 = dw3x3_stream_kernel (round 3: persistent, LDS-DMA staged, row steps behind counted vmcnt waits; bit-identical outputs), 1 = dw3x3_mfma_kernel.
+// The pipelined kernel is correct and MEASURED SLOWER at batch 8 (24 vs 19 us at 30x40x816, profiles/r3_dw3x3_stream.md): its steps
+// run in lock-step (all 8 waves read LDS, then all run the SiLU), and per-lane LDS-DMA costs ~300 cycles per 1 KB instruction.  Off by default.
+int g_dw_no_stream = 1;
 inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out_tile = false) {
   DwPlan best{8, 1, Ho, 0};
   double bc = 1e30;

@@ -15,6 +15,7 @@ ap.add_argument("--ab", action="store_true", help="also time the round-2 single-
 ap.add_argument("--sweep-stream", action="store_true", help="sweep the pipelined kernel's rows per step S and rows per workgroup RT")
 a = ap.parse_args()
 lib = hip.load()
+lib.cfp_debug_set(6, 0)                    # this tool is about the pipelined kernel (opt-in in the library)
 DEV = "cuda:0"
 B = a.batch
 shapes = [(60, 80, 224, 2), (30, 40, 448, 1), (30, 40, 672, 1), (30, 40, 816, 1), (30, 40, 816, 2), (15, 20, 1392, 1)]
@@ -54,12 +55,12 @@ for (H, W, C, s) in shapes:
     if a.ab:
         lib.cfp_debug_set(6, 1)
         told = timeit(run, a.reps)
-        lib.cfp_debug_set(6, 0)
+        lib.cfp_debug_set(6, 0)            # the rest of this tool measures the pipelined kernel
         line += f"   round-2 kernel {told:6.1f} us   pipelined/copy {t / tc:4.2f}x (target <= 1.7x)   old/copy {told / tc:4.2f}x"
     if a.sweep_stream:
         best = (t, "auto")
         for S in (1, 2, 4):
-            for NW in (0, 512):
+            for NW in (0, 512, 768):
                 lib.cfp_debug_set(7, S); lib.cfp_debug_set(8, NW)
                 try:
                     tt = timeit(run, max(5, a.reps // 3))
