@@ -95,8 +95,8 @@ def kernel_times(engine, inputs, return_prob, reps=5):
             piw = a[26] if name.endswith("_ex") else 0
             v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, a[22], Ho * Wo if piw else 0, B, KH, stride)
             fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
-        elif name in ("cfp_dwconv3x3_nhwc", "cfp_dwconv3x3_sum_nhwc"):
-            B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16] if name == "cfp_dwconv3x3_nhwc" else a[8:17]
+        elif name in ("cfp_dwconv3x3_nhwc", "cfp_dwconv3x3_sum_nhwc", "cfp_dwconv3x3_se_nhwc"):
+            B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16] if name == "cfp_dwconv3x3_nhwc" else (a[8:17] if name == "cfp_dwconv3x3_sum_nhwc" else a[10:19])
             fam = "cfp_dwconv3x3_nhwc"
             flops = 2.0 * 9 * B * Ho * Wo * C
             byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)

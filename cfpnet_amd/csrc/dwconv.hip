@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          bf16_t* __restrict__ out, int out_ld, float* __restrict__ partial, int B,
                                                          int H, int W, int C, int pad_t, int pad_l, int Ho, int Wo, int act, int R,
-                                                         int nstrips) {
+                                                         int nstrips, const float* __restrict__ w_red, int RD, float* __restrict__ hpart,
+                                                         int cs_off) {
   constexpr int G = CVB / 2;                      // 16-channel groups per workgroup
   constexpr int GPW = (G + 3) / 4;                // groups per wave
   constexpr int PP = CVB * 16 + 16;               // pixel pitch in bytes
@@ -369,14 +370,50 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
           for (int r4 = 0; r4 < 4; ++r4) dst[r4] = csum[r4];
         }
       }
-    } else if (partial != nullptr && g < G && cbase < C && j == 0) {
-      float* dst = partial + ((long long)b * nstrips + strip) * C + cbase + 4 * q;
+      if (hpart != nullptr) {          // the workgroup's channel sums, for the reduce-FC dot products below
+        if (partial == nullptr) {
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) dst[r4] = 0.f;
+          for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) csum[r4] += __shfl_xor(csum[r4], o, 64);
+          }
+        }
+        if (j == 0) {
+          float* cs = reinterpret_cast<float*>(tile + cs_off);
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) cs[16 * g + 4 * q + r4] = csum[r4];
+        }
+      }
+    } else {
+      if (partial != nullptr && g < G && cbase < C && j == 0) {
+        float* dst = partial + ((long long)b * nstrips + strip) * C + cbase + 4 * q;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) dst[r4] = 0.f;
+      }
+      if (hpart != nullptr && g < G && j == 0) {
+        float* cs = reinterpret_cast<float*>(tile + cs_off);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) cs[16 * g + 4 * q + r4] = 0.f;
+      }
     }
   }
   __syncthreads();
   if (stamps) tk2 = __builtin_amdgcn_s_memtime();
+
+  // squeeze-excite (round 3): the reduce FC is linear in the channel sums, so this workgroup adds ITS part of every hidden unit,
+  //   hpart[b][strip * blocks + block][r] = sum_{c in block} w_reduce[r][c] * csum[c],
+  // and cfp_se_gate_fold2 only has to add K small vectors instead of reading the R x C weights in every workgroup.  Thread = (hidden
+  // unit r = tid >> 2, quarter of the block's channels); the weight loads are issued BEFORE the copy-out so their latency hides under it.
+  constexpr int NCQ = CVB * 2;                    // channels per thread = CVB * 8 / 4
+  f32x4 wq[NCQ / 4];
+  const int hr = tid >> 2, hq = tid & 3;
+  if (hpart != nullptr) {
+#pragma unroll
+    for (int v = 0; v < NCQ / 4; ++v) {
+      const int c = cv0 * 8 + hq * NCQ + v * 4;
+      wq[v] = (hr < RD && c < C) ? *reinterpret_cast<const f32x4*>(w_red + (long long)hr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   // ---- 3. coalesced copy-out of the in-place results -------------------------------------------------
   {
@@ -392,6 +429,18 @@ __global__ __launch_bounds__(256) void dw3x3_mfma_kernel(const bf16_t* __restric
             *reinterpret_cast<const u32x4*>(tile + pxo * PP + cvl * 16);
       }
     }
+  }
+  if (hpart != nullptr) {
+    const float* cs = reinterpret_cast<const float*>(tile + cs_off) + hq * NCQ;
+    float sdot = 0.f;
+#pragma unroll
+    for (int v = 0; v < NCQ / 4; ++v) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + v * 4);
+      sdot = fmaf(wq[v][0], c4[0], sdot); sdot = fmaf(wq[v][1], c4[1], sdot); sdot = fmaf(wq[v][2], c4[2], sdot); sdot = fmaf(wq[v][3], c4[3], sdot);
+    }
+    sdot += __shfl_xor(sdot, 1, 64);
+    sdot += __shfl_xor(sdot, 2, 64);
+    if (hq == 0 && hr < RD) hpart[(((long long)b * nstrips + strip) * gridDim.x + bx) * RD + hr] = sdot;
   }
   if (stamps && partial != nullptr && tid == 0) {
     const unsigned long long tk3 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
@@ -790,6 +839,7 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out
         const int RB = tw == 0 ? 1 : (16 % tw == 0 ? 16 / tw : 1);                        // and a row block has RB * nmain + 1 units even when the
         const int upb = RB * nmain + (tw ? 1 : 0);                                        // strip holds fewer than RB rows (round 3: the old bound
         lds += 16 + (size_t)cdiv(R, RB) * upb * 64;                                       // R * (ceil(Wo/16) + 1) overflowed LDS for Wo = 65, R = 1)
+        lds = ((lds + 15) & ~(size_t)15) + (size_t)cvb * 8 * sizeof(float);                // + the channel sums of the squeeze-excite dot products
       }
       const size_t red = (size_t)(256 / cvb) * cvb * ve * sizeof(float);
       if (lds < red) lds = red;
@@ -812,7 +862,7 @@ inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out
 
 int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld,
                  float* partial, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int dtype,
-                 cfp_stream_t stream, const char* who) {
+                 cfp_stream_t stream, const char* who, const float* w_red = nullptr, int RD = 0, float* hpart = nullptr) {
   CFP_REQUIRE(in && w && out && scale && shift, CFP_EINVAL, std::string(who) + ": null pointer");
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, std::string(who) + ": bad dtype");
   const int ve = vec_elems(dtype);
@@ -822,7 +872,9 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
               std::string(who) + ": pointers must be 16-byte aligned");
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
-  if (mfma && !g_dw_no_stream) {
+  CFP_REQUIRE(hpart == nullptr || (mfma && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
+              std::string(who) + ": the squeeze-excite partials need 16-bit storage, C % 16 == 0 and R <= 64");
+  if (mfma && !g_dw_no_stream && hpart == nullptr) {
     // the software-pipelined kernel (dw3x3_stream.hip): same arithmetic, load / compute / store overlapped inside a workgroup
     const int rc = cfp_dws_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype, stream, who);
     if (rc != 1) return rc;
@@ -853,7 +905,8 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
       attr = true;                                                                                                        \
     }                                                                                                                     \
     hipLaunchKernelGGL((dw3x3_mfma_kernel<HH, S, V>), grid, dim3(256), d.lds, s, (const bf16_t*)in, in_ld, (const bf16_t*)w, scale, \
-                       shift, (bf16_t*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);      \
+                       shift, (bf16_t*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips, w_red, RD, hpart, \
+                       (int)(d.lds - (size_t)V * 8 * sizeof(float)));                                                       \
   } while (0)
 #define DWM_CVB(HH, S) do { if (d.cvb == 16) DWM_LAUNCH(HH, S, 16); else DWM_LAUNCH(HH, S, 8); } while (0)
   if (mfma && dtype == CFP_F16) { if (stride == 1) DWM_CVB(f16_t, 1); else DWM_CVB(f16_t, 2); }
@@ -896,6 +949,20 @@ extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, 
   CFP_REQUIRE(partial, CFP_EINVAL, "cfp_dwconv3x3_sum_nhwc: null pointer");
   return dw3x3_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype,
                       stream, "cfp_dwconv3x3_sum_nhwc");
+}
+
+extern "C" int cfp_dwconv3x3_se_parts(int B, int Ho, int Wo, int C, int stride, int dtype) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2) || !is16(dtype) || C % 16 != 0 || g_dw_valu) return 0;
+  const DwPlan d = dw_plan(B, Ho, Wo, C, stride, 8, true);
+  return d.nstrips * cdiv(C / 8, d.cvb);
+}
+
+extern "C" int cfp_dwconv3x3_se_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld,
+                                     const float* w_reduce, int R, float* hpart, int B, int H, int W, int C, int stride, int pad_t,
+                                     int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(hpart && w_reduce, CFP_EINVAL, "cfp_dwconv3x3_se_nhwc: null pointer");
+  return dw3x3_launch(in, in_ld, w, scale, shift, out, out_ld, nullptr, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype, stream,
+                      "cfp_dwconv3x3_se_nhwc", w_reduce, R, hpart);
 }
 
 extern "C" int cfp_dwconv_large_nhwc(const void* in, int in_ld, const float* w, const float* scale,

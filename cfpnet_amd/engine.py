@@ -38,7 +38,7 @@ _STREAMS: Dict = {}
 _CONCURRENT: Dict[str, list] = {}
 
 
-def concurrent_streams(device, want: int = 4, pool: int = 12) -> list:
+def concurrent_streams(device, want: int = 4, pool: int = 16) -> list:
     """Up to `want` HIP streams that the GPU really runs side by side.
 
     The runtime spreads streams over a handful of hardware queues (4 by default); two streams that share a queue run
@@ -128,6 +128,14 @@ class Engine:
         # Built, parity-tested and MEASURED SLOWER than the two kernels it replaces (40 vs 40 us alone at 30x40x816, 32 vs 23 us with
         # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
         self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
+        # squeeze-excite through cfp_dwconv3x3_se_nhwc + cfp_se_gate_fold2 (16-bit modes; CFP_SE2=0: the round-2 pair)
+        self.se2 = dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1"
+        # DIAGNOSTIC ONLY (tools/precision_family.py --acts): "name:dtype,..." rounds the named encoder tensors of a float32 engine to a
+        # 16-bit format in place right after they are produced, to attribute the 16-bit error to single tensors.  Never set in product use.
+        self._dbg_round = {}
+        for item in filter(None, os.environ.get("CFP_DEBUG_ROUND", "").split(",")):
+            n, d = item.split(":")
+            self._dbg_round[n] = {"f16": torch.float16, "bf16": torch.bfloat16}[d]
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
@@ -247,6 +255,8 @@ class Engine:
                 self.P[q + ".se.we_t"] = self._dev(sd[q + ".se.conv_expand.weight"].reshape(b.mid, b.se_rd).t())
                 self.P[q + ".se.be"] = self._dev(sd[q + ".se.conv_expand.bias"])
                 self._conv(sd, q + ".pwl", q + ".conv_pwl.weight", bn=q + ".bn3", eps=EPS, w2=False)   # folded per image by se_gate_fold
+                # float32 master of the project weights: cfp_se_gate_fold2 rounds (weight x gate) to the storage type ONCE
+                self.P[q + ".pwl.w32"] = self._dev(sd[q + ".conv_pwl.weight"].reshape(b.cout, b.mid))
         # ToF histogram encoder: one float32 parameter blob for the fused kernel (csrc/hist_encoder.hip): per layer W | scale | shift
         parts, layout, off = [], [], 0
         for ex in (1, 2, 3):
@@ -371,6 +381,13 @@ class Engine:
             ws = self._lane_ws[self._lane] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         return ws
 
+    def _dbg(self, name: str, a: Act):
+        if self._dbg_round:
+            for pat, dt in self._dbg_round.items():
+                if name == pat or (pat.endswith("*") and name.startswith(pat[:-1])):
+                    t = a.torch()
+                    t.copy_(t.to(dt).to(t.dtype))
+
     def _encoder(self, plan, rgb: torch.Tensor, B, H, W, taps):
         """encoder.py:71-79 over timm tf_efficientnetv2_b3 blocks; returns the five tap Acts."""
         e = "img_encoder"
@@ -380,6 +397,7 @@ class Engine:
         h, w = math.ceil(H / 2), math.ceil(W / 2)
         x = self._act(plan, "stem", B * h * w, spec.ENC_STEM_OUT)
         self._cv("stem", x8, x, B, H, W, 3, 2, pads, hip.ACT_SILU if self.stem_act else hip.ACT_NONE)
+        self._dbg("stem", x)
         tap_acts: List[Act] = []
         for bi, b in enumerate(spec.ENC_BLOCKS):
             q = f"{e}.{b.prefix}"
@@ -395,6 +413,7 @@ class Engine:
             elif b.kind == "er":
                 mid = self._act(plan, f"enc{bi}.mid", B * ho * wo, b.mid)
                 self._cv(q + ".exp", x, mid, B, h, w, 3, b.stride, pads, hip.ACT_SILU)
+                self._dbg(f"enc{bi}.mid", mid)
                 self._cv(q + ".pwl", mid, out, B, ho, wo, 1, 1, None, hip.ACT_NONE, res)
             else:
                 mid2 = self._act(plan, f"enc{bi}.dw", B * ho * wo, b.mid)
@@ -405,14 +424,36 @@ class Engine:
                     part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
                     ops.mbconv_expand_dw(x, self.P[q + ".pw.wimg"], self.P[q + ".pw.s"], self.P[q + ".pw.t"], self.P[q + ".dw.w"],
                                          self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w)
+                elif self.se2 and ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype]) > 0:
+                    # round 3: the depthwise kernel applies the reduce FC to its own channel sums (it is linear in them), the tail kernel
+                    # adds the K partial vectors, finishes the gate and folds it into float32 project weights in one full-chip launch
+                    mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
+                    self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
+                    K = ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype])
+                    hpart = self._f32(plan, f"enc{bi}.hpart", B * K * b.se_rd)
+                    ops.dwconv3x3_se(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, self.P[q + ".se.wr"], hpart,
+                                     B, h, w, b.stride, pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
+                    wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
+                    ops.se_gate_fold2(hpart, K, 1.0 / (ho * wo), self.P[q + ".se.br"], self.P[q + ".se.we_t"], self.P[q + ".se.be"],
+                                      self.P[q + ".pwl.w32"], wb, B, b.cout, b.mid, b.se_rd)
+                    ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
+                               res, None, per_image_weights=True)
+                    x, h, w = out, ho, wo
+                    if bi in spec.ENC_TAPS:
+                        tap_acts.append(out)
+                        if taps is not None:
+                            taps[f"enc{spec.ENC_TAPS[bi]}"] = self._nchw(out, B, h, w)
+                    continue
                 else:
                     mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
                     self._cv(q + ".pw", x, mid, B, h, w, 1, 1, None, hip.ACT_SILU)
                     # depthwise + BN + SiLU, emitting the per-strip channel sums squeeze-excite needs
                     ns = ops.dwconv3x3_strips(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype])
                     part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
+                    self._dbg(f"enc{bi}.mid", mid)
                     ops.dwconv3x3_sum(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w, b.stride,
                                       pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
+                    self._dbg(f"enc{bi}.dw", mid2)
                 # SE tail (mean -> FC -> SiLU -> FC -> sigmoid) in one launch; the gate multiplies the project conv's
                 # input channels, so it is folded into per-image project weights instead of a pass over mid2
                 wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
@@ -420,6 +461,7 @@ class Engine:
                                  self.P[q + ".se.be"], self.P[q + ".pwl.w"], wb, B, b.cout, b.mid, b.se_rd)
                 ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
                            res, None, per_image_weights=True)
+            self._dbg(f"enc{bi}", out)
             x, h, w = out, ho, wo
             if bi in spec.ENC_TAPS:
                 tap_acts.append(out)
@@ -771,7 +813,7 @@ class Engine:
         return slot["out"], slot["event"]
 
     def capture_best(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None,
-                     candidates: Sequence = (("lanes", 1), ("inflight", 2), ("inflight", 3), ("inflight", 4)),
+                     candidates: Sequence = (("lanes", 1), ("inflight", 2), ("inflight", 3), ("inflight", 4), ("inflight", 6)),
                      reps: int = 16, allow_inflight: bool = True):
         """capture() with the concurrency mode chosen by measurement: `lanes` sub-batches of one batch side by side, or
         `inflight` whole batches in flight (throughput mode, results through `replay_async`).  How well graphs overlap

@@ -36,6 +36,8 @@ SIGNATURES = {
     "cfp_dwconv3x3_sum_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p] + [_i] * 11 + [_p]),
     "cfp_se_fold": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_gate_fold": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "cfp_dwconv3x3_se_parts": (_i, [_i, _i, _i, _i, _i, _i]),
+    "cfp_dwconv3x3_se_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i, _p] + [_i] * 11 + [_p]),
     "cfp_se_gate_fold2": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_dwconv_large_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 7 + [_p]),
     "cfp_dwconv_large_toeplitz_elems": (_sz, [_i, _i]),

@@ -140,6 +140,19 @@ def se_gate_fold(partial, nsplit, inv_hw, wr, br, we_t, be, w_proj: torch.Tensor
              w_proj.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_proj.dtype], _s())
 
 
+def dwconv3x3_se_parts(B: int, Ho: int, Wo: int, C: int, stride: int, dt: int) -> int:
+    return int(hip.load().cfp_dwconv3x3_se_parts(B, Ho, Wo, C, stride, dt))
+
+
+def dwconv3x3_se(x: Act, w, scale, shift, out: Act, w_reduce: torch.Tensor, hpart: torch.Tensor, B, H, W, stride, pad_t, pad_l, Ho, Wo, act):
+    """Depthwise 3x3 + BN + activation + the squeeze-excite reduce FC's partial dot products (hpart [B][K][R])."""
+    R = w_reduce.shape[0]
+    assert w_reduce.dtype == torch.float32 and w_reduce.shape == (R, x.C) and hpart.dtype == torch.float32
+    assert hpart.numel() >= B * dwconv3x3_se_parts(B, Ho, Wo, x.C, stride, x.dt) * R
+    hip.call("cfp_dwconv3x3_se_nhwc", x.ptr, x.ld, w.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
+             w_reduce.data_ptr(), R, hpart.data_ptr(), B, H, W, x.C, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
+
+
 def se_gate_fold2(hpart, K, inv_hw, br, we_t, be, w_proj32: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R):
     assert w_proj32.shape == (Cout, C) and w_proj32.dtype == torch.float32 and w_out.shape == (B, Cout, C)
     assert we_t.shape == (R, C) and hpart.dtype == torch.float32 and hpart.numel() >= B * K * R

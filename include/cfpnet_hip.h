@@ -182,6 +182,17 @@ int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float
                      const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out,
                      int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
+/* cfp_dwconv3x3_nhwc + the squeeze-excite reduce FC applied to the workgroup's channel sums (16-bit storage, C % 16 == 0, R <= 64):
+ * timm InvertedResidual conv_dw -> bn2 -> act, and of SqueezeExcite (x.mean((2, 3)) -> conv_reduce) the part that is LINEAR in the
+ * sums: every workgroup (image b, row strip, channel block) writes
+ *   hpart[b][k][r] = sum_{c in block} w_reduce[r][c] * (sum of its stored output pixels of channel c),   k = strip * blocks + block,
+ * K = cfp_dwconv3x3_se_parts(...) partials per image (0: shape / dtype not supported).  w_reduce [R][C] f32.  cfp_se_gate_fold2 adds
+ * them, scales by 1 / (Ho * Wo) and finishes the block.  Reference: encoder.py:66-69 (timm tf_efficientnetv2_b3 blocks[3..5]). */
+int cfp_dwconv3x3_se_parts(int B, int Ho, int Wo, int C, int stride, int dtype);
+int cfp_dwconv3x3_se_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld,
+                          const float* w_reduce, int R, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
+                          int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
+
 /* The squeeze-excite tail when the depthwise kernel has already applied the reduce FC to its channel sums (the reduce layer is
  * linear in them): hpart [B][K][R] f32 partial dot products (cfp_dwconv3x3_se_nhwc), added in k order;
  *   hidden = silu(inv_hw * sum_k hpart + b_reduce);  gate = sigmoid(hidden . w_expand_t + b_expand);  w_out[b][n][c] = w_proj[n][c] * gate[c]

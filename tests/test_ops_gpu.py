@@ -318,6 +318,53 @@ def test_dwconv3x3_with_fused_channel_sums(case, dtype):
     assert torch.equal(part, part2)             # deterministic reduction order
 
 
+@pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(8, 15, 20, 1392, 1, 58, 232), (8, 30, 40, 816, 1, 34, 136), (2, 30, 40, 448, 1, 28, 112), (8, 60, 80, 224, 2, 14, 112),
+                                  (3, 13, 17, 672, 1, 28, 136), (1, 7, 5, 48, 1, 6, 24)])
+def test_squeeze_excite_through_the_depthwise_kernel(case, dtype):
+    """Round 3's squeeze-excite path: cfp_dwconv3x3_se_nhwc (depthwise 3x3 + BN + SiLU + the reduce FC's partial dot products per
+    workgroup) -> cfp_se_gate_fold2 (sum of the partials -> SiLU -> expand FC -> sigmoid -> gate folded into float32 project weights,
+    rounded once) against timm's SqueezeExcite written out in torch on the kernel's own depthwise output, and against the round-2 pair
+    (cfp_dwconv3x3_sum_nhwc -> cfp_se_gate_fold): same depthwise output bit for bit, same gate to float32 round-off."""
+    B, H, W, C, s, R, Cout = case
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = max((Ho - 1) * s + 3 - H, 0) // 2, max((Wo - 1) * s + 3 - W, 0) // 2
+    x = q(rnd(B, C, H, W, seed=21), dtype)
+    wdw = q(rnd(C, 1, 3, 3, seed=22, scale=0.4), dtype)
+    scale, shift = (rnd(C, seed=23).abs() + 0.5).to(DEV), rnd(C, seed=24).to(DEV)
+    wr, br = rnd(R, C, seed=25, scale=1.0 / math.sqrt(C)).to(DEV), rnd(R, seed=26, scale=0.1).to(DEV)
+    we_t, be = rnd(R, C, seed=27, scale=0.3).to(DEV), rnd(C, seed=28, scale=0.1).to(DEV)
+    wp = rnd(Cout, C, seed=29, scale=1.0 / math.sqrt(C)).to(DEV)
+    wa = wdw.reshape(C, 9).t().contiguous().to(dtype).to(DEV)
+    xin = to_act(nhwc(x), dtype)
+    out1, out2 = ops.new_act(B * Ho * Wo, C, dtype, DEV), ops.new_act(B * Ho * Wo, C, dtype, DEV)
+    K = ops.dwconv3x3_se_parts(B, Ho, Wo, C, s, ops.DT[dtype])
+    assert K > 0
+    hpart = torch.full((B, K, R), float("nan"), device=DEV)
+    ops.dwconv3x3_se(xin, wa, scale, shift, out1, wr, hpart, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    wb = torch.empty(B, Cout, C, dtype=dtype, device=DEV)
+    ops.se_gate_fold2(hpart, K, 1.0 / (Ho * Wo), br, we_t, be, wp, wb, B, Cout, C, R)
+    # the round-2 pair on the same input
+    ns = ops.dwconv3x3_strips(B, Ho, Wo, C, s, ops.DT[dtype])
+    part = torch.empty(B, ns, C, device=DEV)
+    ops.dwconv3x3_sum(xin, wa, scale, shift, out2, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    wb_old = torch.empty_like(wb)
+    ops.se_gate_fold(part, ns, 1.0 / (Ho * Wo), wr, br, we_t, be, wp.to(dtype), wb_old, B, Cout, C, R)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.buf.view(torch.int16), out2.buf.view(torch.int16))
+    assert torch.isfinite(hpart).all()
+    # reference gate from the kernel's own (float32, unrounded) channel sums = part
+    mean = part.sum(1) / (Ho * Wo)
+    hid = F.silu(mean @ wr.t() + br)
+    gate = torch.sigmoid(hid @ we_t + be)
+    want = (wp[None] * gate[:, None, :])
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    err = (wb.float() - want).abs()
+    assert bool((err <= 1.01 * ulp * want.abs() + 1e-6 * float(want.abs().max())).all()), float((err / want.abs().clamp(min=1e-6)).max())
+    # and the old pair agrees up to its double rounding (project weights rounded before the fold)
+    assert float((wb.float() - wb_old.float()).abs().max()) <= 3.0 * ulp * float(want.abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_se_fold_equals_gated_activation(dtype):
     """(x * gate) @ W^T == x @ (W * gate)^T with the gate computed from the squeezed means."""

@@ -22,6 +22,7 @@ ap.add_argument("--seeds", type=int, nargs="*", default=[97, synthetic.SEED, 424
 ap.add_argument("--env", nargs="*", default=[])
 ap.add_argument("--groups", action="store_true")
 ap.add_argument("--taps", action="store_true")
+ap.add_argument("--acts", action="store_true", help="activation-rounding ablation: float32 engine with ONE group of encoder tensors rounded to the 16-bit format")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--dtype", default="f16")
 a = ap.parse_args()
@@ -46,6 +47,13 @@ for s, inp in inps.items():
     ref[s] = e32.forward(inp, taps=t)[1].clone()
     ref_taps[s] = t
 print(f"family {a.family}: pred mean {float(ref[a.seeds[0]].mean()):.3f} std {float(ref[a.seeds[0]].std()):.3f}")
+# conditioning of the network itself: the FLOAT32 engine on the same image rounded once to the 16-bit format (one perturbation of
+# relative size 2^-12 / 2^-9 at the very first tensor, nothing else changed)
+for s_, inp in inps.items():
+    pert = {"rgb": inp["rgb"].to(DT).float(), "additional": inp["additional"]}
+    pp = e32.forward(pert)[1]
+    per = [rel(ref[s_][b], pp[b]) for b in range(pp.shape[0])]
+    print(f"  input-rounding sensitivity ({a.dtype} image, float32 everything else) seed {s_}: rel-L1 {rel(ref[s_], pp):.3e} (worst image {max(per):.3e})")
 
 
 def run(envs):
@@ -111,3 +119,33 @@ if a.groups:
     print(f"  root-sum-square {tot ** 0.5:.3e}")
     e32.load_state_dict({k: (v.to(DT).float() if roundable(k, v) else v) for k, v in sd.items()})
     print(f"  ALL weights rounded (nearest), f32 activations: {rel(ref[s0], e32.forward(inps[s0])[1]):.3e}")
+
+if a.acts:
+    from cfpnet_amd import spec as _spec
+    nb = len(_spec.ENC_BLOCKS)
+    kinds = [b.kind for b in _spec.ENC_BLOCKS]
+    groups = {"input image": None, "stem": "stem"}
+    st = 0
+    names = {}
+    for bi, b in enumerate(_spec.ENC_BLOCKS):
+        stage = b.prefix.rsplit(".", 1)[0]
+        names.setdefault(stage, []).append(bi)
+    for stage, bis in names.items():
+        groups[f"{stage} block outputs"] = ",".join(f"enc{bi}:{a.dtype}" for bi in bis)
+        groups[f"{stage} expanded (mid)"] = ",".join(f"enc{bi}.mid:{a.dtype}" for bi in bis)
+        if kinds[bis[0]] == "ir":
+            groups[f"{stage} depthwise out"] = ",".join(f"enc{bi}.dw:{a.dtype}" for bi in bis)
+    groups["stem"] = f"stem:{a.dtype}"
+    s0 = a.seeds[0]
+    tot = 0.0
+    for gname, spec_ in groups.items():
+        if spec_ is None:
+            continue
+        os.environ["CFP_DEBUG_ROUND"] = spec_
+        e = Engine(sd, layer_names=layers, dtype=torch.float32)
+        r = rel(ref[s0], e.forward(inps[s0])[1])
+        tot += r * r
+        print(f"  activations rounded to {a.dtype} in {gname:36s}: {r:.3e}", flush=True)
+        del e
+    os.environ.pop("CFP_DEBUG_ROUND", None)
+    print(f"  root-sum-square over the encoder groups {tot ** 0.5:.3e}")
