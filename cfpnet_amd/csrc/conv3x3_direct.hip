@@ -29,7 +29,13 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename H, int TH, int BN, int WM, int WN>
+// UP = true (cfp_upsample_cat_conv3x3, decoder.py:51-58 UpSampleBN: interpolate(x, size=skip, bilinear, align_corners=True) -> cat -> conv3x3):
+// the 64-channel chunks below p.up_C are not fetched but COMPUTED into the halo tile -- four 16-byte taps of the low-resolution map,
+// blended in float32 with resize_kernel's own arithmetic and rounded to the storage type as the stored upsampled tensor would have
+// been, so the result is bit-identical to cfp_resize_bilinear + cfp_conv2d_nhwc.  The blend of chunk c + 1 is spread over the three
+// kernel-row steps of chunk c (loads issued before a step's MFMAs, blend + LDS store after them); the upsampled tensor (79 MB at
+// batch 8 for up4) is never written or read back, and every halo pixel is blended once per chunk, not once per tap.
+template <typename H, int TH, int BN, int WM, int WN, bool UP = false>
 __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   static_assert(WM * WN == 4, "four waves");
   constexpr int TW = 16;
@@ -89,6 +95,47 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   }
   const int nchunks = (p.Cin + 63) >> 6;
   const int nsteps = nchunks * 3;
+  // bilinear taps of this lane's halo pixels (UP): element offset of tap (0, 0) in the low-resolution image, flags for +1 column / +1 row,
+  // the two fractions; u_off < 0: pixel outside the image (zeros, like the padding of the stored tensor)
+  int u_off[UP ? NAH : 1], u_dx[UP ? NAH : 1], u_dy[UP ? NAH : 1];
+  float u_lx[UP ? NAH : 1], u_ly[UP ? NAH : 1];
+  const H* __restrict__ low = nullptr;
+  int nup = 0;                                  // chunks computed from the low-resolution map
+  if constexpr (UP) {
+    low = reinterpret_cast<const H*>(p.up_src) + (long long)b * p.up_H * p.up_W * p.up_ld;
+    nup = p.up_C >> 6;
+#pragma unroll
+    for (int i = 0; i < NAH; ++i) {
+      const int hp = (i * 4 + wave) * 8 + rsub;
+      const int hy = hp / HW_, hx = hp - hy * HW_;
+      const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+      const bool ok = hp < HP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const float fy = p.up_sy * (float)y, fx = p.up_sx * (float)x;      // torch: src = scale * dst_index (align_corners=True)
+      const int ys = (int)fy, xs = (int)fx;
+      u_dy[i] = (ys < p.up_H - 1 ? 1 : 0) * p.up_W * p.up_ld;
+      u_dx[i] = (xs < p.up_W - 1 ? 1 : 0) * p.up_ld;
+      u_ly[i] = fy - (float)ys; u_lx[i] = fx - (float)xs;
+      u_off[i] = ok ? (ys * p.up_W + xs) * p.up_ld + lc * 8 : -1;
+    }
+  }
+  // blend items i = i0, i0 + istep, ... of chunk `chunk` into halo buffer `buf` (four loads per item in flight together)
+  auto blend_a = [&](int chunk, int buf, int i0, int istep) {
+    if constexpr (UP) {
+      const int c0 = chunk * 64;
+#pragma unroll
+      for (int i = 0; i < NAH; ++i) {
+        if (i % istep != i0) continue;
+        float t[4][8], o[8];
+        const bool ok = u_off[i] >= 0;
+        const H* s00 = low + (ok ? u_off[i] : lc * 8) + c0;
+        Vec<H>::load(s00, t[0]); Vec<H>::load(s00 + u_dx[i], t[1]); Vec<H>::load(s00 + u_dy[i], t[2]); Vec<H>::load(s00 + u_dy[i] + u_dx[i], t[3]);
+        const float ly1 = u_ly[i], lx1 = u_lx[i], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = ok ? ly0 * (lx0 * t[0][e] + lx1 * t[1][e]) + ly1 * (lx0 * t[2][e] + lx1 * t[3][e]) : 0.f;
+        Vec<H>::store(reinterpret_cast<H*>(sA(buf) + (i * 4 + wave) * 1024 + lane * 16), o);
+      }
+    }
+  };
 
   auto issue_a = [&](int chunk, int buf) {
     const int c0 = chunk * 64;
@@ -112,15 +159,17 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue_a(0, 0);
+  if (UP && nup > 0) blend_a(0, 0, 0, 1); else issue_a(0, 0);
   issue_b(0, 0);
   for (int s = 0; s < nsteps; ++s) {
     const int chunk = s / 3, kh = s - chunk * 3;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (UP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // + this wave's blended halo stores
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // slab s (+ halo of this chunk) landed; everyone is past step s-1
     asm volatile("" ::: "memory");
     if (s + 1 < nsteps) issue_b(s + 1, (s + 1) & 1);
-    if (kh == 0 && chunk + 1 < nchunks) issue_a(chunk + 1, (chunk + 1) & 1);
+    const bool next_up = UP && chunk + 1 < nup;
+    if (kh == 0 && chunk + 1 < nchunks && !next_up) issue_a(chunk + 1, (chunk + 1) & 1);
 
     const unsigned char* cA = sA(chunk & 1);
     const unsigned char* cB = sB(s & 1) + (wn * (BN / WN)) * 128;
@@ -149,6 +198,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
         }
       }
     }
+    if (next_up) blend_a(chunk + 1, (chunk + 1) & 1, kh, 3);      // a third of the next chunk's halo pixels per kernel-row step
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // operand buffers are free: LDS becomes the C tile
@@ -199,13 +249,13 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
   }
 }
 
-template <typename H, int TH, int BN, int WM, int WN>
+template <typename H, int TH, int BN, int WM, int WN, bool UP = false>
 int launch3(const ConvP& p, hipStream_t s) {
   constexpr int HP = (TH + 2) * 18, NAG = (HP + 7) / 8, NAH = (NAG + 3) / 4, A_BYTES = NAH * 4 * 1024;
   constexpr int NBG = BN * 3 / 8, B_BYTES = ((NBG + 3) / 4) * 4 * 1024;
   constexpr size_t lds = 2 * A_BYTES + 2 * B_BYTES;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = conv3x3_direct_kernel<H, TH, BN, WM, WN>;
+  auto k = conv3x3_direct_kernel<H, TH, BN, WM, WN, UP>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
   const long long tiles = (long long)p.B * cdiv(p.Ho, TH) * cdiv(p.Wo, 16) * cdiv(p.Cout, BN);
@@ -225,6 +275,18 @@ void conv3x3_variant_shape(int v, int* th, int* bn) { *th = kCfg3[v].th; *bn = k
 
 // Requirements (checked by the caller): bf16, KH = KW = 3, stride 1, Ho = H + pads - 2 etc. as in ConvP,
 // Cin % 8 == 0, H * W * in_ld < 2^31, Cout * K < 2^31.
+#define L3U(...) (p.f16 ? launch3<f16_t, __VA_ARGS__, true>(p, s) : launch3<bf16_t, __VA_ARGS__, true>(p, s))
+// The same with the upsample + concatenation loader (p.up_src set; up_C % 64 == 0, up_C <= Cin).
+int conv3x3_up_launch(int v, const ConvP& p, hipStream_t s) {
+  switch (v) {
+    case 0: return L3U(8, 128, 2, 2);
+    case 1: return L3U(8, 64, 2, 2);
+    case 4: return L3U(8, 32, 4, 1);
+    case 5: return L3U(16, 16, 4, 1);
+    default: return -3;
+  }
+}
+
 #define L3(...) (p.f16 ? launch3<f16_t, __VA_ARGS__>(p, s) : launch3<bf16_t, __VA_ARGS__>(p, s))
 int conv3x3_launch(int v, const ConvP& p, hipStream_t s) {
   switch (v) {

@@ -446,6 +446,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   p.M = B * Ho * Wo; p.K = KH * KW * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = dil;
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && dil == 1) ? 1 : 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
+  p.up_src = nullptr; p.up_ld = p.up_C = p.up_H = p.up_W = 0; p.up_sy = p.up_sx = 0.f;
   const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
   per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -524,6 +525,43 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
                                   int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   return conv2d_impl(in, in_ld, w, scale, shift, residual, res_ld, out, out_ld, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
                      act, dtype, ln_gamma, ln_beta, ln_eps, per_image_weights, ws, ws_bytes, stream, 1);
+}
+
+int conv3x3_up_launch(int v, const ConvP& p, hipStream_t s);      // conv3x3_direct.hip
+
+// UpSampleBN's first half in one launch (decoder.py:51-58): F.interpolate(low, size=(H, W), bilinear, align_corners=True) -> cat([up, skip],
+// dim=1) -> conv3x3 (+ folded BatchNorm + activation).  Neither the upsampled tensor nor the concatenation exists in memory: the direct
+// 3x3 kernel computes the upsampled channel chunks into its LDS halo tile and fetches the skip chunks.  Bit-identical to
+// cfp_resize_bilinear + cfp_conv2d_nhwc on the concatenation buffer.  -> CFP_ESHAPE when the shape is not taken (caller keeps the pair).
+extern "C" int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int Ws, int Cup, const void* skip, int skip_ld, int Cskip,
+                                        const void* w, const float* scale, const float* shift, void* out, int out_ld, int B, int H, int W,
+                                        int Cout, int act, int dtype, cfp_stream_t stream) {
+  CFP_REQUIRE(low && skip && w && out, CFP_EINVAL, "cfp_upsample_cat_conv3x3: null pointer");
+  CFP_REQUIRE(is16(dtype), CFP_ESHAPE, "cfp_upsample_cat_conv3x3: 16-bit storage types only");
+  CFP_REQUIRE(B > 0 && H > 1 && W > 1 && Hs > 0 && Ws > 0 && Cup > 0 && Cup % 64 == 0 && Cskip > 0 && Cskip % 8 == 0 && Cout % 8 == 0 &&
+                  low_ld % 8 == 0 && low_ld >= Cup && skip_ld % 8 == 0 && skip_ld >= Cskip && out_ld % 8 == 0 && out_ld >= Cout, CFP_ESHAPE,
+              "cfp_upsample_cat_conv3x3: need Cup % 64 == 0 and 16-byte channel vectors");
+  CFP_REQUIRE(aligned16(low) && aligned16(skip) && aligned16(w) && aligned16(out), CFP_EINVAL, "cfp_upsample_cat_conv3x3: pointers must be 16-byte aligned");
+  const int Cin = Cup + Cskip;
+  CFP_REQUIRE(((long long)B * H * W) * skip_ld * 2 < (1ll << 31) - 65536 && ((long long)Hs * Ws) * low_ld * 2 < (1ll << 31) - 65536 &&
+                  (long long)Cout * 9 * Cin * 2 < (1ll << 31) - 65536 && (long long)B * H * W < (1ll << 31), CFP_ESHAPE,
+              "cfp_upsample_cat_conv3x3: tensor too large for 32-bit offsets");
+  ConvP p;
+  const size_t esz = 2;
+  p.in = (const char*)skip - (size_t)Cup * esz;      // virtual base: channel c >= Cup of the concatenation is skip channel c - Cup
+  p.w = w; p.out = out; p.res = nullptr; p.scale = scale; p.shift = shift;
+  p.in_ld = skip_ld; p.out_ld = out_ld; p.res_ld = 0;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.Cout = Cout;
+  p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+  p.M = B * H * W; p.K = 9 * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = 1; p.pointwise = 0;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
+  p.up_src = low; p.up_ld = low_ld; p.up_C = Cup; p.up_H = Hs; p.up_W = Ws;
+  p.up_sy = (float)(Hs - 1) / (float)(H - 1);        // cfp_resize_bilinear's own expression (bit-identical source coordinates)
+  p.up_sx = (float)(Ws - 1) / (float)(W - 1);
+  const int v = Cout <= 16 ? 5 : (Cout <= 32 ? 4 : (Cout <= 64 ? 1 : 0));
+  int rc = conv3x3_up_launch(v, p, reinterpret_cast<hipStream_t>(stream));
+  CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_upsample_cat_conv3x3: kernel launch failed");
+  return cfp_check_launch("cfp_upsample_cat_conv3x3");
 }
 
 // Data gradient of a convolution: dX [B,H,W,Cin] from dY [B,Ho,Wo,Cout] and the flipped weights of cfp_conv2d_weight_flip

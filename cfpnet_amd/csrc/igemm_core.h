@@ -24,6 +24,10 @@ struct ConvP {
   int f16;                 // 16-bit storage is IEEE half (CFP_F16) instead of bf16
   int k2;                  // gen-2, pointwise only: > 0 = two-term weights.  Every weight row is [hi | lo], each half padded to k2 K-steps
                            // (k2 * 64 elements); the kernel walks 2 * k2 K-steps and reads the SAME activations for both halves
+  // --- conv3x3_direct only: bilinear upsample + skip concatenation folded into the halo loader (cfp_upsample_cat_conv3x3, UpSampleBN) ---
+  const void* up_src;      // low-resolution source [B, up_H, up_W, up_ld]: input channels [0, up_C) are its align_corners=True bilinear
+  int up_ld, up_C, up_H, up_W;   // upsampling to H x W, computed in the loader; channels [up_C, Cin) come from `in` (the skip tensor, virtual base: in + c addresses skip channel c - up_C)
+  float up_sy, up_sx;      // (up_H - 1) / (H - 1), (up_W - 1) / (W - 1)
   int dil;                 // input dilation (gen-1 kernels only): the input is read as if `dil - 1` zeros sat between its pixels --
                            // the data gradient of a stride-`dil` convolution; H / W stay the REAL input size
 };

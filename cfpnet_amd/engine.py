@@ -136,6 +136,8 @@ class Engine:
         for item in filter(None, os.environ.get("CFP_DEBUG_ROUND", "").split(",")):
             n, d = item.split(":")
             self._dbg_round[n] = {"f16": torch.float16, "bf16": torch.bfloat16}[d]
+        # decoder stages whose bilinear upsample + skip concat run inside the first conv's loader (cfp_upsample_cat_conv3x3); digits 1-4
+        self.up_fused = os.environ.get("CFP_UP_FUSED", "4")
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
@@ -952,10 +954,16 @@ class Engine:
             self._fusion(plan, name, x, feat, zone_valid, geo, B, hh, ww, out, pos_offsets.get(name, (0, 0)), taps)
 
         def up(i, src: Act, hs_, ws_, hd, wd):
-            ops.resize_bilinear(src, hs_, ws_, (0, 0, hs_, ws_), cat[i].slice(0, src.C), hd, wd, (0, 0, hd, wd), B)
             M = B * hd * wd
             t1 = self._act(plan, f"up{i}.a", M, c[i])
-            self._cv(f"decoder.up{i}.a", cat[i], t1, B, hd, wd, 3, act=hip.ACT_LRELU)
+            if self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None:
+                # cfp_upsample_cat_conv3x3: bilinear + concat computed inside the conv's halo loader (bit-identical to the pair below)
+                n = f"decoder.up{i}.a"
+                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".w"], self.P[n + ".s"], self.P[n + ".t"],
+                                         t1, B, hd, wd, hip.ACT_LRELU)
+            else:
+                ops.resize_bilinear(src, hs_, ws_, (0, 0, hs_, ws_), cat[i].slice(0, src.C), hd, wd, (0, 0, hd, wd), B)
+                self._cv(f"decoder.up{i}.a", cat[i], t1, B, hd, wd, 3, act=hip.ACT_LRELU)
             t2 = self._act(plan, f"up{i}.b", M, c[i])
             self._cv(f"decoder.up{i}.b", t1, t2, B, hd, wd, 3, act=hip.ACT_LRELU)
             return t2

@@ -54,6 +54,7 @@ SIGNATURES = {
     "cfp_loftr_tail": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _f] + [_i] * 5 + [_f, _f, _i, _i, _i, _p]),
     "cfp_resize_bilinear": (_i, [_p, _i] + [_i] * 6 + [_p, _i] + [_i] * 6 + [_p] + [_i] * 7 + [_p]),
     "cfp_add_rowtable": (_i, [_p, _i, _p, _p, _i] + [_i] * 8 + [_p]),
+    "cfp_upsample_cat_conv3x3": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i] + [_i] * 6 + [_p]),
     "cfp_copy_rows": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_copy_rows2": (_i, [_p, _i, _p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p]),
     "cfp_rgb_to_nhwc8": (_i, [_p, _p, _i, _i, _i, _i, _p]),

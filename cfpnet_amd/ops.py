@@ -344,6 +344,13 @@ def copy_rows(x: Act, out: Act, rows):
     hip.call("cfp_copy_rows", x.ptr, x.ld, out.ptr, out.ld, rows, x.C, x.dt, _s())
 
 
+def upsample_cat_conv3x3(low: Act, Hs, Ws, skip: Act, w, scale, shift, out: Act, B, H, W, act):
+    """bilinear (align_corners) upsample of `low` to H x W + concat with `skip` + conv3x3 + BN + activation in one launch (16-bit modes)."""
+    assert w.shape[-1] == 9 * (low.C + skip.C) and low.dt == skip.dt == out.dt
+    hip.call("cfp_upsample_cat_conv3x3", low.ptr, low.ld, Hs, Ws, low.C, skip.ptr, skip.ld, skip.C, w.data_ptr(),
+             hip.ptr(scale), hip.ptr(shift), out.ptr, out.ld, B, H, W, out.C, act, out.dt, _s())
+
+
 def copy_rows2(x0: Act, out0: Act, x1: Act, out1: Act, rows):
     """Two strided row copies in one launch (concatenation / split)."""
     assert x0.dt == x1.dt == out0.dt == out1.dt and out0.C == x0.C and out1.C == x1.C

@@ -267,6 +267,16 @@ int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, int sy0, in
 int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, int out_ld, int rows, int C,
                      int H, int W, int Wt, int oy, int ox, int dtype, cfp_stream_t stream);
 
+/* UpSampleBN's first half in ONE launch (decoder.py:51-58): F.interpolate(low, size=(H, W), mode="bilinear", align_corners=True) ->
+ * torch.cat([up, skip], dim=1) -> conv3x3 (padding 1) + folded BatchNorm (scale / shift) + activation.  low [B,Hs,Ws,low_ld] (Cup channels),
+ * skip [B,H,W,skip_ld] (Cskip channels), w [Cout][3][3][Cup + Cskip] (the concatenation's channel order), out [B,H,W,out_ld].
+ * The upsampled tensor and the concatenation are never materialised: the direct 3x3 kernel computes the upsampled channel chunks into its
+ * LDS halo tile (four taps blended in float32, rounded to `dtype` like a stored tensor) and fetches the skip chunks.  Bit-identical to
+ * cfp_resize_bilinear + cfp_conv2d_nhwc.  bf16 / f16, Cup % 64 == 0, Cskip % 8 == 0, Cout % 8 == 0. */
+int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int Ws, int Cup, const void* skip, int skip_ld, int Cskip,
+                             const void* w, const float* scale, const float* shift, void* out, int out_ld, int B, int H, int W,
+                             int Cout, int act, int dtype, cfp_stream_t stream);
+
 /* Strided row copy out[r, 0:C] = in[r, 0:C]. */
 int cfp_copy_rows(const void* in, int in_ld, void* out, int out_ld, int rows, int C, int dtype, cfp_stream_t stream);
 /* Two such copies in one launch (a channel concatenation [a | b] -> out, or its backward split): copy k moves `rows` rows of Ck channels. */

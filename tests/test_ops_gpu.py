@@ -969,6 +969,41 @@ def test_dwconv3x3_mfma_bit_exact_on_integers(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(2, 120, 160, 240, 320, 64, 16, 32), (2, 60, 80, 120, 160, 128, 40, 64), (1, 30, 40, 60, 80, 256, 56, 128),
+                                  (2, 15, 20, 30, 40, 256, 136, 256), (1, 13, 17, 26, 34, 64, 24, 16), (3, 7, 9, 21, 19, 128, 8, 40)])
+def test_upsample_cat_conv3x3_is_bit_identical_to_resize_then_conv(case, dtype):
+    """cfp_upsample_cat_conv3x3 (decoder.py:51-58: interpolate(bilinear, align_corners=True) -> cat -> conv3x3 + BN + LeakyReLU in ONE launch,
+    the upsampled tensor and the concatenation never in memory) against cfp_resize_bilinear into the concatenation buffer +
+    cfp_conv2d_nhwc: identical bits (same taps, same float32 blend, same rounding point), and both against torch."""
+    B, Hs, Ws, H, W, Cup, Cskip, Cout = case
+    low = q(rnd(B, Cup, Hs, Ws, seed=31), dtype)
+    skip = q(rnd(B, Cskip, H, W, seed=32), dtype)
+    Cin = Cup + Cskip
+    w = q(rnd(Cout, Cin, 3, 3, seed=33, scale=1.0 / math.sqrt(9 * Cin)), dtype)
+    scale, shift = (rnd(Cout, seed=34).abs() + 0.5).to(DEV), rnd(Cout, seed=35, scale=0.1).to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dtype).to(DEV)
+    a_low = to_act(nhwc(low), dtype)
+    cat = ops.new_act(B * H * W, Cin, dtype, DEV)
+    cat.buf[:, Cup:] = nhwc(skip).to(dtype).to(DEV)
+    out1, out2 = ops.new_act(B * H * W, Cout, dtype, DEV), ops.new_act(B * H * W, Cout, dtype, DEV)
+    ops.upsample_cat_conv3x3(a_low, Hs, Ws, cat.slice(Cup, Cskip), wp, scale, shift, out1, B, H, W, hip.ACT_LRELU)
+    ops.resize_bilinear(a_low, Hs, Ws, (0, 0, Hs, Ws), cat.slice(0, Cup), H, W, (0, 0, H, W), B)
+    ops.conv2d(cat, wp, scale, shift, out2, B, H, W, 3, 3, 1, 1, 1, H, W, hip.ACT_LRELU)
+    torch.cuda.synchronize()
+    ref_in = torch.cat([q(F.interpolate(low, size=(H, W), mode="bilinear", align_corners=True), dtype), skip], 1)
+    ref = F.leaky_relu(F.conv2d(ref_in, w, None, 1, 1) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None], 0.01)
+    close(from_nhwc(out2.torch(), B, H, W), ref, dtype, f"resize + conv {case}")
+    close(from_nhwc(out1.torch(), B, H, W), ref, dtype, f"fused {case}")
+    d = (out1.buf.float() - out2.buf.float()).abs()
+    v, _ = ops.conv2d_plan(B * H * W, Cout, 9 * Cin, ops.DT[dtype], 0, B, 3, 1)
+    if v >= 200:       # the unfused pair runs the same direct 3x3 kernel (same summation order): identical bits
+        assert torch.equal(out1.buf.view(torch.int16), out2.buf.view(torch.int16)), f"{int((d > 0).sum())} elements differ, max {float(d.max()):.3e}"
+    else:              # the pair's conv is the implicit GEMM (another K order): equal up to float32 summation order, i.e. one 16-bit ulp
+        ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+        assert bool((d <= ulp * out2.buf.float().abs() + 1e-3 * ulp * float(out2.buf.float().abs().max())).all()), float(d.max())
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(8, 30, 40, 816, 1), (8, 15, 20, 1392, 1), (8, 60, 80, 224, 2), (8, 30, 40, 816, 2), (8, 30, 40, 448, 1),
                                   (2, 26, 34, 672, 1), (2, 13, 17, 1392, 1), (2, 40, 60, 208, 1), (1, 20, 30, 1392, 1), (2, 52, 68, 224, 2),
                                   (1, 7, 5, 16, 1), (3, 16, 16, 80, 1), (1, 33, 130, 48, 2)])
