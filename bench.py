@@ -298,10 +298,14 @@ def training_fidelity(sd, layers, inp, target, dev):
     return out
 
 
-def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2, fidelity: bool = False):
-    """BASELINE.json configs[2..3] shape on ONE GPU: 416x544 crops, 6x6 zones of 64 px, `batch` samples, bf16 activations with
-    float32 master parameters; one step = training forward + SILog + backward + AdamW/OneCycle, replayed as one HIP graph.
-    (Single process: the RCCL gradient all-reduce of the multi-GPU run is not part of this number.)"""
+def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2, fidelity: bool = False, dtype=None):
+    """BASELINE.json configs[2..3] shape: 416x544 crops, 6x6 zones of 64 px, `batch` samples per GPU, 16-bit activations with
+    float32 master parameters; one step = training forward + SILog + backward (+ gradient all-reduce) + AdamW/OneCycle, replayed as
+    HIP graphs.  Headline storage type: fp16 (IEEE half, overflow-guarded optimizer) -- its gradient is the float32 one to a cosine
+    of 0.98, bf16's only to 0.88 at the same speed (profiles/r3_train_fidelity.md); the bf16 step BASELINE.json names is timed
+    beside it (`bf16` sub-object) when `fidelity` is set."""
+    dtype = dtype or torch.float16
+    dname = {torch.float16: "fp16", torch.bfloat16: "bf16"}[dtype]
     import numpy as np
     from cfpnet_amd import spec, synthetic, weights
     from cfpnet_amd.trainer import Trainer
@@ -310,7 +314,7 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
     H, W = 416, 544
     inp = synthetic.to_device(synthetic.make_inputs(batch, H, W, 6, 64, seed=5, drop_hist=0.34), dev)
     target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=50 + i, holes=0.1) for i in range(batch)]))[:, None].to(dev)
-    tr = Trainer(sd, layers, lr=3e-4, total_steps=max(100, steps + warmup + 1), dtype=torch.bfloat16, device=dev, dist=dist, world=world)
+    tr = Trainer(sd, layers, lr=3e-4, total_steps=max(100, steps + warmup + 1), dtype=dtype, device=dev, dist=dist, world=world)
     tr.capture(inp, target)
     l0 = float(tr.step(inp, target)[0])
     for _ in range(max(warmup - 1, 0)):
@@ -350,11 +354,22 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
                               "RGB-encoder backward (second HIP graph of the split step), 1x group after it; backend " + str(dist.get_backend())}
     elif fidelity:
         extra = {"fidelity_vs_f32_same_batch": training_fidelity(sd, layers, inp, target, dev)}
-    return {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": "bf16 activations, f32 master weights", **extra,
+    if dtype == torch.float16:
+        extra["overflow_guard"] = {"skipped_steps": tr.opt.skipped_steps(),
+                                   "what": "a step whose gradient norm is not finite is skipped on the device (cfp_grad_clip_factor / cfp_adamw_step)"}
+    loss_last = float(loss)
+    del tr
+    torch.cuda.empty_cache()
+    if fidelity and dist is None and dtype == torch.float16:
+        b = training_step_rate(batch, dev, steps=steps, warmup=warmup, dtype=torch.bfloat16)
+        extra["bf16"] = {"value": b["value"], "unit": "samples/s", "ms_per_step": b["ms_per_step"],
+                         "note": "the storage type BASELINE.json names; same kernels, same speed, but its gradient has a cosine of ~0.88 to the "
+                                 "float32 one on this shard (fidelity_vs_f32_same_batch) -- a speed number for a noisier optimisation problem"}
+    return {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "dtype": f"{dname} activations, f32 master weights", **extra,
             "config": {"workload": f"batch={batch} 416x544 crops + 6x6-zone ToF, training forward + SILog + backward + AdamW/OneCycle",
                        "launch": "one HIP graph per step" + (", flat-gradient RCCL all-reduce (3 x 32 MB buckets) + AdamW after it" if world > 1 else ""),
                        "n_gpus": world, "global_batch": world * batch},
-            "loss_first_step": l0, "loss_after_%d_steps" % (steps + 2): float(loss)}
+            "loss_first_step": l0, "loss_after_%d_steps" % (steps + 2): loss_last}
 
 
 def main():
@@ -366,10 +381,10 @@ def main():
     if a.train:
         r = training_step_rate(a.train_batch, dev, steps=a.steps, dist=dist, world=world, warmup=a.warmup)
         if rank == 0:
-            print(json.dumps({"metric": "training samples/sec @ 416x544 bf16 (whole job: forward + SILog + backward + gradient all-reduce + AdamW)",
+            print(json.dumps({"metric": "training samples/sec @ 416x544, 16-bit activations (whole job: forward + SILog + backward + gradient all-reduce + AdamW)",
                               "value": r["value"], "unit": "samples/s", "per_gpu": r["value"] / world, "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": r["config"],
+                              "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic", "config": r["config"],
                               "loss_first_step": r["loss_first_step"],
                               **{k: r[k] for k in ("allreduce_ms", "overlap_frac", "ms_per_step_sequential_allreduce", "ms_per_step_no_allreduce", "allreduce") if k in r}}))
         if dist:

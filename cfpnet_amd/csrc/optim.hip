@@ -15,6 +15,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, long long n, float lr, float beta1, float beta2,
                                                     float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
   const float gs = gscale ? gscale[0] : 1.f;
+  if (gs < 0.f) return;            // overflow guard (cfp_grad_clip_factor): the gradient norm was not finite -> the whole step is skipped,
+                                   // parameters and both moments stay as they are (what torch.cuda.amp.GradScaler does with an inf / nan step)
   const float decay = 1.f - lr * wd;
   const float step_size = lr / bc1;
   const long long n4 = n >> 2;
@@ -62,15 +64,17 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// out[0] = clip factor min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_), out[1] = norm
+// out[0] = clip factor min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_), out[1] = norm; a norm that is not finite
+// (an overflow somewhere in a 16-bit backward) makes out[0] = -1 -- cfp_adamw_step then skips the step -- and counts in out[2]
 __global__ void clip_factor_kernel(const double* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double s = 0.0;
   for (int i = 0; i < nblk; ++i) s += partial[i];
   const float norm = (float)sqrt(s);
+  out[1] = norm;
+  if (!(norm < 3.0e38f)) { out[0] = -1.f; out[2] += 1.f; return; }      // inf or nan
   const float c = max_norm / (norm + 1e-6f);
   out[0] = c < 1.f ? c : 1.f;
-  out[1] = norm;
 }
 
 }  // namespace

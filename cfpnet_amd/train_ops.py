@@ -222,23 +222,26 @@ class FlatAdamW:
     `cfp_adamw_step` launch per group (+ optionally the clip-factor kernels), lr / beta1 from OneCycle."""
 
     def __init__(self, flat: FlatParams, schedule: OneCycle, weight_decay: float = 0.1, beta2: float = 0.999, eps: float = 1e-8,
-                 clip_grad_norm: Optional[float] = None):
+                 clip_grad_norm: Optional[float] = None, overflow_guard: bool = False):
         assert flat.param.is_cuda, "FlatAdamW runs the HIP kernel: parameters must be on the GPU"
         self.flat, self.sched = flat, schedule
         self.wd, self.beta2, self.eps, self.clip = weight_decay, beta2, eps, clip_grad_norm
+        # 16-bit training: the gradient norm is always formed and a step whose norm is not finite is skipped on the device
+        # (cfp_grad_clip_factor / cfp_adamw_step); `skipped_steps()` reads the counter
+        self.guard = bool(overflow_guard)
         self.m = torch.zeros_like(flat.param)
         self.v = torch.zeros_like(flat.param)
         self.step_count = 0
         self._clip_ws = torch.empty(int(hip.load().cfp_grad_clip_ws_bytes()) // 8, dtype=torch.float64, device=flat.param.device)
-        self._clip_out = torch.ones(2, dtype=torch.float32, device=flat.param.device)
+        self._clip_out = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=flat.param.device)
 
     def step(self):
         lr, beta1 = self.sched.at(self.step_count)
         self.step_count += 1
         f = self.flat
         scale_ptr = 0
-        if self.clip is not None:
-            hip.call("cfp_grad_clip_factor", f.grad.data_ptr(), f.live, float(self.clip), self._clip_ws.data_ptr(),
+        if self.clip is not None or self.guard:
+            hip.call("cfp_grad_clip_factor", f.grad.data_ptr(), f.live, float(self.clip) if self.clip is not None else 3.0e38, self._clip_ws.data_ptr(),
                      self._clip_ws.numel() * 8, self._clip_out.data_ptr(), hip.current_stream())
             scale_ptr = self._clip_out.data_ptr()
         for grp in (0, 1):
@@ -250,6 +253,10 @@ class FlatAdamW:
                      self.v.data_ptr() + a * es, b - a, float(lr), float(beta1), float(self.beta2), float(self.eps), float(self.wd),
                      self.step_count, scale_ptr, hip.current_stream())
         return lr, beta1
+
+    def skipped_steps(self) -> int:
+        """Steps the overflow guard has skipped so far (device counter; synchronises)."""
+        return int(self._clip_out[2].item())
 
 
 def lr_group_of(hist_encoder_10x: bool):

@@ -58,7 +58,7 @@ class Trainer:
         for name, _ in names:                                     # TrainNet.__init__ keeps device tensors as they are: still views
             assert self.net.sd[name].data_ptr() == self.flat.view(name).data_ptr()
         self.opt = train_ops.FlatAdamW(self.flat, train_ops.OneCycle(lr, total_steps, div_factor, final_div_factor), weight_decay=weight_decay,
-                                       clip_grad_norm=clip_grad_norm)
+                                       clip_grad_norm=clip_grad_norm, overflow_guard=dtype == torch.float16)
         self.min_val = min_val
         self._graph = None
         if overlap_param_grads:        # measured SLOWER inside a captured step (48.8 vs 45.2 ms): off by default, see DESIGN 4.0
@@ -87,7 +87,7 @@ class Trainer:
         assert not bool(self.opt.m.any()) and not bool(self.opt.v.any()), "optimizer moments exist before the kernel layout was bound"
         resumed_at = self.opt.step_count
         self.opt = train_ops.FlatAdamW(kflat, train_ops.OneCycle(k["lr"], k["total_steps"], k["div_factor"], k["final_div_factor"]),
-                                       weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"])
+                                       weight_decay=k["weight_decay"], clip_grad_norm=k["clip_grad_norm"], overflow_guard=self.dtype == torch.float16)
         self.opt.step_count = resumed_at
         if self._pending_opt is not None:
             pending, self._pending_opt = self._pending_opt, None

@@ -169,6 +169,39 @@ def test_silog_loss_training_shape():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_overflow_guard_skips_a_step_with_a_non_finite_gradient(bad):
+    """fp16 training's overflow guard: a gradient whose norm is not finite leaves parameters and both AdamW moments untouched (the
+    step is skipped on the device, no host sync), the next finite step is applied; a guarded optimizer equals the unguarded one on
+    finite gradients (the clip factor is then exactly 1)."""
+    named = [("img_encoder.w", (37, 11)), ("decoder.w", (64, 33)), ("conv_out.0.weight", (1026,))]
+    group = train_ops.lr_group_of(True)
+    torch.manual_seed(1)
+    init = {n: torch.randn(*s) for n, s in named}
+    opts = []
+    for guard in (True, False):
+        flat = train_ops.FlatParams(named, group, device="cuda:0")
+        flat.load(init)
+        opts.append((flat, train_ops.FlatAdamW(flat, train_ops.OneCycle(3e-4, 10, 25, 100), weight_decay=0.1, overflow_guard=guard)))
+    (fg, og), (fu, ou) = opts
+    g1 = torch.randn(fg.total, device="cuda:0")
+    for f, o in opts:
+        f.grad.copy_(g1); o.step()
+    torch.cuda.synchronize()
+    assert torch.equal(fg.param, fu.param) and torch.equal(og.m, ou.m) and og.skipped_steps() == 0
+    before = (fg.param.clone(), og.m.clone(), og.v.clone())
+    fg.grad.copy_(g1); fg.grad[123] = bad
+    og.step()
+    torch.cuda.synchronize()
+    assert torch.equal(fg.param, before[0]) and torch.equal(og.m, before[1]) and torch.equal(og.v, before[2])
+    assert og.skipped_steps() == 1
+    fg.grad.copy_(g1)
+    og.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(fg.param, before[0]) and torch.isfinite(fg.param).all() and og.skipped_steps() == 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("clip", [None, 0.1])
 def test_flat_adamw_matches_torch_adamw(clip):
     torch.manual_seed(0)
