@@ -810,6 +810,11 @@ int cfp_dws_launch(const void* in, int in_ld, const void* w, const float* scale,
                    const char* who);
 int cfp_dws_strips(int B, int Ho, int Wo, int C, int stride);
 void cfp_dws_debug_set(int key, int value);
+// dw3x3_slide.hip
+int cfp_dwl_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld, float* partial,
+                   const float* w_red, int RD, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                   int act, int dtype, cfp_stream_t stream, const char* who);
+int cfp_dwl_slots(int B, int Ho, int Wo, int C, int stride);
 
 namespace {
 // Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
@@ -817,7 +822,8 @@ namespace {
 // (halo read amplification) x (penalty for leaving CUs idle).
 struct DwPlan { int cvb, R, nstrips; size_t lds; };
 int g_dw_force_cvb = 0, g_dw_force_R = 0, g_dw_valu = 0;   // cfp_debug_set keys 3 / 4 / 5 (tools/dw_bench.py)
-// key 6: 0 = dw3x3_stream_kernel (round 3: persistent, LDS-DMA staged, row steps behind counted vmcnt waits; bit-identical outputs), 1 = dw3x3_mfma_kernel.
+// key 6: 2 = dw3x3_slide_kernel (round 3, second design: register window over input columns, one barrier per workgroup),
+//        0 = dw3x3_stream_kernel (round 3: persistent, LDS-DMA staged, row steps behind counted vmcnt waits; bit-identical outputs), 1 = dw3x3_mfma_kernel.
 // The pipelined kernel is correct and MEASURED SLOWER at batch 8 (24 vs 19 us at 30x40x816, profiles/r3_dw3x3_stream.md): its steps
 // run in lock-step (all 8 waves read LDS, then all run the SiLU), and per-lane LDS-DMA costs ~300 cycles per 1 KB instruction.  Off by default.
 int g_dw_no_stream = 1;
@@ -874,6 +880,12 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
   CFP_REQUIRE(hpart == nullptr || (mfma && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
               std::string(who) + ": the squeeze-excite partials need 16-bit storage, C % 16 == 0 and R <= 64");
+  if (mfma && g_dw_no_stream == 2 && act < 99) {
+    // the sliding-window kernel (dw3x3_slide.hip): register window over input columns, one barrier per workgroup
+    const int rc = cfp_dwl_launch(in, in_ld, w, scale, shift, out, out_ld, partial, w_red, RD, hpart, B, H, W, C, stride, pad_t, pad_l, Ho, Wo,
+                                  act, dtype, stream, who);
+    if (rc != 1) return rc;
+  }
   if (mfma && !g_dw_no_stream && hpart == nullptr) {
     // the software-pipelined kernel (dw3x3_stream.hip): same arithmetic, load / compute / store overlapped inside a workgroup
     const int rc = cfp_dws_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, dtype, stream, who);
@@ -936,6 +948,10 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (is16(dtype) && C % 16 == 0 && !g_dw_valu && g_dw_no_stream == 2) {
+    const int n = cfp_dwl_slots(B, Ho, Wo, C, stride);
+    if (n > 0) return n;
+  }
   if (is16(dtype) && C % 16 == 0 && !g_dw_valu && !g_dw_no_stream) {
     const int n = cfp_dws_strips(B, Ho, Wo, C, stride);
     if (n > 0) return n;
@@ -953,6 +969,10 @@ extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, 
 
 extern "C" int cfp_dwconv3x3_se_parts(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2) || !is16(dtype) || C % 16 != 0 || g_dw_valu) return 0;
+  if (g_dw_no_stream == 2) {
+    const int n = cfp_dwl_slots(B, Ho, Wo, C, stride);
+    if (n > 0) return n * cdiv(C, 64);
+  }
   const DwPlan d = dw_plan(B, Ho, Wo, C, stride, 8, true);
   return d.nstrips * cdiv(C / 8, d.cvb);
 }

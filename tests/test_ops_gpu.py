@@ -1049,6 +1049,57 @@ def test_dwconv3x3_stream_kernel_equals_the_single_phase_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(8, 30, 40, 816, 1), (8, 15, 20, 1392, 1), (8, 60, 80, 224, 2), (8, 30, 40, 816, 2), (8, 30, 40, 448, 1),
+                                  (2, 26, 34, 672, 1), (2, 13, 17, 1392, 1), (2, 40, 60, 208, 1), (1, 20, 30, 1392, 1), (2, 52, 68, 224, 2),
+                                  (1, 7, 5, 16, 1), (3, 16, 16, 80, 1), (1, 33, 130, 48, 2), (2, 17, 3, 32, 1)])
+def test_dwconv3x3_sliding_window_kernel(case, dtype):
+    """dw3x3_slide_kernel (round 3: a wave owns 16 output rows of a 16-channel group and slides along x with a register window of three
+    input columns; taps paired along y: 6 diagonal-weight MFMAs and 2 LDS fragment reads per output column; one barrier per workgroup)
+    against dw3x3_mfma_kernel and torch: the same products in another float32 summation order -> within one ulp of the storage type of
+    the round-2 kernel; channel sums, the squeeze-excite partial dot products and the nothing-outside-the-slice property too."""
+    B, H, W, Cc, s = case
+    lib = hip.load()
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = max((Ho - 1) * s + 3 - H, 0) // 2, max((Wo - 1) * s + 3 - W, 0) // 2
+    x = q(rnd(B, Cc, H, W, seed=11), dtype)
+    w = q(rnd(Cc, 1, 3, 3, seed=12, scale=0.4), dtype)
+    scale, shift = (rnd(Cc, seed=13).abs() + 0.5).to(DEV), rnd(Cc, seed=14).to(DEV)
+    R = 24
+    wr = rnd(R, Cc, seed=15, scale=0.1).to(DEV)
+    wa = w.reshape(Cc, 9).t().contiguous().to(dtype).to(DEV)
+    xin = to_act(nhwc(x), dtype, ld=Cc + 24, c0=8)
+    res = []
+    try:
+        for mode in (1, 2):
+            lib.cfp_debug_set(6, mode)
+            buf = ops.new_act(B * Ho * Wo, Cc, dtype, DEV, ld=Cc + 16, zero=True)
+            out = ops.Act(buf.buf, 8, Cc)
+            ns = ops.dwconv3x3_strips(B, Ho, Wo, Cc, s, ops.DT[dtype])
+            part = torch.full((B, ns, Cc), float("nan"), device=DEV)
+            ops.dwconv3x3_sum(xin, wa, scale, shift, out, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+            K = ops.dwconv3x3_se_parts(B, Ho, Wo, Cc, s, ops.DT[dtype])
+            hpart = torch.full((B, K, R), float("nan"), device=DEV)
+            buf2 = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+            ops.dwconv3x3_se(xin, wa, scale, shift, buf2, wr, hpart, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+            torch.cuda.synchronize()
+            assert torch.equal(buf2.buf.view(torch.int16), ops.Act(buf.buf, 8, Cc).torch().contiguous().view(torch.int16))
+            res.append((buf.buf.clone(), part.sum(1).cpu(), hpart.sum(1).cpu()))
+    finally:
+        lib.cfp_debug_set(6, 1)
+    (o_old, s_old, h_old), (o_new, s_new, h_new) = res
+    ref = F.silu(F.conv2d(F.pad(x, (pl, (Wo - 1) * s + 3 - W - pl, pt, (Ho - 1) * s + 3 - H - pt)), w, None, s, 0, 1, Cc)
+                 * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None])
+    close(from_nhwc(ops.Act(o_new, 8, Cc).torch(), B, Ho, Wo), ref, dtype, f"dw3x3 slide {case}")
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    d = (o_old.float() - o_new.float()).abs()
+    assert bool((d <= ulp * o_old.float().abs() + 1e-6).all()), f"{int((d > ulp * o_old.float().abs() + 1e-6).sum())} elements beyond one ulp, max {float(d.max()):.3e}"
+    assert float((d > 0).float().mean()) < 0.02                    # and nearly all of them identical
+    assert float(o_new[:, :8].float().abs().max()) == 0 and float(o_new[:, 8 + Cc:].float().abs().max()) == 0
+    assert torch.isfinite(s_new).all() and torch.allclose(s_new, s_old, rtol=1e-4, atol=1e-4 * float(s_old.abs().max()))
+    assert torch.isfinite(h_new).all() and torch.allclose(h_new, h_old, rtol=1e-4, atol=1e-4 * float(h_old.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (1, 64, 32, 8, 31)])
 def test_dwconv_large_toeplitz_bit_exact_on_integers(case, dtype):
     B, H, W, Cc, k = case

@@ -15,7 +15,8 @@ ap.add_argument("--ab", action="store_true", help="also time the round-2 single-
 ap.add_argument("--sweep-stream", action="store_true", help="sweep the pipelined kernel's rows per step S and rows per workgroup RT")
 a = ap.parse_args()
 lib = hip.load()
-lib.cfp_debug_set(6, 0)                    # this tool is about the pipelined kernel (opt-in in the library)
+MODE = int(os.environ.get("DW_MODE", "2"))  # 2 = sliding-window kernel, 0 = pipelined (LDS-DMA) kernel, 1 = round-2 kernel
+lib.cfp_debug_set(6, MODE)
 DEV = "cuda:0"
 B = a.batch
 shapes = [(60, 80, 224, 2), (30, 40, 448, 1), (30, 40, 672, 1), (30, 40, 816, 1), (30, 40, 816, 2), (15, 20, 1392, 1)]
@@ -55,7 +56,7 @@ for (H, W, C, s) in shapes:
     if a.ab:
         lib.cfp_debug_set(6, 1)
         told = timeit(run, a.reps)
-        lib.cfp_debug_set(6, 0)            # the rest of this tool measures the pipelined kernel
+        lib.cfp_debug_set(6, MODE)
         line += f"   round-2 kernel {told:6.1f} us   pipelined/copy {t / tc:4.2f}x (target <= 1.7x)   old/copy {told / tc:4.2f}x"
     if a.sweep_stream:
         best = (t, "auto")

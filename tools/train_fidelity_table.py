@@ -36,6 +36,8 @@ def group_of(k):
     p = k.split(".")
     if p[0] == "img_encoder":
         return "img_encoder." + (p[1] if p[1] not in ("conv3",) else p[1] + "." + p[2])
+    if p[0] == "decoder" and p[1].startswith("cross_atten") and p[2] != "layers":
+        return f"decoder.{p[1]}.positional tables"
     if p[0] == "decoder" and p[1].startswith("cross_atten"):
         kind = "hist2image" if int(p[3]) in (0, 3) else ("combine1" if int(p[3]) in (1, 4) else "image")
         return f"decoder.{p[1]}.{kind}"
