@@ -83,7 +83,11 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 
 // Two f32 -> one packed dword of H (low half = first element).
 template <typename H> __device__ __forceinline__ uint32_t pack2(float a, float b);
-template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)a, (__bf16)b};          // one v_cvt_pk_bf16_f32 (the scalar form cost two extra shuffles per pair)
+  return __builtin_bit_cast(uint32_t, v);
+}
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float a, float b) {
   f16x2 h = {f2h(a), f2h(b)};
   return __builtin_bit_cast(uint32_t, h);

@@ -36,6 +36,7 @@ struct DwlP {
   int colsA;                 // allocated input columns per LDS row = (XS - 1) * stride + 3
   int rowpitch;              // LDS bytes per input row: colsA * 144 rounded up to 16 x odd (16 consecutive rows hit 16 different bank groups)
   FastDiv dcols;             // item -> (row, column) of the patch
+  float* dbg;                // diagnostic stamps [workgroup][8] (tools/dw_bench.py --stamps), or null; they feed no output value
 };
 
 constexpr int DWL_PP = 144;  // pixel pitch: 8 chunks of 16 bytes + 16 bytes of padding
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
   const int x0 = xs * p.XS, nx = min(p.XS, p.Wo - x0);
   const int iy0 = y0 * STRIDE - p.pad_t, ix0 = x0 * STRIDE - p.pad_l;
   const int nrows_in = (ny - 1) * STRIDE + 3, ncols_in = (nx - 1) * STRIDE + 3;
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tr0 = 0;
+  if (p.dbg) { tk0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- per-lane constants: requested first, their latency hides under the patch loads ------------------------------------------
   const int cbase = (cv0 + 2 * g) * 8;
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
       if (dst[n] >= 0) *reinterpret_cast<u32x4*>(lds + dst[n]) = v[n];
   }
   __syncthreads();
+  if (p.dbg) tk1 = __builtin_amdgcn_s_memtime();
 
   // ---- 2. every wave slides along x on its own ---------------------------------------------------------------------------------------
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -133,37 +137,54 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) f[pr] = *reinterpret_cast<const s16x8*>(lds + roff[pr] + col * DWL_PP);
     };
-    with_act(p.act, [&](auto A) {
-      auto emit = [&](int x, const s16x8 (&f0)[2], const s16x8 (&f1)[2], const s16x8 (&f2)[2]) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // epilogue constants folded for the exponential: silu(z) = z / (1 + 2^(-z log2 e)), z = acc * sc + sh -> t = acc * sc2 + sh2
+    constexpr float NL2E = -1.4426950408889634f;
+    f32x4 sc2, sh2;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          acc = mfma16<HT>(afr[0][pr], f0[pr], acc);
-          acc = mfma16<HT>(afr[1][pr], f1[pr], acc);
-          acc = mfma16<HT>(afr[2][pr], f2[pr], acc);
-        }
+    for (int r4 = 0; r4 < 4; ++r4) { sc2[r4] = sc4[r4] * NL2E; sh2[r4] = sh4[r4] * NL2E; }
+    const float vf = row_ok ? 1.f : 0.f;
+    with_act(p.act, [&](auto A) {
+      constexpr int ACT = decltype(A)::value;
+      auto emit = [&](int x, const s16x8 (&f0)[2], const s16x8 (&f1)[2], const s16x8 (&f2)[2]) {
+        // two independent accumulation chains (pairs (dy0, dy1) and (dy2, -)), added at the end
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        acc0 = mfma16<HT>(afr[0][0], f0[0], acc0); acc1 = mfma16<HT>(afr[0][1], f0[1], acc1);
+        acc0 = mfma16<HT>(afr[1][0], f1[0], acc0); acc1 = mfma16<HT>(afr[1][1], f1[1], acc1);
+        acc0 = mfma16<HT>(afr[2][0], f2[0], acc0); acc1 = mfma16<HT>(afr[2][1], f2[1], acc1);
         float y[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          y[r4] = act_c<decltype(A)::value>(acc[r4] * sc4[r4] + sh4[r4]);
-          csum[r4] += row_ok ? y[r4] : 0.f;
+          const float a = acc0[r4] + acc1[r4];
+          if constexpr (ACT == CFP_ACT_SILU) {
+            // one fused multiply-add each for z and for the exponent (the VALU is what bounds this kernel: 8 of its ~30 instructions per
+            // column are the quarter-rate v_exp / v_rcp, every other one counts)
+            const float z = fmaf(a, sc4[r4], sh4[r4]);
+            const float e = __builtin_amdgcn_exp2f(fmaf(a, sc2[r4], sh2[r4]));
+            y[r4] = z * __builtin_amdgcn_rcpf(1.f + e);
+          } else {
+            y[r4] = act_c<ACT>(fmaf(a, sc4[r4], sh4[r4]));
+          }
+          csum[r4] = fmaf(y[r4], vf, csum[r4]);
         }
         uint2 pk;
         pk.x = pack2<HT>(y[0], y[1]);
         pk.y = pack2<HT>(y[2], y[3]);
         if (row_ok) *reinterpret_cast<uint2*>(obase + (long long)x * opix) = pk;
       };
-      // window of three input columns in three register slots; slot of input column c is c % 3 (stride 1: one new column per output
-      // column, stride 2: two), so the loop is unrolled by three output columns
-      s16x8 F0[2], F1[2], F2[2];
+      // window of input columns in four register slots: three in use by the current output column, the fourth being fetched one
+      // column ahead (the LDS latency hides under the previous column's MFMAs and epilogue); loop unrolled by four
+      s16x8 F0[2], F1[2], F2[2], F3[2];
       if constexpr (STRIDE == 1) {
-        ldf(0, F0); ldf(1, F1);
-        for (int x = 0; x < nx; x += 3) {
-          ldf(x + 2, F2);                 emit(x, F0, F1, F2);
-          if (x + 1 < nx) { ldf(x + 3, F0); emit(x + 1, F1, F2, F0); }
-          if (x + 2 < nx) { ldf(x + 4, F1); emit(x + 2, F2, F0, F1); }
+        ldf(0, F0); ldf(1, F1); ldf(2, F2);
+        for (int x = 0; x < nx; x += 4) {
+          if (x + 1 < nx) ldf(x + 3, F3);
+          emit(x, F0, F1, F2);
+          if (x + 1 < nx) { if (x + 2 < nx) ldf(x + 4, F0); emit(x + 1, F1, F2, F3); }
+          if (x + 2 < nx) { if (x + 3 < nx) ldf(x + 5, F1); emit(x + 2, F2, F3, F0); }
+          if (x + 3 < nx) { if (x + 4 < nx) ldf(x + 6, F2); emit(x + 3, F3, F0, F1); }
         }
       } else {
+        // stride 2: output column x reads input columns 2x, 2x+1, 2x+2 (slots: column c in slot c % 3); two new columns per step
         ldf(0, F0);
         for (int x = 0; x < nx; x += 3) {
           ldf(2 * x + 1, F1); ldf(2 * x + 2, F2);                 emit(x, F0, F1, F2);
@@ -174,6 +195,12 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
     });
   }
 
+  if (p.dbg && tid == 0) {
+    tk2 = __builtin_amdgcn_s_memtime();
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+    float* d = p.dbg + (long long)blockIdx.x * 8;
+    d[0] = (float)(tk1 - tk0); d[1] = (float)(tk2 - tk1); d[2] = 0.f; d[3] = (float)(tr0 & 0xffffff); d[4] = (float)(tr1 & 0xffffff); d[5] = 4.f;
+  }
   // ---- 3. channel sums of the task (rows in the 16-lane butterfly's fixed order) ---------------------------------------------------------
   if (p.partial == nullptr && p.hpart == nullptr) return;
 #pragma unroll
@@ -257,6 +284,11 @@ int cfp_dwl_launch(const void* in, int in_ld, const void* w, const float* scale,
   p.B = B; p.H = H; p.W = W; p.C = C; p.pad_t = pad_t; p.pad_l = pad_l; p.Ho = Ho; p.Wo = Wo; p.act = act;
   p.XS = d.XS; p.nxs = d.nxs; p.nyr = d.nyr; p.ncb = cdiv(C, 64); p.colsA = d.colsA; p.rowpitch = d.rowpitch;
   p.dcols = make_fastdiv((unsigned)d.colsA);
+  p.dbg = nullptr;
+  if (act >= 100) {             // diagnostic launch: stamps behind the partial-sum area (the caller sized it: tools/dw_bench.py)
+    act -= 100; p.act = act;
+    if (partial) p.dbg = partial + (long long)B * d.nyr * d.nxs * C;
+  }
   const long long tasks = (long long)B * p.ncb * d.nyr * d.nxs;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define DWL_LAUNCH(HH, ST)                                                                                                          \

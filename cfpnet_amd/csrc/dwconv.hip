@@ -825,8 +825,9 @@ int g_dw_force_cvb = 0, g_dw_force_R = 0, g_dw_valu = 0;   // cfp_debug_set keys
 // key 6: 2 = dw3x3_slide_kernel (round 3, second design: register window over input columns, one barrier per workgroup),
 //        0 = dw3x3_stream_kernel (round 3: persistent, LDS-DMA staged, row steps behind counted vmcnt waits; bit-identical outputs), 1 = dw3x3_mfma_kernel.
 // The pipelined kernel is correct and MEASURED SLOWER at batch 8 (24 vs 19 us at 30x40x816, profiles/r3_dw3x3_stream.md): its steps
-// run in lock-step (all 8 waves read LDS, then all run the SiLU), and per-lane LDS-DMA costs ~300 cycles per 1 KB instruction.  Off by default.
-int g_dw_no_stream = 1;
+// run in lock-step (all 8 waves read LDS, then all run the SiLU), and per-lane LDS-DMA costs ~300 cycles per 1 KB instruction.  The
+// sliding-window kernel built on those findings is the default: 14 vs 19 us at 30x40x816, 8.8 vs 12.6 at 15x20x1392.
+int g_dw_no_stream = 2;
 inline DwPlan dw_plan(int B, int Ho, int Wo, int C, int stride, int ve, bool out_tile = false) {
   DwPlan best{8, 1, Ho, 0};
   double bc = 1e30;
@@ -880,7 +881,7 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
   CFP_REQUIRE(hpart == nullptr || (mfma && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
               std::string(who) + ": the squeeze-excite partials need 16-bit storage, C % 16 == 0 and R <= 64");
-  if (mfma && g_dw_no_stream == 2 && act < 99) {
+  if (mfma && g_dw_no_stream == 2 && act != 99) {
     // the sliding-window kernel (dw3x3_slide.hip): register window over input columns, one barrier per workgroup
     const int rc = cfp_dwl_launch(in, in_ld, w, scale, shift, out, out_ld, partial, w_red, RD, hpart, B, H, W, C, stride, pad_t, pad_l, Ho, Wo,
                                   act, dtype, stream, who);

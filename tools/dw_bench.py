@@ -78,7 +78,10 @@ for (H, W, C, s) in shapes:
         ops.dwconv3x3_sum(xs[0], w, sc, sh, outs[0], part, B, H, W, s, pt, pl, Ho, Wo, 100 + hip.ACT_SILU)
         torch.cuda.synchronize()
         raw = part[B * ns * C: B * ns * C + 24 * 20000]
-        if float(raw[5]) == 3.0:        # the persistent pipelined kernel: 24 floats per workgroup, per-step stamps
+        if float(raw[5]) == 4.0:        # the sliding-window kernel: 8 floats per workgroup
+            d8 = part[B * ns * C: B * ns * C + 8 * 20000].reshape(-1, 8).cpu()
+            dbg = d8[d8[:, 5] == 4.0][:, :6].clone(); dbg[:, 5] = 1.0
+        elif float(raw[5]) == 3.0:        # the persistent pipelined kernel: 24 floats per workgroup, per-step stamps
             d24 = raw.reshape(-1, 24).cpu()
             d24 = d24[d24[:, 5] == 3.0]
             med = lambda c: float(d24[:, c][d24[:, c] > 0].median()) if bool((d24[:, c] > 0).any()) else 0.0
