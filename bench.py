@@ -77,6 +77,7 @@ def kernel_times(engine, inputs, return_prob, reps=5):
     from cfpnet_amd import hip, ops
     recs = []
     dw_shapes = []
+    dw_calls = []
     real_call = hip.call
     stem_w = engine.P["stem.w"].data_ptr()
 
@@ -101,6 +102,7 @@ def kernel_times(engine, inputs, return_prob, reps=5):
             flops = 2.0 * 9 * B * Ho * Wo * C
             byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)
             dw_shapes.append((B * H * W, B * Ho * Wo, C))
+            dw_calls.append((B, H, W, C, stride, pt, pl, Ho, Wo))
         elif name == "cfp_depth_head_fused":
             B, H, W = a[11:14]
             M = B * H * W
@@ -134,7 +136,82 @@ def kernel_times(engine, inputs, return_prob, reps=5):
     out = {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps) for k, v in agg.items()}
     if dw_shapes:
         out["_dw3x3_copy"] = same_size_copy_ms(dw_shapes[:len(dw_shapes) // reps], engine.dtype, engine.device)
+        out["_dw3x3_in_graph"] = dw3x3_in_graph(dw_calls[:len(dw_calls) // reps], engine.dtype, engine.device)
     return out
+
+
+def _graph_us(fn, calls=24, replays=7):
+    """Per-call time of `fn` back-to-back inside a replayed HIP graph (no per-launch host or event overhead), median of `replays`."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(calls):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(replays):
+        t0 = time.perf_counter()
+        g.replay()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / calls * 1e6)
+    return sorted(ts)[len(ts) // 2]
+
+
+def dw3x3_in_graph(calls, dtype, dev):
+    """The north-star protocol for the depthwise kernels ("% of MEASURED HBM roofline"): every depthwise 3x3 launch of the forward
+    (its shape, with the squeeze-excite partials it produces in the model) and a streaming copy of the same bytes, each timed
+    back-to-back in a HIP graph over 6 rotating buffers (so that a launch does not find its input in L2 from the previous one).
+    -> totals over the forward's launches and the per-shape table."""
+    import math
+    from cfpnet_amd import hip, ops
+    shapes = {}
+    for c in calls:
+        shapes[c] = shapes.get(c, 0) + 1
+    rows, t_k, t_c, byts = [], 0.0, 0.0, 0.0
+    for (B, H, W, C, stride, pt, pl, Ho, Wo), n in shapes.items():
+        NB = 6
+        xs = [ops.new_act(B * H * W, C, dtype, dev) for _ in range(NB)]
+        for x in xs:
+            x.buf.normal_()
+        outs = [ops.new_act(B * Ho * Wo, C, dtype, dev) for _ in range(NB)]
+        w = torch.randn(9, C, device=dev).to(dtype)
+        sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        R = max(8, C // 24)
+        wr = torch.randn(R, C, device=dev) / math.sqrt(C)
+        K = ops.dwconv3x3_se_parts(B, Ho, Wo, C, stride, ops.DT[dtype])
+        hpart = torch.zeros(B * max(K, 1) * R, device=dev)
+        k = [0]
+
+        def run():
+            i = k[0] % NB; k[0] += 1
+            ops.dwconv3x3_se(xs[i], w, sc, sh, outs[i], wr, hpart, B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
+
+        crow = (B * H * W + B * Ho * Wo) // 2                  # a copy that reads and writes the kernel's bytes: (rows_in + rows_out) / 2 rows each way
+        cdst = [ops.new_act(crow, C, dtype, dev) for _ in range(NB)] if crow > B * Ho * Wo else outs
+        csrc = [ops.new_act(crow, C, dtype, dev) for _ in range(NB)] if crow > B * H * W else xs
+
+        def cp():
+            i = k[0] % NB; k[0] += 1
+            ops.copy_rows(csrc[i], cdst[i], crow)
+        tk, tc = _graph_us(run), _graph_us(cp)
+        nbytes = 2.0 * (B * H * W * C + B * Ho * Wo * C)
+        cbytes = 2.0 * 2 * crow * C
+        rows.append({"shape": f"{B}x{H}x{W}x{C} s{stride}", "launches": n, "us": tk, "GBps": nbytes / tk / 1e3, "copy_us": tc, "copy_GBps": cbytes / tc / 1e3,
+                     "frac_of_measured_copy_rate": (nbytes / tk) / (cbytes / tc)})
+        t_k += n * tk; t_c += n * tc * nbytes / cbytes; byts += n * nbytes
+        del xs, outs
+    torch.cuda.empty_cache()
+    return {"us_per_step": t_k, "GBps": byts / t_k / 1e3, "copy_us_same_bytes": t_c, "copy_GBps": byts / t_c / 1e3,
+            "frac_of_measured_copy_rate": t_c / t_k, "shapes": rows,
+            "protocol": "back-to-back in a HIP graph, 6 rotating buffers, median of 7 replays of 24 launches; the copy is cfp_copy_rows reading and writing "
+                        "(rows_in + rows_out) / 2 rows of the same channel count: the kernel's bytes"}
 
 
 def same_size_copy_ms(shapes, dtype, dev, reps=5):
@@ -166,7 +243,7 @@ def pmc_traffic(kernel_family: str):
     (profiles/pmc_traffic.json, profiles/r2f_pmc_traffic.json, profiles/r2k_pmc_traffic.json and profiles/r2n_pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for
     16-byte streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
     table = {}
-    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json", "r2n_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
+    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json", "r2n_pmc_traffic.json", "r3_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -498,6 +575,7 @@ def main():
         if not a.no_kernel_times:
             kt = kernel_times(engine, inputs, return_prob)
             dw_copy_ms = kt.pop("_dw3x3_copy", None)
+            dw_in_graph = kt.pop("_dw3x3_in_graph", None)
             total_ms = sum(v["ms"] for v in kt.values())
             convs = {k: v for k, v in kt.items() if k.startswith(("conv_igemm", "igemm2", "conv3x3_direct", "depth_head_fused"))}
             # one hand-written kernel = one row: the tile shapes of igemm2_kernel are template instantiations of the same code
@@ -544,7 +622,7 @@ def main():
                 w = kt["cfp_dwconv3x3_nhwc"]
                 gbs = w["bytes"] / (w["ms"] * 1e-3) / 1e9
                 line["dw3x3"] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                 "traffic": pmc_traffic("dw3x3_mfma_kernel"), "launches_per_step": w["launches"],
+                                 "traffic": pmc_traffic("dw3x3_slide_kernel") or pmc_traffic("dw3x3_mfma_kernel"), "launches_per_step": w["launches"],
                                  "avg_launch_us": w["ms"] * 1e3 / w["launches"], "bytes_per_launch": w["bytes"] / w["launches"]}
                 if dw_copy_ms:
                     # north_star: ">= 60 % of MEASURED HBM roofline on the depthwise-conv kernels": the measured roofline of a
@@ -554,6 +632,14 @@ def main():
                                           "copy_avg_launch_us": dw_copy_ms * 1e3 / w["launches"],
                                           "protocol": "median of 5 event-pair timings per launch for the kernel AND the copy; the pair adds several us "
                                                       "to both, which flatters the ratio -- see in_graph for the back-to-back figure"})
+            if "dw3x3" in line and dw_in_graph:
+                # the figures the north star asks for: in-graph bandwidth against the nominal peak and against the measured copy
+                line["dw3x3"]["in_graph"] = dw_in_graph
+                line["dw3x3"]["achieved_event_pairs"] = line["dw3x3"]["achieved"]
+                line["dw3x3"]["achieved"] = dw_in_graph["GBps"]
+                line["dw3x3"]["frac"] = dw_in_graph["GBps"] / PEAK_HBM_GBS
+                line["dw3x3"]["frac_of_measured_copy_in_graph"] = dw_in_graph["frac_of_measured_copy_rate"]
+                line["dw3x3"]["target"] = {"frac_of_measured_copy_rate": 0.6, "met": bool(dw_in_graph["frac_of_measured_copy_rate"] >= 0.6)}
             line["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
             line["kernel_ms_total"] = total_ms
         if world == 1 and not a.no_cpu_baseline:

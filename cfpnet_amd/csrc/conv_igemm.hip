@@ -302,7 +302,7 @@ static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
 void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic), 5 = 1 forces the VALU kernel
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
-    case 3: case 4: case 5: case 6: case 7: case 8: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
     case 2: g_use_v1 = value; return CFP_OK;

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
 // Work decomposition: y-runs of 16 output rows, x-segments of XS columns chosen so that the launch has >= ~3 workgroups per CU with
 // the least halo; the patch must fit the per-thread load count of the kernel.
 struct DwlPlan { int XS, nxs, nyr, colsA, rowpitch; size_t lds; };
+int g_dwl_force_xs = 0;        // cfp_debug_set key 9 (tools/dw_bench.py --sweep-xs)
 
 static bool dwl_plan(int B, int Ho, int Wo, int C, int stride, DwlPlan& d) {
   const int ncb = cdiv(C, 64), nyr = cdiv(Ho, 16);
@@ -248,6 +249,7 @@ static bool dwl_plan(int B, int Ho, int Wo, int C, int stride, DwlPlan& d) {
   for (int XS = 2; XS <= xs_max && XS <= std::max(Wo, 2); ++XS) {
     const int colsA = (XS - 1) * stride + 3;
     if (rows * colsA * 8 > 256 * nld) continue;
+    if (g_dwl_force_xs && XS != g_dwl_force_xs) continue;
     const int nxs = cdiv(Wo, XS);
     const long long tasks = (long long)B * ncb * nyr * nxs;
     const double halo = (double)((std::min(XS, Wo) - 1) * stride + 3) / (std::min(XS, Wo) * stride);
@@ -265,6 +267,8 @@ static bool dwl_plan(int B, int Ho, int Wo, int C, int stride, DwlPlan& d) {
   if (d.lds < 1024) d.lds = 1024;
   return d.lds <= 64 * 1024 && (long long)B * ncb * nyr * d.nxs < (1ll << 31);
 }
+
+void cfp_dwl_debug_set(int value) { g_dwl_force_xs = value; }
 
 int cfp_dwl_slots(int B, int Ho, int Wo, int C, int stride) {
   DwlPlan d;

@@ -815,6 +815,7 @@ int cfp_dwl_launch(const void* in, int in_ld, const void* w, const float* scale,
                    const float* w_red, int RD, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo,
                    int act, int dtype, cfp_stream_t stream, const char* who);
 int cfp_dwl_slots(int B, int Ho, int Wo, int C, int stride);
+void cfp_dwl_debug_set(int value);
 
 namespace {
 // Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
@@ -937,7 +938,7 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
 
 void cfp_dw_debug_set(int key, int value) {
   if (key == 3) g_dw_force_cvb = value; else if (key == 4) g_dw_force_R = value; else if (key == 5) g_dw_valu = value;
-  else if (key == 6) g_dw_no_stream = value; else cfp_dws_debug_set(key, value);
+  else if (key == 6) g_dw_no_stream = value; else if (key == 9) cfp_dwl_debug_set(value); else cfp_dws_debug_set(key, value);
 }
 
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,

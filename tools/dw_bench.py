@@ -12,6 +12,7 @@ ap.add_argument("--stamps", action="store_true", help="in-kernel phase stamps of
 ap.add_argument("--phases", action="store_true", help="also time the kernel with its compute phase skipped (act=99)")
 ap.add_argument("--ld-align", type=int, default=0, help="pad the row pitch of input and output to a multiple of this many elements (64 = whole 128-byte lines per channel block)")
 ap.add_argument("--ab", action="store_true", help="also time the round-2 single-phase kernel (cfp_debug_set(6, 1)) beside the pipelined one")
+ap.add_argument("--sweep-xs", action="store_true", help="sweep the sliding-window kernel's output columns per task")
 ap.add_argument("--sweep-stream", action="store_true", help="sweep the pipelined kernel's rows per step S and rows per workgroup RT")
 a = ap.parse_args()
 lib = hip.load()
@@ -58,6 +59,15 @@ for (H, W, C, s) in shapes:
         told = timeit(run, a.reps)
         lib.cfp_debug_set(6, MODE)
         line += f"   round-2 kernel {told:6.1f} us   pipelined/copy {t / tc:4.2f}x (target <= 1.7x)   old/copy {told / tc:4.2f}x"
+    if a.sweep_xs:
+        for XS in (2, 3, 4, 5, 6, 7, 8, 10, 12):
+            lib.cfp_debug_set(9, XS)
+            try:
+                tt = min(timeit(run, a.reps) for _ in range(2))
+            except RuntimeError:
+                continue
+            line += f"\n      XS{XS}: {tt:6.1f}"
+        lib.cfp_debug_set(9, 0)
     if a.sweep_stream:
         best = (t, "auto")
         for S in (1, 2, 4):
