@@ -329,6 +329,8 @@ constexpr Cfg kCfg[] = {
     {128, 64, 2},   // 14
     {64, 128, 2},   // 15
     {128, 32, 2},   // 16
+    {32, 64, 3},    // 17: few-row / long-K problems with per-image weights (the squeeze-excite project GEMMs at 1/32: 300 rows per image):
+    {32, 128, 3},   // 18  twice the workgroups of the 64-row tiles, so that 8 images x 232 channels fill the chip
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -378,6 +380,8 @@ int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s
     case 14: return L2(128, 64, 2, 2, 2);
     case 15: return L2(64, 128, 2, 2, 2);
     case 16: return L2(128, 32, 4, 1, 2);
+    case 17: return L2(32, 64, 1, 4, 3);
+    case 18: return L2(32, 128, 1, 4, 3);
     default: return -3;
   }
 }

@@ -486,12 +486,34 @@ class Engine:
         return outs
 
     # -- LoFTR encoder layer (transformer.py:41-71) on tokens living in xb[:, 0:D] of a [rows, 2D] buffer
-    def _loftr(self, plan, tag, p, xb: Act, rows_q, src: Optional[Act], rows_s, heads, out: Act, kvmode: dict, apmode: dict):
+    def _kv_state(self, plan, tag, p, src: Act, rows_s, D, heads, kvmode: dict):
+        """k|v projection of `src` + the linear-attention key/value state (KV, Ksum) of its groups -> (kv, ks).  For hist2image the
+        source is the ToF embedding (fusion.py:123-125, 143): it depends on nothing the image path computes, so `forward` runs it
+        for all six hist2image layers on the side stream beside the RGB encoder (18 launches off the critical path)."""
+        d = D // heads
+        kvb = self._act(plan, f"{tag}.kvsrc", rows_s, 2 * D)
+        self._lin(p + ".kv", src, kvb, rows_s)
+        G = kvmode["groups"]
+        kv = self._f32(plan, f"{tag}.kv", G * heads * d * d)
+        ks = self._f32(plan, f"{tag}.ks", G * heads * d)
+        nws = ops.attn_kv_ws_floats(kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"], heads, d)
+        ws = self._f32(plan, f"{tag}.kvws", nws)
+        ops.attn_kv_reduce(kvb.slice(0, D), kvb.slice(D, D), kv, ks, ws, kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"],
+                           kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
+        return kv, ks
+
+    def _loftr(self, plan, tag, p, xb: Act, rows_q, src: Optional[Act], rows_s, heads, out: Act, kvmode: dict, apmode: dict, pre=None):
         D = xb.C // 2
         d = D // heads
         x = xb.slice(0, D)
         qb = self._act(plan, f"{tag}.qkv", rows_q, 3 * D)
         tail_q = self.half and self.tail_q        # the fused tail projects q for its own rows: no q GEMM, no q tensor
+        if pre is not None and tail_q:
+            kv, ks = pre                              # key/value state computed ahead of time (hist2image: _kv_state on the side stream)
+            ops.loftr_tail(None, kv, ks, x, out, self.P[p + ".q1"], self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
+                           (self.P[p + ".norm1.g"], self.P[p + ".norm1.b"]), (self.P[p + ".norm2.g"], self.P[p + ".norm2.b"]),
+                           apmode["NB"], apmode["Hq"], apmode["Wq"], apmode["qth"], apmode["qtw"], kvmode["v_length"], heads)
+            return
         if src is None and tail_q:
             self._lin(p + ".kv", x, qb.slice(D, 2 * D), rows_q)
             kA, vA = qb.slice(D, D), qb.slice(2 * D, D)
@@ -567,7 +589,7 @@ class Engine:
                 zout = self._act(plan, f"{name}.zout", Mz, D)
                 self._loftr(plan, f"{name}.x2i", l, zin, Mz, src, B * Z * N, spec.X2I_HEADS, zout,
                             dict(groups=B * Z, NB=B * Z, Hk=1, Wk=N, th=1, tw=N, clip=(0, 1, 0, N), count_pad=False, v_length=float(N)),
-                            dict(NB=B, Hq=gh, Wq=gw, qth=geo.p1, qtw=geo.p2))
+                            dict(NB=B, Hq=gh, Wq=gw, qth=geo.p1, qtw=geo.p2), pre=plan.get("x2i_kv", {}).get((name, i)))
                 ops.resize_bilinear(zout, gh, gw, (0, 0, gh, gw), tok[cur].slice(0, D), H, W, rect, B, zone_valid=zone_valid,
                                     zn=geo.zone_num, p1=geo.p1, p2=geo.p2, accumulate=not self.no_skip_inside)
             elif ln == "image":
@@ -939,6 +961,16 @@ class Engine:
         side.wait_stream(main)
         with torch.cuda.stream(side):                # ToF branch: 10 tiny launches, hidden under the RGB encoder
             hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
+            plan["x2i_kv"] = {}
+            if self.half and self.tail_q and self._hist_pe_fused and os.environ.get("CFP_X2I_HOIST", "1") == "1":
+                # the key/value states of all hist2image layers depend on the ToF embeddings only: beside the RGB encoder too
+                for fname, feat in (("cross_atten3", hfeat[2]), ("cross_atten2", hfeat[1]), ("cross_atten1", hfeat[0])):
+                    D = self.fusion[fname][0]
+                    for i, ln in enumerate(self.layer_names):
+                        if ln == "hist2image":
+                            plan["x2i_kv"][(fname, i)] = self._kv_state(
+                                plan, f"{fname}.x2i{i}", f"decoder.{fname}.layers.{i}", feat, B * Z * N, D, spec.X2I_HEADS,
+                                dict(groups=B * Z, NB=B * Z, Hk=1, Wk=N, th=1, tw=N, clip=(0, 1, 0, N), count_pad=False, v_length=float(N)))
         if img_features is not None:      # test hook: bypass the RGB encoder with given NCHW features
             for f, dst in zip(img_features, plan["tap_dst"]):
                 dst.torch().copy_(f.permute(0, 2, 3, 1).reshape(-1, f.shape[1]).to(device=dev, dtype=self.dtype))

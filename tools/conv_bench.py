@@ -66,7 +66,7 @@ def timeit(name, args, reps):
     return graph_time_us(fn, calls=max(4, reps // 2), replays=4)
 
 
-nvar = 17
+nvar = lib.cfp_conv2d_num_variants() if hasattr(lib, "cfp_conv2d_num_variants") else 19
 rows = []
 tot_auto = tot_v1 = tot_best = 0.0
 for key, (name, args, cnt) in uniq.items():
