@@ -67,13 +67,20 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
   // ---- per-lane constants: requested first, their latency hides under the patch loads ------------------------------------------
   const int cbase = (cv0 + 2 * g) * 8;
   const bool g_ok = cbase < p.C;
-  short wv[3][2];                                // weight of tap (dy = 2 pr + (q >> 1), dx) for this lane's diagonal element
+  // k-chunk q of the MFMA's reduction axis <-> (row of the tap pair, 8-channel half of the group).  Stride 1 puts the ROW in the low
+  // bit: the 16-lane groups ds_read_b128 is banked over mix lanes of q and q ^ 1 ({0-3, 12-15, 20-27}, ...; MI355X_MICROARCH.md,
+  // LDS table), and with the half in the low bit lanes (j = 12, q = 0) and (j = 11, q = 1) fell 16 bytes apart on the same 256-byte
+  // bank row -- a 2-way conflict in every group, 25 % of the LDS cycles by SQ_LDS_BANK_CONFLICT.  With the row there, those two lanes
+  // read the SAME 16 bytes (row 12 as dy 0 and as dy 1), which is a broadcast.  Stride 2 is conflict-free the other way round.
+  constexpr bool ROW_LOW = STRIDE == 1;
+  const int q_dy = ROW_LOW ? (q & 1) : (q >> 1), q_half = ROW_LOW ? (q >> 1) : (q & 1);
+  short wv[3][2];                                // weight of tap (dy = 2 pr + q_dy, dx) for this lane's diagonal element
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-      const int dy = 2 * pr + (q >> 1);
-      const bool on = g_ok && dy < 3 && (j >> 3) == (q & 1);
+      const int dy = 2 * pr + q_dy;
+      const bool on = g_ok && dy < 3 && (j >> 3) == q_half;
       wv[dx][pr] = on ? (short)p.w[(long long)(min(dy, 2) * 3 + dx) * p.C + cbase + j] : (short)0;
     }
   f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
@@ -125,11 +132,11 @@ __global__ __launch_bounds__(256, 4) void dw3x3_slide_kernel(DwlP p) {
       for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int e = 0; e < 8; ++e) afr[dx][pr][e] = (e == (j & 7)) ? wv[dx][pr] : (short)0;
-    // B fragment pr of input column c: lane (j, q) reads 8 channels (half q & 1 of the group) of pixel (row j * STRIDE + dy, column c),
-    // dy = 2 pr + (q >> 1) clamped to the window (the matching A element is zero for dy = 3)
+    // B fragment pr of input column c: lane (j, q) reads 8 channels (half q_half of the group) of pixel (row j * STRIDE + dy, column c),
+    // dy = 2 pr + q_dy clamped to the window (the matching A element is zero for dy = 3)
     int roff[2];
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) roff[pr] = (j * STRIDE + min(2 * pr + (q >> 1), 2)) * p.rowpitch + (2 * g + (q & 1)) * 16;
+    for (int pr = 0; pr < 2; ++pr) roff[pr] = (j * STRIDE + min(2 * pr + q_dy, 2)) * p.rowpitch + (2 * g + q_half) * 16;
     const bool row_ok = j < ny;
     unsigned char* obase = reinterpret_cast<unsigned char*>(p.out + ((long long)(b * p.Ho + y0 + (row_ok ? j : 0)) * p.Wo + x0) * p.out_ld + cbase + 4 * q);
     const int opix = p.out_ld * 2;

@@ -319,6 +319,21 @@ def conv2d_dgrad(dy2d: torch.Tensor, wt: torch.Tensor, B, H, W, Cin, KH, KW, str
     return dx
 
 
+_BN_WS = {}
+
+
+def bn_workspace(C: int, device, stream: int):
+    """The reduction workspace of cfp_bn_train_stats / cfp_bn_train_bwd for a channel count: ONE per (device, stream, C), shared
+    by every layer of that width -- the calls of a stream run one after the other and nothing in it outlives a call.  (Round 2 gave
+    every layer call a workspace of its own: 32 KB x C each, 122 of them alive over a training step.)"""
+    from . import hip
+    key = (str(device), int(stream), C)
+    ws = _BN_WS.get(key)
+    if ws is None:
+        ws = _BN_WS[key] = torch.empty(hip.load().cfp_bn_ws_bytes(C) // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 class BatchNormTrain:
     """act(BatchNorm(x)) with batch statistics on [rows, C] NHWC rows: forward keeps what backward needs."""
 
@@ -328,7 +343,12 @@ class BatchNormTrain:
         f = lambda: torch.empty(C, dtype=torch.float32, device=device)
         self.mean, self.var, self.invstd, self.scale, self.shift = f(), f(), f(), f(), f()
         self.nbytes = hip.load().cfp_bn_ws_bytes(C)
-        self.ws = torch.empty(self.nbytes // 4, dtype=torch.float32, device=device)
+        self.device = device
+
+    @property
+    def ws(self):
+        from . import hip
+        return bn_workspace(self.C, self.device, hip.current_stream())
 
     def forward(self, x2d, gamma, beta, running_mean, running_var, act: int, residual: Optional[torch.Tensor] = None):
         """`residual` [rows, C]: added after the activation in the apply pass (the block's skip connection)."""
