@@ -1,0 +1,303 @@
+// 16-bit 3x3 stride-1 convolution for FEW input channels (Cin <= 64): the whole-depth input halo of a pixel tile stays in LDS.
+//
+// Reference ops: the EfficientNetV2 stem-side blocks of the RGB encoder (timm ConvBnAct / EdgeResidual: conv 3x3 -> BatchNorm -> SiLU
+// [+ skip], oracle/cfpnet_oracle.py encoder()) and the decoder's 3x3 convolutions on 32 / 64 channels (decoder.py:51-58 UpSampleBN).
+// They are this network's many-pixel, short-K problems (6 x 10^5 ... 4 x 10^4 pixels, K = 144 ... 576): by FLOPs they are nothing,
+// by HBM bytes they should take 5-15 us each at batch 8, and as implicit GEMMs they take 16-54 us (profiles/r3_conv_sweep: 2.7x
+// their ideal over the family) because the im2col A operand is fetched from L2 nine times -- once per tap -- and once more per
+// N-tile: 442 MB of L2->LDS traffic for a 49 MB input.  conv3x3_direct.hip removed the nine but re-staged the halo per 64-channel
+// chunk and per 32-cout tile behind three coarse pipeline steps, and lost to the implicit GEMM on every one of these shapes.
+//
+// This kernel:
+//   * a workgroup owns TH x 16 output pixels (TH = 16 or 8) and ALL output channels; the (TH + 2) x 18 input halo with all Cin
+//     channels is loaded ONCE (16-byte pieces, register-staged, pixel pitch an odd number of 16-byte slots so that the 16 lanes of
+//     an MFMA operand read -- 16 consecutive pixels of a row -- fall on 16 different slots of the 256-byte bank row);
+//   * K runs over (tap, 8-channel chunk) in the weight tensor's own order [Cout][kh][kw][Cin]: the B fragment of k-chunk c is the
+//     halo pixel shifted by tap c / (Cin / 8), so the nine taps are address arithmetic on the resident tile (per lane, two
+//     compare-and-subtract updates per 32-deep MFMA step);
+//   * the weights are the only streamed operand: 64-deep K-steps of [Cout][64] rows, `global_load_lds_dwordx4` into XOR-swizzled
+//     128-byte rows exactly as conv_igemm2.hip stages its W tile, 2-3 stages, counted `s_waitcnt vmcnt`, one raw barrier per K-step;
+//   * a wave computes 4 pixel rows x NT 16-channel tiles; accumulators transposed (weights as the MFMA row operand): a lane owns 4
+//     consecutive channels of one pixel and the epilogue (folded BatchNorm, activation, optional skip) stores 8 bytes from registers.
+//
+// Same products, float32 accumulation in a different order than the implicit GEMM: results agree to float32 re-association
+// (tests: <= 1 ulp of the storage type against cfp_conv2d_nhwc's other kernels, bit-exact on small integers).
+#include "igemm_core.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16h[4] = {0u, 0u, 0u, 0u};
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct HaloP {
+  int PP;          // halo pixel pitch in bytes (Cin * 2 rounded up to an odd number of 16-byte slots)
+  int CPT;         // 16-byte chunks per pixel = Cin / 8
+  int tiles_x, tiles_y;
+};
+
+template <typename H, int NT, int WN, int STAGES>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp) {
+  constexpr int WM = 4 / WN;
+  constexpr int TH = 4 * WM;                 // output rows per workgroup (a wave owns 4)
+  constexpr int HC = 18;                     // halo columns
+  constexpr int HPIX = (TH + 2) * HC;
+  constexpr int NPAD = NT * WN * 16;         // weight rows staged per K-step
+  constexpr int NBG = NPAD / 8;              // 8-row DMA groups
+  constexpr int NB = (NBG + 3) / 4;          // DMA instructions per wave per stage
+  constexpr int WSTAGE = NPAD * 128;
+  constexpr int MAXLD = TH == 16 ? 11 : 6;   // 16-byte halo pieces per thread: (TH + 2) * 18 pixels x up to 8 chunks
+  static_assert((STAGES - 2) * NB <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;                              // STAGES weight stages
+  unsigned char* sX = smem + STAGES * WSTAGE;            // the halo tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_ = bid % hp.tiles_x; bid /= hp.tiles_x;
+  const int ty_ = bid % hp.tiles_y;
+  const int b = bid / hp.tiles_y;
+  const int x0 = tx_ * 16, y0 = ty_ * TH;
+
+  const H* __restrict__ in = reinterpret_cast<const H*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
+  const H* __restrict__ wt = reinterpret_cast<const H*>(p.w);
+  const H* zsrc = reinterpret_cast<const H*>(g_zero16h);
+  const int nk = (p.K + 63) >> 6;
+
+  // ---- weight stages: lane (row rsub of an 8-row group, logical chunk lc) -------------------------------------------------------
+  const H* b_ptr[NB];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = ((j * 4 + wave) % NBG) * 8 + rsub;
+    const bool ok = n < p.Cout;
+    if (ok) b_okmask |= 1u << j;
+    b_ptr[j] = wt + (long long)(ok ? n : 0) * p.K;
+  }
+  auto issue = [&](int ks, int buf) {
+    unsigned char* s = sW + buf * WSTAGE;
+    const int kk = (ks * 8 + lc) * 8;
+    const bool kok = kk < p.K;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = kok && ((b_okmask >> j) & 1u);
+      glds16(ok ? b_ptr[j] + kk : zsrc, s + ((j * 4 + wave) % NBG) * 1024);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  // ---- the halo: all pieces of the thread in flight, then the LDS stores (the compiler drains the DMA queue before them; both are
+  //      needed before the first MFMA anyway) ---------------------------------------------------------------------------------------
+  {
+    const int nitems = HPIX * hp.CPT;
+    u32x4 v[MAXLD];
+    int dst[MAXLD];
+#pragma unroll
+    for (int n = 0; n < MAXLD; ++n) {
+      const int i = tid + n * 256;
+      const int px = i / hp.CPT, ch = i - px * hp.CPT;
+      const int hy = px / HC, hx = px - hy * HC;
+      const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+      const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      dst[n] = i < nitems ? px * hp.PP + ch * 16 : -1;
+      v[n] = u32x4{0u, 0u, 0u, 0u};
+      if (ok) v[n] = *reinterpret_cast<const u32x4*>(in + ((long long)y * p.W + x) * p.in_ld + ch * 8);
+    }
+#pragma unroll
+    for (int n = 0; n < MAXLD; ++n)
+      if (dst[n] >= 0) *reinterpret_cast<u32x4*>(sX + dst[n]) = v[n];
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // im2col position of this lane's k-chunk (c = 4 * step + fq): tap offset inside the halo and chunk inside the pixel
+  const int ntap_chunks = 9 * hp.CPT;
+  int c_cc, c_dx = 0, c_off = 0, c_idx = fq;
+  {
+    const int tap = fq / hp.CPT;
+    c_cc = fq - tap * hp.CPT;
+    c_dx = tap;                                  // fq <= 3 and CPT >= 1: tap <= 3; normalised below
+    while (c_dx >= 3) { c_dx -= 3; c_off += HC * hp.PP; }
+    c_off += c_dx * hp.PP;
+  }
+  const unsigned char* xrow = sX + ((wm * 4) * HC + fr) * hp.PP;      // pixel (row wm * 4, column fr) of the halo = tap (0, 0) of output row wm * 4
+  const int growb = HC * hp.PP;
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks % STAGES;
+    const int ahead = min(nk - 1 - ks, STAGES - 2);
+    if (ahead >= 1) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores (first time round) and fragment reads of the previous step
+    __builtin_amdgcn_s_barrier();          // stage `buf` (and the halo) landed for every wave; stage buf-1 fully consumed.  Raw: a __syncthreads() would drain the DMA queue
+    asm volatile("" ::: "memory");
+    if (ks + STAGES - 1 < nk) issue(ks + STAGES - 1, (ks + STAGES - 1) % STAGES);
+    const unsigned char* cW = sW + buf * WSTAGE + (wn * NT * 16) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      s16x8 wf[NT], xf[4];
+      const int pc = ((s * 4 + fq) ^ (fr & 7)) * 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const s16x8*>(cW + (j * 16 + fr) * 128 + pc);
+      // chunks past the ninth tap meet zero weights: read any finite data (the tile's first piece)
+      const int xo = c_idx < ntap_chunks ? c_off + c_cc * 16 : 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xf[g] = *reinterpret_cast<const s16x8*>(xrow + g * growb + xo);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[g][j] = mfma16<H>(wf[j], xf[g], acc[g][j]);   // acc[r] = channel 4 fq + r of tile j, pixel fr
+      // next 32-deep step: four chunks further
+      c_idx += 4;
+      c_cc += 4;
+      while (c_cc >= hp.CPT) {
+        c_cc -= hp.CPT;
+        c_off += hp.PP;
+        if (++c_dx == 3) { c_dx = 0; c_off += (HC - 3) * hp.PP; }
+      }
+    }
+  }
+
+  // ---- epilogue: folded BatchNorm / bias, activation, optional skip; 8-byte stores from the accumulators -------------------------------
+  H* __restrict__ out = reinterpret_cast<H*>(p.out) + (long long)b * p.Ho * p.Wo * p.out_ld;
+  const H* __restrict__ res = p.res ? reinterpret_cast<const H*>(p.res) + (long long)b * p.Ho * p.Wo * p.res_ld : nullptr;
+  const int x = x0 + fr;
+  f32x4 sc[NT], sh[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = (wn * NT + j) * 16 + fq * 4;
+    const bool ok = n < p.Cout;
+    sc[j] = (ok && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[j] = (ok && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  with_act(p.act, [&](auto A) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int y = y0 + wm * 4 + g;
+      const bool pix_ok = y < p.Ho && x < p.Wo;
+      const long long pix = (long long)y * p.Wo + x;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = (wn * NT + j) * 16 + fq * 4;
+        float yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = act_c<decltype(A)::value>(acc[g][j][r] * sc[j][r] + sh[j][r]);
+        uint2 pk;
+        pk.x = pack2<H>(yv[0], yv[1]);
+        pk.y = pack2<H>(yv[2], yv[3]);
+        if (!(pix_ok && n < p.Cout)) continue;
+        if (res) {
+          // the skip is added to the ROUNDED activation, as the other conv kernels do (they round into their LDS C tile first)
+          const uint2 rr = *reinterpret_cast<const uint2*>(res + pix * p.res_ld + n);
+          const H* ph = reinterpret_cast<const H*>(&pk);
+          const H* rh = reinterpret_cast<const H*>(&rr);
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = to_f32<H>(ph[r]) + to_f32<H>(rh[r]);
+          H oh[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oh[r] = from_f32<H>(o[r]);
+          pk = *reinterpret_cast<const uint2*>(oh);
+        }
+        *reinterpret_cast<uint2*>(out + pix * p.out_ld + n) = pk;
+      }
+    }
+  });
+}
+
+struct HCfg { int nt, wn; };
+constexpr HCfg kHCfg[] = {
+    {1, 1},  // 0: Cout <= 16, 16 x 16 pixels
+    {2, 1},  // 1: <= 32
+    {4, 1},  // 2: <= 64
+    {2, 2},  // 3: <= 64, 8 x 16 pixels
+    {4, 2},  // 4: <= 128
+    {5, 2},  // 5: <= 160
+    {7, 2},  // 6: <= 224
+    {1, 2},  // 7: <= 32, 8 x 16 pixels
+};
+constexpr int kNumHCfg = sizeof(kHCfg) / sizeof(kHCfg[0]);
+
+template <typename H, int NT, int WN>
+int launch_h(const ConvP& p, hipStream_t s) {
+  constexpr int TH = 4 * (4 / WN);
+  constexpr int NPAD = NT * WN * 16;
+  HaloP hp;
+  hp.CPT = p.Cin / 8;
+  int slots = hp.CPT;
+  if ((slots & 1) == 0) ++slots;
+  hp.PP = slots * 16;
+  hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
+  const int hpix = (TH + 2) * 18;
+  if (hpix * hp.CPT > 256 * (TH == 16 ? 11 : 6)) return -1;
+  const size_t halo = (size_t)hpix * hp.PP;
+  const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y;
+  const bool three = (size_t)3 * NPAD * 128 + halo <= 48 * 1024;      // a third weight stage while three workgroups still fit a CU
+  const size_t lds = (size_t)(three ? 3 : 2) * NPAD * 128 + halo;
+  if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
+#define HL(ST)                                                                                                                      \
+  do {                                                                                                                              \
+    auto k = conv3x3_halo_kernel<H, NT, WN, ST>;                                                                                    \
+    static bool attr = false;                                                                                                       \
+    if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; } \
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);                                                         \
+  } while (0)
+  if (three) HL(3); else HL(2);
+#undef HL
+  return 0;
+}
+
+}  // namespace
+
+int conv3x3_halo_num_variants() { return kNumHCfg; }
+
+// The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 64, no LayerNorm epilogue / per-image weights.
+bool conv3x3_halo_takes(const ConvP& p) {
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 64 && p.Cout % 8 == 0 &&
+         p.Cout <= 224 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.up_src == nullptr && p.K == 9 * p.Cin &&
+         p.pad_t >= 0 && p.pad_l >= 0 && p.pad_t <= 2 && p.pad_l <= 2;
+}
+
+// variant < 0: chosen from Cout and the number of tiles.  Returns 0, or a negative value if the variant cannot run this problem.
+int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s) {
+  if (v < 0) {
+    const long long t16 = (long long)p.B * cdiv(p.Wo, 16) * cdiv(p.Ho, 16);
+    if (p.Cout <= 16) v = 0;
+    else if (p.Cout <= 32) v = t16 >= 1024 ? 1 : 7;
+    else if (p.Cout <= 64) v = t16 >= 1024 ? 2 : 3;
+    else if (p.Cout <= 128) v = 4;
+    else if (p.Cout <= 160) v = 5;
+    else v = 6;
+  }
+  if (v >= kNumHCfg || kHCfg[v].nt * kHCfg[v].wn * 16 < p.Cout) return -3;
+#define HV(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN>(p, s) : launch_h<bf16_t, NT, WN>(p, s))
+  switch (v) {
+    case 0: return HV(1, 1);
+    case 1: return HV(2, 1);
+    case 2: return HV(4, 1);
+    case 3: return HV(2, 2);
+    case 4: return HV(4, 2);
+    case 5: return HV(5, 2);
+    case 6: return HV(7, 2);
+    case 7: return HV(1, 2);
+    default: return -3;
+  }
+#undef HV
+}

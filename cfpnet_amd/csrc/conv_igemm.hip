@@ -299,10 +299,19 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whole-depth halo kernel, 2 = wherever it can run
+// Where conv3x3_halo.hip beats the implicit GEMMs (tools/conv_bench.py --halo at batch 8, us halo / without: 614400 px x 16 ch, K = 360:
+// 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
+// x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
+static bool halo_wins(long long M, int Cout) {
+  if (g_halo == 2) return true;
+  return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160));
+}
 void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic), 5 = 1 forces the VALU kernel
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 12: g_halo = value; return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
     case 2: g_use_v1 = value; return CFP_OK;
@@ -384,7 +393,12 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int d
                                int* splits) {
   if (is16(dtype) && !g_use_v1) {
     Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
-    if (pl.direct >= 0) {
+    const int cin = K / 9;
+    if (KH == 3 && stride == 1 && K % 9 == 0 && cin % 8 == 0 && cin <= 64 && Cout % 8 == 0 && Cout <= 224 && rows_per_batch <= 0 &&
+        (g_force_variant < 0 ? halo_wins(M, Cout) : g_force_variant >= 300)) {
+      if (variant) *variant = 300;          // conv3x3_halo.hip (the tile is chosen from Cout and the pixel count)
+      if (splits) *splits = 1;
+    } else if (pl.direct >= 0) {
       if (variant) *variant = 200 + pl.direct;
       if (splits) *splits = 1;
     } else if (pl.gen1) {
@@ -463,6 +477,13 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     const bool c33 = KH == 3 && KW == 3 && stride == 1 && !ln_gamma && rpb == 0 && (long long)Cout * p.K < (1ll << 31);
     Plan2 pl = plan2(p.M, Cout, w2 ? 2 * cdiv(p.K, 64) * 64 : p.K, rpb, B, rpb == 0 && ln_variant < 0, c33);
     if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
+    // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
+    // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
+    if (!w2 && c33 && conv3x3_halo_takes(p) && (g_force_variant < 0 ? halo_wins(p.M, Cout) : g_force_variant >= 300)) {
+      int rc = conv3x3_halo_launch(g_force_variant >= 300 ? g_force_variant - 300 : -1, p, s);
+      if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
+      CFP_REQUIRE(g_force_variant < 0, CFP_EHIP, "cfp_conv2d_nhwc: the forced halo variant cannot run this problem");
+    }
     if (pl.direct >= 0) {
       int rc = conv3x3_launch(pl.direct, p, s);
       CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: direct 3x3 kernel launch failed");

@@ -42,6 +42,11 @@ int conv3x3_num_variants();
 void conv3x3_variant_shape(int v, int* th, int* bn);
 int conv3x3_launch(int v, const ConvP& p, hipStream_t s);
 
+// conv3x3_halo.hip
+int conv3x3_halo_num_variants();
+bool conv3x3_halo_takes(const ConvP& p);
+int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s);
+
 __device__ __forceinline__ int swz(int row, int chunk) {
   // physical 16-byte chunk of (row, logical chunk); g = [0,3,2,1][(row >> 2) & 3]
   int q = (row >> 2) & 3;

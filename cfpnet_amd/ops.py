@@ -88,7 +88,9 @@ DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
 
 def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
     t = {hip.BF16: "bf16", hip.F16: "f16"}.get(dt, "f32")
-    if variant >= 200:
+    if variant >= 300:
+        n = f"conv3x3_halo<{t}>"
+    elif variant >= 200:
         th, bn = DIRECT3_TILES[variant - 200]
         n = f"conv3x3_direct<{t},{th}x16px,{bn}>"
     elif variant >= 100:

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--halo", action="store_true", help="3x3 stride-1 problems with <= 64 input channels only: every conv3x3_halo variant and the plan without that kernel")
 ap.add_argument("--out", default="gpurun_out/conv_bench.json")
 ap.add_argument("--inflight", type=int, default=1, help="time every candidate with this many copies running side by side on "
                 "probed-concurrent streams (throughput mode) instead of alone")
@@ -71,6 +72,8 @@ rows = []
 tot_auto = tot_v1 = tot_best = 0.0
 for key, (name, args, cnt) in uniq.items():
     B, H, W, Cin, Cout, KH, st, Ho, Wo, ln, piw, has_res = key
+    if a.halo and not (KH == 3 and st == 1 and Cin <= 64):
+        continue
     M, K = B * Ho * Wo, KH * KH * Cin
     fl = 2.0 * M * Cout * K
     byts = 2.0 * (B * H * W * Cin + M * Cout * (2 if has_res else 1) + Cout * K)
@@ -97,6 +100,24 @@ for key, (name, args, cnt) in uniq.items():
                 sweep[f"d{v}/1"] = t
                 if t < best[0]:
                     best = (t, f"d{v}")
+    if (a.sweep or a.halo) and not ln and KH == 3 and st == 1 and Cin <= 64 and Cin % 8 == 0 and not piw:
+        lib.cfp_debug_set(1, 1)
+        for v in range(8):
+            if Cout > (16, 32, 64, 64, 128, 160, 224, 32)[v]:
+                continue
+            lib.cfp_debug_set(0, 300 + v)
+            try:
+                t = timeit(name, args, max(5, a.reps // 2))
+            except RuntimeError:
+                continue
+            sweep[f"h{v}/1"] = t
+            if t < best[0]:
+                best = (t, f"h{v}")
+    if a.halo:
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
+        lib.cfp_debug_set(12, 0)
+        sweep["no_halo"] = timeit(name, args, a.reps)
+        lib.cfp_debug_set(12, 1)
         lib.cfp_debug_set(0, -1)
         lib.cfp_debug_set(1, -1)
     import ctypes
@@ -104,14 +125,15 @@ for key, (name, args, cnt) in uniq.items():
     lib.cfp_conv2d_plan(M, Cout, K, KH, st, 1, Ho * Wo if piw else 0, B, ctypes.byref(pv), ctypes.byref(ps))
     ideal = max(fl / 1.5e15, byts / 5e12) * 1e6 + 1.5
     rows.append(dict(M=M, N=Cout, K=K, k=KH, stride=st, ln=ln, piw=piw, count=cnt, auto_us=t_auto, v1_us=t_v1, best_us=best[0],
-                     best=best[1], plan=(f"d{pv.value - 200}" if pv.value >= 200 else f"v{pv.value - 100}/s{ps.value}" if pv.value >= 100 else f"g1.{pv.value}/s{ps.value}"), ideal_us=ideal, gflop=fl / 1e9, sweep=sweep))
+                     best=best[1], plan=("halo" if pv.value >= 300 else f"d{pv.value - 200}" if pv.value >= 200 else f"v{pv.value - 100}/s{ps.value}" if pv.value >= 100 else f"g1.{pv.value}/s{ps.value}"), ideal_us=ideal, gflop=fl / 1e9, sweep=sweep))
     tot_auto += cnt * t_auto; tot_v1 += cnt * t_v1; tot_best += cnt * best[0]
 
 rows.sort(key=lambda r: -r["auto_us"] * r["count"])
 print(f"{'M':>7} {'N':>5} {'K':>5} k s  x  {'auto':>8} {'v1':>8} {'best':>8} {'ideal':>7}  plan      best       TF/s(auto)")
 for r in rows:
     print(f"{r['M']:7d} {r['N']:5d} {r['K']:5d} {r['k']} {r['stride']} {r['count']:2d} {r['auto_us']:8.1f} {r['v1_us']:8.1f} {r['best_us']:8.1f} "
-          f"{r['ideal_us']:7.1f}  {r['plan']:9s} {r['best']:10s} {r['gflop'] / r['auto_us'] * 1e-3:7.1f}" + (" LN" if r["ln"] else "") + (" PIW" if r["piw"] else ""))
+          f"{r['ideal_us']:7.1f}  {r['plan']:9s} {r['best']:10s} {r['gflop'] / r['auto_us'] * 1e-3:7.1f}" + (" LN" if r["ln"] else "") + (" PIW" if r["piw"] else "")
+          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] in "hn") if a.halo else ""))
 print(f"total per forward: auto {tot_auto / 1e3:.3f} ms, v1 {tot_v1 / 1e3:.3f} ms, best-of-sweep {tot_best / 1e3:.3f} ms, launches {len(calls)}")
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
 json.dump(rows, open(a.out, "w"))
