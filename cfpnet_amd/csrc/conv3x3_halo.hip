@@ -9,7 +9,7 @@
 // chunk and per 32-cout tile behind three coarse pipeline steps, and lost to the implicit GEMM on every one of these shapes.
 //
 // This kernel:
-//   * a workgroup owns TH x 16 output pixels (TH = 16 or 8) and ALL output channels; the (TH + 2) x 18 input halo with all Cin
+//   * a workgroup owns TH x 16 output pixels (TH = 16 or 8) and all output channels, or one of 2-3 blocks of them; the (TH + 2) x 18 input halo with all Cin
 //     channels is loaded ONCE (16-byte pieces, register-staged, pixel pitch an odd number of 16-byte slots so that the 16 lanes of
 //     an MFMA operand read -- 16 consecutive pixels of a row -- fall on 16 different slots of the 256-byte bank row);
 //   * K runs over (tap, 8-channel chunk) in the weight tensor's own order [Cout][kh][kw][Cin]: the B fragment of k-chunk c is the
@@ -39,6 +39,8 @@ struct HaloP {
   int PP;          // halo pixel pitch in bytes (Cin * 2 rounded up to an odd number of 16-byte slots)
   int CPT;         // 16-byte chunks per pixel = Cin / 8
   int tiles_x, tiles_y;
+  int n_blocks;    // workgroups per pixel tile: each owns NT * WN * 16 output channels (they re-read the halo from L2)
+  FastDiv dcpt;    // piece -> (pixel, chunk)
 };
 
 template <typename H, int NT, int WN, int STAGES>
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   const int lc = (lane & 7) ^ rsub;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_base = (bid % hp.n_blocks) * NPAD; bid /= hp.n_blocks;      // channel blocks of one tile are neighbours: they share the halo in L2
   const int tx_ = bid % hp.tiles_x; bid /= hp.tiles_x;
   const int ty_ = bid % hp.tiles_y;
   const int b = bid / hp.tiles_y;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   unsigned b_okmask = 0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    const int n = ((j * 4 + wave) % NBG) * 8 + rsub;
+    const int n = n_base + ((j * 4 + wave) % NBG) * 8 + rsub;
     const bool ok = n < p.Cout;
     if (ok) b_okmask |= 1u << j;
     b_ptr[j] = wt + (long long)(ok ? n : 0) * p.K;
@@ -109,13 +112,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
 #pragma unroll
     for (int n = 0; n < MAXLD; ++n) {
       const int i = tid + n * 256;
-      const int px = i / hp.CPT, ch = i - px * hp.CPT;
+      unsigned upx, uch;
+      fd_rowcol((unsigned)i, hp.dcpt, upx, uch);
+      const int px = (int)upx, ch = (int)uch;
       const int hy = px / HC, hx = px - hy * HC;
       const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
       const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       dst[n] = i < nitems ? px * hp.PP + ch * 16 : -1;
       v[n] = u32x4{0u, 0u, 0u, 0u};
-      if (ok) v[n] = *reinterpret_cast<const u32x4*>(in + ((long long)y * p.W + x) * p.in_ld + ch * 8);
+      if (ok) v[n] = *reinterpret_cast<const u32x4*>(in + (y * p.W + x) * p.in_ld + ch * 8);      // one image < 2^31 elements (host check)
     }
 #pragma unroll
     for (int n = 0; n < MAXLD; ++n)
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   f32x4 sc[NT], sh[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = (wn * NT + j) * 16 + fq * 4;
+    const int n = n_base + (wn * NT + j) * 16 + fq * 4;
     const bool ok = n < p.Cout;
     sc[j] = (ok && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     sh[j] = (ok && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
       const long long pix = (long long)y * p.Wo + x;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = (wn * NT + j) * 16 + fq * 4;
+        const int n = n_base + (wn * NT + j) * 16 + fq * 4;
         float yv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) yv[r] = act_c<decltype(A)::value>(acc[g][j][r] * sc[j][r] + sh[j][r]);
@@ -240,7 +245,10 @@ int launch_h(const ConvP& p, hipStream_t s) {
   constexpr int TH = 4 * (4 / WN);
   constexpr int NPAD = NT * WN * 16;
   HaloP hp;
+  hp.n_blocks = cdiv(p.Cout, NPAD);
   hp.CPT = p.Cin / 8;
+  hp.dcpt = make_fastdiv((unsigned)hp.CPT);
+  if ((long long)p.H * p.W * p.in_ld >= (1ll << 31)) return -1;
   int slots = hp.CPT;
   if ((slots & 1) == 0) ++slots;
   hp.PP = slots * 16;
@@ -248,7 +256,7 @@ int launch_h(const ConvP& p, hipStream_t s) {
   const int hpix = (TH + 2) * 18;
   if (hpix * hp.CPT > 256 * (TH == 16 ? 11 : 6)) return -1;
   const size_t halo = (size_t)hpix * hp.PP;
-  const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y;
+  const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
   const bool three = (size_t)3 * NPAD * 128 + halo <= 48 * 1024;      // a third weight stage while three workgroups still fit a CU
   const size_t lds = (size_t)(three ? 3 : 2) * NPAD * 128 + halo;
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
@@ -271,7 +279,7 @@ int conv3x3_halo_num_variants() { return kNumHCfg; }
 // The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 64, no LayerNorm epilogue / per-image weights.
 bool conv3x3_halo_takes(const ConvP& p) {
   return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 64 && p.Cout % 8 == 0 &&
-         p.Cout <= 224 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.up_src == nullptr && p.K == 9 * p.Cin &&
+         p.Cout <= 512 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.up_src == nullptr && p.K == 9 * p.Cin &&
          p.pad_t >= 0 && p.pad_l >= 0 && p.pad_t <= 2 && p.pad_l <= 2;
 }
 
@@ -284,9 +292,9 @@ int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s) {
     else if (p.Cout <= 64) v = t16 >= 1024 ? 2 : 3;
     else if (p.Cout <= 128) v = 4;
     else if (p.Cout <= 160) v = 5;
-    else v = 6;
+    else v = 4;                      // two or more 128-channel blocks
   }
-  if (v >= kNumHCfg || kHCfg[v].nt * kHCfg[v].wn * 16 < p.Cout) return -3;
+  if (v >= kNumHCfg) return -3;
 #define HV(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN>(p, s) : launch_h<bf16_t, NT, WN>(p, s))
   switch (v) {
     case 0: return HV(1, 1);

@@ -305,7 +305,8 @@ int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whol
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
 static bool halo_wins(long long M, int Cout) {
   if (g_halo == 2) return true;
-  return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160));
+  return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
+                         (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
 void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic), 5 = 1 forces the VALU kernel
 extern "C" int cfp_debug_set(int key, int value) {
@@ -394,7 +395,7 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int d
   if (is16(dtype) && !g_use_v1) {
     Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
     const int cin = K / 9;
-    if (KH == 3 && stride == 1 && K % 9 == 0 && cin % 8 == 0 && cin <= 64 && Cout % 8 == 0 && Cout <= 224 && rows_per_batch <= 0 &&
+    if (KH == 3 && stride == 1 && K % 9 == 0 && cin % 8 == 0 && cin >= 8 && cin <= 64 && Cout % 8 == 0 && Cout <= 512 && rows_per_batch <= 0 &&
         (g_force_variant < 0 ? halo_wins(M, Cout) : g_force_variant >= 300)) {
       if (variant) *variant = 300;          // conv3x3_halo.hip (the tile is chosen from Cout and the pixel count)
       if (splits) *splits = 1;

@@ -103,7 +103,7 @@ for key, (name, args, cnt) in uniq.items():
     if (a.sweep or a.halo) and not ln and KH == 3 and st == 1 and Cin <= 64 and Cin % 8 == 0 and not piw:
         lib.cfp_debug_set(1, 1)
         for v in range(8):
-            if Cout > (16, 32, 64, 64, 128, 160, 224, 32)[v]:
+            if Cout > 4 * (16, 32, 64, 64, 128, 160, 224, 32)[v]:
                 continue
             lib.cfp_debug_set(0, 300 + v)
             try:
