@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks % STAGES;
     const int ahead = min(nk - 1 - ks, STAGES - 2);
-    if (ahead >= 1) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+    if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * NB>();
+    else if (ahead == 1) wait_vmcnt<NB>();
+    else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores (first time round) and fragment reads of the previous step
     __builtin_amdgcn_s_barrier();          // stage `buf` (and the halo) landed for every wave; stage buf-1 fully consumed.  Raw: a __syncthreads() would drain the DMA queue
     asm volatile("" ::: "memory");
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   });
 }
 
+int g_halo_stages = 0;      // cfp_debug_set key 13: force the number of weight stages (2-4), 0 = automatic
+
 struct HCfg { int nt, wn; };
 constexpr HCfg kHCfg[] = {
     {1, 1},  // 0: Cout <= 16, 16 x 16 pixels
@@ -257,8 +261,11 @@ int launch_h(const ConvP& p, hipStream_t s) {
   if (hpix * hp.CPT > 256 * (TH == 16 ? 11 : 6)) return -1;
   const size_t halo = (size_t)hpix * hp.PP;
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
-  const bool three = (size_t)3 * NPAD * 128 + halo <= 48 * 1024;      // a third weight stage while three workgroups still fit a CU
-  const size_t lds = (size_t)(three ? 3 : 2) * NPAD * 128 + halo;
+  // weight stages: two.  More would hide more of the DMA latency behind MFMAs, but measured (tools/conv_bench.py --halo, us with
+  // 2 / 3 / 4 stages: 614400 px x 128 ch 82 / 93 / 96, 153600 x 160 36 / 38 / 52, 614400 x 16 23 / 25 / 25, 38400 x 224 19 / 24 / 32)
+  // the LDS they take costs more in resident workgroups than it gains -- the same finding as for the implicit GEMM's tiles
+  int stages = g_halo_stages ? g_halo_stages : 2;
+  const size_t lds = (size_t)stages * NPAD * 128 + halo;
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
 #define HL(ST)                                                                                                                      \
   do {                                                                                                                              \
@@ -267,7 +274,7 @@ int launch_h(const ConvP& p, hipStream_t s) {
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; } \
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);                                                         \
   } while (0)
-  if (three) HL(3); else HL(2);
+  if (stages == 4) HL(4); else if (stages == 3) HL(3); else HL(2);
 #undef HL
   return 0;
 }
@@ -275,6 +282,7 @@ int launch_h(const ConvP& p, hipStream_t s) {
 }  // namespace
 
 int conv3x3_halo_num_variants() { return kNumHCfg; }
+void conv3x3_halo_debug_stages(int v) { g_halo_stages = v; }
 
 // The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 64, no LayerNorm epilogue / per-image weights.
 bool conv3x3_halo_takes(const ConvP& p) {

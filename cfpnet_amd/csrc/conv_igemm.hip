@@ -313,6 +313,7 @@ extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
+    case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
     case 2: g_use_v1 = value; return CFP_OK;

@@ -115,6 +115,14 @@ for key, (name, args, cnt) in uniq.items():
                 best = (t, f"h{v}")
     if a.halo:
         lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
+        lib.cfp_debug_set(12, 2)                      # the halo kernel wherever it can run, its automatic tile, 2 / 3 / 4 weight stages
+        for st in (2, 3, 4):
+            lib.cfp_debug_set(13, st)
+            try:
+                sweep[f"n_st{st}"] = timeit(name, args, a.reps)
+            except RuntimeError:
+                pass
+        lib.cfp_debug_set(13, 0)
         lib.cfp_debug_set(12, 0)
         sweep["no_halo"] = timeit(name, args, a.reps)
         lib.cfp_debug_set(12, 1)
