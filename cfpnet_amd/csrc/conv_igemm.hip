@@ -370,11 +370,18 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
     else pl.variant = 4;
   }
   if (rpb > 0) { pl.gen1 = false; pl.direct = -1; if (pl.variant != 12) pl.variant = 4; }
+  // long K on fewer 64x64 tiles than CUs (the 1/32-scale project GEMMs: 160 tiles x 22 K-steps): two K groups per workgroup
+  // (tools/conv_bench.py --kgroups: 12.8 -> 9.3 us at 2400 x 232 x 1392, 8.7 -> 7.1 at K = 816; no gain once two workgroups share a CU)
+  if (pl.variant == 4 && !pl.gen1 && pl.direct < 0 && K >= 768) {
+    const long long tm = rpb > 0 ? (long long)B * ((rpb + 63) / 64) : (M + 63) / 64;
+    if (tm * ((N + 63) / 64) <= 256) pl.variant = 19;
+  }
   if (allow_split && K >= 2048 && (M <= 1100 || ((M + 63) / 64) * ((N + 63) / 64) <= 48)) { pl.variant = 4; pl.splits = 8; pl.gen1 = false; pl.direct = -1; }
   if (g_force_variant >= 200 && conv3x3s1 && g_force_variant - 200 < conv3x3_num_variants()) { pl.direct = g_force_variant - 200; pl.gen1 = false; pl.splits = 1; }
   else if (g_force_variant >= 0) pl.direct = -1;
   if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }
   if (g_force_splits >= 1) pl.splits = g_force_splits;
+  if (pl.splits > 1 && pl.variant >= 19 && pl.variant <= 21 && g_force_variant < 0) pl.variant = 4;      // K groups and split-K exclude each other
   if (pl.direct >= 0) { pl.gen1 = false; pl.splits = 1; }
   return pl;
 }

@@ -44,9 +44,15 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename H, int BM, int BN, int WM, int WN, int STAGES, bool SPLITK>
-__global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict__ slabs, int splits) {
-  static_assert(WM * WN == 4, "four waves");
+// KG = 2 (round 3): EIGHT waves, two groups of four.  Both groups own the whole tile; group g takes the K-steps k0 + g, k0 + g + 2, ...
+// through its own LDS stages, and the groups' accumulators are added through LDS before the epilogue.  For the launches that cannot
+// fill the chip (a 64 x 64 tile of a 9600 x 136 x 816 layer is 450 workgroups, each walking 13 K-steps at ~0.57 us per step whatever
+// the stage count -- tools/conv_bench.py) this halves the K loop's latency at the cost of one LDS round trip, without the slabs and
+// the reduce launch of the split-K form.
+template <typename H, int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm2_kernel(ConvP p, float* __restrict__ slabs, int splits) {
+  static_assert(WM * WN == 4, "four waves per group");
+  static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
   constexpr int NA = BM / 32;                    // A DMA instructions per wave per K-step
@@ -59,11 +65,14 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 2 ? wave8 >> 2 : 0;        // K group
+  const int wave = wave8 & 3;
   const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fq = lane >> 4;
   const int rsub = lane >> 3;
   const int lc = (lane & 7) ^ rsub;              // logical K-chunk this lane fetches
+  unsigned char* gsm = smem + kg * (STAGES * STAGE_BYTES);      // this group's operand stages
 
   // ---- tile coordinates -------------------------------------------------------------------
   const int tiles_n = (p.Cout + BN - 1) / BN;
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   // issued; advanced by 64 channels per K-step without divisions (K-steps are issued in order).
   int i_cc = 0, i_kh = 0, i_kw = 0;
   if (!p.pointwise) {
-    const int kk = (k0 * 8 + lc) * 8;
+    const int kk = ((k0 + kg) * 8 + lc) * 8;
     const int tap = kk / p.Cin;
     i_cc = kk - tap * p.Cin;
     i_kh = tap / p.KW;
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   }
 
   auto issue = [&](int ks, int buf) {
-    unsigned char* sA = smem + buf * STAGE_BYTES;
+    unsigned char* sA = gsm + buf * STAGE_BYTES;
     unsigned char* sB = sA + BM * 128;
     const int kk = (ks * 8 + lc) * 8;
     bool kok = kk < p.K;
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
                         (unsigned)(a_wi0[i] + i_kw) < (unsigned)p.W;
         glds16(ok ? a_ptr[i] + off : zsrc, sA + (i * 4 + wave) * 1024);
       }
-      i_cc += 64;
+      i_cc += 64 * KG;
       while (i_cc >= p.Cin) {
         i_cc -= p.Cin;
         if (++i_kw == p.KW) { i_kw = 0; ++i_kh; }
@@ -182,25 +191,27 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: STAGES-1 K-steps in flight -----------------------------------------------
+  // ---- prologue: STAGES-1 K-steps in flight (of this group's steps k0 + kg, k0 + kg + KG, ...) ------------------
+  const int nkg = max(0, (k1 - k0 - kg + KG - 1) / KG);      // this group's K-steps
+  const int nit = (k1 - k0 + KG - 1) / KG;                     // barrier rounds = group 0's steps (the other group has as many or one fewer)
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (k0 + s < k1) issue(k0 + s, s);
+    if (s < nkg) issue(k0 + kg + s * KG, s);
 
   const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
-  for (int ks = k0; ks < k1; ++ks) {
-    const int it = ks - k0;
+  for (int it = 0; it < nit; ++it) {
     const int buf = it % STAGES;
-    const int ahead = min(k1 - 1 - ks, STAGES - 2);   // younger stages that may stay in flight
+    const int ahead = min(nkg - 1 - it, STAGES - 2);   // younger stages that may stay in flight
     if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * LPS>();
     else if (ahead == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                     // stage `buf` landed for every wave; stage buf-1 fully consumed
     asm volatile("" ::: "memory");
-    if (ks + STAGES - 1 < k1) issue(ks + STAGES - 1, (it + STAGES - 1) % STAGES);
+    if (KG == 2 && it >= nkg) continue;               // the second group's missing last step (odd step count): it only keeps the barrier count
+    if (it + STAGES - 1 < nkg) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
 
-    const unsigned char* cA = smem + buf * STAGE_BYTES + a_row0 * 128;
-    const unsigned char* cB = smem + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
+    const unsigned char* cA = gsm + buf * STAGE_BYTES + a_row0 * 128;
+    const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       s16x8 af[TM], bfr[TN];
@@ -218,6 +229,29 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   }
   wait_vmcnt<0>();
   __syncthreads();   // every wave is done with the operand stages: LDS becomes the C tile
+  if constexpr (KG == 2) {
+    // the second group's accumulators travel through LDS (float32, lane-contiguous 16-byte pieces) and are added by the first
+    static_assert(BM * BN * 4 <= KG * STAGES * STAGE_BYTES, "accumulator exchange must fit in the operand LDS");
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + wave * (TM * TN * 64) + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xch[(i * TN + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 o = xch[(i * TN + j) * 64];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+        }
+    }
+    __syncthreads();
+  }
 
   // The accumulators are held transposed (weights as the MFMA's row operand): a lane owns four consecutive output channels of one
   // pixel, so the epilogue moves 8-byte (16-bit) / 16-byte (float32 slab) vectors instead of sixteen 2-byte LDS writes per thread.
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       sc[j] = (ok && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
       sh[j] = (ok && p.shift) ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    with_act(p.act, [&](auto A) {
+    if (kg == 0) with_act(p.act, [&](auto A) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -271,7 +305,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
       Vec<float>::load(p.ln_gamma + ch * 8, g); Vec<float>::load(p.ln_gamma + ch * 8 + 4, g + 4);
       Vec<float>::load(p.ln_beta + ch * 8, bt); Vec<float>::load(p.ln_beta + ch * 8 + 4, bt + 4);
     }
-    for (int q = tid; q < BM * CH; q += 256) {
+    for (int q = tid; q < BM * CH; q += 256 * KG) {
       const int row = q / CH, ch = q % CH;
       const int m = m0 + row, n = n0 + ch * 8;
       const bool live = m < m_end && n < p.Cout;
@@ -309,7 +343,7 @@ __global__ __launch_bounds__(256) void igemm2_kernel(ConvP p, float* __restrict_
   }
 }
 
-struct Cfg { int bm, bn, stages; };
+struct Cfg { int bm, bn, stages, kg = 1; };
 // variant ids (cfp_conv2d_variant2): keep in sync with launch_variant below
 constexpr Cfg kCfg[] = {
     {128, 128, 3},  // 0
@@ -331,21 +365,25 @@ constexpr Cfg kCfg[] = {
     {128, 32, 2},   // 16
     {32, 64, 3},    // 17: few-row / long-K problems with per-image weights (the squeeze-excite project GEMMs at 1/32: 300 rows per image):
     {32, 128, 3},   // 18  twice the workgroups of the 64-row tiles, so that 8 images x 232 channels fill the chip
+    {64, 64, 2, 2},   // 19: two K groups (eight waves): long-K launches of a few hundred tiles
+    {64, 64, 3, 2},   // 20
+    {64, 128, 2, 2},  // 21
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <typename H, int BM, int BN, int WM, int WN, int STAGES>
+template <typename H, int BM, int BN, int WM, int WN, int STAGES, int KG = 1>
 int launch2(const ConvP& p, float* slabs, int splits, hipStream_t s) {
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  const size_t lds = (size_t)KG * STAGES * (BM + BN) * 128;
   if (lds > 160 * 1024) return -1;
+  if (KG == 2 && splits > 1) return -4;
   long long tiles_m = p.rows_per_batch > 0 ? (long long)p.B * cdiv(p.rows_per_batch, BM) : cdiv(p.M, BM);
   long long tiles = tiles_m * cdiv(p.Cout, BN);
   if (splits <= 1) {
-    auto k = igemm2_kernel<H, BM, BN, WM, WN, STAGES, false>;
+    auto k = igemm2_kernel<H, BM, BN, WM, WN, STAGES, false, KG>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, slabs, 1);
-  } else {
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1);
+  } else if constexpr (KG == 1) {
     auto k = igemm2_kernel<H, BM, BN, WM, WN, STAGES, true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
@@ -382,6 +420,9 @@ int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s
     case 16: return L2(128, 32, 4, 1, 2);
     case 17: return L2(32, 64, 1, 4, 3);
     case 18: return L2(32, 128, 1, 4, 3);
+    case 19: return L2(64, 64, 2, 2, 2, 2);
+    case 20: return L2(64, 64, 2, 2, 3, 2);
+    case 21: return L2(64, 128, 2, 2, 2, 2);
     default: return -3;
   }
 }

@@ -80,7 +80,8 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
 
 # tile shape (BM, BN, LDS stages) of second-generation variant v (conv_igemm2.hip kCfg)
 GEN2_TILES = [(128, 128, 3), (128, 128, 2), (128, 64, 3), (128, 64, 4), (64, 64, 3), (64, 64, 4), (256, 32, 3), (256, 32, 2),
-              (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3), (64, 64, 2), (128, 64, 2), (64, 128, 2), (128, 32, 2)]
+              (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3), (64, 64, 2), (128, 64, 2), (64, 128, 2), (128, 32, 2),
+              (32, 64, 3), (32, 128, 3), (64, 64, 2), (64, 64, 3), (64, 128, 2)]      # 19-21: eight waves, two K groups
 GEN1_TILES = [(256, 16), (256, 32), (128, 64), (128, 128)]
 # (tile rows, BN) of direct 3x3 variant v (conv3x3_direct.hip kCfg3); pixel tile = rows x 16
 DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
@@ -95,7 +96,7 @@ def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
         n = f"conv3x3_direct<{t},{th}x16px,{bn}>"
     elif variant >= 100:
         bm, bn, st = GEN2_TILES[variant - 100]
-        n = f"igemm2<{t},{bm}x{bn},s{st}>"
+        n = f"igemm2<{t},{bm}x{bn},s{st}" + (",kg2>" if variant - 100 >= 19 else ">")
     else:
         bm, bn = GEN1_TILES[variant]
         n = f"conv_igemm<{t},{bm}x{bn}>"

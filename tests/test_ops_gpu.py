@@ -122,7 +122,8 @@ def _conv_ref_and_args(case, dtype, seed=1):
     return ref, xa, wa, scale.to(DEV), shift.to(DEV), ra, Ho, Wo
 
 
-GEN2_VARIANTS = list(range(17))
+GEN2_VARIANTS = list(range(22))
+GEN2_KGROUPS = (19, 20, 21)          # eight-wave variants (two K groups per workgroup): the in-workgroup alternative to split-K
 
 
 @pytest.mark.parametrize("dtype", HALF)
@@ -136,7 +137,7 @@ def test_conv2d_gen2_every_tile_variant(variant, dtype):
         for case in CONV_CASES:
             B, H, W, Cin, Cout, k, s, _ = case
             ref, xa, wa, scale, shift, ra, Ho, Wo = _conv_ref_and_args(case, dtype)
-            for splits in (1, 4):
+            for splits in ((1,) if variant in GEN2_KGROUPS else (1, 4)):
                 lib.cfp_debug_set(1, splits)
                 out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True)
                 out = ops.Act(out.buf, 16, Cout)
@@ -1002,7 +1003,7 @@ INT_CONV_CASES = [(2, 20, 24, 40, 48, 3, 1, (1, 1, 1, 1)), (1, 17, 33, 168, 64, 
 
 
 @pytest.mark.parametrize("dtype", HALF)
-@pytest.mark.parametrize("variant", list(range(17)) + [200 + v for v in range(6)] + ["gen1"])
+@pytest.mark.parametrize("variant", list(range(22)) + [200 + v for v in range(6)] + ["gen1"])
 def test_conv_fast_paths_bit_exact_on_integers(variant, dtype):
     lib = hip.load()
     try:

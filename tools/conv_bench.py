@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--sweep", action="store_true")
+ap.add_argument("--kgroups", action="store_true", help="pointwise problems: the plan against the eight-wave two-K-group tiles (variants 19-21)")
 ap.add_argument("--halo", action="store_true", help="3x3 stride-1 problems with <= 64 input channels only: every conv3x3_halo variant and the plan without that kernel")
 ap.add_argument("--out", default="gpurun_out/conv_bench.json")
 ap.add_argument("--inflight", type=int, default=1, help="time every candidate with this many copies running side by side on "
@@ -74,6 +75,8 @@ for key, (name, args, cnt) in uniq.items():
     B, H, W, Cin, Cout, KH, st, Ho, Wo, ln, piw, has_res = key
     if a.halo and not (KH == 3 and st == 1 and Cin <= 64):
         continue
+    if a.kgroups and (ln or B * Ho * Wo * Cout > 9600 * 1400):
+        continue
     M, K = B * Ho * Wo, KH * KH * Cin
     fl = 2.0 * M * Cout * K
     byts = 2.0 * (B * H * W * Cin + M * Cout * (2 if has_res else 1) + Cout * K)
@@ -88,7 +91,10 @@ for key, (name, args, cnt) in uniq.items():
             for sp in ((1, 2, 4, 8, 16) if (M * Cout < 2_000_000 and K >= 512 and not piw) else (1,)):
                 lib.cfp_debug_set(0, v)
                 lib.cfp_debug_set(1, sp)
-                t = timeit(name, args, max(5, a.reps // 2))
+                try:
+                    t = timeit(name, args, max(5, a.reps // 2))
+                except RuntimeError:
+                    continue
                 sweep[f"{v}/{sp}"] = t
                 if t < best[0]:
                     best = (t, f"v{v}/s{sp}")
@@ -100,6 +106,18 @@ for key, (name, args, cnt) in uniq.items():
                 sweep[f"d{v}/1"] = t
                 if t < best[0]:
                     best = (t, f"d{v}")
+    if a.kgroups:
+        lib.cfp_debug_set(1, 1)
+        for v in (4, 13, 19, 20, 21):
+            lib.cfp_debug_set(0, v)
+            try:
+                t = timeit(name, args, a.reps)
+            except RuntimeError:
+                continue
+            sweep[f"k{v}"] = t
+            if t < best[0]:
+                best = (t, f"v{v}")
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
     if (a.sweep or a.halo) and not ln and KH == 3 and st == 1 and Cin <= 64 and Cin % 8 == 0 and not piw:
         lib.cfp_debug_set(1, 1)
         for v in range(8):
@@ -141,7 +159,8 @@ print(f"{'M':>7} {'N':>5} {'K':>5} k s  x  {'auto':>8} {'v1':>8} {'best':>8} {'i
 for r in rows:
     print(f"{r['M']:7d} {r['N']:5d} {r['K']:5d} {r['k']} {r['stride']} {r['count']:2d} {r['auto_us']:8.1f} {r['v1_us']:8.1f} {r['best_us']:8.1f} "
           f"{r['ideal_us']:7.1f}  {r['plan']:9s} {r['best']:10s} {r['gflop'] / r['auto_us'] * 1e-3:7.1f}" + (" LN" if r["ln"] else "") + (" PIW" if r["piw"] else "")
-          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] in "hn") if a.halo else ""))
+          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] in "hn") if a.halo else "")
+          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] == "k") if a.kgroups else ""))
 print(f"total per forward: auto {tot_auto / 1e3:.3f} ms, v1 {tot_v1 / 1e3:.3f} ms, best-of-sweep {tot_best / 1e3:.3f} ms, launches {len(calls)}")
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
 json.dump(rows, open(a.out, "w"))

@@ -8,7 +8,7 @@ python - "$TAG" <<'PY'
 import json, sys
 d = json.loads(open(f"gpurun_out/{sys.argv[1]}/bench_quick.json").read().strip().splitlines()[-1])
 print("maps/s", round(d["value"], 1), "ms/step", round(d["ms_per_step"], 4), "rel_l1", d.get("rel_l1"), "f16", d.get("f16", {}).get("value"), d.get("f16", {}).get("rel_l1"))
-print("latency", d["latency"])
+print("latency", d.get("latency"), d["config"].get("lane_choice_ms_per_step"))
 print("roofline frac", d["roofline"]["frac"], "dw in_graph", d["dw3x3"].get("in_graph"), d["dw3x3"].get("frac_of_measured_copy_in_graph"))
 print("kernel_ms_per_step", d.get("kernel_ms_per_step"))
 PY
