@@ -502,6 +502,7 @@ struct ResizeP {
   int dst_ld, Hd, Wd, dy0, dx0, dh, dw;
   int zn, p1, p2, accumulate, B, C;
   float scale_y, scale_x;
+  FastDiv fcv, fdw, fdh;      // element index -> (b, dy, dx, channel vector) without 64-bit divisions (the first version's four cost more than the taps)
 };
 
 template <typename T>
@@ -509,14 +510,13 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeP p) {
   constexpr int VE = Vec<T>::N;
   const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
   T* __restrict__ dst = reinterpret_cast<T*>(p.dst);
-  const int CV = p.C / VE;
-  const long long total = (long long)p.B * p.dh * p.dw * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int cv = (int)(i % CV);
-    long long t = i / CV;
-    int dx = (int)(t % p.dw); t /= p.dw;
-    int dy = (int)(t % p.dh);
-    int b = (int)(t / p.dh);
+  const unsigned total = (unsigned)p.B * p.dh * p.dw * p.fcv.d;      // < 2^31: host check
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned t, cvu, q, dxu, bu, dyu;
+    fd_rowcol(i, p.fcv, t, cvu);
+    fd_rowcol(t, p.fdw, q, dxu);
+    fd_rowcol(q, p.fdh, bu, dyu);
+    const int cv = (int)cvu, dx = (int)dxu, dy = (int)dyu, b = (int)bu;
     const int oy = p.dy0 + dy, ox = p.dx0 + dx;
     if (oy < 0 || oy >= p.Hd || ox < 0 || ox >= p.Wd) continue;
     // source coordinate inside the source rectangle (torch: src = scale * dst_index)
@@ -569,24 +569,32 @@ __global__ __launch_bounds__(256) void resize_kernel(ResizeP p) {
 template <typename T>
 __global__ __launch_bounds__(256) void add_rowtable_kernel(const T* __restrict__ in, int in_ld, const float* __restrict__ table,
                                                            T* __restrict__ out, int out_ld, long long rows, int C, int H, int W,
-                                                           int Wt, int oy, int ox, const int* __restrict__ dev_off, int Ht) {
+                                                           int Wt, int oy, int ox, const int* __restrict__ dev_off, int Ht,
+                                                           FastDiv fcv, FastDiv fw, FastDiv fh) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = rows * CV;
+  const unsigned total = (unsigned)(rows * fcv.d);      // < 2^31 (host check): 32-bit indices and magic-number divisions -- the first
   if (dev_off) {          // window origin read from device memory (a captured graph replays with a new random window), clamped to the table
     oy = min(max(dev_off[0], 0), Ht - H);
     ox = min(max(dev_off[1], 0), Wt - W);
-  }
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    int cv = (int)(i % CV);
-    long long r = i / CV;
-    long long trow = ((r / W) % H + oy) * (long long)Wt + (r % W) + ox;
+  }                                                      // version's five 64-bit divisions per element made this 10 MB pass cost 12 us
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned r, cv, q, x, b, y;
+    fd_rowcol(i, fcv, r, cv);
+    fd_rowcol(r, fw, q, x);
+    fd_rowcol(q, fh, b, y);
+    const long long trow = (long long)(y + oy) * Wt + x + ox;
     float v[VE];
-    Vec<T>::load(in + r * in_ld + cv * VE, v);
+    Vec<T>::load(in + (long long)r * in_ld + cv * VE, v);
     const float* tp = table + trow * C + cv * VE;
+    if constexpr (VE == 8) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) v[e] += tp[e];
-    Vec<T>::store(out + r * out_ld + cv * VE, v);
+      for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[e] += tp[e];
+    }
+    Vec<T>::store(out + (long long)r * out_ld + cv * VE, v);
   }
 }
 
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(256) void copy_rows2_kernel(Copy2P p, long long row
 template <typename T>
 __global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restrict__ rgb, T* __restrict__ out, int HW, long long total) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long b = i / HW, hw = i % HW;
+    const long long b = (unsigned long long)i / (unsigned)HW, hw = i - b * HW;      // one division (images x pixels < 2^32 in every caller would allow 32 bits; kept general)
     const float* p = rgb + b * 3 * HW + hw;
     float v[8] = {p[0], p[HW], p[2 * (long long)HW], 0.f, 0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) Vec<T>::store(out + i * 8, v);
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(256) void rgb_to_nhwc8_kernel(const float* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void rgb_to_nhwc8_hilo_kernel(const float* __restrict__ rgb, T* __restrict__ out, int HW, long long total) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long b = i / HW, hw = i % HW;
+    const long long b = (unsigned long long)i / (unsigned)HW, hw = i - b * HW;      // one division (images x pixels < 2^32 in every caller would allow 32 bits; kept general)
     const float* p = rgb + b * 3 * HW + hw;
     float v[8];
 #pragma unroll
@@ -866,6 +874,8 @@ extern "C" int cfp_resize_bilinear(const void* src, int src_ld, int Hs, int Ws, 
   p.scale_y = dh > 1 ? (float)(sh - 1) / (float)(dh - 1) : 0.f;
   p.scale_x = dw > 1 ? (float)(sw - 1) / (float)(dw - 1) : 0.f;
   long long total = (long long)B * dh * dw * (C / ve);
+  CFP_REQUIRE(total < (1ll << 31), CFP_ESHAPE, "cfp_resize_bilinear: too many elements");
+  p.fcv = make_fastdiv((unsigned)(C / ve)); p.fdw = make_fastdiv((unsigned)dw); p.fdh = make_fastdiv((unsigned)dh);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == CFP_BF16) hipLaunchKernelGGL(resize_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
   else if (dtype == CFP_F16) hipLaunchKernelGGL(resize_kernel<f16_t>, dim3(ew_blocks(total)), dim3(256), 0, s, p);
@@ -881,9 +891,11 @@ static int add_rowtable_impl(const void* in, int in_ld, const float* table, void
   CFP_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && H > 0 && W > 0 && Wt >= W + ox && oy >= 0 && ox >= 0 && in_ld % ve == 0 &&
                   out_ld % ve == 0 && in_ld >= C && out_ld >= C && (!dev_off || Ht >= H), CFP_ESHAPE, std::string(who) + ": bad shape");
   long long total = (long long)rows * (C / ve);
+  CFP_REQUIRE(total < (1ll << 31) && aligned16(table), CFP_ESHAPE, std::string(who) + ": too many elements / table not 16-byte aligned");
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve)), fw = make_fastdiv((unsigned)W), fh = make_fastdiv((unsigned)H);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define AR(T) hipLaunchKernelGGL(add_rowtable_kernel<T>, dim3(ew_blocks(total)), dim3(256), 0, s, (const T*)in, in_ld, table, (T*)out, out_ld, \
-                                 (long long)rows, C, H, W, Wt, oy, ox, dev_off, Ht)
+                                 (long long)rows, C, H, W, Wt, oy, ox, dev_off, Ht, fcv, fw, fh)
   if (dtype == CFP_BF16) AR(bf16_t); else if (dtype == CFP_F16) AR(f16_t); else AR(float);
 #undef AR
   return cfp_check_launch(who);
