@@ -43,7 +43,10 @@ struct HaloP {
   FastDiv dcpt;    // piece -> (pixel, chunk)
 };
 
-template <typename H, int NT, int WN, int STAGES>
+// UP = true (cfp_upsample_cat_conv3x3, decoder.py:51-58 UpSampleBN): the 16-byte pieces of the halo that belong to channels below p.up_C
+// are not fetched but BLENDED from four taps of the low-resolution map (resize_kernel's own float32 arithmetic, rounded to the storage
+// type as the stored upsampled tensor would have been); the other channels come from the skip tensor.
+template <typename H, int NT, int WN, int STAGES, bool UP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp) {
   constexpr int WM = 4 / WN;
   constexpr int TH = 4 * WM;                 // output rows per workgroup (a wave owns 4)
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   constexpr int NBG = NPAD / 8;              // 8-row DMA groups
   constexpr int NB = (NBG + 3) / 4;          // DMA instructions per wave per stage
   constexpr int WSTAGE = NPAD * 128;
-  constexpr int MAXLD = TH == 16 ? 11 : 6;   // 16-byte halo pieces per thread: (TH + 2) * 18 pixels x up to 8 chunks
+  constexpr int LB = UP ? 4 : 6;             // halo pieces per thread and loader pass (UP: four taps each)
   static_assert((STAGES - 2) * NB <= 63, "vmcnt field");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem;                              // STAGES weight stages
@@ -107,24 +110,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
   //      needed before the first MFMA anyway) ---------------------------------------------------------------------------------------
   {
     const int nitems = HPIX * hp.CPT;
-    u32x4 v[MAXLD];
-    int dst[MAXLD];
+    const H* __restrict__ low = nullptr;
+    int upc = 0;
+    if constexpr (UP) { low = reinterpret_cast<const H*>(p.up_src) + (long long)b * p.up_H * p.up_W * p.up_ld; upc = p.up_C >> 3; }
+    for (int base = 0; base < nitems; base += 256 * LB) {
+      u32x4 v[LB][UP ? 4 : 1];
+      int dst[LB];
+      float lyx[LB][UP ? 2 : 1];
+      bool blend[LB];
 #pragma unroll
-    for (int n = 0; n < MAXLD; ++n) {
-      const int i = tid + n * 256;
-      unsigned upx, uch;
-      fd_rowcol((unsigned)i, hp.dcpt, upx, uch);
-      const int px = (int)upx, ch = (int)uch;
-      const int hy = px / HC, hx = px - hy * HC;
-      const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
-      const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      dst[n] = i < nitems ? px * hp.PP + ch * 16 : -1;
-      v[n] = u32x4{0u, 0u, 0u, 0u};
-      if (ok) v[n] = *reinterpret_cast<const u32x4*>(in + (y * p.W + x) * p.in_ld + ch * 8);      // one image < 2^31 elements (host check)
+      for (int n = 0; n < LB; ++n) {
+        const int i = base + tid + n * 256;
+        unsigned upx, uch;
+        fd_rowcol((unsigned)i, hp.dcpt, upx, uch);
+        const int px = (int)upx, ch = (int)uch;
+        const int hy = px / HC, hx = px - hy * HC;
+        const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+        const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        dst[n] = i < nitems ? px * hp.PP + ch * 16 : -1;
+        blend[n] = false;
+#pragma unroll
+        for (int t = 0; t < (UP ? 4 : 1); ++t) v[n][t] = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (UP) {
+          if (ch < upc) {
+            blend[n] = ok;
+            const float fy = p.up_sy * (float)y, fx = p.up_sx * (float)x;      // torch: src = scale * dst_index (align_corners=True)
+            const int ys = (int)fy, xs = (int)fx;
+            lyx[n][0] = fy - (float)ys; lyx[n][1] = fx - (float)xs;
+            if (ok) {
+              const int dyo = (ys < p.up_H - 1 ? 1 : 0) * p.up_W * p.up_ld, dxo = (xs < p.up_W - 1 ? 1 : 0) * p.up_ld;
+              const H* s00 = low + (ys * p.up_W + xs) * p.up_ld + ch * 8;
+              v[n][0] = *reinterpret_cast<const u32x4*>(s00); v[n][1] = *reinterpret_cast<const u32x4*>(s00 + dxo);
+              v[n][2] = *reinterpret_cast<const u32x4*>(s00 + dyo); v[n][3] = *reinterpret_cast<const u32x4*>(s00 + dyo + dxo);
+            }
+            continue;
+          }
+        }
+        if (ok) v[n][0] = *reinterpret_cast<const u32x4*>(in + (y * p.W + x) * p.in_ld + ch * 8);      // one image < 2^31 elements (host check)
+      }
+#pragma unroll
+      for (int n = 0; n < LB; ++n) {
+        if (dst[n] < 0) continue;
+        if constexpr (UP) {
+          if (blend[n]) {
+            float t[4][8], o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Vec<H>::load(reinterpret_cast<const H*>(&v[n][q]), t[q]);
+            const float ly1 = lyx[n][0], lx1 = lyx[n][1], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ly0 * (lx0 * t[0][e] + lx1 * t[1][e]) + ly1 * (lx0 * t[2][e] + lx1 * t[3][e]);
+            Vec<H>::store(reinterpret_cast<H*>(sX + dst[n]), o);
+            continue;
+          }
+        }
+        *reinterpret_cast<u32x4*>(sX + dst[n]) = v[n][0];
+      }
     }
-#pragma unroll
-    for (int n = 0; n < MAXLD; ++n)
-      if (dst[n] >= 0) *reinterpret_cast<u32x4*>(sX + dst[n]) = v[n];
   }
 
   f32x4 acc[4][NT];
@@ -244,7 +285,7 @@ constexpr HCfg kHCfg[] = {
 };
 constexpr int kNumHCfg = sizeof(kHCfg) / sizeof(kHCfg[0]);
 
-template <typename H, int NT, int WN>
+template <typename H, int NT, int WN, bool UP = false>
 int launch_h(const ConvP& p, hipStream_t s) {
   constexpr int TH = 4 * (4 / WN);
   constexpr int NPAD = NT * WN * 16;
@@ -258,7 +299,6 @@ int launch_h(const ConvP& p, hipStream_t s) {
   hp.PP = slots * 16;
   hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
   const int hpix = (TH + 2) * 18;
-  if (hpix * hp.CPT > 256 * (TH == 16 ? 11 : 6)) return -1;
   const size_t halo = (size_t)hpix * hp.PP;
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
   // weight stages: two.  More would hide more of the DMA latency behind MFMAs, but measured (tools/conv_bench.py --halo, us with
@@ -269,12 +309,12 @@ int launch_h(const ConvP& p, hipStream_t s) {
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
 #define HL(ST)                                                                                                                      \
   do {                                                                                                                              \
-    auto k = conv3x3_halo_kernel<H, NT, WN, ST>;                                                                                    \
+    auto k = conv3x3_halo_kernel<H, NT, WN, ST, UP>;                                                                                \
     static bool attr = false;                                                                                                       \
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; } \
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);                                                         \
   } while (0)
-  if (stages == 4) HL(4); else if (stages == 3) HL(3); else HL(2);
+  if constexpr (UP) { HL(2); } else { if (stages == 4) HL(4); else if (stages == 3) HL(3); else HL(2); }
 #undef HL
   return 0;
 }
@@ -284,10 +324,11 @@ int launch_h(const ConvP& p, hipStream_t s) {
 int conv3x3_halo_num_variants() { return kNumHCfg; }
 void conv3x3_halo_debug_stages(int v) { g_halo_stages = v; }
 
-// The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 64, no LayerNorm epilogue / per-image weights.
+// The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 128 (the plan uses it up to 64), no
+// LayerNorm epilogue / per-image weights.
 bool conv3x3_halo_takes(const ConvP& p) {
-  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 64 && p.Cout % 8 == 0 &&
-         p.Cout <= 512 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.up_src == nullptr && p.K == 9 * p.Cin &&
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 128 && p.Cout % 8 == 0 &&
+         p.Cout <= 512 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.K == 9 * p.Cin &&
          p.pad_t >= 0 && p.pad_l >= 0 && p.pad_t <= 2 && p.pad_l <= 2;
 }
 
@@ -295,7 +336,9 @@ bool conv3x3_halo_takes(const ConvP& p) {
 int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s) {
   if (v < 0) {
     const long long t16 = (long long)p.B * cdiv(p.Wo, 16) * cdiv(p.Ho, 16);
-    if (p.Cout <= 16) v = 0;
+    if (p.up_src != nullptr && p.Cout > 64) return -3;
+    if (p.up_src != nullptr) v = p.Cout <= 32 ? 7 : 3;       // 8 x 16 pixel tiles: the blended halo is large, four workgroups per CU matter more (up4: 85 us, 16 x 16 tiles 104, direct kernel 112)
+    else if (p.Cout <= 16) v = 0;
     else if (p.Cout <= 32) v = t16 >= 1024 ? 1 : 7;
     else if (p.Cout <= 64) v = t16 >= 1024 ? 2 : 3;
     else if (p.Cout <= 128) v = 4;
@@ -303,6 +346,18 @@ int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s) {
     else v = 4;                      // two or more 128-channel blocks
   }
   if (v >= kNumHCfg) return -3;
+  if (p.up_src != nullptr) {      // upsample + concatenation in the loader: the thin-output tiles only (the decoder's first conv of a stage)
+#define HU(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN, true>(p, s) : launch_h<bf16_t, NT, WN, true>(p, s))
+    switch (v) {
+      case 0: return HU(1, 1);
+      case 1: return HU(2, 1);
+      case 2: return HU(4, 1);
+      case 3: return HU(2, 2);
+      case 7: return HU(1, 2);
+      default: return -3;
+    }
+#undef HU
+  }
 #define HV(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN>(p, s) : launch_h<bf16_t, NT, WN>(p, s))
   switch (v) {
     case 0: return HV(1, 1);

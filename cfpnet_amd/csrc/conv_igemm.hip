@@ -299,6 +299,7 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
 int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whole-depth halo kernel, 2 = wherever it can run
 // Where conv3x3_halo.hip beats the implicit GEMMs (tools/conv_bench.py --halo at batch 8, us halo / without: 614400 px x 16 ch, K = 360:
 // 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
@@ -312,6 +313,7 @@ void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vect
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 14: g_up_halo = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
@@ -488,7 +490,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
     // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
     // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
-    if (!w2 && c33 && conv3x3_halo_takes(p) && (g_force_variant < 0 ? halo_wins(p.M, Cout) : g_force_variant >= 300)) {
+    if (!w2 && c33 && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout)) : g_force_variant >= 300)) {
       int rc = conv3x3_halo_launch(g_force_variant >= 300 ? g_force_variant - 300 : -1, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
       CFP_REQUIRE(g_force_variant < 0, CFP_EHIP, "cfp_conv2d_nhwc: the forced halo variant cannot run this problem");
@@ -588,6 +590,12 @@ extern "C" int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int
   p.up_src = low; p.up_ld = low_ld; p.up_C = Cup; p.up_H = Hs; p.up_W = Ws;
   p.up_sy = (float)(Hs - 1) / (float)(H - 1);        // cfp_resize_bilinear's own expression (bit-identical source coordinates)
   p.up_sx = (float)(Ws - 1) / (float)(W - 1);
+  // few concatenated channels and a thin output at many pixels (up4: 64 + 24 -> 32 at 240 x 320): the whole-depth halo kernel blends
+  // into its resident tile once per workgroup; the 64-channel-chunk direct kernel otherwise.  cfp_debug_set(14, 0) keeps the direct kernel.
+  if (g_up_halo && conv3x3_halo_takes(p) && Cout <= 64 && (g_up_halo == 2 || (long long)B * H * W >= 300000)) {
+    int rc = conv3x3_halo_launch(g_force_variant >= 300 ? g_force_variant - 300 : -1, p, reinterpret_cast<hipStream_t>(stream));
+    if (rc == 0) return cfp_check_launch("cfp_upsample_cat_conv3x3");
+  }
   const int v = Cout <= 16 ? 5 : (Cout <= 32 ? 4 : (Cout <= 64 ? 1 : 0));
   int rc = conv3x3_up_launch(v, p, reinterpret_cast<hipStream_t>(stream));
   CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_upsample_cat_conv3x3: kernel launch failed");

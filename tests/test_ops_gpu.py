@@ -1087,6 +1087,47 @@ def test_upsample_cat_conv3x3_is_bit_identical_to_resize_then_conv(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("case", [(2, 120, 160, 240, 320, 64, 24, 32, 1), (1, 13, 17, 26, 34, 64, 24, 16, 0), (2, 15, 20, 45, 50, 64, 8, 64, 2),
+                                  (1, 9, 11, 20, 33, 64, 64, 40, 3), (1, 30, 40, 60, 80, 64, 16, 24, 7)])
+def test_upsample_cat_conv3x3_through_the_halo_kernel(case, dtype):
+    """The same fused op with the blend done in the whole-depth halo kernel's loader (up4 of the benched forward): against torch, against
+    the direct-kernel form (float32 re-association only), and BIT-identical to the halo kernel run on the materialised
+    resize + concatenation with the same tile (same taps, same blend arithmetic, same rounding point, same summation order)."""
+    B, Hs, Ws, H, W, Cup, Cskip, Cout, variant = case
+    lib = hip.load()
+    low = q(rnd(B, Cup, Hs, Ws, seed=31), dtype)
+    skip = q(rnd(B, Cskip, H, W, seed=32), dtype)
+    Cin = Cup + Cskip
+    w = q(rnd(Cout, Cin, 3, 3, seed=33, scale=1.0 / math.sqrt(9 * Cin)), dtype)
+    scale, shift = (rnd(Cout, seed=34).abs() + 0.5).to(DEV), rnd(Cout, seed=35, scale=0.1).to(DEV)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dtype).to(DEV)
+    a_low = to_act(nhwc(low), dtype)
+    cat = ops.new_act(B * H * W, Cin, dtype, DEV)
+    cat.buf[:, Cup:] = nhwc(skip).to(dtype).to(DEV)
+    o_halo, o_direct, o_pair = (ops.new_act(B * H * W, Cout, dtype, DEV) for _ in range(3))
+    try:
+        lib.cfp_debug_set(14, 2)
+        lib.cfp_debug_set(0, 300 + variant)           # the tile of the fused launch and of the reference launch below
+        ops.upsample_cat_conv3x3(a_low, Hs, Ws, cat.slice(Cup, Cskip), wp, scale, shift, o_halo, B, H, W, hip.ACT_LRELU)
+        ops.resize_bilinear(a_low, Hs, Ws, (0, 0, Hs, Ws), cat.slice(0, Cup), H, W, (0, 0, H, W), B)
+        ops.conv2d(cat, wp, scale, shift, o_pair, B, H, W, 3, 3, 1, 1, 1, H, W, hip.ACT_LRELU)
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(14, 0)
+        ops.upsample_cat_conv3x3(a_low, Hs, Ws, cat.slice(Cup, Cskip), wp, scale, shift, o_direct, B, H, W, hip.ACT_LRELU)
+        torch.cuda.synchronize()
+    finally:
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(14, 1)
+    ref_in = torch.cat([q(F.interpolate(low, size=(H, W), mode="bilinear", align_corners=True), dtype), skip], 1)
+    ref = F.leaky_relu(F.conv2d(ref_in, w, None, 1, 1) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None], 0.01)
+    close(from_nhwc(o_halo.torch(), B, H, W), ref, dtype, f"halo fused {case}")
+    assert torch.equal(o_halo.buf.view(torch.int16), o_pair.buf.view(torch.int16)), "fused != resize + halo conv with the same tile"
+    d = (o_halo.buf.float() - o_direct.buf.float()).abs()
+    ulp = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    assert bool((d <= ulp * o_direct.buf.float().abs() + 1e-3 * ulp * float(o_direct.buf.float().abs().max())).all()), float(d.max())
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(8, 30, 40, 816, 1), (8, 15, 20, 1392, 1), (8, 60, 80, 224, 2), (8, 30, 40, 816, 2), (8, 30, 40, 448, 1),
                                   (2, 26, 34, 672, 1), (2, 13, 17, 1392, 1), (2, 40, 60, 208, 1), (1, 20, 30, 1392, 1), (2, 52, 68, 224, 2),
                                   (1, 7, 5, 16, 1), (3, 16, 16, 80, 1), (1, 33, 130, 48, 2)])

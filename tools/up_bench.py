@@ -24,4 +24,17 @@ for name, (Hs, Ws, H, W, Cup, Cskip, Cout) in {"up1.a": (15, 20, 30, 40, 256, 13
     def pair():
         rs(); cv()
     tf, tr, tc, tp = (graph_time_us(f, calls=8, replays=4) for f in (fused, rs, cv, pair))
-    print(f"{name}: fused {tf:7.1f} us   resize {tr:6.1f} + conv {tc:7.1f} = pair {tp:7.1f} us   ({2e-6 * B * H * W * Cout * 9 * Cin / tf:6.1f} TFLOP/s fused)", flush=True)
+    lib = hip.load()
+    lib.cfp_debug_set(14, 0)
+    td = graph_time_us(fused, calls=8, replays=4)
+    lib.cfp_debug_set(14, 2)
+    extra = f"   fused through the direct kernel {td:7.1f}"
+    if Cin <= 128 and Cout <= 64:
+        for v in (0, 1, 2, 3, 7):
+            if Cout > (16, 32, 64, 64, 0, 0, 0, 32)[v]:
+                continue
+            lib.cfp_debug_set(0, 300 + v)
+            extra += f"  halo h{v} {graph_time_us(fused, calls=8, replays=4):6.1f}"
+        lib.cfp_debug_set(0, -1)
+    lib.cfp_debug_set(14, 1)
+    print(f"{name}: fused {tf:7.1f} us   resize {tr:6.1f} + conv {tc:7.1f} = pair {tp:7.1f} us   ({2e-6 * B * H * W * Cout * 9 * Cin / tf:6.1f} TFLOP/s fused){extra}", flush=True)
