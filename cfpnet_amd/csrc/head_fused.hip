@@ -73,7 +73,7 @@ template <int N> __device__ __forceinline__ void hf_wait_vmcnt() { asm volatile(
 #endif
 
 template <typename H, bool RAMLO>
-__global__ __launch_bounds__(256) void depth_head_fused_kernel(HeadP p) {
+__global__ __launch_bounds__(256, 2) void depth_head_fused_kernel(HeadP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
