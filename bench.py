@@ -243,7 +243,7 @@ def pmc_traffic(kernel_family: str):
     (profiles/pmc_traffic.json, profiles/r2f_pmc_traffic.json, profiles/r2k_pmc_traffic.json and profiles/r2n_pmc_traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 for
     16-byte streaming reads + WRITE_SIZE, separate passes).  None if no PMC summary is committed for it."""
     table = {}
-    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json", "r2n_pmc_traffic.json", "r3_pmc_traffic.json", "r3c_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
+    for name in ("pmc_traffic.json", "r2f_pmc_traffic.json", "r2k_pmc_traffic.json", "r2n_pmc_traffic.json", "r3_pmc_traffic.json", "r3c_pmc_traffic.json", "r3e_pmc_traffic.json"):          # later rounds override earlier ones, kernel by kernel
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:

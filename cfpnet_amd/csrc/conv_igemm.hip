@@ -299,6 +299,7 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
 int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whole-depth halo kernel, 2 = wherever it can run
 // Where conv3x3_halo.hip beats the implicit GEMMs (tools/conv_bench.py --halo at batch 8, us halo / without: 614400 px x 16 ch, K = 360:
@@ -313,6 +314,7 @@ void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vect
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
@@ -379,6 +381,10 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
     if (tm * ((N + 63) / 64) <= 256) pl.variant = 19;
   }
   if (allow_split && K >= 2048 && (M <= 1100 || ((M + 63) / 64) * ((N + 63) / 64) <= 48)) { pl.variant = 4; pl.splits = 8; pl.gen1 = false; pl.direct = -1; }
+  // the 64x64 tile with two stages instead of three wherever K is not split: alone it is 3 % faster over the network's small GEMMs
+  // (tools/conv_bench.py --kgroups, k13 vs k4), and at 32 KB instead of 48 KB of LDS five of them share a CU with the other batches'
+  // kernels instead of three
+  if (pl.variant == 4 && pl.splits == 1 && !pl.gen1 && pl.direct < 0 && g_small_s2) pl.variant = 13;
   if (g_force_variant >= 200 && conv3x3s1 && g_force_variant - 200 < conv3x3_num_variants()) { pl.direct = g_force_variant - 200; pl.gen1 = false; pl.splits = 1; }
   else if (g_force_variant >= 0) pl.direct = -1;
   if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }

@@ -10,8 +10,9 @@ import csv, json, re, sys, collections
 
 def family(name):
     dt = lambda t: "f16" if "Float16" in t else "bf16"
-    m = re.search(r"igemm2_kernel<(unsigned short|_Float16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)>", name)
-    if m: return f"igemm2<{dt(m.group(1))},{m.group(2)}x{m.group(3)},s{m.group(4)}>"
+    m = re.search(r"igemm2_kernel<(unsigned short|_Float16), (\d+), (\d+), \d+, \d+, (\d+), (true|false)(?:, (\d+))?>", name)
+    if m: return f"igemm2<{dt(m.group(1))},{m.group(2)}x{m.group(3)},s{m.group(4)}" + (",kg2>" if m.group(6) == "2" else ">")
+    if "conv3x3_halo_kernel" in name: return "conv3x3_halo<" + dt(name) + ">"
     m = re.search(r"conv_igemm(?:_splitk)?_kernel<(unsigned short|_Float16), (\d+), (\d+)", name)
     if m: return f"conv_igemm<{dt(m.group(1))},{m.group(2)}x{m.group(3)}>"
     m = re.search(r"conv3x3_direct_kernel<(unsigned short|_Float16), (\d+), (\d+)", name)
