@@ -131,8 +131,8 @@ for key, (name, args, cnt) in uniq.items():
             sweep[f"h{v}/1"] = t
             if t < best[0]:
                 best = (t, f"h{v}")
+    lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
     if a.halo:
-        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
         lib.cfp_debug_set(12, 2)                      # the halo kernel wherever it can run, its automatic tile, 2 / 3 / 4 weight stages
         for st in (2, 3, 4):
             lib.cfp_debug_set(13, st)
