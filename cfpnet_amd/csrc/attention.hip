@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void kv_finalize_kernel(const float* __restric
   // independent loads in flight at a time (the serial chain of up to 64 dependent loads was the whole kernel)
   const int per = d * d + d;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < items * per; i += (long long)gridDim.x * 256) {
-    long long gh = i / per;
-    int e = (int)(i % per);
+    const long long gh = (long long)((unsigned long long)i / (unsigned)per);      // one division; the remainder by multiply-subtract
+    const int e = (int)(i - gh * per);
     const float* base = ws + gh * nsplit * per + e;
     float s = 0.f;
     int j = 0;
@@ -145,27 +145,28 @@ struct ApP {
   int q_ld, out_ld, NB, Hq, Wq, qth, qtw, ggy, ggx;
   int ey0, ey1, ex0, ex1, heads;
   float v_length, eps;
+  FastDiv fheads, fwq, fhq, fqth, fqtw;      // (token, head) index arithmetic without 64-bit divisions (five per element in the first version)
 };
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_apply_kernel(ApP p) {
   const T* __restrict__ Q = reinterpret_cast<const T*>(p.q);
   T* __restrict__ O = reinterpret_cast<T*>(p.out);
-  const long long total = (long long)p.NB * p.Hq * p.Wq * p.heads;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int h = (int)(i % p.heads);
-    const long long tok = i / p.heads;
-    const int x = (int)(tok % p.Wq);
-    const long long t = tok / p.Wq;
-    const int y = (int)(t % p.Hq);
-    const int b = (int)(t / p.Hq);
+  const unsigned total = (unsigned)p.NB * p.Hq * p.Wq * p.heads;      // < 2^31: host check
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned toku, hu, tu, xu, bu, yu;
+    fd_rowcol(i, p.fheads, toku, hu);
+    fd_rowcol(toku, p.fwq, tu, xu);
+    fd_rowcol(tu, p.fhq, bu, yu);
+    const int h = (int)hu, x = (int)xu, y = (int)yu, b = (int)bu;
+    const long long tok = toku;
     T* op = O + tok * p.out_ld + h * D;
     float o[D];
     if (y >= p.ey0 && y < p.ey1 && x >= p.ex0 && x < p.ex1) {
 #pragma unroll
       for (int j = 0; j < D; ++j) o[j] = 0.f;
     } else {
-      const long long g = ((long long)b * p.ggy + y / p.qth) * p.ggx + x / p.qtw;
+      const long long g = ((long long)b * p.ggy + fd_div((unsigned)y, p.fqth)) * p.ggx + fd_div((unsigned)x, p.fqtw);
       const float* kv = p.kv + (g * p.heads + h) * D * D;
       const float* ks = p.ksum + (g * p.heads + h) * D;
       const T* qp = Q + tok * p.q_ld + h * D;
@@ -255,6 +256,9 @@ extern "C" int cfp_attn_apply(const void* q, int q_ld, const float* kv, const fl
   p.NB = NB; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
   p.ey0 = ey0; p.ey1 = ey1; p.ex0 = ex0; p.ex1 = ex1; p.heads = heads; p.v_length = v_length; p.eps = eps;
   long long total = (long long)NB * Hq * Wq * heads;
+  CFP_REQUIRE(total < (1ll << 31), CFP_ESHAPE, "cfp_attn_apply: too many (token, head) pairs");
+  p.fheads = make_fastdiv((unsigned)heads); p.fwq = make_fastdiv((unsigned)Wq); p.fhq = make_fastdiv((unsigned)Hq);
+  p.fqth = make_fastdiv((unsigned)qth); p.fqtw = make_fastdiv((unsigned)qtw);
   int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define AP_LAUNCH(T, D) hipLaunchKernelGGL((attn_apply_kernel<T, D>), dim3(blocks), dim3(256), 0, s, p)

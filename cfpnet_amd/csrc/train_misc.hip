@@ -169,16 +169,16 @@ __global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ w, T* __restrict__ dx,
                                                           int dx_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho,
-                                                          int Wo, int accumulate) {
+                                                          int Wo, int accumulate, FastDiv fcv, FastDiv fw, FastDiv fh) {
   constexpr int VE = Vec<T>::N;
-  const int CV = C / VE;
-  const long long total = (long long)B * H * W * CV;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long px = i / CV;
-    const int c = (int)(i - px * CV) * VE;
-    const int wi = (int)(px % W);
-    const long long t = px / W;
-    const int hi = (int)(t % H), b = (int)(t / H);
+  const unsigned total = (unsigned)B * H * W * fcv.d;      // < 2^31 (host check): 32-bit indices, magic-number divisions
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned pxu, cvu, tu, wiu, bu, hiu;
+    fd_rowcol(i, fcv, pxu, cvu);
+    fd_rowcol(pxu, fw, tu, wiu);
+    fd_rowcol(tu, fh, bu, hiu);
+    const long long px = pxu;
+    const int c = (int)cvu * VE, wi = (int)wiu, hi = (int)hiu, b = (int)bu;
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const T* __restrict__ x, int x_ld, const T* __restrict__ dy, int dy_ld,
                                                           float* __restrict__ partial, int B, int H, int W, int C, int stride, int pad_t,
-                                                          int pad_l, int Ho, int Wo, long long rows_per_split) {
+                                                          int pad_l, int Ho, int Wo, long long rows_per_split, FastDiv fwo, FastDiv fho) {
   constexpr int VE = Vec<T>::N;
   __shared__ float red[8][32 * 8];
   const int tid = threadIdx.x, cl = tid & 31, rl = tid >> 5;
@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < VE; ++e) s[t][e] = 0.f;
   for (long long m = r0 + rl; m < r1; m += 8) {
-    const int wo = (int)(m % Wo);
-    const long long tt = m / Wo;
-    const int ho = (int)(tt % Ho), b = (int)(tt / Ho);
+    unsigned ttu, wou, bu, hou;                 // M < 2^31 (host check)
+    fd_rowcol((unsigned)m, fwo, ttu, wou);
+    fd_rowcol(ttu, fho, bu, hou);
+    const int wo = (int)wou, ho = (int)hou, b = (int)bu;
     float g[VE];
     Vec<T>::load(dy + m * dy_ld + cc, g);
 #pragma unroll
@@ -396,9 +397,11 @@ extern "C" int cfp_dwconv3x3_dgrad(const void* dy, int dy_ld, const void* w, voi
   TM_COMMON("cfp_dwconv3x3_dgrad");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % ve == 0 && dy_ld % ve == 0 && dx_ld % ve == 0 && dy_ld >= C &&
                   dx_ld >= C && (stride == 1 || stride == 2), CFP_ESHAPE, "cfp_dwconv3x3_dgrad: bad shape");
+  CFP_REQUIRE((long long)B * H * W * (C / ve) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv3x3_dgrad: too many elements");
   const dim3 grid(ew_grid2((long long)B * H * W * (C / ve)));
+  const FastDiv fcv = make_fastdiv((unsigned)(C / ve)), fw = make_fastdiv((unsigned)W), fh = make_fastdiv((unsigned)H);
 #define L(T) hipLaunchKernelGGL(dw3x3_dgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, (const T*)w, (T*)dx, dx_ld, B, H, W, C, stride, \
-                                pad_t, pad_l, Ho, Wo, accumulate)
+                                pad_t, pad_l, Ho, Wo, accumulate, fcv, fw, fh)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_dwconv3x3_dgrad");
@@ -420,8 +423,10 @@ extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int 
   const int nsplit = (int)((M + rps - 1) / rps);
   float* partial = reinterpret_cast<float*>(ws);
   const dim3 grid(cdiv(C, 32 * ve), nsplit);
+  CFP_REQUIRE(M < (1ll << 31), CFP_ESHAPE, "cfp_dwconv3x3_wgrad: too many output pixels");
+  const FastDiv fwo = make_fastdiv((unsigned)Wo), fho = make_fastdiv((unsigned)Ho);
 #define L(T) hipLaunchKernelGGL(dw3x3_wgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)x, x_ld, (const T*)dy, dy_ld, partial, B, H, W, C, stride, \
-                                pad_t, pad_l, Ho, Wo, rps)
+                                pad_t, pad_l, Ho, Wo, rps, fwo, fho)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   const long long n = 9ll * C;
