@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Tuple
 
+import os
 import torch
 
 from . import hip, ops, train_ops
@@ -16,10 +17,11 @@ from . import hip, ops, train_ops
 
 class V:
     """A value on the tape: `t` [rows, C] device tensor, `g` its gradient (same shape) once backward reached it."""
-    __slots__ = ("t", "g", "needs_grad", "g_owned")
+    __slots__ = ("t", "g", "needs_grad", "g_owned", "mom")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t, self.g, self.needs_grad, self.g_owned = t, None, needs_grad, True
+        self.mom = None        # (partials, nsplit, rows_per_split): channel moments of `t` left by the convolution that produced it
 
     @property
     def rows(self):
@@ -60,6 +62,7 @@ class Tape:
         self._const: Dict[Tuple[str, int], torch.Tensor] = {}
         self.side, self._forked = side, False
         self.marks: Dict[str, int] = {}          # name -> tape position: `backward(stop=...)` runs the closures recorded after it
+        self.conv_stats = os.environ.get("CFP_CONV_STATS", "1") != "0"      # BatchNorm statistics from the producing conv's epilogue (16-bit modes)
 
     # ------------------------------------------------------------------ helpers
     def new(self, rows: int, C: int, dtype=None) -> torch.Tensor:
@@ -132,14 +135,18 @@ class Tape:
         self.bw = self.bw[:lo]
 
     # ------------------------------------------------------------------ dense conv / linear
-    def conv(self, x: V, w: P, bias: Optional[P], B, H, W, k, stride, pt, pl, Ho, Wo) -> V:
-        """w.t [Cout, k*k*Cin]; bias.t [Cout] f32."""
+    def conv(self, x: V, w: P, bias: Optional[P], B, H, W, k, stride, pt, pl, Ho, Wo, stats: bool = False) -> V:
+        """w.t [Cout, k*k*Cin]; bias.t [Cout] f32.  `stats`: a batch-statistics BatchNorm follows -- in the 16-bit modes the conv kernel
+        leaves the per-row-tile channel moments of its output beside it (V.mom) and bn_act merges them instead of reading the tensor."""
         Cout = w.t.shape[0]
         y = V(self.new(B * Ho * Wo, Cout, x.t.dtype))
         # split-K slabs (few rows, long K: the sr convs) in the 16-bit modes; float32 parity mode keeps its single summation chain
         nws = ops.conv2d_ws_bytes(B * Ho * Wo, Cout, w.t.shape[1], ops.DT[x.t.dtype]) if x.t.dtype != torch.float32 else 0
         ws = torch.empty(nws // 4, dtype=torch.float32, device=self.dev) if nws else None
-        ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo, ws=ws)
+        if stats and self.conv_stats and x.t.dtype != torch.float32:
+            y.mom = ops.conv2d_moments(_act(x.t), w.t, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo, ws=None)
+        else:
+            ops.conv2d(_act(x.t), w.t, None, bias.t if bias is not None else None, _act(y.t), B, H, W, k, k, stride, pt, pl, Ho, Wo, ws=ws)
 
         def bw():
             g = y.g
@@ -197,14 +204,14 @@ class Tape:
             Tape._patch_maps[key] = full.to(torch.int32).to(self.dev)
         return Tape._patch_maps[key]
 
-    def linear(self, x: V, w: P, bias: Optional[P] = None) -> V:
-        return self.conv(x, w, bias, 1, 1, x.rows, 1, 1, 0, 0, 1, x.rows)
+    def linear(self, x: V, w: P, bias: Optional[P] = None, stats: bool = False) -> V:
+        return self.conv(x, w, bias, 1, 1, x.rows, 1, 1, 0, 0, 1, x.rows, stats=stats)
 
     # ------------------------------------------------------------------ normalisation / activation
     def bn_act(self, x: V, gamma: P, beta: P, running_mean, running_var, eps, momentum, act, residual: Optional[V] = None) -> V:
         """act(BatchNorm(x)) [+ residual]: the skip connection of a residual block rides on the apply pass instead of a separate add."""
         bn = train_ops.BatchNormTrain(x.C, self.dev, eps=eps, momentum=momentum)
-        y = V(bn.forward(x.t, gamma.t, beta.t, running_mean, running_var, act, residual.t if residual is not None else None))
+        y = V(bn.forward(x.t, gamma.t, beta.t, running_mean, running_var, act, residual.t if residual is not None else None, mom=x.mom))
 
         def bw():
             if y.g is None:

@@ -195,12 +195,24 @@ __global__ __launch_bounds__(256) void colmoments_final_kernel(const float* __re
                                                                float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
-  Mom a{0.f, 0.f, 0.f};
-  for (int j = lane; j < nsplit; j += 64) {
-    const long long r0 = (long long)j * rows_per_split;
-    const float n = (float)(min(rows, r0 + rows_per_split) - r0);
-    a = mom_merge(a, Mom{n, partial[((long long)j * 2 + 0) * C + c], partial[((long long)j * 2 + 1) * C + c]});
+  // four independent merge chains per lane (splits j, j + 64, j + 128, j + 192 of every 256): with the thousands of row tiles a
+  // convolution's epilogue leaves (cfp_conv2d_nhwc_moments) one chain of dependent loads + divisions per lane was the whole launch
+  Mom a4[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int j0 = lane; j0 < nsplit; j0 += 256) {
+    float pm[4], pq[4], pn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + 64 * u;
+      const bool ok = j < nsplit;
+      const long long r0 = (long long)j * rows_per_split;
+      pn[u] = ok ? (float)(min(rows, r0 + rows_per_split) - r0) : 0.f;
+      pm[u] = ok ? partial[((long long)j * 2 + 0) * C + c] : 0.f;
+      pq[u] = ok ? partial[((long long)j * 2 + 1) * C + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] = mom_merge(a4[u], Mom{pn[u], pm[u], pq[u]});
   }
+  Mom a = mom_merge(mom_merge(a4[0], a4[1]), mom_merge(a4[2], a4[3]));
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     Mom b{__shfl_xor(a.n, o, 64), __shfl_xor(a.mean, o, 64), __shfl_xor(a.m2, o, 64)};
@@ -468,6 +480,20 @@ extern "C" int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, 
                        running_mean, running_var, mean, var, invstd, scale, shift);
   }
   return cfp_check_launch("cfp_bn_train_stats");
+}
+
+// The same layer constants from per-split (mean, M2) partials a producer already wrote (cfp_conv2d_nhwc_moments): split j holds the rows
+// [j * rows_per_split, min(rows, (j + 1) * rows_per_split)), layout [split][2][C].  One launch instead of a pass over the tensor + one.
+extern "C" int cfp_bn_train_stats_partials(const float* partial, int nsplit, long long rows, long long rows_per_split, int C, const float* gamma,
+                                           const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                           float* var, float* invstd, float* scale, float* shift, cfp_stream_t stream) {
+  CFP_REQUIRE(partial && mean && var && invstd && scale && shift, CFP_EINVAL, "cfp_bn_train_stats_partials: bad pointer");
+  CFP_REQUIRE(nsplit > 0 && rows > 0 && rows_per_split > 0 && C > 0 && (long long)(nsplit - 1) * rows_per_split < rows &&
+                  (long long)nsplit * rows_per_split >= rows, CFP_ESHAPE, "cfp_bn_train_stats_partials: splits do not cover the rows");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(colmoments_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, partial, nsplit, rows, rows_per_split, C, gamma, beta, eps, momentum,
+                     running_mean, running_var, mean, var, invstd, scale, shift);
+  return cfp_check_launch("cfp_bn_train_stats_partials");
 }
 
 extern "C" int cfp_scale_shift_act(const void* x, int ld, const float* scale, const float* shift, int act, void* out, int out_ld,

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           }
     });
     __syncthreads();
+    if (p.mom != nullptr) tile_moments<T, BN, 256>(sC, CP, min(BM, p.M - m0), n0, p.Cout, p.mom + (long long)tile_m * 2 * p.Cout, tid);
     constexpr int CH = BN / 8;   // 16-byte chunks per tile row
     for (int q = tid; q < BM * CH; q += 256) {
       int row = q / CH, ch = q % CH;
@@ -447,8 +448,11 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
                                   const void* residual, int res_ld, void* out, int out_ld, int B, int H, int W, int Cin,
                                   int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int act,
                                   int dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream, int dil) {
+                                  int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream, int dil,
+                                  float* mom = nullptr, size_t mom_floats = 0, int* mom_nsplit = nullptr, int* mom_rps = nullptr) {
   CFP_REQUIRE(in && w && out, CFP_EINVAL, "cfp_conv2d_nhwc: null pointer");
+  if (mom_nsplit) *mom_nsplit = 0;
+  if (mom_rps) *mom_rps = 0;
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_nhwc: bad dtype");
   const int ve = vec_elems(dtype);
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0,
@@ -478,6 +482,16 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && dil == 1) ? 1 : 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
   p.up_src = nullptr; p.up_ld = p.up_C = p.up_H = p.up_W = 0; p.up_sy = p.up_sx = 0.f;
+  p.mom = nullptr;
+  // channel moments of the output for the BatchNorm that follows (training): only the kernels that end with the output tile in LDS
+  // produce them (gen-2 without split-K, gen-1 16-bit); every other route reports 0 row tiles and the caller runs its statistics pass
+  const bool want_mom = mom && mom_nsplit && mom_rps && is16(dtype) && !residual && !ln_gamma && !per_image_weights && act == CFP_ACT_NONE && dil == 1;
+  auto offer_mom = [&](int bm) {
+    const long long tiles = cdiv(p.M, bm);
+    if (!want_mom || (size_t)tiles * 2 * Cout > mom_floats) return false;
+    p.mom = mom; *mom_nsplit = (int)tiles; *mom_rps = bm;
+    return true;
+  };
   const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
   per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -496,16 +510,17 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
     // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
     // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
-    if (!w2 && c33 && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout)) : g_force_variant >= 300)) {
+    if (!w2 && c33 && !want_mom && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout)) : g_force_variant >= 300)) {
       int rc = conv3x3_halo_launch(g_force_variant >= 300 ? g_force_variant - 300 : -1, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
       CFP_REQUIRE(g_force_variant < 0, CFP_EHIP, "cfp_conv2d_nhwc: the forced halo variant cannot run this problem");
     }
-    if (pl.direct >= 0) {
+    if (pl.direct >= 0 && !want_mom) {
       int rc = conv3x3_launch(pl.direct, p, s);
       CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: direct 3x3 kernel launch failed");
       return cfp_check_launch("cfp_conv2d_nhwc");
     }
+    if (pl.direct >= 0) { pl.direct = -1; pl.variant = 14; pl.splits = 1; }      // statistics wanted: the implicit GEMM (it ends with the tile in LDS)
     if (pl.gen1 && !ln_gamma) goto gen1_path;
     if (ln_variant >= 0 && g_force_variant < 0) pl.variant = ln_variant;
     if (ln_variant >= 0) { p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; pl.splits = 1; }
@@ -513,6 +528,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) pl.splits = 1;
     const bool ln_after = ln_gamma && ln_variant < 0;   // Cout has no exact-width tile: LayerNorm as a second kernel
     if (ln_after) p.res = nullptr;
+    if (pl.splits == 1) { int bm, bn, st; igemm2_variant_shape(pl.variant, &bm, &bn, &st); offer_mom(bm); }
     int rc = igemm2_launch(pl.variant, p, (float*)ws, pl.splits, s);
     CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: gen-2 kernel launch failed");
     if (pl.splits > 1) {
@@ -549,6 +565,10 @@ gen1_path:
     }
     int splits = pick_splits(q.M, Cout, q.K, dtype);
     if (splits > 1 && (!ws || ws_bytes < (size_t)splits * q.M * Cout * sizeof(float))) splits = 1;
+    if (splits == 1 && is16(dtype) && !per_image_weights) {
+      const int v1 = cfp_conv2d_variant(q.M, Cout);
+      if (offer_mom(v1 <= 1 ? 256 : 128)) q.mom = p.mom;
+    }
     if (dtype == CFP_BF16) dispatch<bf16_t>(q, (float*)ws, splits, s); else if (dtype == CFP_F16) dispatch<f16_t>(q, (float*)ws, splits, s); else dispatch<float>(q, (float*)ws, splits, s);
   }
   int e = cfp_check_launch("cfp_conv2d_nhwc");
@@ -563,6 +583,19 @@ extern "C" int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, cons
                                   int per_image_weights, void* ws, size_t ws_bytes, cfp_stream_t stream) {
   return conv2d_impl(in, in_ld, w, scale, shift, residual, res_ld, out, out_ld, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
                      act, dtype, ln_gamma, ln_beta, ln_eps, per_image_weights, ws, ws_bytes, stream, 1);
+}
+
+// cfp_conv2d_nhwc + the per-row-tile channel moments of its (rounded, stored) output for a batch-statistics BatchNorm that follows
+// (training: timm / torch `conv -> BatchNorm2d` in model.train()).  mom: [row tiles][2][Cout] float32 (mean, M2 about it); on return
+// *nsplit = row tiles written (0: this problem's kernel does not produce them -- run cfp_bn_train_stats) and *rows_per_split = rows
+// per tile; feed them to cfp_bn_train_stats_partials.
+extern "C" int cfp_conv2d_nhwc_moments(const void* in, int in_ld, const void* w, const float* bias, void* out, int out_ld, int B, int H, int W,
+                                       int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int dtype,
+                                       void* ws, size_t ws_bytes, float* mom, size_t mom_floats, int* nsplit, int* rows_per_split,
+                                       cfp_stream_t stream) {
+  CFP_REQUIRE(mom && nsplit && rows_per_split, CFP_EINVAL, "cfp_conv2d_nhwc_moments: null moments pointer");
+  return conv2d_impl(in, in_ld, w, nullptr, bias, nullptr, 0, out, out_ld, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo,
+                     CFP_ACT_NONE, dtype, nullptr, nullptr, 0.f, 0, ws, ws_bytes, stream, 1, mom, mom_floats, nsplit, rows_per_split);
 }
 
 int conv3x3_up_launch(int v, const ConvP& p, hipStream_t s);      // conv3x3_direct.hip
@@ -593,6 +626,7 @@ extern "C" int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int
   p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
   p.M = B * H * W; p.K = 9 * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = 1; p.pointwise = 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
+  p.mom = nullptr;
   p.up_src = low; p.up_ld = low_ld; p.up_C = Cup; p.up_H = Hs; p.up_W = Ws;
   p.up_sy = (float)(Hs - 1) / (float)(H - 1);        // cfp_resize_bilinear's own expression (bit-identical source coordinates)
   p.up_sx = (float)(Ws - 1) / (float)(W - 1);

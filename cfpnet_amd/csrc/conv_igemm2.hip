@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256 * KG) void igemm2_kernel(ConvP p, float* __rest
         }
     });
     __syncthreads();
+    if (p.mom != nullptr) tile_moments<H, BN, 256 * KG>(sC, CP, min(BM, m_end - m0), n0, p.Cout, p.mom + (long long)tile_m * 2 * p.Cout, tid);
     constexpr int CH = BN / 8;   // 16-byte chunks per tile row (a power of two <= 16)
     H* __restrict__ out = reinterpret_cast<H*>(p.out);
     const H* __restrict__ res = reinterpret_cast<const H*>(p.res);

@@ -28,6 +28,8 @@ struct ConvP {
   const void* up_src;      // low-resolution source [B, up_H, up_W, up_ld]: input channels [0, up_C) are its align_corners=True bilinear
   int up_ld, up_C, up_H, up_W;   // upsampling to H x W, computed in the loader; channels [up_C, Cin) come from `in` (the skip tensor, virtual base: in + c addresses skip channel c - up_C)
   float up_sy, up_sx;      // (up_H - 1) / (H - 1), (up_W - 1) / (W - 1)
+  float* mom;              // optional (training): per ROW TILE channel moments of the stored output, [tile_m][2][Cout] = (mean, M2 about that mean)
+                           // of the tile's valid rows -- the batch-statistics BatchNorm that follows merges them instead of reading the tensor again
   int dil;                 // input dilation (gen-1 kernels only): the input is read as if `dil - 1` zeros sat between its pixels --
                            // the data gradient of a stride-`dil` convolution; H / W stay the REAL input size
 };
@@ -47,6 +49,38 @@ int conv3x3_halo_num_variants();
 void conv3x3_halo_debug_stages(int v);
 bool conv3x3_halo_takes(const ConvP& p);
 int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s);
+
+// Channel moments of a 16-bit output tile that sits in LDS as [rows][CP] (the values as STORED, i.e. rounded: what a statistics pass
+// over the tensor would read).  TPC = NTHR / BN adjacent lanes share a channel: each takes every TPC-th row with sums shifted by the
+// tile's first row (no cancellation), then the (n, mean, M2) triples are merged exactly in a fixed butterfly order.
+template <typename T, int BN, int NTHR>
+__device__ __forceinline__ void tile_moments(const T* sC, int CP, int rows_valid, int n0, int Cout, float* __restrict__ mom_tile, int tid) {
+  constexpr int TPC = NTHR / BN;
+  static_assert(NTHR % BN == 0 && TPC >= 1 && TPC <= 64 && (TPC & (TPC - 1)) == 0, "threads per channel");
+  const int c = tid / TPC, part = tid % TPC;
+  const float shift = to_f32<T>(sC[c]);
+  float n = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int r = part; r < rows_valid; r += TPC) {
+    const float v = to_f32<T>(sC[r * CP + c]) - shift;
+    s1 += v; s2 = fmaf(v, v, s2); n += 1.f;
+  }
+  float mean = n > 0.f ? shift + s1 / n : 0.f;
+  float m2 = n > 0.f ? fmaxf(s2 - s1 * s1 / n, 0.f) : 0.f;
+#pragma unroll
+  for (int o = 1; o < TPC; o <<= 1) {
+    const float bn = __shfl_xor(n, o, 64), bmean = __shfl_xor(mean, o, 64), bm2 = __shfl_xor(m2, o, 64);
+    // merge(lower lane, upper lane), computed identically by both partners
+    const bool up = (part & o) != 0;
+    const float an = up ? bn : n, amean = up ? bmean : mean, am2 = up ? bm2 : m2;
+    const float cn = up ? n : bn, cmean = up ? mean : bmean, cm2 = up ? m2 : bm2;
+    const float tn = an + cn;
+    if (tn > 0.f) {
+      const float d = cmean - amean, f = cn / tn;
+      mean = amean + d * f; m2 = am2 + cm2 + d * d * an * f; n = tn;
+    } else { mean = 0.f; m2 = 0.f; n = 0.f; }
+  }
+  if (part == 0 && n0 + c < Cout) { mom_tile[n0 + c] = mean; mom_tile[Cout + n0 + c] = m2; }
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) {
   // physical 16-byte chunk of (row, logical chunk); g = [0,3,2,1][(row >> 2) & 3]

@@ -27,6 +27,7 @@ SIGNATURES = {
     "cfp_last_error": (C.c_char_p, []),
     "cfp_conv2d_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
     "cfp_conv2d_nhwc_ex": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _p, _f, _i, _p, _sz, _p]),
+    "cfp_conv2d_nhwc_moments": (_i, [_p, _i, _p, _p, _p, _i] + [_i] * 13 + [_p, _sz, _p, _sz, _p, _p, _p]),
     "cfp_conv2d_ws_bytes": (_sz, [_i, _i, _i, _i]),
     "cfp_conv2d_plan": (_i, [_i] * 8 + [_p, _p]),
     "cfp_debug_set": (_i, [_i, _i]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "cfp_conv2d_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 14 + [_p, _sz, _p]),
     "cfp_bn_ws_bytes": (_sz, [_i]),
     "cfp_bn_train_stats": (_i, [_p, _i, C.c_longlong, _i, _i, _p, _p, _f, _f] + [_p] * 7 + [_p, _sz, _p]),
+    "cfp_bn_train_stats_partials": (_i, [_p, _i, C.c_longlong, C.c_longlong, _i, _p, _p, _f, _f] + [_p] * 7 + [_p]),
     "cfp_scale_shift_act": (_i, [_p, _i, _p, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_scale_shift_act_res": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_bn_train_bwd": (_i, [_p, _i, _p, _i, C.c_longlong, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _sz, _p]),

@@ -78,6 +78,20 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 
+def conv2d_moments(x: Act, w: torch.Tensor, bias, out: Act, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, ws: Optional[torch.Tensor] = None):
+    """conv2d (no activation / residual) + per-row-tile channel moments of the stored output for a following batch-statistics BatchNorm.
+    -> (partials [tiles, 2, Cout] float32, nsplit, rows_per_split); nsplit == 0: the kernel chosen does not produce them."""
+    import ctypes
+    M = B * Ho * Wo
+    assert w.dtype == x.buf.dtype and tuple(w.shape) == (out.C, KH * KW * x.C) and w.is_contiguous()
+    mom = torch.empty(((M + 63) // 64) * 2 * out.C, dtype=torch.float32, device=x.buf.device)
+    ns, rps = ctypes.c_int(0), ctypes.c_int(0)
+    hip.call("cfp_conv2d_nhwc_moments", x.ptr, x.ld, w.data_ptr(), hip.ptr(bias), out.ptr, out.ld, B, H, W, x.C, out.C, KH, KW, stride,
+             pad_t, pad_l, Ho, Wo, x.dt, hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, mom.data_ptr(), mom.numel(),
+             ctypes.byref(ns), ctypes.byref(rps), _s())
+    return mom, ns.value, rps.value
+
+
 # tile shape (BM, BN, LDS stages) of second-generation variant v (conv_igemm2.hip kCfg)
 GEN2_TILES = [(128, 128, 3), (128, 128, 2), (128, 64, 3), (128, 64, 4), (64, 64, 3), (64, 64, 4), (256, 32, 3), (256, 32, 2),
               (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3), (64, 64, 2), (128, 64, 2), (64, 128, 2), (128, 32, 2),

@@ -161,20 +161,20 @@ class TrainNet:
         return t.bn_act(x, self._vec(prefix + ".weight"), self._vec(prefix + ".bias"), self.buf[prefix + ".running_mean"],
                         self.buf[prefix + ".running_var"], eps, mom, act, residual=residual)
 
-    def _conv_same(self, t: Tape, x: V, wname: str, B, H, W, stride, cin_pad=None, bias: Optional[str] = None):
+    def _conv_same(self, t: Tape, x: V, wname: str, B, H, W, stride, cin_pad=None, bias: Optional[str] = None, stats: bool = False):
         w = self._conv_w(wname, cin_pad)
         k = self.sd[wname].shape[-1]
         Ho, Wo = -(-H // stride), -(-W // stride)
         pt, _ = same_pad(H, k, stride)
         pl, _ = same_pad(W, k, stride)
-        return t.conv(x, w, self._vec(bias) if bias else None, B, H, W, k, stride, pt, pl, Ho, Wo), Ho, Wo
+        return t.conv(x, w, self._vec(bias) if bias else None, B, H, W, k, stride, pt, pl, Ho, Wo, stats=stats), Ho, Wo
 
-    def _conv3(self, t: Tape, x: V, wname: str, bias: Optional[str], B, H, W) -> V:
-        return t.conv(x, self._conv_w(wname), self._vec(bias) if bias else None, B, H, W, 3, 1, 1, 1, H, W)
+    def _conv3(self, t: Tape, x: V, wname: str, bias: Optional[str], B, H, W, stats: bool = False) -> V:
+        return t.conv(x, self._conv_w(wname), self._vec(bias) if bias else None, B, H, W, 3, 1, 1, 1, H, W, stats=stats)
 
     def _encoder(self, t: Tape, x: V, B, H, W) -> List[Tuple[V, int, int]]:
         p = "img_encoder"
-        x, H, W = self._conv_same(t, x, f"{p}.conv0.0.weight", B, H, W, 2, cin_pad=8)
+        x, H, W = self._conv_same(t, x, f"{p}.conv0.0.weight", B, H, W, 2, cin_pad=8, stats=True)
         x = self._bn(t, x, f"{p}.conv0.1", hip.ACT_SILU if self.stem_act else hip.ACT_NONE, ENC_EPS, ENC_MOM)
         taps = []
         for stage, stride in ENC_STAGES:
@@ -184,18 +184,18 @@ class TrainNet:
                 s = stride if i == 0 else 1
                 inp, Hi, Wi = x, H, W
                 if f"{q}.conv.weight" in self.sd:
-                    x, H, W = self._conv_same(t, x, q + ".conv.weight", B, H, W, s)
+                    x, H, W = self._conv_same(t, x, q + ".conv.weight", B, H, W, s, stats=True)
                     x = self._bn(t, x, q + ".bn1", hip.ACT_SILU, ENC_EPS, ENC_MOM)
                 elif f"{q}.conv_exp.weight" in self.sd:
-                    x, H, W = self._conv_same(t, x, q + ".conv_exp.weight", B, H, W, s)
+                    x, H, W = self._conv_same(t, x, q + ".conv_exp.weight", B, H, W, s, stats=True)
                     x = self._bn(t, x, q + ".bn1", hip.ACT_SILU, ENC_EPS, ENC_MOM)
-                    x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
+                    x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W, stats=True)
                     skip = inp if (self.res_fused and s == 1 and inp.C == x.C) else None       # the skip connection rides on the last BatchNorm's apply pass
                     x = self._bn(t, x, q + ".bn2", hip.ACT_NONE, ENC_EPS, ENC_MOM, residual=skip)
                     if skip is not None:
                         inp = None
                 else:
-                    x = t.conv(x, self._conv_w(q + ".conv_pw.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
+                    x = t.conv(x, self._conv_w(q + ".conv_pw.weight"), None, B, H, W, 1, 1, 0, 0, H, W, stats=True)
                     x = self._bn(t, x, q + ".bn1", hip.ACT_SILU, ENC_EPS, ENC_MOM)
                     Ho, Wo = -(-H // s), -(-W // s)
                     x = t.dw3x3(x, self._dw3(q + ".conv_dw.weight"), B, H, W, s, same_pad(H, 3, s)[0], same_pad(W, 3, s)[0], Ho, Wo)
@@ -212,7 +212,7 @@ class TrainNet:
                         g = t.act(t.linear(g, w1, b1), hip.ACT_SILU)
                         g = t.act(t.linear(g, w2, b2), hip.ACT_SIGMOID)
                         x = t.mul_bcast(x, g, B, H * W)
-                    x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W)
+                    x = t.conv(x, self._conv_w(q + ".conv_pwl.weight"), None, B, H, W, 1, 1, 0, 0, H, W, stats=True)
                     skip = inp if (self.res_fused and s == 1 and inp.C == x.C) else None
                     x = self._bn(t, x, q + ".bn3", hip.ACT_NONE, ENC_EPS, ENC_MOM, residual=skip)
                     if skip is not None:
@@ -234,7 +234,7 @@ class TrainNet:
         for e in (1, 2, 3):
             q = f"hist_encoder.hist_extractor{e}.pointnet_encoder"
             for j in (1, 2, 3):
-                x = t.linear(x, self._conv_w(f"{q}.conv{j}.weight", cin_pad=8 if (e == 1 and j == 1) else None), self._vec(f"{q}.conv{j}.bias"))
+                x = t.linear(x, self._conv_w(f"{q}.conv{j}.weight", cin_pad=8 if (e == 1 and j == 1) else None), self._vec(f"{q}.conv{j}.bias"), stats=True)
                 x = self._bn(t, x, f"{q}.bn{j}", hip.ACT_RELU)
             outs.append(x)
         return outs
@@ -303,10 +303,10 @@ class TrainNet:
         msg = t.attention(q, k, v, B, H * W, S, heads, D // heads)
         msg = t.gather(msg, idx_out, inv_out)                              # only outside tokens receive a message
         f = t.concat(tok, msg)
-        f = self._bn(t, self._conv3(t, f, p + ".conv1.weight", None, B, H, W), p + ".bn1", hip.ACT_NONE)
+        f = self._bn(t, self._conv3(t, f, p + ".conv1.weight", None, B, H, W, stats=True), p + ".bn1", hip.ACT_NONE)
         if self.res_fused:
-            return self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W), p + ".bn2", hip.ACT_NONE, residual=tok)     # bn2(conv2) + feat
-        return t.add(self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W), p + ".bn2", hip.ACT_NONE), tok)
+            return self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W, stats=True), p + ".bn2", hip.ACT_NONE, residual=tok)     # bn2(conv2) + feat
+        return t.add(self._bn(t, self._conv3(t, f, p + ".conv2.weight", None, B, H, W, stats=True), p + ".bn2", hip.ACT_NONE), tok)
 
     def _lkpm(self, t: Tape, p: str, tok: V, B, H, W) -> V:
         k = self.sd[p + ".dwconv2.weight"].shape[-1]
@@ -386,7 +386,7 @@ class TrainNet:
         x = t.resize(x, B, Hs, Ws, H, W)
         x = t.concat(x, skip)
         for c, b in ((0, 1), (3, 4)):
-            x = self._conv3(t, x, f"{p}._net.{c}.weight", f"{p}._net.{c}.bias", B, H, W)
+            x = self._conv3(t, x, f"{p}._net.{c}.weight", f"{p}._net.{c}.bias", B, H, W, stats=True)
             x = self._bn(t, x, f"{p}._net.{b}", hip.ACT_LRELU)
         return x
 

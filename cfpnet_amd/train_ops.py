@@ -350,13 +350,20 @@ class BatchNormTrain:
         from . import hip
         return bn_workspace(self.C, self.device, hip.current_stream())
 
-    def forward(self, x2d, gamma, beta, running_mean, running_var, act: int, residual: Optional[torch.Tensor] = None):
-        """`residual` [rows, C]: added after the activation in the apply pass (the block's skip connection)."""
+    def forward(self, x2d, gamma, beta, running_mean, running_var, act: int, residual: Optional[torch.Tensor] = None, mom=None):
+        """`residual` [rows, C]: added after the activation in the apply pass (the block's skip connection).
+        `mom` = (partials, nsplit, rows_per_split) from the producing convolution (ops.conv2d_moments): the statistics are then merged
+        from them in one small launch instead of a pass over x2d + that launch."""
         from . import hip, ops
         rows = x2d.shape[0]
-        hip.call("cfp_bn_train_stats", x2d.data_ptr(), x2d.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.ptr(gamma), hip.ptr(beta), self.eps,
-                 self.momentum, hip.ptr(running_mean), hip.ptr(running_var), self.mean.data_ptr(), self.var.data_ptr(), self.invstd.data_ptr(),
-                 self.scale.data_ptr(), self.shift.data_ptr(), self.ws.data_ptr(), self.nbytes, hip.current_stream())
+        if mom is not None and mom[1] > 0:
+            hip.call("cfp_bn_train_stats_partials", mom[0].data_ptr(), mom[1], rows, mom[2], self.C, hip.ptr(gamma), hip.ptr(beta), self.eps,
+                     self.momentum, hip.ptr(running_mean), hip.ptr(running_var), self.mean.data_ptr(), self.var.data_ptr(),
+                     self.invstd.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), hip.current_stream())
+        else:
+            hip.call("cfp_bn_train_stats", x2d.data_ptr(), x2d.stride(0), rows, self.C, ops.DT[x2d.dtype], hip.ptr(gamma), hip.ptr(beta), self.eps,
+                     self.momentum, hip.ptr(running_mean), hip.ptr(running_var), self.mean.data_ptr(), self.var.data_ptr(), self.invstd.data_ptr(),
+                     self.scale.data_ptr(), self.shift.data_ptr(), self.ws.data_ptr(), self.nbytes, hip.current_stream())
         y = torch.empty_like(x2d)
         hip.call("cfp_scale_shift_act_res", x2d.data_ptr(), x2d.stride(0), self.scale.data_ptr(), self.shift.data_ptr(), act,
                  hip.ptr(residual), residual.stride(0) if residual is not None else 0, y.data_ptr(), y.stride(0), rows, self.C,

@@ -463,6 +463,20 @@ int cfp_conv2d_dgrad(const void* dy, int dy_ld, const void* wt, void* dx, int dx
                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int accumulate, int dtype, void* ws,
                      size_t ws_bytes, cfp_stream_t stream);
 
+/* cfp_conv2d_nhwc (no activation / residual) that ALSO emits, per tile of output rows, the channel moments of its stored output for the
+ * batch-statistics BatchNorm that follows it in model.train() (timm ConvBnAct / torch `Conv2d -> BatchNorm2d`): mom[tile][0][c] = mean,
+ * mom[tile][1][c] = sum of squared deviations from that mean, over the tile's rows.  On return *nsplit = tiles written and
+ * *rows_per_split = rows per tile -- or *nsplit = 0 when the kernel chosen for this problem does not produce them (float32, split-K,
+ * mom_floats too small): then run cfp_bn_train_stats.  Saves one pass over the activation and one launch per layer. */
+int cfp_conv2d_nhwc_moments(const void* in, int in_ld, const void* w, const float* bias, void* out, int out_ld, int B, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, int dtype,
+                            void* ws, size_t ws_bytes, float* mom, size_t mom_floats, int* nsplit, int* rows_per_split,
+                            cfp_stream_t stream);
+/* cfp_bn_train_stats from such partials ([split][2][C]; split j covers rows [j * rows_per_split, min(rows, (j + 1) * rows_per_split))). */
+int cfp_bn_train_stats_partials(const float* partial, int nsplit, long long rows, long long rows_per_split, int C, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                                float* var, float* invstd, float* scale, float* shift, cfp_stream_t stream);
+
 /* Training-mode BatchNorm over `rows` NHWC rows (nn.BatchNorm2d/1d in model.train()): batch mean / biased variance
  * (one pass: shifted sums merged as exact (n, mean, M2) triples), running statistics updated with `momentum` (running_var from the unbiased variance), and the folded
  * per-channel scale = gamma*invstd, shift = beta - mean*scale that cfp_scale_shift_act applies with the activation. */

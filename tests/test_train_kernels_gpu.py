@@ -128,6 +128,45 @@ def test_batchnorm_training_forward_backward(rows, C, act, dtype):
     assert float((dbeta.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 30, 40, 112, 448, 1, 1), (2, 60, 80, 40, 160, 3, 1), (1, 120, 160, 8, 40, 3, 2), (3, 13, 17, 136, 816, 1, 1),
+                                  (1, 9, 11, 232, 1392, 1, 1), (16, 26, 34, 448, 112, 1, 1), (2, 104, 136, 16, 16, 3, 1), (1, 1, 70, 8, 32, 1, 1)])
+def test_conv_epilogue_moments_feed_batchnorm(case, dtype):
+    """cfp_conv2d_nhwc_moments: the conv kernel leaves per-row-tile (mean, M2) of its STORED output; BatchNorm merged from them must equal
+    BatchNorm with its own statistics pass over that output (same values, another exact merge order) and torch's batch statistics of it.
+    Data with a large common offset (mean >> std): the tile sums are shifted, so nothing cancels."""
+    B, H, W, Cin, Cout, k, s = case
+    pt = pl = (k - 1) // 2 if s == 1 else 0
+    Ho, Wo = (H + 2 * pt - k) // s + 1, (W + 2 * pl - k) // s + 1
+    x = (rnd(B * H * W, Cin, seed=1) + 3.0).to(dtype).to(DEV)
+    w = (rnd(Cout, k * k * Cin, seed=2) / math.sqrt(k * k * Cin)).to(dtype).to(DEV)
+    bias = (rnd(Cout, seed=3) * 4.0).to(DEV)
+    M = B * Ho * Wo
+    y1, y2 = torch.empty(M, Cout, dtype=dtype, device=DEV), torch.empty(M, Cout, dtype=dtype, device=DEV)
+    A = lambda t: ops.Act(t, 0, t.shape[1])
+    mom, ns, rps = ops.conv2d_moments(A(x), w, bias, A(y1), B, H, W, k, k, s, pt, pl, Ho, Wo)
+    ops.conv2d(A(x), w, None, bias, A(y2), B, H, W, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    assert ns > 0 and (ns - 1) * rps < M <= ns * rps, (ns, rps, M)
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)), "the moments epilogue must not change the output"
+    gamma, beta = (rnd(Cout, seed=4).abs() + 0.5).to(DEV), rnd(Cout, seed=5).to(DEV)
+    res = []
+    for m in ((mom, ns, rps), None):
+        bn = train_ops.BatchNormTrain(Cout, DEV, eps=1e-3, momentum=0.1)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        out = bn.forward(y1, gamma, beta, rm, rv, hip.ACT_SILU, mom=m)
+        torch.cuda.synchronize()
+        res.append((bn.mean.clone(), bn.var.clone(), rm, rv, out.float()))
+    yf = y1.double()
+    mean64, var64 = yf.mean(0), yf.var(0, unbiased=False)
+    for mean, var, rm, rv, out in res:
+        assert float((mean.double() - mean64).abs().max()) <= 2e-6 * float(mean64.abs().max()) + 1e-6
+        assert float(((var.double() - var64).abs() / var64.clamp(min=1e-9)).max()) <= 2e-4
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(mean64.abs().max()) + 1e-6
+    assert float((res[0][4] - res[1][4]).abs().max()) <= {torch.bfloat16: 2.0 ** -6, torch.float16: 2.0 ** -9}[dtype] * float(res[1][4].abs().max())
+    assert torch.allclose(res[0][3], res[1][3], rtol=1e-4, atol=1e-7)
+
+
 @pytest.mark.parametrize("rows,C", [(20000, 16), (333, 264), (1, 8), (200000, 8)])
 def test_batchnorm_statistics_one_pass_is_stable(rows, C):
     """The statistics are taken in one pass over x (shifted sums per thread + exact merging of (n, mean, M2) triples): data whose
