@@ -300,6 +300,7 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
 int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
 int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whole-depth halo kernel, 2 = wherever it can run
@@ -315,6 +316,7 @@ void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vect
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 16: g_probe = value; return CFP_OK;
     case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
@@ -482,7 +484,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   p.pointwise = (KH == 1 && KW == 1 && stride == 1 && pad_t == 0 && pad_l == 0 && Ho == H && Wo == W && dil == 1) ? 1 : 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = ln_eps; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
   p.up_src = nullptr; p.up_ld = p.up_C = p.up_H = p.up_W = 0; p.up_sy = p.up_sx = 0.f;
-  p.mom = nullptr;
+  p.mom = nullptr; p.probe = g_probe;
   // channel moments of the output for the BatchNorm that follows (training): only the kernels that end with the output tile in LDS
   // produce them (gen-2 without split-K, gen-1 16-bit); every other route reports 0 row tiles and the caller runs its statistics pass
   const bool want_mom = mom && mom_nsplit && mom_rps && is16(dtype) && !residual && !ln_gamma && !per_image_weights && act == CFP_ACT_NONE && dil == 1;
@@ -626,7 +628,7 @@ extern "C" int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int
   p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
   p.M = B * H * W; p.K = 9 * Cin; p.act = act; p.f16 = dtype == CFP_F16; p.dil = 1; p.pointwise = 0;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.k2 = 0;
-  p.mom = nullptr;
+  p.mom = nullptr; p.probe = 0;
   p.up_src = low; p.up_ld = low_ld; p.up_C = Cup; p.up_H = Hs; p.up_W = Ws;
   p.up_sy = (float)(Hs - 1) / (float)(H - 1);        // cfp_resize_bilinear's own expression (bit-identical source coordinates)
   p.up_sx = (float)(Ws - 1) / (float)(W - 1);

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256 * KG) void igemm2_kernel(ConvP p, float* __rest
     __builtin_amdgcn_s_barrier();                     // stage `buf` landed for every wave; stage buf-1 fully consumed
     asm volatile("" ::: "memory");
     if (KG == 2 && it >= nkg) continue;               // the second group's missing last step (odd step count): it only keeps the barrier count
-    if (it + STAGES - 1 < nkg) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
+    if (it + STAGES - 1 < nkg && !(p.probe & 1)) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
+    if (p.probe & 2) continue;
 
     const unsigned char* cA = gsm + buf * STAGE_BYTES + a_row0 * 128;
     const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;

@@ -284,7 +284,7 @@ extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const 
   p.in_ld = x_ld; p.out_ld = 0; p.res_ld = 0;
   p.B = 1; p.H = 1; p.W = B * HW; p.Cin = Cin; p.Ho = 1; p.Wo = B * HW; p.Cout = HBN_;
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
-  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.f16 = dtype == CFP_F16; p.dil = 1; p.mom = nullptr;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.f16 = dtype == CFP_F16; p.dil = 1; p.mom = nullptr; p.probe = 0;
   size_t lds = (size_t)HBN_ * HPITCH * sizeof(bf16_t);
   size_t ops_lds = 2 * (HBM_ + HBN_) * 64;
   if (lds < ops_lds) lds = ops_lds;

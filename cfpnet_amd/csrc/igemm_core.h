@@ -28,6 +28,8 @@ struct ConvP {
   const void* up_src;      // low-resolution source [B, up_H, up_W, up_ld]: input channels [0, up_C) are its align_corners=True bilinear
   int up_ld, up_C, up_H, up_W;   // upsampling to H x W, computed in the loader; channels [up_C, Cin) come from `in` (the skip tensor, virtual base: in + c addresses skip channel c - up_C)
   float up_sy, up_sx;      // (up_H - 1) / (H - 1), (up_W - 1) / (W - 1)
+  int probe;               // timing probes of the gen-2 loop (cfp_debug_set key 16; results are garbage): 1 = no operand DMA after the prologue,
+                           // 2 = no fragment reads / MFMAs, 3 = neither (barriers and waits only)
   float* mom;              // optional (training): per ROW TILE channel moments of the stored output, [tile_m][2][Cout] = (mean, M2 about that mean)
                            // of the tile's valid rows -- the batch-statistics BatchNorm that follows merges them instead of reading the tensor again
   int dil;                 // input dilation (gen-1 kernels only): the input is read as if `dil - 1` zeros sat between its pixels --
