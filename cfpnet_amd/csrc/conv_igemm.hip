@@ -300,6 +300,10 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
+int g_tput = 0;                 // cfp_debug_set key 17: 1 = plan for several batches in flight (Engine sets it while it captures in-flight slots).
+                                // Side by side, what a launch costs is the resources it holds, not its own latency, and the sweep with four
+                                // copies running together (tools/conv_bench.py --sweep --inflight 4, three runs, profiles/r3_conv_sweep_inflight4.json)
+                                // prefers larger tiles than the isolated sweep the default plan is fitted on
 int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
 int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
@@ -309,6 +313,7 @@ int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whol
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
 static bool halo_wins(long long M, int Cout) {
   if (g_halo == 2) return true;
+  if (g_halo == 1 && g_tput && M >= 100000 && Cout <= 64) return true;      // 153600 px x 32 / 64 ch: 8 x 16 pixel tiles, 10.6 -> 7.6 / 12.9 -> 10.8 / 20.8 -> 16.7 us per call in flight
   return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
                          (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
@@ -316,6 +321,7 @@ void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vect
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = value; return CFP_OK;
     case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
@@ -388,6 +394,14 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
   // (tools/conv_bench.py --kgroups, k13 vs k4), and at 32 KB instead of 48 KB of LDS five of them share a CU with the other batches'
   // kernels instead of three
   if (pl.variant == 4 && pl.splits == 1 && !pl.gen1 && pl.direct < 0 && g_small_s2) pl.variant = 13;
+  // ... and the 64x128 tile with two stages instead of three (2400 x 1392 x 232: 9.3 vs 9.7 us alone, 4.7 vs 5.5 per call in flight); wide
+  // pointwise layers at the 1/16 scale on 128x64 tiles (9600 x 816 x 136: equal alone, 8.4 vs 9.6 in flight)
+  if (pl.variant == 12 && pl.splits == 1 && !pl.gen1 && pl.direct < 0 && g_small_s2) pl.variant = 15;
+  if (pl.variant == 13 && !pl.gen1 && pl.direct < 0 && rpb == 0 && M >= 9000 && M < 30000 && N >= 512 && K <= 256 && g_small_s2) pl.variant = 14;
+  if (g_tput && !pl.gen1 && pl.splits == 1) {
+    if (pl.direct < 0 && M <= 20000 && N >= 256 && K >= 2048) pl.variant = 1;                    // 9600 x 256 x 3528: 20.6 vs 31.0 us per call in flight (alone: 51 vs 42)
+    if (pl.direct < 0 && pl.variant == 13 && rpb == 0 && M >= 30000 && M < 100000 && N <= 64 && K >= 512) pl.variant = 14;      // 38400 x 64 x 1152: 7.8 vs 10.1
+  }
   if (g_force_variant >= 200 && conv3x3s1 && g_force_variant - 200 < conv3x3_num_variants()) { pl.direct = g_force_variant - 200; pl.gen1 = false; pl.splits = 1; }
   else if (g_force_variant >= 0) pl.direct = -1;
   if (g_force_variant >= 0 && g_force_variant < nv) { pl.variant = g_force_variant; pl.gen1 = false; }
@@ -513,7 +527,9 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
     // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
     if (!w2 && c33 && !want_mom && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout)) : g_force_variant >= 300)) {
-      int rc = conv3x3_halo_launch(g_force_variant >= 300 ? g_force_variant - 300 : -1, p, s);
+      int hv = g_force_variant >= 300 ? g_force_variant - 300 : -1;
+      if (hv < 0 && g_tput) hv = (p.M < 300000 && Cout <= 32) ? 7 : (p.M < 300000 && Cout <= 64) ? 3 : (Cout > 160 && Cout <= 224) ? 6 : -1;
+      int rc = conv3x3_halo_launch(hv, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
       CFP_REQUIRE(g_force_variant < 0, CFP_EHIP, "cfp_conv2d_nhwc: the forced halo variant cannot run this problem");
     }

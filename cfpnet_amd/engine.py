@@ -773,7 +773,21 @@ class Engine:
         self._graph = (graphs, static, (edges, pred, prob))
         return edges, pred, prob
 
+    def plan_mode(self, throughput: bool):
+        """Which of the two kernel plans launches issued from now on follow (process-wide switch of the library, `cfp_debug_set(17, .)`):
+        the default one, fitted on isolated timings, or the one for several batches in flight (larger tiles: a launch's cost is then the
+        resources it holds, not its own latency).  `capture(inflight=n)` switches to the second while it records its slots; results of
+        the two plans differ by float32 summation order."""
+        hip.load().cfp_debug_set(17, 1 if (throughput and os.environ.get("CFP_TPUT_PLAN", "1") != "0") else 0)
+
     def _capture_inflight(self, input_data, inflight, return_prob, pos_offsets):
+        self.plan_mode(True)
+        try:
+            return self._capture_inflight_impl(input_data, inflight, return_prob, pos_offsets)
+        finally:
+            self.plan_mode(False)
+
+    def _capture_inflight_impl(self, input_data, inflight, return_prob, pos_offsets):
         dev = self.device
         add = input_data["additional"]
         B = input_data["rgb"].shape[0]
