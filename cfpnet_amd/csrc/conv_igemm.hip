@@ -300,7 +300,8 @@ void dispatch(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // ---- debug knobs (tools/conv_bench.py): key 0 = force gen-2 variant (-1 auto), key 1 = force K-splits
 // (-1 auto), key 2 = 1 routes bf16 through the first-generation kernel.  Not thread-safe; test use only.
 static int g_force_variant = -1, g_force_splits = -1, g_use_v1 = 0;
-int g_tput = 0;                 // cfp_debug_set key 17: 1 = plan for several batches in flight (Engine sets it while it captures in-flight slots).
+int g_tput = 0;                 // cfp_debug_set key 17 (tools): 1 = every call plans for several batches in flight; callers say it per call with the
+                                // CFP_CONV_IN_FLIGHT bit of cfp_conv2d_nhwc_ex's flags (Engine does while it captures in-flight slots).
                                 // Side by side, what a launch costs is the resources it holds, not its own latency, and the sweep with four
                                 // copies running together (tools/conv_bench.py --sweep --inflight 4, three runs, profiles/r3_conv_sweep_inflight4.json)
                                 // prefers larger tiles than the isolated sweep the default plan is fitted on
@@ -311,9 +312,9 @@ int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whol
 // Where conv3x3_halo.hip beats the implicit GEMMs (tools/conv_bench.py --halo at batch 8, us halo / without: 614400 px x 16 ch, K = 360:
 // 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
-static bool halo_wins(long long M, int Cout) {
+static bool halo_wins(long long M, int Cout, bool tput) {
   if (g_halo == 2) return true;
-  if (g_halo == 1 && g_tput && M >= 100000 && Cout <= 64) return true;      // 153600 px x 32 / 64 ch: 8 x 16 pixel tiles, 10.6 -> 7.6 / 12.9 -> 10.8 / 20.8 -> 16.7 us per call in flight
+  if (g_halo == 1 && tput && M >= 100000 && Cout <= 64) return true;      // 153600 px x 32 / 64 ch: 8 x 16 pixel tiles, 10.6 -> 7.6 / 12.9 -> 10.8 / 20.8 -> 16.7 us per call in flight
   return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
                          (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
@@ -361,7 +362,7 @@ namespace {
 //   * few-row / long-K problems (GSA sr convs) want 8 K-splits.
 struct Plan2 { int variant, splits; bool gen1; int direct; };   // direct >= 0: conv3x3_direct variant
 
-Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool conv3x3s1 = false) {
+Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool conv3x3s1 = false, bool tput = false) {
   Plan2 pl{4, 1, false, -1};
   const int nv = igemm2_num_variants();
   const bool big = M >= 100000, mid = M >= 30000;
@@ -398,7 +399,7 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
   // pointwise layers at the 1/16 scale on 128x64 tiles (9600 x 816 x 136: equal alone, 8.4 vs 9.6 in flight)
   if (pl.variant == 12 && pl.splits == 1 && !pl.gen1 && pl.direct < 0 && g_small_s2) pl.variant = 15;
   if (pl.variant == 13 && !pl.gen1 && pl.direct < 0 && rpb == 0 && M >= 9000 && M < 30000 && N >= 512 && K <= 256 && g_small_s2) pl.variant = 14;
-  if (g_tput && !pl.gen1 && pl.splits == 1) {
+  if ((tput || g_tput) && !pl.gen1 && pl.splits == 1) {
     if (pl.direct < 0 && M <= 20000 && N >= 256 && K >= 2048) pl.variant = 1;                    // 9600 x 256 x 3528: 20.6 vs 31.0 us per call in flight (alone: 51 vs 42)
     if (pl.direct < 0 && pl.variant == 13 && rpb == 0 && M >= 30000 && M < 100000 && N <= 64 && K >= 512) pl.variant = 14;      // 38400 x 64 x 1152: 7.8 vs 10.1
   }
@@ -429,7 +430,7 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int d
     Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
     const int cin = K / 9;
     if (KH == 3 && stride == 1 && K % 9 == 0 && cin % 8 == 0 && cin >= 8 && cin <= 64 && Cout % 8 == 0 && Cout <= 512 && rows_per_batch <= 0 &&
-        (g_force_variant < 0 ? halo_wins(M, Cout) : g_force_variant >= 300)) {
+        (g_force_variant < 0 ? halo_wins(M, Cout, g_tput != 0) : g_force_variant >= 300)) {
       if (variant) *variant = 300;          // conv3x3_halo.hip (the tile is chosen from Cout and the pixel count)
       if (splits) *splits = 1;
     } else if (pl.direct >= 0) {
@@ -509,6 +510,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     return true;
   };
   const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
+  const bool tput = (per_image_weights & CFP_CONV_IN_FLIGHT) != 0 || g_tput != 0;
   per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
@@ -522,13 +524,13 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     const int rpb = per_image_weights ? Ho * Wo : 0;
     int ln_variant = ln_gamma ? pick_ln_variant(Cout, p.M) : -1;
     const bool c33 = KH == 3 && KW == 3 && stride == 1 && !ln_gamma && rpb == 0 && (long long)Cout * p.K < (1ll << 31);
-    Plan2 pl = plan2(p.M, Cout, w2 ? 2 * cdiv(p.K, 64) * 64 : p.K, rpb, B, rpb == 0 && ln_variant < 0, c33);
+    Plan2 pl = plan2(p.M, Cout, w2 ? 2 * cdiv(p.K, 64) * 64 : p.K, rpb, B, rpb == 0 && ln_variant < 0, c33, tput);
     if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
     // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
     // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
-    if (!w2 && c33 && !want_mom && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout)) : g_force_variant >= 300)) {
+    if (!w2 && c33 && !want_mom && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout, tput)) : g_force_variant >= 300)) {
       int hv = g_force_variant >= 300 ? g_force_variant - 300 : -1;
-      if (hv < 0 && g_tput) hv = (p.M < 300000 && Cout <= 32) ? 7 : (p.M < 300000 && Cout <= 64) ? 3 : (Cout > 160 && Cout <= 224) ? 6 : -1;
+      if (hv < 0 && tput) hv = (p.M < 300000 && Cout <= 32) ? 7 : (p.M < 300000 && Cout <= 64) ? 3 : (Cout > 160 && Cout <= 224) ? 6 : -1;
       int rc = conv3x3_halo_launch(hv, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
       CFP_REQUIRE(g_force_variant < 0, CFP_EHIP, "cfp_conv2d_nhwc: the forced halo variant cannot run this problem");

@@ -774,11 +774,11 @@ class Engine:
         return edges, pred, prob
 
     def plan_mode(self, throughput: bool):
-        """Which of the two kernel plans launches issued from now on follow (process-wide switch of the library, `cfp_debug_set(17, .)`):
-        the default one, fitted on isolated timings, or the one for several batches in flight (larger tiles: a launch's cost is then the
-        resources it holds, not its own latency).  `capture(inflight=n)` switches to the second while it records its slots; results of
-        the two plans differ by float32 summation order."""
-        hip.load().cfp_debug_set(17, 1 if (throughput and os.environ.get("CFP_TPUT_PLAN", "1") != "0") else 0)
+        """Which of the two kernel plans the convolutions launched from now on follow: the default one, fitted on isolated timings, or the
+        one for several batches in flight (larger tiles: a launch's cost is then the resources it holds, not its own latency; the
+        CFP_CONV_IN_FLIGHT hint of cfp_conv2d_nhwc_ex).  `capture(inflight=n)` switches to the second while it records its slots.  Results
+        do not depend on the plan (every tile walks K in the same order)."""
+        ops.PLAN_IN_FLIGHT = bool(throughput) and os.environ.get("CFP_TPUT_PLAN", "1") != "0"
 
     def _capture_inflight(self, input_data, inflight, return_prob, pos_offsets):
         self.plan_mode(True)

@@ -17,7 +17,7 @@ F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
 TOF_SAMPLE_UNIFORM, TOF_SAMPLE_ICDF = 0, 1
 HEAD_WOUT_HILO, HEAD_RAM_HILO = 1, 2
-CONV_PER_IMAGE, CONV_W2 = 1, 2
+CONV_PER_IMAGE, CONV_W2, CONV_IN_FLIGHT = 1, 2, 4
 
 _p, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 

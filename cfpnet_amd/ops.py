@@ -60,6 +60,9 @@ def conv2d_ws_bytes(M: int, Cout: int, K: int, dt: int) -> int:
     return int(hip.load().cfp_conv2d_ws_bytes(M, Cout, K, dt))
 
 
+PLAN_IN_FLIGHT = False      # set by Engine.plan_mode while it records in-flight slots: conv2d() then passes the CFP_CONV_IN_FLIGHT hint
+
+
 def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo,
            act=hip.ACT_NONE, residual: Optional[Act] = None, ws: Optional[torch.Tensor] = None, ln=None,
            per_image_weights: bool = False):
@@ -74,7 +77,7 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
     hip.call("cfp_conv2d_nhwc_ex", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
              B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
-             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights) | (hip.CONV_W2 if w2 else 0),
+             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights) | (hip.CONV_W2 if w2 else 0) | (hip.CONV_IN_FLIGHT if PLAN_IN_FLIGHT else 0),
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 

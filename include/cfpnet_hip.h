@@ -68,7 +68,9 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
  *     the K loop over both halves against the same activations, so the layer sees its weights with ~22 (fp16) / ~16 (bf16)
  *     significant bits instead of 11 / 8.  Weight rounding of the pointwise layers is 0.8e-3 of the fp16 engine's 0.9e-3
  *     relative-L1 error (profiles/r2_precision_budget.md). */
-enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument */
+enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2, CFP_CONV_IN_FLIGHT = 4 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument.
+ * CFP_CONV_IN_FLIGHT: a hint -- this launch will run beside launches of other batches (several captured forwards in flight): the tile is then
+ * chosen for the resources it holds rather than for its own latency (larger tiles).  Results do not depend on it: every tile walks K in the same order. */
 int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                        const void* residual, int res_ld, void* out, int out_ld,
                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
