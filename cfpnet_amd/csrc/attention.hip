@@ -21,9 +21,12 @@ struct KvP {
 
 // IC rows of the d x d accumulator per lane; TPK = d / IC lanes per key; KL = 64 / TPK key lanes.
 template <int D> struct KvCfg;
-template <> struct KvCfg<4>  { static constexpr int IC = 4; };
-template <> struct KvCfg<8>  { static constexpr int IC = 8; };
-template <> struct KvCfg<16> { static constexpr int IC = 4; };
+// The cross-lane sum over the KL key lanes is a butterfly of log2(KL) steps x (IC * d + IC) `ds_bpermute`s: with a lane holding all d
+// rows (IC = d at d = 8) that was 432 of the kernel's 946 vector instructions.  Two rows per lane (TPK = d / 2 lanes share a key and
+// load its V row together) leave 16 / 8 key lanes: 72 / 102 permutes at d = 8 / 16, the same two to four load rounds per lane.
+template <> struct KvCfg<4>  { static constexpr int IC = 1; };
+template <> struct KvCfg<8>  { static constexpr int IC = 2; };
+template <> struct KvCfg<16> { static constexpr int IC = 2; };
 template <> struct KvCfg<32> { static constexpr int IC = 2; };
 
 template <typename T, int D>
