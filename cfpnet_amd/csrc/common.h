@@ -139,6 +139,16 @@ template <typename F> __device__ __forceinline__ void with_act(int act, F&& f) {
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x + 1.f : __expf(x); }  // elu(x)+1
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane: four `v_add_f32 ... row_ror` -- rotations inside the
+// row are a VALU operand modifier, where `__shfl_xor` compiles to `ds_bpermute_b32` (an LDS-crossbar round trip per step).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -99,14 +99,12 @@ __device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) { acc[j][r] = to_f32<H>(from_f32<H>(acc[j][r])); s += acc[j][r]; }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = row16_sum(s);
     const float mean = s * inv_n;
     float qq = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) { const float dlt = acc[j][r] - mean; qq = fmaf(dlt, dlt, qq); }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) qq += __shfl_xor(qq, o, 64);
+    qq = row16_sum(qq);
     const float rstd = rsqrtf(qq * inv_n + eps);
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j][r] = (acc[j][r] - mean) * rstd * g[j] + bt[j];
