@@ -16,7 +16,10 @@
 namespace {
 
 constexpr int HE_P = 32;          // sample points per workgroup
-constexpr int HE_PITCH = 132;     // floats per activation row in LDS: 132 / 4 is odd -> 16-byte reads of 16 rows hit every bank once
+constexpr int HE_PITCH = 136;     // floats per activation row in LDS: 34 sixteen-byte slots = 2 (mod 4).  `ds_read_b128` is banked over 16-lane
+                                  // groups that pair rows {0-3, 12-15} of chunk q with rows {4-11} of chunk q + 1: the first eight rows then
+                                  // cover the even slots of the 256-byte bank row, the others the odd ones (an ODD slot count -- 132 floats,
+                                  // round 2 -- is conflict-free only for the 16 rows of ONE chunk: 42 % conflict cycles by the SQ counters)
 constexpr int HE_LAYERS = 9;
 
 struct HistEncP {
