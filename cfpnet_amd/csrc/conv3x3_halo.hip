@@ -46,12 +46,15 @@ struct HaloP {
 // UP = true (cfp_upsample_cat_conv3x3, decoder.py:51-58 UpSampleBN): the 16-byte pieces of the halo that belong to channels below p.up_C
 // are not fetched but BLENDED from four taps of the low-resolution map (resize_kernel's own float32 arithmetic, rounded to the storage
 // type as the stored upsampled tensor would have been); the other channels come from the skip tensor.
-template <typename H, int NT, int WN, int STAGES, bool UP = false>
+// STRIDE = 2 (the stem and the first block of an encoder stage, TF-"same" padding): the halo is (2 TH + 1) x 33 input pixels, an output pixel's
+// tap (dy, dx) is input pixel (2 y + dy, 2 x + dx) of it.
+template <typename H, int NT, int WN, int STAGES, bool UP = false, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp) {
   constexpr int WM = 4 / WN;
   constexpr int TH = 4 * WM;                 // output rows per workgroup (a wave owns 4)
-  constexpr int HC = 18;                     // halo columns
-  constexpr int HPIX = (TH + 2) * HC;
+  constexpr int HC = 15 * STRIDE + 3;        // halo columns
+  constexpr int HPIX = ((TH - 1) * STRIDE + 3) * HC;
+  static_assert(!(UP && STRIDE != 1), "the upsampling loader is stride 1");
   constexpr int NPAD = NT * WN * 16;         // weight rows staged per K-step
   constexpr int NBG = NPAD / 8;              // 8-row DMA groups
   constexpr int NB = (NBG + 3) / 4;          // DMA instructions per wave per stage
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
         fd_rowcol((unsigned)i, hp.dcpt, upx, uch);
         const int px = (int)upx, ch = (int)uch;
         const int hy = px / HC, hx = px - hy * HC;
-        const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+        const int y = y0 * STRIDE - p.pad_t + hy, x = x0 * STRIDE - p.pad_l + hx;
         const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         dst[n] = i < nitems ? px * hp.PP + ch * 16 : -1;
         blend[n] = false;
@@ -184,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
     while (c_dx >= 3) { c_dx -= 3; c_off += HC * hp.PP; }
     c_off += c_dx * hp.PP;
   }
-  const unsigned char* xrow = sX + ((wm * 4) * HC + fr) * hp.PP;      // pixel (row wm * 4, column fr) of the halo = tap (0, 0) of output row wm * 4
-  const int growb = HC * hp.PP;
+  const unsigned char* xrow = sX + ((wm * 4 * STRIDE) * HC + fr * STRIDE) * hp.PP;      // tap (0, 0) of output pixel (row wm * 4, column fr)
+  const int growb = STRIDE * HC * hp.PP;                                                 // one output row further
 
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks % STAGES;
@@ -285,7 +288,7 @@ constexpr HCfg kHCfg[] = {
 };
 constexpr int kNumHCfg = sizeof(kHCfg) / sizeof(kHCfg[0]);
 
-template <typename H, int NT, int WN, bool UP = false>
+template <typename H, int NT, int WN, bool UP = false, int STRIDE = 1>
 int launch_h(const ConvP& p, hipStream_t s) {
   constexpr int TH = 4 * (4 / WN);
   constexpr int NPAD = NT * WN * 16;
@@ -298,7 +301,7 @@ int launch_h(const ConvP& p, hipStream_t s) {
   if ((slots & 1) == 0) ++slots;
   hp.PP = slots * 16;
   hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
-  const int hpix = (TH + 2) * 18;
+  const int hpix = ((TH - 1) * STRIDE + 3) * (15 * STRIDE + 3);
   const size_t halo = (size_t)hpix * hp.PP;
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
   // weight stages: two.  More would hide more of the DMA latency behind MFMAs, but measured (tools/conv_bench.py --halo, us with
@@ -309,12 +312,12 @@ int launch_h(const ConvP& p, hipStream_t s) {
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
 #define HL(ST)                                                                                                                      \
   do {                                                                                                                              \
-    auto k = conv3x3_halo_kernel<H, NT, WN, ST, UP>;                                                                                \
+    auto k = conv3x3_halo_kernel<H, NT, WN, ST, UP, STRIDE>;                                                                        \
     static bool attr = false;                                                                                                       \
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; } \
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);                                                         \
   } while (0)
-  if constexpr (UP) { HL(2); } else { if (stages == 4) HL(4); else if (stages == 3) HL(3); else HL(2); }
+  if constexpr (UP || STRIDE != 1) { HL(2); } else { if (stages == 4) HL(4); else if (stages == 3) HL(3); else HL(2); }
 #undef HL
   return 0;
 }
@@ -324,10 +327,10 @@ int launch_h(const ConvP& p, hipStream_t s) {
 int conv3x3_halo_num_variants() { return kNumHCfg; }
 void conv3x3_halo_debug_stages(int v) { g_halo_stages = v; }
 
-// The problems this kernel takes: 3x3, stride 1, undilated, 16-bit, Cin a multiple of 8 and <= 128 (the plan uses it up to 64), no
+// The problems this kernel takes: 3x3, stride 1 or 2, undilated, 16-bit, Cin a multiple of 8 and <= 128 (the plan uses it up to 64), no
 // LayerNorm epilogue / per-image weights.
 bool conv3x3_halo_takes(const ConvP& p) {
-  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 128 && p.Cout % 8 == 0 &&
+  return p.KH == 3 && p.KW == 3 && (p.stride == 1 || (p.stride == 2 && p.up_src == nullptr)) && p.dil <= 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cin <= 128 && p.Cout % 8 == 0 &&
          p.Cout <= 512 && p.ln_gamma == nullptr && p.rows_per_batch == 0 && p.k2 == 0 && p.K == 9 * p.Cin &&
          p.pad_t >= 0 && p.pad_l >= 0 && p.pad_t <= 2 && p.pad_l <= 2;
 }
@@ -357,6 +360,20 @@ int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s) {
       default: return -3;
     }
 #undef HU
+  }
+  if (p.stride == 2) {
+#define HS(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN, false, 2>(p, s) : launch_h<bf16_t, NT, WN, false, 2>(p, s))
+    switch (v) {
+      case 0: return HS(1, 1);
+      case 1: return HS(2, 1);
+      case 2: return HS(4, 1);
+      case 3: return HS(2, 2);
+      case 4: return HS(4, 2);
+      case 5: return HS(5, 2);
+      case 7: return HS(1, 2);
+      default: return -3;
+    }
+#undef HS
   }
 #define HV(NT, WN) (p.f16 ? launch_h<f16_t, NT, WN>(p, s) : launch_h<bf16_t, NT, WN>(p, s))
   switch (v) {

@@ -308,10 +308,13 @@ int g_tput = 0;                 // cfp_debug_set key 17 (tools): 1 = every call 
 int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
 int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
+int g_halo_s2 = 1;              // cfp_debug_set key 18: 0 = stride-2 convs never take the halo kernel
 int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whole-depth halo kernel, 2 = wherever it can run
 // Where conv3x3_halo.hip beats the implicit GEMMs (tools/conv_bench.py --halo at batch 8, us halo / without: 614400 px x 16 ch, K = 360:
 // 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
+// stride 2 (tools/conv_bench.py --halo, us with / without): stem 614400 x 40 x 72 25.5-27 / 29, 153600 x 64 x 144 23.4 / 26, 38400 x 160 x 360 20.8 / 23.4
+static bool halo_wins_s2(long long M, int Cout) { return g_halo == 2 || (g_halo == 1 && g_halo_s2 && M >= 30000 && Cout <= 160); }
 static bool halo_wins(long long M, int Cout, bool tput) {
   if (g_halo == 2) return true;
   if (g_halo == 1 && tput && M >= 100000 && Cout <= 64) return true;      // 153600 px x 32 / 64 ch: 8 x 16 pixel tiles, 10.6 -> 7.6 / 12.9 -> 10.8 / 20.8 -> 16.7 us per call in flight
@@ -326,6 +329,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 16: g_probe = value; return CFP_OK;
     case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
+    case 18: g_halo_s2 = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
@@ -528,8 +532,11 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (w2) { pl.gen1 = false; pl.direct = -1; p.k2 = cdiv(p.K, 64); }
     // few input channels, many pixels: the whole-depth halo kernel (conv3x3_halo.hip); cfp_debug_set(0, 300 + v) forces its variant v,
     // any other forced variant / the gen-1 switch keeps the implicit GEMMs (A/B, tests)
-    if (!w2 && c33 && !want_mom && conv3x3_halo_takes(p) && (g_force_variant < 0 ? (Cin <= 64 && halo_wins(p.M, Cout, tput)) : g_force_variant >= 300)) {
+    const bool c33s2 = KH == 3 && KW == 3 && stride == 2 && !ln_gamma && rpb == 0;
+    if (!w2 && (c33 || c33s2) && !want_mom && conv3x3_halo_takes(p) &&
+        (g_force_variant < 0 ? (Cin <= 64 && (stride == 1 ? halo_wins(p.M, Cout, tput) : halo_wins_s2(p.M, Cout))) : g_force_variant >= 300)) {
       int hv = g_force_variant >= 300 ? g_force_variant - 300 : -1;
+      if (hv < 0 && stride == 2 && Cout > 64) hv = 3;
       if (hv < 0 && tput) hv = (p.M < 300000 && Cout <= 32) ? 7 : (p.M < 300000 && Cout <= 64) ? 3 : (Cout > 160 && Cout <= 224) ? 6 : -1;
       int rc = conv3x3_halo_launch(hv, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");

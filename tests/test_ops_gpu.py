@@ -237,6 +237,54 @@ def test_conv3x3_halo_every_variant(variant, dtype):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
+def test_conv3x3_halo_stride2(variant, dtype):
+    """The halo kernel's stride-2 form (stem, first block of an encoder stage; TF-"same" padding = 0 top / left, 1 bottom / right on even
+    inputs): against float32 torch, against the implicit GEMM on the same operands, and bit-exact on small integers."""
+    lib = hip.load()
+    cases = [(1, 34, 46, 8, 40, 3, 2, (0, 0, 1, 1)), (2, 24, 32, 16, 64, 3, 2, (0, 0, 1, 1)), (1, 21, 35, 40, 160, 3, 2, (1, 1, 1, 1)),
+             (1, 66, 20, 24, 16, 3, 2, (0, 0, 1, 1)), (1, 10, 130, 64, 32, 3, 2, (1, 0, 0, 1))]
+    ran = 0
+    try:
+        for case in cases:
+            B, H, W, Cin, Cout, k, s, pads = case
+            if Cout > 4 * HALO_CAP[variant]:
+                continue
+            th = 16 if variant in (0, 1, 2) else 8
+            slots = Cin // 8 + (1 - (Cin // 8) % 2)
+            if ((th - 1) * 2 + 3) * 33 * slots * 16 + 2 * min(HALO_CAP[variant], 224) * 128 > 160 * 1024:
+                continue                                    # the stride-2 halo of this tile does not fit the LDS: the plan never picks it
+            ref, xa, wa, scale, shift, ra, Ho, Wo = _conv_ref_and_args(case, dtype)
+            lib.cfp_debug_set(0, 300 + variant)
+            out = ops.new_act(B * Ho * Wo, Cout, dtype, DEV, ld=Cout + 24, zero=True)
+            out = ops.Act(out.buf, 16, Cout)
+            ops.conv2d(xa, wa, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            close(from_nhwc(out.torch(), B, Ho, Wo), ref, dtype, f"halo3x3 stride 2 v{variant} conv {case}")
+            assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+            lib.cfp_debug_set(0, 4)
+            out2 = ops.new_act(B * Ho * Wo, Cout, dtype, DEV)
+            ops.conv2d(xa, wa, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            assert torch.equal(out.torch().view(torch.int16), out2.torch().view(torch.int16)), f"halo stride 2 v{variant} != igemm2 {case}"      # same K order
+            # integers
+            x = _int_tensor((B, Cin, H, W), -3, 3, 1)
+            w = _int_tensor((Cout, Cin, k, k), -2, 2, 2)
+            refi = F.conv2d(F.pad(x.double(), (pads[1], pads[3], pads[0], pads[2])), w.double(), None, s).float()
+            lib.cfp_debug_set(0, 300 + variant)
+            outi = ops.new_act(B * Ho * Wo, Cout, dtype, DEV)
+            wi = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dtype).to(DEV)
+            ops.conv2d(to_act(nhwc(x), dtype), wi, None, None, outi, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_NONE, None, None)
+            torch.cuda.synchronize()
+            got = outi.torch().cpu().reshape(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+            assert torch.equal(got.view(torch.int16), _bits(refi, dtype)), f"halo stride 2 variant {variant} integers {case}"
+            ran += 1
+    finally:
+        lib.cfp_debug_set(0, -1)
+    assert ran > 0
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", list(range(8)))
 def test_conv3x3_halo_bit_exact_on_integers(variant, dtype):
     lib = hip.load()

@@ -73,7 +73,7 @@ rows = []
 tot_auto = tot_v1 = tot_best = 0.0
 for key, (name, args, cnt) in uniq.items():
     B, H, W, Cin, Cout, KH, st, Ho, Wo, ln, piw, has_res = key
-    if a.halo and not (KH == 3 and st == 1 and Cin <= 64):
+    if a.halo and not (KH == 3 and st in (1, 2) and Cin <= 64):
         continue
     if a.kgroups and (ln or B * Ho * Wo * Cout > 9600 * 1400):
         continue
@@ -118,10 +118,10 @@ for key, (name, args, cnt) in uniq.items():
             if t < best[0]:
                 best = (t, f"v{v}")
         lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
-    if (a.sweep or a.halo) and not ln and KH == 3 and st == 1 and Cin <= 64 and Cin % 8 == 0 and not piw:
+    if (a.sweep or a.halo) and not ln and KH == 3 and st in (1, 2) and Cin <= 64 and Cin % 8 == 0 and not piw:
         lib.cfp_debug_set(1, 1)
         for v in range(8):
-            if Cout > 4 * (16, 32, 64, 64, 128, 160, 224, 32)[v]:
+            if Cout > 4 * (16, 32, 64, 64, 128, 160, 224, 32)[v] or (st == 2 and v == 6):
                 continue
             lib.cfp_debug_set(0, 300 + v)
             try:
@@ -134,10 +134,10 @@ for key, (name, args, cnt) in uniq.items():
     lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
     if a.halo:
         lib.cfp_debug_set(12, 2)                      # the halo kernel wherever it can run, its automatic tile, 2 / 3 / 4 weight stages
-        for st in (2, 3, 4):
-            lib.cfp_debug_set(13, st)
+        for stages in (2, 3, 4):
+            lib.cfp_debug_set(13, stages)
             try:
-                sweep[f"n_st{st}"] = timeit(name, args, a.reps)
+                sweep[f"n_st{stages}"] = timeit(name, args, a.reps)
             except RuntimeError:
                 pass
         lib.cfp_debug_set(13, 0)
