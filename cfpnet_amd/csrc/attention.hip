@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) void attn_apply_kernel(ApP p) {
   }
 }
 
+int g_kv_target_waves = 2048;      // cfp_debug_set key 19 (A/B)
 int pick_nsplit(int S, long long groups_heads) {
   // enough waves to cover the chip, at least ~64 keys per wave
-  long long want = (2048 + groups_heads - 1) / groups_heads;
+  long long want = (g_kv_target_waves + groups_heads - 1) / groups_heads;
   int by_keys = (S + 63) / 64;
   long long n = want < by_keys ? want : by_keys;
   if (n < 1) n = 1;
@@ -203,6 +204,8 @@ int pick_nsplit(int S, long long groups_heads) {
 }
 
 }  // namespace
+
+void cfp_attn_debug_set(int value) { g_kv_target_waves = value; }
 
 extern "C" size_t cfp_attn_kv_ws_floats(int NB, int Hk, int Wk, int th, int tw, int heads, int d) {
   if (NB <= 0 || Hk <= 0 || Wk <= 0 || th <= 0 || tw <= 0 || heads <= 0 || d <= 0) return 0;
