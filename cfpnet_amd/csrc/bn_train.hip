@@ -404,10 +404,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, i
   }
 }
 
+int g_red_target = 1024;         // cfp_debug_set key 20: workgroups a column reduction aims for
+int g_ew_target = 2048;          // cfp_debug_set key 21: workgroups an elementwise sweep aims for
 inline int red_splits(long long rows, int C, int ve) {
   const int colbits = rc_colbits(C, ve);
   const int colblk = cdiv(C, ve << colbits);
-  long long ns = 1024 / colblk;
+  long long ns = g_red_target / colblk;
   const long long mx = (rows + 8 * (256 >> colbits) - 1) / (8 * (256 >> colbits));      // at least 8 rows per row lane
   if (ns > mx) ns = mx;
   if (ns > 4096) ns = 4096;
@@ -421,7 +423,7 @@ inline EwGrid ew_cols(long long rows, int C, int ve) {
   while ((1 << colbits) < cv && colbits < 5) ++colbits;            // 1 .. 32 column lanes
   const int cols = 1 << colbits, lanes = 256 >> colbits;
   const unsigned gx = (unsigned)cdiv(cv, cols);
-  long long ns = 2048 / gx;                                          // ~8 workgroups per CU over the launch
+  long long ns = g_ew_target / gx;                                   // ~8 workgroups per CU over the launch
   const long long mx = (rows + 4 * lanes - 1) / (4 * lanes);
   if (ns > mx) ns = mx;
   if (ns > 65535) ns = 65535;
@@ -451,6 +453,8 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
 }
 
 }  // namespace
+
+void cfp_bn_debug_set(int key, int value) { (key == 20 ? g_red_target : g_ew_target) = value; }
 
 extern "C" size_t cfp_bn_ws_bytes(int C) { return C > 0 ? (size_t)4096 * 2 * C * sizeof(float) : 0; }
 

@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int kNormBlocks = 256;
+constexpr int kNormBlocks = 1024;
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long long n, float lr, float beta1, float beta2,
@@ -48,14 +48,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// 16-byte loads, four independent f64 chains per thread (the scalar-load form ran at 0.65 TB/s: 134 us for 21.8 M gradients)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ partial) {
   __shared__ double red[256];
-  double s = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const double t = (double)x[i];
-    s += t * t;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 t = reinterpret_cast<const f32x4*>(x)[i];
+    s0 = fma((double)t[0], (double)t[0], s0); s1 = fma((double)t[1], (double)t[1], s1);
+    s2 = fma((double)t[2], (double)t[2], s2); s3 = fma((double)t[3], (double)t[3], s3);
   }
-  red[threadIdx.x] = s;
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double t = (double)x[i];
+    s0 += t * t;
+  }
+  red[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
@@ -65,12 +72,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 }
 
 // out[0] = clip factor min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_), out[1] = norm; a norm that is not finite
-// (an overflow somewhere in a 16-bit backward) makes out[0] = -1 -- cfp_adamw_step then skips the step -- and counts in out[2]
+// (an overflow somewhere in a 16-bit backward) makes out[0] = -1 -- cfp_adamw_step then skips the step -- and counts in out[2].
+// One wave: lanes stride over the partials, then a fixed-order tree through LDS.
 __global__ void clip_factor_kernel(const double* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ double red[64];
+  if (blockIdx.x != 0) return;
   double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += partial[i];
-  const float norm = (float)sqrt(s);
+  for (int i = threadIdx.x; i < nblk; i += 64) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float norm = (float)sqrt(red[0]);
   out[1] = norm;
   if (!(norm < 3.0e38f)) { out[0] = -1.f; out[2] += 1.f; return; }      // inf or nan
   const float c = max_norm / (norm + 1e-6f);
@@ -100,7 +116,7 @@ extern "C" size_t cfp_grad_clip_ws_bytes(void) { return (size_t)kNormBlocks * si
 
 extern "C" int cfp_grad_clip_factor(const float* grad, long long n, float max_norm, void* ws, size_t ws_bytes, float* out,
                                     cfp_stream_t stream) {
-  CFP_REQUIRE(grad && ws && out, CFP_EINVAL, "cfp_grad_clip_factor: null pointer");
+  CFP_REQUIRE(grad && ws && out && aligned16(grad), CFP_EINVAL, "cfp_grad_clip_factor: null or misaligned pointer");
   CFP_REQUIRE(n > 0 && max_norm > 0.f, CFP_ESHAPE, "cfp_grad_clip_factor: bad arguments");
   CFP_REQUIRE(ws_bytes >= cfp_grad_clip_ws_bytes() && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, CFP_EINVAL,
               "cfp_grad_clip_factor: workspace too small or misaligned");

@@ -385,7 +385,7 @@ int cfp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 /* nn.utils.clip_grad_norm_ (train.py:130) without a host sync: out[0] = min(1, max_norm / (||grad||_2 + 1e-6)),
  * out[1] = ||grad||_2, both on the device; `out` holds 3 floats.  OVERFLOW GUARD of the 16-bit training modes: when the norm is not
  * finite (an inf / nan anywhere in the gradient) out[0] = -1 and out[2] is incremented; cfp_adamw_step given such a grad_scale leaves
- * parameters and moments untouched (the step is skipped, like torch.cuda.amp.GradScaler does). */
+ * parameters and moments untouched (the step is skipped, like torch.cuda.amp.GradScaler does).  `grad` must be 16-byte aligned. */
 size_t cfp_grad_clip_ws_bytes(void);
 int cfp_grad_clip_factor(const float* grad, long long n, float max_norm, void* ws, size_t ws_bytes, float* out,
                          cfp_stream_t stream);

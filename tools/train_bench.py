@@ -7,8 +7,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfpnet_amd import spec, synthetic, weights
 from cfpnet_amd.trainer import Trainer
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16")); ap.add_argument("--graph", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16")); ap.add_argument("--graph", action="store_true"); ap.add_argument("--debug", default="", help="cfp_debug_set switches, e.g. 20=2048,21=4096")
 a = ap.parse_args()
+if a.debug:
+    from cfpnet_amd import hip
+    for kv in a.debug.split(","):
+        k, v = kv.split("="); hip.load().cfp_debug_set(int(k), int(v))
 layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
 H, W = 416, 544
