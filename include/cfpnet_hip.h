@@ -97,7 +97,8 @@ int cfp_conv2d_variant(int M, int Cout);
 /* Test/benchmark knobs, not for production use (process-global, not thread-safe):
  * key 0 = force second-generation variant v, or 200 + v = direct 3x3 variant v (-1 = automatic), key 1 = force K-splits (-1 = automatic),
  * key 2 = 1 routes bf16 through the first-generation kernel; keys 3 / 4 = depthwise 3x3 channel vectors per
- * workgroup (8 / 16) and output rows per strip (0 = automatic); key 5 = 1 forces the VALU depthwise kernel. */
+ * workgroup (8 / 16) and output rows per strip (0 = automatic); key 5 = 1 forces the VALU depthwise kernel; keys 6-21 are
+ * listed in README.md ("Kernel choices") and at the dispatch in csrc/conv_igemm.hip. */
 int cfp_debug_set(int key, int value);
 
 /* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused
