@@ -62,6 +62,8 @@ class Tape:
         self._const: Dict[Tuple[str, int], torch.Tensor] = {}
         self.side, self._forked = side, False
         self.marks: Dict[str, int] = {}          # name -> tape position: `backward(stop=...)` runs the closures recorded after it
+        # weight-gradient slab reductions batched into a few launches at the end of backward() (train_ops.WgradQueue; CFP_WGRAD_DEFER=0: per layer)
+        self.wq = train_ops.WgradQueue() if os.environ.get("CFP_WGRAD_DEFER", "1") != "0" else None
         self.conv_stats = os.environ.get("CFP_CONV_STATS", "1") != "0"      # BatchNorm statistics from the producing conv's epilogue (16-bit modes)
 
     # ------------------------------------------------------------------ helpers
@@ -95,7 +97,20 @@ class Tape:
             compute(p.gview, 0.0)
             p.g = p.gview
         else:
+            self.flush_wgrad()          # a postponed reduction may still owe this view its first term
             compute(p.gview, 1.0)
+
+    def _queue(self, out, beta) -> Optional["train_ops.WgradQueue"]:
+        """The reduction queue for a weight gradient written (not accumulated) into a preallocated view, else None."""
+        return self.wq if (out is not None and beta == 0.0) else None
+
+    def flush_wgrad(self) -> None:
+        if self.wq is None or not self.wq.jobs:
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        if self.side is not None and cur != self.side:
+            cur.wait_stream(self.side)          # the slab launches run on the side stream
+        self.wq.flush()
 
     @staticmethod
     def _direct(p: P) -> Optional[torch.Tensor]:
@@ -132,6 +147,7 @@ class Tape:
         if self._forked:
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
             self._forked = False
+        self.flush_wgrad()
         self.bw = self.bw[:lo]
 
     # ------------------------------------------------------------------ dense conv / linear
@@ -156,12 +172,17 @@ class Tape:
                 if bias is not None and g.dtype != torch.float32 and bias.gview is not None and w.gview is not None:
                     # 16-bit modes: the bias gradient comes out of the weight-gradient launch (one more matrix-core product per step)
                     bw_, bb_ = (0.0 if w.g is None else 1.0), (0.0 if bias.g is None else 1.0)
-                    train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=w.gview, beta=bw_, db=bias.gview, beta_b=bb_)
+                    first = bw_ == 0.0 and bb_ == 0.0
+                    if not first:
+                        self.flush_wgrad()
+                    train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=w.gview, beta=bw_, db=bias.gview, beta_b=bb_,
+                                           queue=self.wq if first else None)
                     w.g, bias.g = w.gview, bias.gview
                     return
                 if bias is not None:
                     self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
-                self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta))
+                self.pgrad(w, lambda out, beta: train_ops.conv2d_wgrad(x.t, g, B, H, W, k, k, stride, pt, pl, Ho, Wo, dw=out, beta=beta,
+                                                                       queue=self._queue(out, beta)))
             self.off_path(param_grads)
             if x.needs_grad and k == stride and k > 1 and pt == 0 and pl == 0:
                 # non-overlapping patches (the GSA sub-sampling conv, kernel = stride = window size): every input pixel belongs to

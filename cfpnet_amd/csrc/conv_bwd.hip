@@ -17,6 +17,7 @@
 //                    Wt[ci][KH-1-kh][KW-1-kw][co] = W[co][kh][kw][ci], after which dX is a plain cfp_conv2d_nhwc call
 //                    (stride 1, padding K-1-pad, input dilation = the forward stride).
 #include "common.h"
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -370,6 +371,59 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for MANY layers in one launch (cfp_wgrad_reduce_jobs): the slab sets of up to WJ_MAX weight-gradient launches
+// travel by value in the kernel arguments (a graph node then carries them; no table in device memory), a workgroup finds its job by
+// a uniform binary search over the block prefix and walks it exactly like wgrad_reduce_kernel<EW> does -- same lanes, same order, so
+// the gradients are bit-identical to the per-layer launches.
+constexpr int WJ_MAX = 48;
+struct WJob { const float* slabs; float* dw; float* db; long long n, n_dw; int nsplit, ewbits; float beta, beta_b; };
+struct WJobBatch { WJob j[WJ_MAX]; int start[WJ_MAX + 1]; int njobs; };
+static_assert(sizeof(WJobBatch) <= 4000, "the job table travels in the kernel arguments");
+
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const WJobBatch b) {
+  __shared__ float red[256];
+  int lo = 0, hi = b.njobs;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= b.start[mid]) lo = mid; else hi = mid;
+  }
+  const float* __restrict__ slabs = b.j[lo].slabs;
+  float* __restrict__ dw = b.j[lo].dw;
+  float* __restrict__ db = b.j[lo].db;
+  const long long n = b.j[lo].n, n_dw = b.j[lo].n_dw;
+  const int nsplit = b.j[lo].nsplit, ewbits = b.j[lo].ewbits;
+  const float beta = b.j[lo].beta, beta_b = b.j[lo].beta_b;
+  const int nblk = b.start[lo + 1] - b.start[lo], lb = (int)blockIdx.x - b.start[lo];
+  const int EW = 1 << ewbits, LANES = 256 >> ewbits;
+  const int e = threadIdx.x & (EW - 1), sl = threadIdx.x >> ewbits;
+  for (long long i0 = (long long)lb * EW; i0 < n; i0 += (long long)nblk * EW) {
+    const long long i = i0 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int j = sl;
+      for (; j + 3 * LANES < nsplit; j += 4 * LANES) {
+        s0 += slabs[(long long)j * n + i]; s1 += slabs[(long long)(j + LANES) * n + i];
+        s2 += slabs[(long long)(j + 2 * LANES) * n + i]; s3 += slabs[(long long)(j + 3 * LANES) * n + i];
+      }
+      for (; j < nsplit; j += LANES) s0 += slabs[(long long)j * n + i];
+    }
+    float s = (s0 + s1) + (s2 + s3);
+    if (LANES > 1) {
+      red[sl * EW + e] = s;
+      __syncthreads();
+      if (sl == 0) {
+        s = 0.f;
+        for (int l = 0; l < LANES; ++l) s += red[l * EW + e];
+      }
+    }
+    if (sl == 0 && i < n) {
+      if (i < n_dw) dw[i] = beta != 0.f ? beta * dw[i] + s : s;
+      else db[i - n_dw] = beta_b != 0.f ? beta_b * db[i - n_dw] + s : s;
+    }
+    if (LANES > 1) __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void weight_flip_kernel(const T* __restrict__ w, T* __restrict__ wt, int Cout, int KH, int KW, int Cin) {
   const long long n = (long long)Cout * KH * KW * Cin;
@@ -464,9 +518,9 @@ extern "C" int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_
                                ws_bytes, stream);
 }
 
-extern "C" int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
-                                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
-                                     int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+static int wgrad_impl(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                      int dtype, void* ws, size_t ws_bytes, cfp_wgrad_job* job, cfp_stream_t stream) {
   CFP_REQUIRE(x && dy && dw && ws, CFP_EINVAL, "cfp_conv2d_wgrad: null pointer");
   CFP_REQUIRE(!db || is16(dtype), CFP_EINVAL, "cfp_conv2d_wgrad_bias: the fused bias gradient is a 16-bit path (float32: cfp_colsum)");
   CFP_REQUIRE(dtype_ok(dtype), CFP_EINVAL, "cfp_conv2d_wgrad: bad dtype");
@@ -510,15 +564,61 @@ extern "C" int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, in
 #undef WG16_T
 #undef WG16
   const long long n_dw = (long long)Cout * K, n = n_dw + (db ? Cout : 0);
+  if (job) std::memset(job, 0, sizeof(*job));                  // nsplit = 0: nothing left to reduce
   if (p.nsplit > 1 || beta != 0.f || db) {
     // enough workgroups first, then as few split lanes as that allows
     const int ew = (n >= 256 * 512 || p.nsplit < 8) ? 256 : (n >= 64 * 512 || p.nsplit < 32) ? 64 : 32;
     const int blocks = (int)std::min<long long>(2048, (n + ew - 1) / ew);
-    if (ew == 256) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
+    if (job) {                                                 // the caller reduces later, with other layers (cfp_wgrad_reduce_jobs)
+      job->slabs = p.slabs; job->dw = dw; job->db = db; job->n = n; job->n_dw = n_dw; job->nsplit = p.nsplit; job->ew = ew;
+      job->beta = beta; job->beta_b = beta_b;
+    } else if (ew == 256) hipLaunchKernelGGL(wgrad_reduce_kernel<256>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
     else if (ew == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
     else hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, p.slabs, p.nsplit, n, dw, beta, n_dw, db, beta_b);
   }
   return cfp_check_launch("cfp_conv2d_wgrad");
+}
+
+extern "C" int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                                     int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                                     int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream) {
+  return wgrad_impl(x, x_ld, dy, dy_ld, dw, db, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, beta_b, dtype, ws, ws_bytes,
+                    nullptr, stream);
+}
+
+extern "C" int cfp_conv2d_wgrad_deferred(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                                         int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                                         int dtype, void* ws, size_t ws_bytes, cfp_wgrad_job* job, cfp_stream_t stream) {
+  CFP_REQUIRE(job, CFP_EINVAL, "cfp_conv2d_wgrad_deferred: null job");
+  return wgrad_impl(x, x_ld, dy, dy_ld, dw, db, B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, beta_b, dtype, ws, ws_bytes,
+                    job, stream);
+}
+
+extern "C" int cfp_wgrad_reduce_jobs(const cfp_wgrad_job* jobs, int njobs, cfp_stream_t stream) {
+  CFP_REQUIRE(njobs >= 0 && (jobs || njobs == 0), CFP_EINVAL, "cfp_wgrad_reduce_jobs: bad arguments");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  WJobBatch b;
+  int nb = 0, blocks = 0;
+  auto flush = [&]() {
+    if (nb == 0) return;
+    b.njobs = nb; b.start[nb] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
+    nb = 0; blocks = 0;
+  };
+  for (int i = 0; i < njobs; ++i) {
+    const cfp_wgrad_job& j = jobs[i];
+    if (j.nsplit <= 0) continue;                               // written in place by its launch
+    CFP_REQUIRE(j.slabs && j.dw && j.n > 0 && j.n_dw > 0 && j.n_dw <= j.n && (j.db || j.n_dw == j.n) &&
+                (j.ew == 32 || j.ew == 64 || j.ew == 256), CFP_EINVAL, "cfp_wgrad_reduce_jobs: bad job");
+    for (int k = 0; k < nb; ++k)                               // two jobs of one launch must not write the same tensor: a new launch
+      if (b.j[k].dw == j.dw || (j.db && b.j[k].db == j.db)) { flush(); break; }
+    b.j[nb] = WJob{j.slabs, j.dw, j.db, j.n, j.n_dw, j.nsplit, j.ew == 256 ? 8 : j.ew == 64 ? 6 : 5, j.beta, j.beta_b};
+    b.start[nb] = blocks;
+    blocks += (int)std::min<long long>(2048, (j.n + j.ew - 1) / j.ew);
+    if (++nb == WJ_MAX) flush();
+  }
+  flush();
+  return cfp_check_launch("cfp_wgrad_reduce_jobs");
 }
 
 extern "C" int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream) {

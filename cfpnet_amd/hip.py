@@ -74,6 +74,8 @@ SIGNATURES = {
     "cfp_conv2d_wgrad_ws_bytes": (_sz, [_i, _i, _i]),
     "cfp_conv2d_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 12 + [_f, _i, _p, _sz, _p]),
     "cfp_conv2d_wgrad_bias": (_i, [_p, _i, _p, _i, _p, _p] + [_i] * 12 + [_f, _f, _i, _p, _sz, _p]),
+    "cfp_conv2d_wgrad_deferred": (_i, [_p, _i, _p, _i, _p, _p] + [_i] * 12 + [_f, _f, _i, _p, _sz, _p, _p]),
+    "cfp_wgrad_reduce_jobs": (_i, [_p, _i, _p]),
     "cfp_conv2d_weight_flip": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_weight_flip_blocks": (_i, [_ll]),
     "cfp_conv2d_weight_flip_batch": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -125,6 +127,12 @@ SIGNATURES = {
     "cfp_depth_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_bin_head_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
 }
+
+class WgradJob(C.Structure):
+    """cfp_wgrad_job of include/cfpnet_hip.h."""
+    _fields_ = [("slabs", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("n", C.c_longlong), ("n_dw", C.c_longlong),
+                ("nsplit", C.c_int), ("ew", C.c_int), ("beta", C.c_float), ("beta_b", C.c_float)]
+
 
 _lib: Optional[C.CDLL] = None
 

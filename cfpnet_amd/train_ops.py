@@ -10,6 +10,7 @@ import math
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
+import ctypes
 import torch
 
 from . import hip
@@ -277,10 +278,28 @@ def lr_group_of(hist_encoder_10x: bool):
 # Backward building blocks of the conv / BatchNorm layers (csrc/conv_bwd.hip, csrc/bn_train.hip).  Thin wrappers over
 # the C ABI on NHWC row tensors [rows, C]; `autograd_hip.Tape` chains them into the backward of the whole network.
 # ------------------------------------------------------------------------------------------------------------------
+class WgradQueue:
+    """Weight-gradient reductions put off until `flush()`: cfp_conv2d_wgrad_deferred leaves its slabs in `ws` and a job record here,
+    cfp_wgrad_reduce_jobs finishes up to 48 layers per launch (bit-identical to the per-layer reduction).  The queue keeps the slab
+    tensors alive until they have been reduced."""
+
+    def __init__(self):
+        self.jobs: list = []
+        self.keep: list = []
+
+    def flush(self) -> None:
+        if self.jobs:
+            from . import hip
+            arr = (hip.WgradJob * len(self.jobs))(*self.jobs)
+            hip.call("cfp_wgrad_reduce_jobs", ctypes.addressof(arr), len(self.jobs), hip.current_stream())
+        self.jobs, self.keep = [], []
+
+
 def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, dw: Optional[torch.Tensor] = None,
-                 beta: float = 0.0, db: Optional[torch.Tensor] = None, beta_b: float = 0.0) -> torch.Tensor:
+                 beta: float = 0.0, db: Optional[torch.Tensor] = None, beta_b: float = 0.0, queue: Optional[WgradQueue] = None) -> torch.Tensor:
     """x2d [B*H*W, Cin], dy2d [B*Ho*Wo, Cout] (same dtype: f32 / bf16 / f16) -> dw [Cout, KH*KW*Cin] f32 (= beta*dw + grad).
-    `db` (16-bit dtypes): float32 [>= Cout], receives beta_b*db + the bias gradient (column sums of dy) from the same launch."""
+    `db` (16-bit dtypes): float32 [>= Cout], receives beta_b*db + the bias gradient (column sums of dy) from the same launch.
+    `queue`: leave the reduction of the split slabs to `queue.flush()` (dw / db hold the result only after it)."""
     from . import hip, ops
     Cin, Cout = x2d.shape[1], dy2d.shape[1]
     K, M = KH * KW * Cin, B * Ho * Wo
@@ -291,6 +310,16 @@ def conv2d_wgrad(x2d: torch.Tensor, dy2d: torch.Tensor, B, H, W, KH, KW, stride,
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x2d.device)
     if db is not None:
         assert x2d.dtype != torch.float32 and db.dtype == torch.float32 and db.numel() >= Cout
+    if queue is not None:
+        job = hip.WgradJob()
+        hip.call("cfp_conv2d_wgrad_deferred", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), hip.ptr(db), B, H, W,
+                 Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, beta_b, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, ctypes.addressof(job),
+                 hip.current_stream())
+        if job.nsplit > 0:
+            queue.jobs.append(job)
+            queue.keep.append((ws, dw, db))
+        return dw
+    if db is not None:
         hip.call("cfp_conv2d_wgrad_bias", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), db.data_ptr(), B, H, W,
                  Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo, beta, beta_b, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
         return dw

@@ -451,6 +451,22 @@ int cfp_conv2d_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* 
 int cfp_conv2d_wgrad_bias(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
                           int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
                           int dtype, void* ws, size_t ws_bytes, cfp_stream_t stream);
+/* The reduction of the slabs postponed and batched: cfp_conv2d_wgrad_deferred runs the slab launch of cfp_conv2d_wgrad_bias and
+ * describes the remaining reduction in *job (host memory; job->nsplit = 0 when the launch already wrote dw in place) instead of
+ * launching it; cfp_wgrad_reduce_jobs(jobs, n) then finishes up to 48 layers per launch (the job table travels in the kernel
+ * arguments), in the same summation order as the per-layer reduction: bit-identical gradients, ~240 launches fewer per training
+ * step.  `ws` of a deferred call must stay untouched until its job has been reduced; jobs that write the same dw / db are put
+ * into separate launches, in the order given. */
+typedef struct cfp_wgrad_job {
+  const float* slabs; float* dw; float* db;
+  long long n, n_dw;
+  int nsplit, ew;
+  float beta, beta_b;
+} cfp_wgrad_job;
+int cfp_conv2d_wgrad_deferred(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, float* db, int B, int H, int W, int Cin,
+                              int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
+                              int dtype, void* ws, size_t ws_bytes, cfp_wgrad_job* job, cfp_stream_t stream);
+int cfp_wgrad_reduce_jobs(const cfp_wgrad_job* jobs, int njobs, cfp_stream_t stream);
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: the weights the data gradient convolves with. */
 int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream);
 /* The same for n weight tensors in one launch (a training step flips every convolution's weights once).  `desc` is a DEVICE

@@ -552,3 +552,46 @@ def test_conv_weight_gradient_with_fused_bias_gradient(case, dtype):
     got = db.cpu()
     assert float((got[:Cout] - (1.0 + want)).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-4
     assert float((got[Cout:] - 2.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_batched_weight_gradient_reduction_is_bit_identical(dtype):
+    """cfp_conv2d_wgrad_deferred + cfp_wgrad_reduce_jobs (many layers' slab reductions in one launch, the job table in the kernel
+    arguments) == the per-layer launches, bit for bit: with and without the fused bias gradient, with beta, with more jobs than one
+    launch holds (48) and with two jobs that write the same tensor (they must land in separate launches, in order)."""
+    cases = (CASES[:6] + BIG_WGRAD) * 6                      # 66 calls (a few finish in place): two launches
+    q = train_ops.WgradQueue()
+    want, got = [], []
+    for n, case in enumerate(cases):
+        B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+        Ho, Wo = (H + pt + pb - k) // s + 1, (W + pl + pr - k) // s + 1
+        xd = rnd(B * H * W, Cin, seed=3 * n).to(dtype).to(DEV)
+        dyd = rnd(B * Ho * Wo, Cout, seed=3 * n + 1).to(dtype).to(DEV)
+        with_bias = dtype != torch.float32 and n % 2 == 1
+        beta = 0.5 if n % 3 == 2 else 0.0
+        base = rnd(Cout, k * k * Cin, seed=3 * n + 2).to(DEV)
+        db0 = torch.full((Cout,), 2.0, device=DEV) if with_bias else None
+        a, adb = base.clone(), (db0.clone() if with_bias else None)
+        b, bdb = base.clone(), (db0.clone() if with_bias else None)
+        train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=a, beta=beta, db=adb, beta_b=0.25)
+        train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=b, beta=beta, db=bdb, beta_b=0.25, queue=q)
+        want.append((a, adb)); got.append((b, bdb))
+    # the same tensor twice: dw = grad, then dw = 1 * dw + grad
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = BIG_WGRAD[0]
+    Ho, Wo = (H + pt + pb - k) // s + 1, (W + pl + pr - k) // s + 1
+    xd, dyd = rnd(B * H * W, Cin, seed=900).to(dtype).to(DEV), rnd(B * Ho * Wo, Cout, seed=901).to(dtype).to(DEV)
+    twice_ref = torch.empty(Cout, k * k * Cin, device=DEV)
+    train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=twice_ref, beta=0.0)
+    train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=twice_ref, beta=1.0)
+    twice = torch.empty(Cout, k * k * Cin, device=DEV)
+    train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=twice, beta=0.0, queue=q)
+    train_ops.conv2d_wgrad(xd, dyd, B, H, W, k, k, s, pt, pl, Ho, Wo, dw=twice, beta=1.0, queue=q)
+    assert len(q.jobs) > 48
+    q.flush()
+    assert not q.jobs and not q.keep
+    torch.cuda.synchronize()
+    for n, ((a, adb), (b, bdb)) in enumerate(zip(want, got)):
+        assert torch.equal(a, b), (n, cases[n])
+        if adb is not None:
+            assert torch.equal(adb, bdb), (n, cases[n])
+    assert torch.equal(twice, twice_ref)
