@@ -466,9 +466,10 @@ __global__ __launch_bounds__(256) void weight_flip_batch_kernel(const T* __restr
   }
 }
 
+int g_wgrad_target = 768;          // cfp_debug_set key 22: workgroups a 64 x 64-tile weight-gradient launch aims for
 inline int wgrad_nsplit(int Cout, int K, int M) {
   const long long tiles = (long long)cdiv(Cout, WB) * cdiv(K, WB);
-  long long ns = (768 + tiles - 1) / tiles;                  // ~3 workgroups per CU in total; every split costs a slab to add up
+  long long ns = (g_wgrad_target + tiles - 1) / tiles;                  // ~3 workgroups per CU in total; every split costs a slab to add up
   const long long max_ns = cdiv(M, 4 * WM);                  // at least 128 rows per chunk
   if (ns > max_ns) ns = max_ns;
   if (ns > 1024) ns = 1024;
@@ -500,6 +501,8 @@ inline WgPlan wgrad_plan16(int Cout, int K, int M) {
 }
 
 }  // namespace
+
+void cfp_wgrad_debug_set(int value) { g_wgrad_target = value; }
 
 extern "C" size_t cfp_conv2d_wgrad_ws_bytes(int Cout, int K, int M) {
   if (Cout <= 0 || K <= 0 || M <= 0) return 0;
