@@ -1,0 +1,12 @@
+import os, sys, json, torch
+sys.path.insert(0, os.getcwd())
+from cfpnet_amd import spec, synthetic, weights
+from cfpnet_amd.engine import Engine
+layers = spec.COMBINE1_LAYERS
+sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+inp = synthetic.to_device(synthetic.make_inputs(8), "cuda:0")
+eng = Engine(sd, layer_names=layers, dtype=torch.bfloat16)
+for tput in (False, True):
+    eng.plan_mode(tput)
+    (kind, n), times = eng.capture_best(inp, reps=30, candidates=(("lanes", 1), ("lanes", 2), ("lanes", 3), ("lanes", 4)), allow_inflight=False)
+    print(json.dumps({"tput_plan": tput, "times": times}))
