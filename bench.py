@@ -288,12 +288,10 @@ def cpu_baseline(budget_s, layers, sd, batch_inputs=None):
                                      sample=f"{len(times)} x B=1 480x640 full forward of the CPU oracle (PyTorch CPU fp32), median {med * 1e3:.0f} ms")
 
 
-def reference_latency_ms(engine, inputs, warmup=100, iters=500, lanes=1):
+def reference_latency_ms(engine, inputs, warmup=100, iters=500):
     """The reference's own latency protocol (evaluate_time.py:56-82): `warmup` forwards, then `iters` forwards each bracketed by
-    a device synchronize, sorted, the fastest one and the two slowest dropped, mean of the rest.  One HIP graph per forward, or
-    (`lanes` > 1) the batch cut into that many sub-batch graphs launched together on concurrent streams (Engine.capture(lanes=n):
-    same outputs, tests/test_forward_gpu.py::test_batch_lanes_match_single_stream)."""
-    engine.capture(inputs, return_prob=True, lanes=lanes)
+    a device synchronize, sorted, the fastest one and the two slowest dropped, mean of the rest.  One HIP graph per forward."""
+    engine.capture(inputs, return_prob=True)
     for _ in range(warmup):
         engine.replay()
     diff = []
@@ -681,18 +679,7 @@ def main():
                 li = synthetic.to_device(synthetic.make_inputs(bsz, a.height, a.width, zones, zone_px, seed=synthetic.SEED, image_hw=base), dev)
                 mean_ms, med_ms = reference_latency_ms(engine, li)
                 lat[f"latency_b{bsz}"] = {"ms": mean_ms, "median_ms": med_ms, "maps_per_s": bsz / mean_ms * 1e3}
-                if bsz >= 4:
-                    # the same forward call with the batch cut into sub-batch graphs that run side by side (one call, one synchronise, same
-                    # outputs): ~250 dependent small kernels leave most CUs idle, independent sample groups fill them
-                    by_lanes = {1: (mean_ms, med_ms)}
-                    for ln in (2, 4):
-                        by_lanes[ln] = reference_latency_ms(engine, li, lanes=ln)
-                    best = min(by_lanes, key=lambda k: by_lanes[k][0])
-                    lat[f"latency_b{bsz}"].update({"single_graph_ms": mean_ms, "ms_by_batch_lanes": {str(k): v[0] for k, v in by_lanes.items()},
-                                                   "batch_lanes": best, "ms": by_lanes[best][0], "median_ms": by_lanes[best][1],
-                                                   "maps_per_s": bsz / by_lanes[best][0] * 1e3})
-            lat["protocol"] = ("evaluate_time.py:56-82: 100 warm-up + 500 timed forwards, each synchronised, min 1 / max 2 dropped, mean; single HIP graph "
-                               "per forward (`single_graph_ms`), and for the batch-8 call also 2 / 4 sub-batch graphs launched together (`ms` = the best)")
+            lat["protocol"] = "evaluate_time.py:56-82: 100 warm-up + 500 timed forwards, each synchronised, min 1 / max 2 dropped, mean; single HIP graph per forward"
             line["latency"] = lat
         if world == 1 and not a.no_train and not a.no_cpu_baseline:
             line["training"] = training_step_rate(a.train_batch, dev, fidelity=True)

@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Batch 8 cut into 1 / 2 / 3 / 4 sub-batch graphs launched together (Engine.capture(lanes=n)), timed back to back WITHOUT a
+synchronise between forwards: lanes:4 3.78-3.80 ms vs 4.01 ms for one graph.  Under the reference's latency protocol (each forward
+bracketed by a device synchronise, bench.py::reference_latency_ms) the same split measures 6.5 ms: four graph launches from an idle
+queue cost more host time than the overlap wins, so the latency figures of the bench line stay single-graph."""
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd())
 from cfpnet_amd import spec, synthetic, weights
