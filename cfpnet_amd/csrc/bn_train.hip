@@ -14,6 +14,7 @@
 // combined in a fixed order (run-to-run deterministic); the variance is the two-pass form (no E[x^2] - E[x]^2
 // cancellation).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -23,21 +24,28 @@ inline int rc_colbits(int C, int ve) {          // column lanes of the column re
   return b;
 }
 
-// The training path uses the full-precision expf and true division: the inference kernels' v_exp_f32 / v_rcp_f32 forms carry
-// ~1e-6 relative error, which the batch-statistics BatchNorms of this network amplify into ~1e-2 of a gradient tensor.
-__device__ __forceinline__ float act_grad(float z, int act) {
-  switch (act) {
-    case CFP_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-    case CFP_ACT_LRELU: return z > 0.f ? 1.f : 0.01f;
-    case CFP_ACT_SILU: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
-    case CFP_ACT_GELU: return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
-    case CFP_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
-    default: return 1.f;
-  }
+// The float32 parity mode of the training path uses the full-precision expf and true division: the inference kernels' v_exp_f32 /
+// v_rcp_f32 forms carry ~1e-6 relative error, which the batch-statistics BatchNorms of this network amplify into ~1e-2 of a gradient
+// tensor -- visible against a float32 reference, invisible under 16-bit storage (see sigmoid_t below).
+// FAST (the 16-bit storage modes): sigmoid through v_exp_f32 / v_rcp_f32 -- ~1e-6 relative, three orders of magnitude under the
+// rounding of the stored activations / gradients, and ~3x fewer VALU instructions per element: these "bandwidth-bound" sweeps were
+// VALU-bound (a wave64 VALU op occupies its SIMD for 4 cycles; SiLU's derivative with expf + a true division is ~30 of them per
+// element, 8 elements per 16-byte load).  The float32 parity mode keeps expf and the true division.
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float z) {
+  if constexpr (FAST) return __frcp_rn(1.f + __expf(-z));
+  else return 1.f / (1.f + expf(-z));
 }
-template <int ACT> __device__ __forceinline__ float act_precise(float x) {
-  if constexpr (ACT == CFP_ACT_SILU) return x / (1.f + expf(-x));
-  else if constexpr (ACT == CFP_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+template <int ACT, bool FAST = false> __device__ __forceinline__ float act_grad_c(float z) {      // act_grad, selected at compile time
+  if constexpr (ACT == CFP_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  else if constexpr (ACT == CFP_ACT_LRELU) return z > 0.f ? 1.f : 0.01f;
+  else if constexpr (ACT == CFP_ACT_SILU) { const float s = sigmoid_t<FAST>(z); return s * (1.f + z * (1.f - s)); }
+  else if constexpr (ACT == CFP_ACT_GELU) return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * expf(-0.5f * z * z);
+  else if constexpr (ACT == CFP_ACT_SIGMOID) { const float s = sigmoid_t<FAST>(z); return s * (1.f - s); }
+  else return 1.f;
+}
+template <int ACT, bool FAST = false> __device__ __forceinline__ float act_precise(float x) {
+  if constexpr (ACT == CFP_ACT_SILU) return FAST ? x * sigmoid_t<FAST>(x) : x / (1.f + expf(-x));
+  else if constexpr (ACT == CFP_ACT_SIGMOID) return sigmoid_t<FAST>(x);
   else return act_c<ACT>(x);
 }
 
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
 #pragma unroll
   for (int e = 0; e < VE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   constexpr int U = 4;
+  with_act(MODE == 2 ? act : CFP_ACT_NONE, [&](auto A) {          // the activation's derivative chosen once, not per element
   for (long long r = r0 + rl; r < r1; r += RC_LANES * U) {
     float v[U][VE], g[U][VE], rmean[U], rrstd[U];
 #pragma unroll
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
         if (MODE == 0) s1[e] += v[u][e];
         else if (MODE == 1) { const float d = v[u][e] - a0[e]; s1[e] = fmaf(d, d, s1[e]); }
         else if (MODE == 2) {
-          const float dz = g[u][e] * act_grad(v[u][e] * a2[e] + a3[e], act);
+          const float dz = g[u][e] * act_grad_c<decltype(A)::value, !std::is_same<T, float>::value>(v[u][e] * a2[e] + a3[e]);
           s1[e] += dz;
           s2[e] = fmaf(dz, (v[u][e] - a0[e]) * a1[e], s2[e]);
         } else {
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ x,
       }
     }
   }
+  });
 #pragma unroll
   for (int e = 0; e < VE; ++e) { red[tid][e * 2] = s1[e]; red[tid][e * 2 + 1] = s2[e]; }
   __syncthreads();
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
         if (rr >= r1) continue;
 #pragma unroll
         for (int e = 0; e < VE; ++e) {
-          v[u][e] = act_precise<decltype(A)::value>(v[u][e] * sc[e] + sh[e]);
+          v[u][e] = act_precise<decltype(A)::value, !std::is_same<T, float>::value>(v[u][e] * sc[e] + sh[e]);
           if (res) v[u][e] = to_f32<T>(from_f32<T>(v[u][e])) + rs[u][e];      // same rounding as the separate add of a stored tensor
         }
         Vec<T>::store(out + rr * out_ld + c, v[u]);
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
   const long long r0 = (long long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
   constexpr int U = 2;
+  with_act(act, [&](auto A) {
   for (long long r = r0 + rl; r < r1; r += lanes * U) {
     float v[U][VE], g[U][VE];
 #pragma unroll
@@ -318,13 +329,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (rr >= r1) continue;
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
-        const float dz = g[u][e] * act_grad(v[u][e] * sc[e] + sh[e], act);
+        const float dz = g[u][e] * act_grad_c<decltype(A)::value, !std::is_same<T, float>::value>(v[u][e] * sc[e] + sh[e]);
         const float xh = (v[u][e] - mu[e]) * is[e];
         v[u][e] = sc[e] * (dz - k0[e] - xh * k1[e]);                     // scale = gamma * invstd
       }
       Vec<T>::store(dx + rr * dx_ld + c, v[u]);
     }
   }
+  });
 }
 
 // LayerNorm backward, data part: one row per LPR lanes (LPR = C / VE, a power of two <= 64), like the forward kernel.
@@ -390,6 +402,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, i
                                                       T* __restrict__ dz, int dz_ld, long long rows, int C, FastDiv fcv) {
   constexpr int VE = Vec<T>::N;
   const unsigned total = (unsigned)(rows * fcv.d);
+  with_act(act, [&](auto A) {
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     unsigned ru, cvu;
     fd_rowcol(i, fcv, ru, cvu);
@@ -399,9 +412,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ z, i
     Vec<T>::load(z + r * ld + c, v);
     Vec<T>::load(dy + r * dy_ld + c, g);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) v[e] = g[e] * act_grad(v[e], act);
+    for (int e = 0; e < VE; ++e) v[e] = g[e] * act_grad_c<decltype(A)::value, !std::is_same<T, float>::value>(v[e]);
     Vec<T>::store(dz + r * dz_ld + c, v);
   }
+  });
 }
 
 int g_red_target = 1024;         // cfp_debug_set key 20: workgroups a column reduction aims for

@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void softmax_expect_kernel(const T* __restrict
       mx = wave_max(mx);
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < NPL; ++k) { v[k] = expf(v[k] - mx); s += v[k]; }      // full-precision exp: training parity
+      for (int k = 0; k < NPL; ++k) {      // full-precision exp in the float32 parity mode; v_exp_f32 under 16-bit storage (1e-6 vs 1e-3)
+        v[k] = sizeof(T) == 2 ? __expf(v[k] - mx) : expf(v[k] - mx);
+        s += v[k];
+      }
       s = wave_sum(s);
       const float inv = 1.f / s;
       float dot = 0.f;
