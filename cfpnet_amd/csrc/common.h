@@ -125,6 +125,20 @@ template <int ACT> __device__ __forceinline__ float act_c(float x) {
   else if constexpr (ACT == CFP_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-x));
   else return x;
 }
+// GELU(erf) for results that are stored in 16 bits: erf by Abramowitz & Stegun 7.1.26 (|error| < 5e-7 in float32, four orders of
+// magnitude under the storage rounding) -- 14 VALU instructions instead of erff's 33; the LKPM MLP applies it to 4 D values per token
+// (19.7 M per launch at 1/4 scale: ~16 us of VALU issue with erff).  Float32 storage keeps act_c's erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.f));
+  const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = 1.f - p * __expf(-u * u);
+  return 0.5f * x * (1.f + copysignf(e, x));
+}
+template <int ACT> __device__ __forceinline__ float act_c16(float x) {      // act_c for kernels whose results leave in 16 bits
+  if constexpr (ACT == CFP_ACT_GELU) return gelu_fast(x);
+  else return act_c<ACT>(x);
+}
 template <int V> struct IntC { static constexpr int value = V; };
 template <typename F> __device__ __forceinline__ void with_act(int act, F&& f) {
   switch (act) {

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(ConvP p) {
         for (int r = 0; r < 4; ++r) {
           const int row = (wm * TM + i) * 16 + fq * 4 + r;
           const int col = wn * (BN / WN) + j * 16 + fr;
-          sC[row * CP + col] = from_f32<H>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+          sC[row * CP + col] = from_f32<H>(act_c16<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
         }
   });
   __syncthreads();

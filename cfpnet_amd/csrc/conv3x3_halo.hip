@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvP p, HaloP hp)
         const int n = n_base + (wn * NT + j) * 16 + fq * 4;
         float yv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = act_c<decltype(A)::value>(acc[g][j][r] * sc[j][r] + sh[j][r]);
+        for (int r = 0; r < 4; ++r) yv[r] = act_c16<decltype(A)::value>(acc[g][j][r] * sc[j][r] + sh[j][r]);
         uint2 pk;
         pk.x = pack2<H>(yv[0], yv[1]);
         pk.y = pack2<H>(yv[2], yv[3]);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           for (int r = 0; r < 4; ++r) {
             int row = wm * (BM / WM) + i * 16 + fq * 4 + r;
             int col = wn * (BN / WN) + j * 16 + fr;
-            sC[row * CP + col] = from_f32<T>(act_c<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
+            sC[row * CP + col] = from_f32<T>(act_c16<decltype(A)::value>(acc[i][j][r] * sc[j] + sh[j]));
           }
     });
     __syncthreads();
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < VE; ++e) {
         float sc = p.scale ? p.scale[n + e] : 1.f, sh = p.shift ? p.shift[n + e] : 0.f;
-        v[e] = act_c<decltype(A)::value>(v[e] * sc + sh);
+        if constexpr (sizeof(T) == 2) v[e] = act_c16<decltype(A)::value>(v[e] * sc + sh);      // like the gen-2 epilogue: same results whether K was split or not
+        else v[e] = act_c<decltype(A)::value>(v[e] * sc + sh);
       }
     });
     if (res) {

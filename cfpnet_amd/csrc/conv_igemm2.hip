@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256 * KG) void igemm2_kernel(ConvP p, float* __rest
           const int col = b_row0 + j * 16 + fq * 4;
           float y[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y[r] = act_c<decltype(A)::value>(acc[i][j][r] * sc[j][r] + sh[j][r]);
+          for (int r = 0; r < 4; ++r) y[r] = act_c16<decltype(A)::value>(acc[i][j][r] * sc[j][r] + sh[j][r]);
           uint2 pk;
           pk.x = pack2<H>(y[0], y[1]);
           pk.y = pack2<H>(y[2], y[3]);

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_kernel(LkpmP<H> p) {
       const float bj = p.b1[half * 2 * D + j * 16 + fr];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        tH[(fq * 4 + r) * PH + half * 2 * D + j * 16 + fr] = from_f32<H>(act_c<CFP_ACT_GELU>(acc[j][r] + bj));
+        tH[(fq * 4 + r) * PH + half * 2 * D + j * 16 + fr] = from_f32<H>(act_c16<CFP_ACT_GELU>(acc[j][r] + bj));
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
