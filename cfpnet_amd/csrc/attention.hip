@@ -61,12 +61,22 @@ __global__ __launch_bounds__(64) void kv_reduce_kernel(KvP p) {
   }
   // KU keys per iteration, their loads issued together: the loop is a chain of memory round trips (one per key before), not FMAs
   constexpr int KU = 4;
+  // key s of the rectangle sits at (y0 + s / rw, x0 + s % rw): the lane's position advances by KL keys per load, so the division happens
+  // once (the quotient / remainder of the step and of the first and last key) and every step after that is an add and one wrap -- the
+  // per-key signed division was ~35 VALU instructions against 2 D = 8 .. 64 FMAs
+  const int rwd = max(rw, 1);
+  const int step_q = KL / rwd, step_r = KL - step_q * rwd;
+  const int s_first = min(s_begin + kl, max(s_end - 1, 0));
+  int cy = s_first / rwd, cx = s_first - cy * rwd;                      // (row, column) of key s0 + u * KL, before clamping
+  const int ly = max(s_end - 1, 0) / rwd, lx = max(s_end - 1, 0) - ly * rwd;      // of the last key (what the clamped tail loads read)
   for (int s0 = s_begin + kl; s0 < s_end; s0 += KL * KU) {
     float kf[KU][IC], vf[KU][D];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const int s = min(s0 + u * KL, s_end - 1);
-      const int yy = y0 + s / rw, xx = x0 + s % rw;
+      const bool in = s0 + u * KL < s_end;
+      const int yy = y0 + (in ? cy : ly), xx = x0 + (in ? cx : lx);
+      cx += step_r; cy += step_q;
+      if (cx >= rwd) { cx -= rwd; ++cy; }
       const long long row = ((long long)b * p.Hk + yy) * p.Wk + xx;
       const T* kp = K + row * p.k_ld + h * D + ip * IC;
       const T* vp = V + row * p.v_ld + h * D;

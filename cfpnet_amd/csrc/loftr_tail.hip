@@ -32,6 +32,8 @@ template <typename H> struct TailP {
   const float* g1; const float* b1; const float* g2; const float* b2;
   int q_ld, x_ld, out_ld;
   int rows, Hq, Wq, qth, qtw, ggy, ggx;
+  FastDiv fwq, fhq, fqth, fqtw;  // rows < 2^31: the token -> (image, y, x) -> key-group split without 64-bit divisions (four of them per lane and
+                                 // row tile were ~600 VALU instructions: about a third of the kernel at D = 32)
   float v_length, eps, ln_eps;
 };
 
@@ -158,11 +160,9 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
     const long long m = row0 + r;
     const bool ok = m < p.rows;
     const long long mm = ok ? m : 0;
-    const int xq = (int)(mm % p.Wq);
-    const long long t = mm / p.Wq;
-    const int yq = (int)(t % p.Hq);
-    const int b = (int)(t / p.Hq);
-    const long long g = ((long long)b * p.ggy + yq / p.qth) * p.ggx + xq / p.qtw;
+    const unsigned t = fd_div((unsigned)mm, p.fwq), xq = (unsigned)mm - t * (unsigned)p.Wq;
+    const unsigned b = fd_div(t, p.fhq), yq = t - b * (unsigned)p.Hq;
+    const long long g = ((long long)b * p.ggy + fd_div(yq, p.fqth)) * p.ggx + fd_div(xq, p.fqtw);
 #pragma unroll
     for (int hs = 0; hs < HEADS / 4; ++hs) {
       const int h = fq + 4 * hs;
@@ -416,6 +416,7 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
     p.g1 = ln1_g; p.b1 = ln1_b; p.g2 = ln2_g; p.b2 = ln2_b;
     p.q_ld = q_ld; p.x_ld = x_ld; p.out_ld = out_ld;
     p.rows = NB * Hq * Wq; p.Hq = Hq; p.Wq = Wq; p.qth = qth; p.qtw = qtw; p.ggy = cdiv(Hq, qth); p.ggx = cdiv(Wq, qtw);
+    p.fwq = make_fastdiv((unsigned)Wq); p.fhq = make_fastdiv((unsigned)Hq); p.fqth = make_fastdiv((unsigned)qth); p.fqtw = make_fastdiv((unsigned)qtw);
     p.v_length = v_length; p.eps = eps; p.ln_eps = ln_eps;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (D == 32 && heads == 4) rc = launch_tail<H, 32, 4>(p, s);
