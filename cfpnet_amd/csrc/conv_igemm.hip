@@ -322,6 +322,7 @@ static bool halo_wins(long long M, int Cout, bool tput) {
   return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
                          (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
+void cfp_dwl_wgrad_debug_set(int value);     // train_misc2.hip: key 23 = 1 keeps the VALU kernels for the large depthwise weight gradient
 void cfp_wgrad_debug_set(int value);         // conv_bwd.hip: key 22 = workgroups a small weight-gradient launch aims for (sets the slab count)
 void cfp_bn_debug_set(int key, int value);   // bn_train.hip: 20 / 21 = workgroup targets of the column reductions / elementwise sweeps
 void cfp_attn_debug_set(int value);          // attention.hip: key 19 = waves the key / value reduction aims for when it splits a group's keys
@@ -336,6 +337,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 19: cfp_attn_debug_set(value); return CFP_OK;
     case 20: case 21: cfp_bn_debug_set(key, value); return CFP_OK;
     case 22: cfp_wgrad_debug_set(value); return CFP_OK;
+    case 23: cfp_dwl_wgrad_debug_set(value); return CFP_OK;
     case 18: g_halo_s2 = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;

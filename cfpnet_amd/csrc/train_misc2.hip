@@ -299,6 +299,7 @@ extern "C" int cfp_softmax_expect(const void* logits, int ld, const float* cente
 // One workgroup per (32 x 32 pixel tile, 16-byte channel vector): dy tile and the haloed x tile are staged in LDS once,
 // thread t owns taps t, t + 256, ...; every pixel's dy vector is an LDS broadcast, the x reads of neighbouring taps are
 // neighbouring vectors.  Per-tile partial sums are added in tile order by a second kernel (bit-reproducible).
+int g_dwl_wgrad_valu = 0;          // cfp_debug_set key 23: 1 = the VALU kernels for 16-bit storage too (A/B, tests)
 namespace {
 constexpr int LWT = 32;
 
@@ -451,6 +452,146 @@ __global__ __launch_bounds__(256) void dwlarge_wgrad31_kernel(const T* __restric
   }
 }
 
+// 16-bit storage (k = 31 / 15 / 7): the same sums on the matrix cores.  Per channel and per row r of the haloed x tile,
+//   dW[ky][kx] += sum_x  X[r][x + kx] * dY[r - ky][x]           (x = 0..31: ONE k = 32 MFMA step)
+// is a 16 x 16 x 32 product with A[m = kx][k = x] = X[r][x + kx] (a Toeplitz view of one x row) and B[k = x][n = ky] = dY[r - ky][x] (the
+// dY rows the x row meets), accumulated over the 62 (46) rows r: 186 (46) MFMAs per channel and tile instead of 31 * 31 * 1024 FMAs on
+// the vector ALUs (the VALU kernel above ran at 53 % of the float32 VALU peak: 334 us per launch at 16 x 104 x 136 x 32).
+// The tile is staged TRANSPOSED into per-channel planes (the operands want x along k, the tensors are channels-last); a wave owns one
+// of the 8 channels of the vector.  The A fragment of lane (m, q) starts at element 8 q + kx of the row -- any 16-bit offset -- so it
+// reads the five dwords around it and funnel-shifts odd offsets by 16 bits (v_alignbit_b32); the B fragment is one aligned 16-byte
+// read of row r - ky, zero where that row is outside the dY tile.  Products are exact (16-bit x 16-bit in float32), sums float32 like
+// the VALU kernels; same partial layout, same reduce kernel.
+template <typename H, int K>
+__global__ __launch_bounds__(512, 2) void dwlarge_wgrad_mfma_kernel(const H* __restrict__ x, int x_ld, const H* __restrict__ dy, int dy_ld,
+                                                                 float* __restrict__ partial, int B, int Hh, int W, int C) {
+  constexpr int HALO = (K - 1) / 2, PW = LWT + K - 1;
+  constexpr int NTL = (K + 15) / 16;                       // 16-wide tap tiles along kx and along ky
+  constexpr int PX = 64, PD = 36;                          // plane row pitches in elements (x: 62 + the fragment's look-ahead; dY: 32 + 4: rows stay
+                                                           // 8-byte aligned and k = 31 takes 81 920 B of LDS -- two workgroups per CU)
+  constexpr int XPLANE = PW * PX, DPLANE = LWT * PD;
+  static_assert(PW + 2 <= PX && (PX % 2) == 0 && (PD % 4) == 0, "plane pitches");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+  unsigned short* sx = reinterpret_cast<unsigned short*>(lsm);            // [8][PW][PX]
+  unsigned short* sd = sx + 8 * XPLANE;                                   // [8][LWT][PD]
+  const int tid = threadIdx.x;
+  const int CV = C / 8;
+  const int tiles_x = (W + LWT - 1) / LWT, tiles_y = (Hh + LWT - 1) / LWT;
+  // The CV workgroups of one pixel tile read the same cache lines (a pixel's channels are contiguous: each takes 16 of every 2 C bytes).
+  // Hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so ids are laid out (tile group, channel vector, XCD): the CV
+  // workgroups of a tile run on ONE XCD, eight launch slots apart, and three of four fetches hit its L2 (2 560 x 254 KB = 650 MB of
+  // fabric traffic per launch at k = 31 otherwise).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int cv = slot % CV;
+  int bid = (slot / CV) * 8 + xcd;                          // pixel tile
+  if (bid >= B * tiles_y * tiles_x) return;                 // padding of the tile count to a multiple of 8 (before any barrier)
+  const long long pidx = (long long)bid * CV + cv;          // partial slot: [tile][cv], as the reduce kernel expects
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * LWT, x0 = tx * LWT;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // ---- staging: [pixel][8 channels] vectors -> 8 channel planes; every load of the thread is issued before the first LDS write (a loop of
+  // load -> eight 2-byte writes was ten dependent memory round trips per workgroup) ----------------------------------------------
+  constexpr int NX = (PW * PX + 511) / 512, ND = LWT * LWT / 512;
+  u32x4 vx[NX], vd[ND];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int i = tid + j * 512;
+    const int py = min(i / PX, PW - 1), px = i % PX;
+    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+    const bool ok = i < PW * PX && px < PW && (unsigned)gy < (unsigned)Hh && (unsigned)gx < (unsigned)W;
+    const int cy = min(max(gy, 0), Hh - 1), cx = min(max(gx, 0), W - 1);
+    vx[j] = *reinterpret_cast<const u32x4*>(x + (((long long)b * Hh + cy) * W + cx) * x_ld + cv * 8);
+    if (!ok) vx[j] = zero4;
+  }
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int i = tid + j * 512;
+    const int py = i / LWT, px = i - py * LWT;
+    const int gy = y0 + py, gx = x0 + px;
+    const bool ok = gy < Hh && gx < W;
+    const int cy = min(gy, Hh - 1), cx = min(gx, W - 1);
+    vd[j] = *reinterpret_cast<const u32x4*>(dy + (((long long)b * Hh + cy) * W + cx) * dy_ld + cv * 8);
+    if (!ok) vd[j] = zero4;
+  }
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int i = tid + j * 512;
+    if (i < PW * PX) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sx[c * XPLANE + i] = (unsigned short)(vx[j][c >> 1] >> ((c & 1) * 16));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int i = tid + j * 512;
+    const int py = i / LWT, px = i - py * LWT;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sd[c * DPLANE + py * PD + px] = (unsigned short)(vd[j][c >> 1] >> ((c & 1) * 16));
+  }
+  __syncthreads();
+  // ---- one channel per wave ----------------------------------------------------------------------------------------------------
+  const int lane = tid & 63, ch = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const unsigned int* xp = reinterpret_cast<const unsigned int*>(sx + ch * XPLANE);      // dword view of the channel's x plane
+  const unsigned short* dp = sd + ch * DPLANE;
+  f32x4 acc[NTL][NTL];
+#pragma unroll
+  for (int a = 0; a < NTL; ++a)
+#pragma unroll
+    for (int c = 0; c < NTL; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int a_dw[NTL];
+  unsigned a_sh[NTL];
+#pragma unroll
+  for (int a = 0; a < NTL; ++a) {
+    const int o = 8 * q + 16 * a + m;                      // first element of the lane's A fragment inside the row
+    a_dw[a] = o >> 1;
+    a_sh[a] = (unsigned)(o & 1) * 16u;
+  }
+#pragma unroll 2
+  for (int r = 0; r < PW; ++r) {
+    s16x8 af[NTL];
+#pragma unroll
+    for (int a = 0; a < NTL; ++a) {
+      const unsigned int* src = xp + r * (PX / 2) + a_dw[a];
+      unsigned int w[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) w[i] = src[i];
+      u32x4 f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], a_sh[a]);
+      af[a] = __builtin_bit_cast(s16x8, f);
+    }
+#pragma unroll
+    for (int c = 0; c < NTL; ++c) {
+      // dY rows r - ky, ky = 16 c + 0..15: the tile meets [0, 32) only for r in [16 c, 16 c + 46]  (wave-uniform)
+      if (r < 16 * c || r > 16 * c + LWT + 14) continue;
+      const int row = r - (16 * c + m);
+      const bool in = (unsigned)row < (unsigned)LWT;
+      const uint2* gp = reinterpret_cast<const uint2*>(dp + (in ? row : 0) * PD + 8 * q);      // two 8-byte reads (72-byte rows)
+      const uint2 g0 = gp[0], g1 = gp[1];
+      u32x4 g = {g0.x, g0.y, g1.x, g1.y};
+      if (!in) g = zero4;
+      const s16x8 bf = __builtin_bit_cast(s16x8, g);
+#pragma unroll
+      for (int a = 0; a < NTL; ++a) acc[a][c] = mfma16<H>(af[a], bf, acc[a][c]);      // D[kx = 16 a + 4 q + i][ky = 16 c + m]
+    }
+  }
+  float* dst = partial + pidx * K * K * 8;
+#pragma unroll
+  for (int a = 0; a < NTL; ++a)
+#pragma unroll
+    for (int c = 0; c < NTL; ++c) {
+      const int ky = 16 * c + m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kx = 16 * a + 4 * q + i;
+        if (ky < K && kx < K) dst[(ky * K + kx) * 8 + ch] = acc[a][c][i];
+      }
+    }
+}
+
 // dw[c][tap] = beta * dw + sum over tiles (b, ty, tx) of partial[tile][cv][tap][e]; 64 outputs per workgroup, 4 lanes over the
 // tiles with 4 loads in flight each (a chain of hundreds of dependent adds per output otherwise), combined in lane order.
 __global__ __launch_bounds__(256) void dwlarge_wgrad_reduce_kernel(const float* __restrict__ partial, int ntiles, int CV, int VE, int KK,
@@ -491,6 +632,21 @@ hipError_t launch_dwl_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, 
     attr = true;
   }
   const long long blocks = (long long)B * cdiv(H, LWT) * cdiv(W, LWT) * (C / VE);
+  if constexpr (sizeof(T) == 2) {
+    if (!g_dwl_wgrad_valu) {
+      constexpr size_t lds_m = (size_t)8 * ((LWT + K - 1) * 64 + LWT * 36) * 2;
+      static bool attr_m = false;
+      if (!attr_m) {
+        hipError_t e = hipFuncSetAttribute((const void*)dwlarge_wgrad_mfma_kernel<T, K>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_m = true;
+      }
+      const long long blocks_m = (long long)cdiv(B * cdiv(H, LWT) * cdiv(W, LWT), 8) * 8 * (C / VE);      // tiles padded to whole XCD rounds
+      hipLaunchKernelGGL((dwlarge_wgrad_mfma_kernel<T, K>), dim3((unsigned)blocks_m), dim3(512), lds_m, s, (const T*)x, x_ld, (const T*)dy, dy_ld,
+                         partial, B, H, W, C);
+      return hipSuccess;
+    }
+  }
   if constexpr (K == 31) {
     static bool attr31 = false;
     if (!attr31) {
@@ -507,6 +663,8 @@ hipError_t launch_dwl_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, 
   return hipSuccess;
 }
 }  // namespace
+
+void cfp_dwl_wgrad_debug_set(int value) { g_dwl_wgrad_valu = value; }
 
 extern "C" size_t cfp_dwconv_large_wgrad_ws_bytes(int B, int H, int W, int C, int k) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0) return 0;

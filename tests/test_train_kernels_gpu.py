@@ -376,6 +376,27 @@ def test_large_depthwise_weight_gradient(B, H, W, C, k, dtype):
     assert float((dw.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,C,k", [(2, 104, 136, 32, 31), (2, 52, 68, 64, 15), (1, 31, 33, 8, 31), (2, 26, 34, 128, 7), (1, 65, 33, 16, 7)])
+def test_large_depthwise_weight_gradient_matrix_core_kernel_matches_the_vector_kernel(B, H, W, C, k, dtype):
+    """dwlarge_wgrad_mfma_kernel (16-bit storage: Toeplitz view of the x rows on the matrix cores) against the VALU kernels
+    (cfp_debug_set key 23) at the training step's shapes: the products are the same exact float32 values, only the summation order
+    differs."""
+    x = rnd(B * H * W, C, seed=11).to(dtype).to(DEV)
+    dy = rnd(B * H * W, C, seed=12).to(dtype).to(DEV)
+    lib = hip.load()
+    try:
+        lib.cfp_debug_set(23, 1)
+        ref = train_ops.dwconv_large_wgrad(x, dy, B, H, W, k)
+    finally:
+        lib.cfp_debug_set(23, 0)
+    got = train_ops.dwconv_large_wgrad(x, dy, B, H, W, k)
+    again = train_ops.dwconv_large_wgrad(x, dy, B, H, W, k)
+    torch.cuda.synchronize()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batched_weight_flip_equals_the_single_launches(dtype):
     """cfp_conv2d_weight_flip_batch: every tensor of a flat parameter buffer flipped in one launch == one launch per tensor."""
