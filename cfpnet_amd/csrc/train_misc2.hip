@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void softmax_expect_kernel(const T* __restrict
   float cen[NPL];
 #pragma unroll
   for (int k = 0; k < NPL; ++k) cen[k] = centers[(long long)b_blk * NB + NPL * lane + k];
-  constexpr int RU = 2;
+  constexpr int RU = 4;
   for (long long r = r0 + wave; r < r1; r += 4 * RU) {
     T raw[RU][NPL];
     float g[RU];
