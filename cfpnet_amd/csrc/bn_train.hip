@@ -197,22 +197,29 @@ __global__ __launch_bounds__(256) void colmoments_kernel(const T* __restrict__ x
 // One wave per channel merges the splits' triples (lanes stride over the splits, then a butterfly: a fixed tree), and finishes
 // the layer's constants in the same launch: mean, biased variance, 1/std, the folded scale / shift of the apply pass and the
 // running statistics (momentum update with the unbiased variance, like torch).
+// WPC = waves per channel: 1 (four channels per workgroup), or 4 for the thousands of row tiles a convolution's epilogue leaves at the
+// full-resolution layers (7 072 - 14 144 partials per channel and only 16 - 128 channels: one wave per channel was a ~55-round chain of
+// dependent loads on a handful of workgroups); the four waves' results meet in LDS in wave order.
+template <int WPC>
 __global__ __launch_bounds__(256) void colmoments_final_kernel(const float* __restrict__ partial, int nsplit, long long rows,
                                                                long long rows_per_split, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps, float momentum,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                float* __restrict__ mean, float* __restrict__ var, float* __restrict__ invstd,
                                                                float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
-  // four independent merge chains per lane (splits j, j + 64, j + 128, j + 192 of every 256): with the thousands of row tiles a
+  __shared__ float wres[4][3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = WPC == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (c >= C) return;                                   // WPC = 4: whole workgroups only (grid = C)
+  const int first = WPC == 1 ? lane : (int)threadIdx.x, step = 64 * WPC;
+  // four independent merge chains per lane (splits j, j + step, j + 2 step, j + 3 step of every 4 step): with the thousands of row tiles a
   // convolution's epilogue leaves (cfp_conv2d_nhwc_moments) one chain of dependent loads + divisions per lane was the whole launch
   Mom a4[4] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  for (int j0 = lane; j0 < nsplit; j0 += 256) {
+  for (int j0 = first; j0 < nsplit; j0 += 4 * step) {
     float pm[4], pq[4], pn[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int j = j0 + 64 * u;
+      const int j = j0 + step * u;
       const bool ok = j < nsplit;
       const long long r0 = (long long)j * rows_per_split;
       pn[u] = ok ? (float)(min(rows, r0 + rows_per_split) - r0) : 0.f;
@@ -228,7 +235,16 @@ __global__ __launch_bounds__(256) void colmoments_final_kernel(const float* __re
     Mom b{__shfl_xor(a.n, o, 64), __shfl_xor(a.mean, o, 64), __shfl_xor(a.m2, o, 64)};
     a = (lane & o) ? mom_merge(b, a) : mom_merge(a, b);      // both partners compute the same (lower lane first) merge
   }
-  if (lane != 0) return;
+  if (WPC == 4) {
+    if (lane == 0) { wres[wave][0] = a.n; wres[wave][1] = a.mean; wres[wave][2] = a.m2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    a = Mom{wres[0][0], wres[0][1], wres[0][2]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) a = mom_merge(a, Mom{wres[w][0], wres[w][1], wres[w][2]});
+  } else if (lane != 0) {
+    return;
+  }
   const float v = a.m2 / (float)rows;
   const float is = 1.f / sqrtf(v + eps);
   const float g = gamma ? gamma[c] : 1.f, b0 = beta ? beta[c] : 0.f;
@@ -466,6 +482,17 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
   return 0;
 }
 
+inline void launch_moments_final(const float* partial, int nsplit, long long rows, long long rps, int C, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, float* mean, float* var, float* invstd,
+                                 float* scale, float* shift, hipStream_t s) {
+  if (nsplit >= 256)
+    hipLaunchKernelGGL(colmoments_final_kernel<4>, dim3(C), dim3(256), 0, s, partial, nsplit, rows, rps, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, var, invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(colmoments_final_kernel<1>, dim3(cdiv(C, 4)), dim3(256), 0, s, partial, nsplit, rows, rps, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, var, invstd, scale, shift);
+}
+
 }  // namespace
 
 void cfp_bn_debug_set(int key, int value) { (key == 20 ? g_red_target : g_ew_target) = value; }
@@ -494,8 +521,7 @@ extern "C" int cfp_bn_train_stats(const void* x, int ld, long long rows, int C, 
 #define ML(T) hipLaunchKernelGGL(colmoments_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ld, rows, C, partial, rps, colbits)
     if (dtype == CFP_BF16) ML(bf16_t); else if (dtype == CFP_F16) ML(f16_t); else ML(float);
 #undef ML
-    hipLaunchKernelGGL(colmoments_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, partial, nsplit, rows, rps, C, gamma, beta, eps, momentum,
-                       running_mean, running_var, mean, var, invstd, scale, shift);
+    launch_moments_final(partial, nsplit, rows, rps, C, gamma, beta, eps, momentum, running_mean, running_var, mean, var, invstd, scale, shift, s);
   }
   return cfp_check_launch("cfp_bn_train_stats");
 }
@@ -509,8 +535,7 @@ extern "C" int cfp_bn_train_stats_partials(const float* partial, int nsplit, lon
   CFP_REQUIRE(nsplit > 0 && rows > 0 && rows_per_split > 0 && C > 0 && (long long)(nsplit - 1) * rows_per_split < rows &&
                   (long long)nsplit * rows_per_split >= rows, CFP_ESHAPE, "cfp_bn_train_stats_partials: splits do not cover the rows");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(colmoments_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, s, partial, nsplit, rows, rows_per_split, C, gamma, beta, eps, momentum,
-                     running_mean, running_var, mean, var, invstd, scale, shift);
+  launch_moments_final(partial, nsplit, rows, rows_per_split, C, gamma, beta, eps, momentum, running_mean, running_var, mean, var, invstd, scale, shift, s);
   return cfp_check_launch("cfp_bn_train_stats_partials");
 }
 
