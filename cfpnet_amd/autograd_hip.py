@@ -279,7 +279,9 @@ class Tape:
             if residual is not None:
                 self.acc(residual, y.g, own=False)
             go, bo = self._direct(gamma), self._direct(beta)
-            dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps, dgamma_out=go, dbeta_out=bo)
+            # both parameter gradients written (not accumulated) into their views: their finishing sums wait for the batched reduction
+            q = self.wq if (go is not None and bo is not None) else None
+            dx, dg, db = train_ops.layernorm_bwd(x.t, y.g, gamma.t, eps, dgamma_out=go, dbeta_out=bo, queue=q)
             self._pvec(gamma, dg, go); self._pvec(beta, db, bo); self.acc(x, dx)
         self.bw.append(bw)
         return y
@@ -294,7 +296,8 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.off_path(lambda: self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta)))
+            self.off_path(lambda: self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta,
+                                                                                            queue=self._queue(out, beta))))
             self.acc(x, train_ops.dwconv3x3_dgrad(y.g, w.t, B, H, W, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
         return y

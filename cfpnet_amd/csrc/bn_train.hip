@@ -466,7 +466,7 @@ inline int ew_grid(long long total) { long long b = (total + 255) / 256; return 
 template <int MODE>
 int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long rows, int C, const float* a0, const float* a1,
                   const float* a2, const float* a3, int act, int dtype, float* partial, float* out0, float* out1, float inv_n,
-                  hipStream_t s) {
+                  hipStream_t s, cfp_wgrad_job* job = nullptr) {
   const int ve = vec_elems(dtype);
   const int ns = red_splits(rows, C, ve);
   const long long rps = (rows + ns - 1) / ns;
@@ -478,6 +478,11 @@ int launch_reduce(const void* x, int ld, const void* dy, int dy_ld, long long ro
   if (dtype == CFP_BF16) RL(bf16_t); else if (dtype == CFP_F16) RL(f16_t); else RL(float);
 #undef RL
   const int nsum = MODE >= 2 ? 2 : 1;
+  if (job) {      // partial is [split][out0 (C) | out1 (C)]: the slab layout of cfp_wgrad_reduce_jobs (inv_n must be 1)
+    job->slabs = partial; job->dw = out0; job->db = nsum == 2 ? out1 : nullptr; job->n = (long long)C * nsum; job->n_dw = C; job->nsplit = nsplit;
+    job->ew = nsplit < 8 ? 256 : nsplit < 32 ? 64 : 32; job->beta = 0.f; job->beta_b = 0.f;
+    return 0;
+  }
   hipLaunchKernelGGL(colfinal_kernel, dim3(cdiv(C * nsum, 4)), dim3(256), 0, s, partial, nsplit, nsum, C, inv_n, out0, out1);
   return 0;
 }
@@ -609,9 +614,9 @@ extern "C" size_t cfp_layernorm_bwd_ws_bytes(long long rows, int C) {
 }
 
 /* Backward of nn.LayerNorm over the channel axis: dx (+= when accumulate), dgamma, dbeta. */
-extern "C" int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
-                                 int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
-                                 cfp_stream_t stream) {
+static int layernorm_bwd_impl(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                              int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
+                              cfp_wgrad_job* job, cfp_stream_t stream) {
   CFP_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && ws && aligned16(x) && aligned16(dy) && aligned16(dx), CFP_EINVAL,
               "cfp_layernorm_bwd: bad pointer");
   BN_COMMON("cfp_layernorm_bwd");
@@ -627,6 +632,21 @@ extern "C" int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_l
                                  (T*)dx, dx_ld, stats, rows, C, accumulate)
   if (dtype == CFP_BF16) LL(bf16_t); else if (dtype == CFP_F16) LL(f16_t); else LL(float);
 #undef LL
-  launch_reduce<3>(x, ld, dy, dy_ld, rows, C, stats, nullptr, nullptr, nullptr, 0, dtype, partial, dbeta, dgamma, 1.f, s);
+  launch_reduce<3>(x, ld, dy, dy_ld, rows, C, stats, nullptr, nullptr, nullptr, 0, dtype, partial, dbeta, dgamma, 1.f, s, job);
   return cfp_check_launch("cfp_layernorm_bwd");
+}
+
+extern "C" int cfp_layernorm_bwd(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                                 int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
+                                 cfp_stream_t stream) {
+  return layernorm_bwd_impl(x, ld, dy, dy_ld, gamma, eps, dx, dx_ld, accumulate, dgamma, dbeta, rows, C, dtype, ws, ws_bytes, nullptr, stream);
+}
+
+/* The same with the finishing sum of the parameter-gradient partials left to cfp_wgrad_reduce_jobs (a job record like the dense weight
+ * gradients': [split][dbeta | dgamma] slabs); `ws` must stay untouched until the job has been reduced. */
+extern "C" int cfp_layernorm_bwd_deferred(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                                          int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws,
+                                          size_t ws_bytes, cfp_wgrad_job* job, cfp_stream_t stream) {
+  CFP_REQUIRE(job, CFP_EINVAL, "cfp_layernorm_bwd_deferred: null job");
+  return layernorm_bwd_impl(x, ld, dy, dy_ld, gamma, eps, dx, dx_ld, accumulate, dgamma, dbeta, rows, C, dtype, ws, ws_bytes, job, stream);
 }

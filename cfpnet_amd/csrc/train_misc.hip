@@ -409,9 +409,9 @@ extern "C" int cfp_dwconv3x3_dgrad(const void* dy, int dy_ld, const void* w, voi
 
 extern "C" size_t cfp_dwconv3x3_wgrad_ws_bytes(int C) { return C > 0 ? (size_t)2048 * 9 * C * sizeof(float) : 0; }
 
-extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
-                                   int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes,
-                                   cfp_stream_t stream) {
+static int dw3x3_wgrad_impl(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                            int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes, cfp_wgrad_job* job,
+                            cfp_stream_t stream) {
   CFP_REQUIRE(x && dy && dw && ws && aligned16(x) && aligned16(dy), CFP_EINVAL, "cfp_dwconv3x3_wgrad: bad pointer");
   TM_COMMON("cfp_dwconv3x3_wgrad");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % ve == 0 && x_ld % ve == 0 && dy_ld % ve == 0 && x_ld >= C &&
@@ -430,6 +430,24 @@ extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int 
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   const long long n = 9ll * C;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<long long>(4096, cdiv(n, 32))), dim3(256), 0, s, partial, nsplit, n, dw, beta);
+  if (job) {      // the sum over the splits joins the batched reduction of the dense weight gradients (cfp_wgrad_reduce_jobs)
+    job->slabs = partial; job->dw = dw; job->db = nullptr; job->n = n; job->n_dw = n; job->nsplit = nsplit;
+    job->ew = nsplit < 8 ? 256 : nsplit < 32 ? 64 : 32; job->beta = beta; job->beta_b = 0.f;
+  } else {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<long long>(4096, cdiv(n, 32))), dim3(256), 0, s, partial, nsplit, n, dw, beta);
+  }
   return cfp_check_launch("cfp_dwconv3x3_wgrad");
+}
+
+extern "C" int cfp_dwconv3x3_wgrad(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                                   int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes,
+                                   cfp_stream_t stream) {
+  return dw3x3_wgrad_impl(x, x_ld, dy, dy_ld, dw, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, beta, dtype, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int cfp_dwconv3x3_wgrad_deferred(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                                            int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes,
+                                            cfp_wgrad_job* job, cfp_stream_t stream) {
+  CFP_REQUIRE(job, CFP_EINVAL, "cfp_dwconv3x3_wgrad_deferred: null job");
+  return dw3x3_wgrad_impl(x, x_ld, dy, dy_ld, dw, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, beta, dtype, ws, ws_bytes, job, stream);
 }

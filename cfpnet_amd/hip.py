@@ -90,6 +90,7 @@ SIGNATURES = {
     "cfp_act_bwd": (_i, [_p, _i, _p, _i, _i, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_layernorm_bwd_ws_bytes": (_sz, [C.c_longlong, _i]),
     "cfp_layernorm_bwd": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _i, _p, _p, C.c_longlong, _i, _i, _p, _sz, _p]),
+    "cfp_layernorm_bwd_deferred": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _i, _p, _p, C.c_longlong, _i, _i, _p, _sz, _p, _p]),
     "cfp_axpby": (_i, [_p, _i, _p, _i, _f, _f, _p, _i, C.c_longlong, _i, _i, _p]),
     "cfp_rowtable_grad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "cfp_se_train_ws_floats": (_sz, [_i, _i, _i]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "cfp_dwconv3x3_dgrad": (_i, [_p, _i, _p, _p, _i] + [_i] * 11 + [_p]),
     "cfp_dwconv3x3_wgrad_ws_bytes": (_sz, [_i]),
     "cfp_dwconv3x3_wgrad": (_i, [_p, _i, _p, _i, _p] + [_i] * 9 + [_f, _i, _p, _sz, _p]),
+    "cfp_dwconv3x3_wgrad_deferred": (_i, [_p, _i, _p, _i, _p] + [_i] * 9 + [_f, _i, _p, _sz, _p, _p]),
     "cfp_index_rows": (_i, [_p, _i, _p, _p, _i, C.c_longlong, _i, _i, _i, _p]),
     "cfp_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "cfp_bin_centers": (_i, [_p, _f, _f, _p, _p, _i, _i, _p]),

@@ -444,8 +444,10 @@ def act_bwd(z2d: torch.Tensor, dy2d: torch.Tensor, act: int) -> torch.Tensor:
 
 
 def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, eps: float, dx: Optional[torch.Tensor] = None,
-                  accumulate: bool = False, dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None):
-    """-> (dx, dgamma, dbeta)"""
+                  accumulate: bool = False, dgamma_out: Optional[torch.Tensor] = None, dbeta_out: Optional[torch.Tensor] = None,
+                  queue: Optional["WgradQueue"] = None):
+    """-> (dx, dgamma, dbeta).  `queue`: the finishing sum of the parameter-gradient partials joins the batched reduction (WgradQueue);
+    dgamma / dbeta then hold the result only after queue.flush()."""
     from . import hip, ops
     rows, C = x2d.shape
     if dx is None:
@@ -454,6 +456,14 @@ def layernorm_bwd(x2d: torch.Tensor, dy2d: torch.Tensor, gamma: torch.Tensor, ep
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=x2d.device)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=x2d.device)
+    if queue is not None:
+        job = hip.WgradJob()
+        hip.call("cfp_layernorm_bwd_deferred", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), gamma.data_ptr(), eps, dx.data_ptr(),
+                 dx.stride(0), int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ops.DT[x2d.dtype], ws.data_ptr(), nbytes,
+                 ctypes.addressof(job), hip.current_stream())
+        queue.jobs.append(job)
+        queue.keep.append((ws, dgamma, dbeta))
+        return dx, dgamma, dbeta
     hip.call("cfp_layernorm_bwd", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), gamma.data_ptr(), eps, dx.data_ptr(),
              dx.stride(0), int(accumulate), dgamma.data_ptr(), dbeta.data_ptr(), rows, C, ops.DT[x2d.dtype], ws.data_ptr(), nbytes,
              hip.current_stream())
@@ -529,13 +539,20 @@ def dwconv3x3_dgrad(dy2d, w9c, B, H, W, stride, pad_t, pad_l, Ho, Wo, dx=None, a
     return dx
 
 
-def dwconv3x3_wgrad(x2d, dy2d, B, H, W, stride, pad_t, pad_l, Ho, Wo, dw=None, beta: float = 0.0):
+def dwconv3x3_wgrad(x2d, dy2d, B, H, W, stride, pad_t, pad_l, Ho, Wo, dw=None, beta: float = 0.0, queue: Optional["WgradQueue"] = None):
     from . import hip, ops
     C = x2d.shape[1]
     if dw is None:
         dw, beta = torch.empty(9, C, dtype=torch.float32, device=x2d.device), 0.0
     nbytes = hip.load().cfp_dwconv3x3_wgrad_ws_bytes(C)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x2d.device)
+    if queue is not None:
+        job = hip.WgradJob()
+        hip.call("cfp_dwconv3x3_wgrad_deferred", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, C, stride,
+                 pad_t, pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, ctypes.addressof(job), hip.current_stream())
+        queue.jobs.append(job)
+        queue.keep.append((ws, dw))
+        return dw
     hip.call("cfp_dwconv3x3_wgrad", x2d.data_ptr(), x2d.stride(0), dy2d.data_ptr(), dy2d.stride(0), dw.data_ptr(), B, H, W, C, stride, pad_t,
              pad_l, Ho, Wo, beta, ops.DT[x2d.dtype], ws.data_ptr(), nbytes, hip.current_stream())
     return dw

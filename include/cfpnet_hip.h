@@ -467,6 +467,15 @@ int cfp_conv2d_wgrad_deferred(const void* x, int x_ld, const void* dy, int dy_ld
                               int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float beta, float beta_b,
                               int dtype, void* ws, size_t ws_bytes, cfp_wgrad_job* job, cfp_stream_t stream);
 int cfp_wgrad_reduce_jobs(const cfp_wgrad_job* jobs, int njobs, cfp_stream_t stream);
+/* Two more producers of such jobs (their finishing sums are [split][n] slabs too): the depthwise 3x3 weight gradient
+ * (cfp_dwconv3x3_wgrad) and the LayerNorm parameter gradients (cfp_layernorm_bwd: dbeta | dgamma).  Same contract: `ws` untouched
+ * until cfp_wgrad_reduce_jobs has run; the results equal the immediate calls up to float32 summation order. */
+int cfp_dwconv3x3_wgrad_deferred(const void* x, int x_ld, const void* dy, int dy_ld, float* dw, int B, int H, int W, int C, int stride,
+                                 int pad_t, int pad_l, int Ho, int Wo, float beta, int dtype, void* ws, size_t ws_bytes,
+                                 cfp_wgrad_job* job, cfp_stream_t stream);
+int cfp_layernorm_bwd_deferred(const void* x, int ld, const void* dy, int dy_ld, const float* gamma, float eps, void* dx, int dx_ld,
+                               int accumulate, float* dgamma, float* dbeta, long long rows, int C, int dtype, void* ws, size_t ws_bytes,
+                               cfp_wgrad_job* job, cfp_stream_t stream);
 /* wt[Cin][KH][KW][Cout] = w[Cout][KH-1-kh][KW-1-kw][Cin]: the weights the data gradient convolves with. */
 int cfp_conv2d_weight_flip(const void* w, void* wt, int Cout, int KH, int KW, int Cin, int dtype, cfp_stream_t stream);
 /* The same for n weight tensors in one launch (a training step flips every convolution's weights once).  `desc` is a DEVICE

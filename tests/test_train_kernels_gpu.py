@@ -616,3 +616,35 @@ def test_batched_weight_gradient_reduction_is_bit_identical(dtype):
         if adb is not None:
             assert torch.equal(adb, bdb), (n, cases[n])
     assert torch.equal(twice, twice_ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_and_depthwise_parameter_gradients_through_the_batched_reduction(dtype):
+    """cfp_layernorm_bwd_deferred / cfp_dwconv3x3_wgrad_deferred leave their finishing sums to cfp_wgrad_reduce_jobs (the job table of the
+    dense weight gradients): same values as the immediate calls up to float32 summation order, dx untouched by the deferral."""
+    q = train_ops.WgradQueue()
+    checks = []
+    for n, (rows, C) in enumerate([(9600, 128), (38400, 64), (153600, 32), (240, 128), (77, 64)]):
+        x, dy = rnd(rows, C, seed=20 + n).to(dtype).to(DEV), rnd(rows, C, seed=30 + n).to(dtype).to(DEV)
+        g = (1.0 + 0.1 * rnd(C, seed=40 + n)).to(DEV)
+        dx0, dg0, db0 = train_ops.layernorm_bwd(x, dy, g, 1e-5)
+        dx1, dg1, db1 = train_ops.layernorm_bwd(x, dy, g, 1e-5, queue=q)
+        checks.append((dx0, dx1, True)); checks.append((dg0, dg1, False)); checks.append((db0, db1, False))
+    for n, (B, H, W, C, s) in enumerate([(2, 26, 34, 816, 1), (2, 52, 68, 224, 2), (1, 13, 17, 1392, 1)]):
+        pt, pl = (1, 1) if s == 1 else (0, 0)
+        Ho, Wo = (H + 2 - 3) // s + 1 if s == 1 else -(-H // s), (W + 2 - 3) // s + 1 if s == 1 else -(-W // s)
+        x, dy = rnd(B * H * W, C, seed=50 + n).to(dtype).to(DEV), rnd(B * Ho * Wo, C, seed=60 + n).to(dtype).to(DEV)
+        base = rnd(9, C, seed=70 + n).to(DEV)
+        beta = 0.5 if n == 1 else 0.0
+        a, b = base.clone(), base.clone()
+        train_ops.dwconv3x3_wgrad(x, dy, B, H, W, s, pt, pl, Ho, Wo, dw=a, beta=beta)
+        train_ops.dwconv3x3_wgrad(x, dy, B, H, W, s, pt, pl, Ho, Wo, dw=b, beta=beta, queue=q)
+        checks.append((a, b, False))
+    assert len(q.jobs) == 8
+    q.flush()
+    torch.cuda.synchronize()
+    for want, got, exact in checks:
+        if exact:
+            assert torch.equal(want, got)
+        else:
+            assert float((want - got).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
