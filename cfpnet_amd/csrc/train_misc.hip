@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void channel_dot_kernel(const T* __restrict__ 
 // image changes.  2^colbits column lanes, the rest of the workgroup are row lanes; blockIdx.y = row chunk.
 template <typename T>
 __global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy, int dy_ld, const float* __restrict__ gate,
-                                                        const float* __restrict__ add, T* __restrict__ dx, int dx_ld, int HW, int C,
+                                                        const float* __restrict__ add, T* __restrict__ dx, int dx_ld, FastDiv fhw, int C,
                                                         int rows, int rows_per_chunk, int colbits) {
   constexpr int VE = Vec<T>::N;
   const int cols = 1 << colbits, lanes = 256 >> colbits;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy
     for (int u = 0; u < U; ++u) {
       const int rr = r + u * lanes;
       if (rr >= r1) continue;
-      const int b = rr / HW;
+      const int b = (int)fd_div((unsigned)rr, fhw);      // rows < 2^31
       if (b != bcur) {
         bcur = b;
 #pragma unroll
@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256) void bcast_fma_kernel(const T* __restrict__ dy
   }
 }
 
-// depthwise 3x3 data gradient, any stride: dx[hi][wi][c] = sum_{kh,kw} dy[(hi + pt - kh)/s][(wi + pl - kw)/s][c] * w[kh][kw][c]
-template <typename T>
+// depthwise 3x3 data gradient, stride S = 1 / 2: dx[hi][wi][c] = sum_{kh,kw} dy[(hi + pt - kh)/S][(wi + pl - kw)/S][c] * w[kh][kw][c]
+// (S is a template parameter: with a runtime stride the twelve `% stride` / `/ stride` tests per output vector were ~800 VALU
+// instructions of signed division against 72 FMAs)
+template <typename T, int S>
 __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ dy, int dy_ld, const T* __restrict__ w, T* __restrict__ dx,
                                                           int dx_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho,
                                                           int Wo, int accumulate, FastDiv fcv, FastDiv fw, FastDiv fh) {
@@ -185,13 +187,17 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const T* __restrict__ 
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hn = hi + pad_t - kh;
-      if (hn < 0 || hn % stride != 0 || hn / stride >= Ho) continue;
+      if (hn < 0 || (S == 2 && (hn & 1))) continue;
+      const int hq = S == 2 ? hn >> 1 : hn;
+      if (hq >= Ho) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int wn = wi + pad_l - kw;
-        if (wn < 0 || wn % stride != 0 || wn / stride >= Wo) continue;
+        if (wn < 0 || (S == 2 && (wn & 1))) continue;
+        const int wq = S == 2 ? wn >> 1 : wn;
+        if (wq >= Wo) continue;
         float g[VE], ww[VE];
-        Vec<T>::load(dy + (((long long)b * Ho + hn / stride) * Wo + wn / stride) * dy_ld + c, g);
+        Vec<T>::load(dy + (((long long)b * Ho + hq) * Wo + wq) * dy_ld + c, g);
         Vec<T>::load(w + (long long)(kh * 3 + kw) * C + c, ww);
 #pragma unroll
         for (int e = 0; e < VE; ++e) acc[e] = fmaf(g[e], ww[e], acc[e]);
@@ -385,7 +391,7 @@ extern "C" int cfp_bcast_fma(const void* dy, int dy_ld, const float* gate, const
   ns = std::max<long long>(1, std::min<long long>(ns, 65535));
   const int rpc = cdiv(rows, (int)ns);
   const dim3 grid(gx, cdiv(rows, rpc));
-#define L(T) hipLaunchKernelGGL(bcast_fma_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, gate, add, (T*)dx, dx_ld, HW, C, rows, rpc, colbits)
+#define L(T) hipLaunchKernelGGL(bcast_fma_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, gate, add, (T*)dx, dx_ld, make_fastdiv((unsigned)HW), C, rows, rpc, colbits)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
   return cfp_check_launch("cfp_bcast_fma");
@@ -400,10 +406,12 @@ extern "C" int cfp_dwconv3x3_dgrad(const void* dy, int dy_ld, const void* w, voi
   CFP_REQUIRE((long long)B * H * W * (C / ve) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv3x3_dgrad: too many elements");
   const dim3 grid(ew_grid2((long long)B * H * W * (C / ve)));
   const FastDiv fcv = make_fastdiv((unsigned)(C / ve)), fw = make_fastdiv((unsigned)W), fh = make_fastdiv((unsigned)H);
-#define L(T) hipLaunchKernelGGL(dw3x3_dgrad_kernel<T>, grid, dim3(256), 0, s, (const T*)dy, dy_ld, (const T*)w, (T*)dx, dx_ld, B, H, W, C, stride, \
-                                pad_t, pad_l, Ho, Wo, accumulate, fcv, fw, fh)
+#define L2(T, S) hipLaunchKernelGGL((dw3x3_dgrad_kernel<T, S>), grid, dim3(256), 0, s, (const T*)dy, dy_ld, (const T*)w, (T*)dx, dx_ld, B, H, W, C, stride, \
+                                    pad_t, pad_l, Ho, Wo, accumulate, fcv, fw, fh)
+#define L(T) do { if (stride == 1) L2(T, 1); else L2(T, 2); } while (0)
   if (dtype == CFP_BF16) L(bf16_t); else if (dtype == CFP_F16) L(f16_t); else L(float);
 #undef L
+#undef L2
   return cfp_check_launch("cfp_dwconv3x3_dgrad");
 }
 
