@@ -70,10 +70,23 @@ __global__ __launch_bounds__(256) void silog_fwd_kernel(SilogP p) {
 }
 
 // stats: [0] loss, [1] mean, [2] n, [3] Dg
+// One wave: lanes stride over the block partials, then a fixed-order tree through LDS (a single thread walking them was 61 us on the
+// critical path between the forward and the backward pass).
 __global__ void silog_finalize_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ stats) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ double red[3][64];
+  if (blockIdx.x != 0) return;
   double s = 0.0, s2 = 0.0, n = 0.0;
-  for (int i = 0; i < nblk; ++i) { s += partial[i * 3]; s2 += partial[i * 3 + 1]; n += partial[i * 3 + 2]; }
+  for (int i = threadIdx.x; i < nblk; i += 64) { s += partial[i * 3]; s2 += partial[i * 3 + 1]; n += partial[i * 3 + 2]; }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2; red[2][threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; red[2][threadIdx.x] += red[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  s = red[0][0]; s2 = red[1][0]; n = red[2][0];
   const double mean = s / n;
   const double var = (s2 - s * s / n) / (n - 1.0);      // unbiased, torch.var default
   const double dg = var + 0.15 * mean * mean;
