@@ -81,6 +81,20 @@ template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return f
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
 
+// Pre-split weight rows of the f16x3 kernels (conv_igemm_x3.hip, cfp_pack_w_x3): row `row` holds nk = ceil(K / 32) K-steps of 64 halves
+// [hi(32) | lo(32)], channel r of a step at position 8 * ((r % 16) / 4) + r % 4 + 4 * (r / 16).  Four consecutive channels c .. c + 3
+// (c % 4 == 0) are therefore four consecutive halves in each half-row: two 8-byte stores.
+__device__ __forceinline__ void x3_store4(f16_t* __restrict__ wout, long long row, int nk, int c, const float* v) {
+  const int ks = c >> 5, r = c & 31;
+  f16_t* d = wout + (row * nk + ks) * 64 + ((r & 15) >> 2) * 8 + ((r >> 4) << 2);
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { hi[e] = f2h(v[e]); lo[e] = (f16_t)(v[e] - (float)hi[e]); }
+  *reinterpret_cast<f16x4*>(d) = hi;
+  *reinterpret_cast<f16x4*>(d + 32) = lo;
+}
+
 // Two f32 -> one packed dword of H (low half = first element).
 template <typename H> __device__ __forceinline__ uint32_t pack2(float a, float b);
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float a, float b) {

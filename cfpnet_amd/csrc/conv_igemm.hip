@@ -437,8 +437,25 @@ int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cou
 
 }  // namespace
 
+// Plan of the f16x3 kernels (float32 storage, conv_igemm_x3.hip): the gen-2 rules on the equivalent 16-bit problem.  A K-step of 32
+// channels moves the bytes and takes the LDS reads of a 64-channel 16-bit step, so the rules see twice the K.
+static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split, bool tput) {
+  Plan2 pl = plan2(M, N, 2 * (cdiv(K, 32) * 32), rpb, B, allow_split, false, tput);
+  // short-K, many-row problems (the rules' "first-generation" answer) and the direct 3x3 kernel have no f16x3 form: row-heavy tiles
+  if (pl.gen1 || pl.direct >= 0) pl.variant = N <= 16 ? 10 : N <= 32 ? 16 : N <= 64 ? 14 : 1;
+  pl.gen1 = false; pl.direct = -1;
+  if (pl.variant < 0 || pl.variant >= igemm_x3_num_variants()) pl.variant = 13;
+  return pl;
+}
+
 extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                                int* splits) {
+  if (dtype == CFP_F32X3) {
+    Plan2 pl = plan_x3(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, g_tput != 0);
+    if (variant) *variant = 400 + pl.variant;
+    if (splits) *splits = pl.splits;
+    return CFP_OK;
+  }
   if (is16(dtype) && !g_use_v1) {
     Plan2 pl = plan2(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, KH == 3 && stride == 1 && K % 9 == 0);
     const int cin = K / 9;
@@ -523,9 +540,36 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     return true;
   };
   const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
+  const bool x3 = (per_image_weights & CFP_CONV_X3) != 0;
   const bool tput = (per_image_weights & CFP_CONV_IN_FLIGHT) != 0 || g_tput != 0;
   per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+  if (x3) {
+    // float32 storage, split-precision matrix math: `w` is the pre-split operand of cfp_pack_w_x3 (conv_igemm_x3.hip)
+    CFP_REQUIRE(dtype == CFP_F32 && dil == 1 && !w2 && !mom, CFP_EINVAL, "cfp_conv2d_nhwc: CFP_CONV_X3 is for float32 storage (forward convolutions)");
+    CFP_REQUIRE(KH < 256 && KW < 256 && (long long)H * W * in_ld < (1ll << 31) && (long long)cdiv(p.K, 32) * 64 * Cout < (1ll << 40), CFP_ESHAPE,
+                "cfp_conv2d_nhwc: problem too large for the f16x3 kernel");
+    CFP_REQUIRE(aligned16(scale) && aligned16(shift), CFP_EINVAL, "cfp_conv2d_nhwc: scale / shift must be 16-byte aligned (read as 4-float vectors)");
+    const int rpb = per_image_weights ? Ho * Wo : 0;
+    Plan2 pl = plan_x3(p.M, Cout, p.K, rpb, B, rpb == 0, tput);
+    if (g_force_variant >= 400 && g_force_variant - 400 < igemm_x3_num_variants()) pl.variant = g_force_variant - 400;
+    if (g_force_splits >= 1) pl.splits = g_force_splits;
+    if (pl.splits > 1 && pl.variant >= 19) pl.variant = 4;
+    if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * cdiv(p.K, 32) * 64; pl.splits = 1; }
+    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) pl.splits = 1;
+    if (ln_gamma) p.res = nullptr;      // LayerNorm as a second kernel (the residual is added after it)
+    int rc = igemm_x3_launch(pl.variant, p, (float*)ws, pl.splits, s);
+    CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: f16x3 kernel launch failed");
+    if (pl.splits > 1) {
+      long long total = (long long)p.M * (Cout / 4);
+      int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
+    }
+    int e = cfp_check_launch("cfp_conv2d_nhwc");
+    if (e != CFP_OK || !ln_gamma) return e;
+    return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
+  }
 
   CFP_REQUIRE(!w2 || (p.pointwise && is16(dtype) && !per_image_weights && dil == 1 && !g_use_v1), CFP_EINVAL,
               "cfp_conv2d_nhwc: two-term weights (CFP_CONV_W2) are for 16-bit pointwise layers with shared weights");

@@ -1,0 +1,390 @@
+// Implicit-GEMM convolution / linear layer for FLOAT32 STORAGE with split-precision matrix math ("f16x3"):
+//
+//   x = x_hi + x_lo   (x_hi = the value rounded toward zero to IEEE half, x_lo = half(x - x_hi): 21-22 significant bits together)
+//   A . W  ~=  A_hi . W_hi  +  A_hi . W_lo  +  A_lo . W_hi          three v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block, f32 accumulate
+//
+// i.e. 3/16 of the bf16 / fp16 matrix rate instead of the 1/16 of v_mfma_f32_16x16x4_f32 that the float32 parity kernels (conv_igemm.hip)
+// run at, with a product error of ~2^-21 (the dropped lo x lo term and the two representation errors) -- three orders of magnitude
+// inside the north-star tolerance (1e-3 relative L1 on the depth map) on every weight family, where one-term fp16 / bf16 storage is
+// at 0.8e-3 ... 1.2e-2 depending on the conditioning of the network (tests/test_forward_gpu.py).
+//
+// Layout and pipeline are those of the second-generation 16-bit kernel (conv_igemm2.hip): both operand tiles travel global -> LDS with
+// `global_load_lds_dwordx4`, 128-byte LDS rows, XOR chunk swizzle applied on the DMA source side, STAGES K-steps in flight, one raw
+// barrier per K-step.  What differs:
+//   * a K-step is 32 input channels.  An A row in LDS is the 32 FLOAT32 values as they sit in the NHWC tensor (eight 16-byte chunks);
+//     lane (fr, fq) reads chunks fq and fq + 4 (the two reads of the 16-bit kernel, so the same banks) = channels 4 fq .. 4 fq + 3 and
+//     16 + 4 fq .. 16 + 4 fq + 3, and splits its eight values into the hi / lo operands in registers: 4 x v_cvt_pkrtz_f16_f32,
+//     8 x v_fma_mix_f32 (x - hi, exact), 4 x v_cvt_pk_f16_f32 per fragment.  Tiles with WN = 1 convert every A element exactly once.
+//   * the weights are PRE-SPLIT by cfp_pack_w_x3 (or by the squeeze-excite fold kernels, per image): row n holds, per K-step, 64 halves
+//     [hi(32) | lo(32)] in the lane order above (position 8 fq + e <-> channel 4 fq + e for e < 4, 16 + 4 fq + e - 4 for e >= 4), zero
+//     padded to whole K-steps -- the B fragments are plain 16-byte LDS reads.
+//   * the epilogue stores float32 straight from the accumulators (a lane owns 4 consecutive output channels of one pixel: 16 bytes).
+#include "igemm_core.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16_x3[4] = {0u, 0u, 0u, 0u};
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// eight float32 -> (hi, lo) half operands.  hi by truncation (v_cvt_pkrtz never rounds a finite value up to infinity), x - hi is exact in
+// float32, lo rounds it to nearest-even: |x - hi - lo| <= 2^-11 |x - hi| <= 2^-21 |x|.
+__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
+  typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4& x = h == 0 ? x0 : x1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const h2_t t = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
+      const f16x2 t2 = __builtin_bit_cast(f16x2, t);
+      const float r0 = __builtin_fmaf((float)t2[0], -1.f, x[2 * q]);
+      const float r1 = __builtin_fmaf((float)t2[1], -1.f, x[2 * q + 1]);
+      hi[4 * h + 2 * q] = t2[0]; hi[4 * h + 2 * q + 1] = t2[1];
+      lo[4 * h + 2 * q] = (_Float16)r0; lo[4 * h + 2 * q + 1] = (_Float16)r1;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __restrict__ slabs, int splits) {
+  static_assert(WM * WN == 4, "four waves per group");
+  static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int NA = BM / 32;                    // A DMA instructions per wave per K-step
+  constexpr int NBG = BN / 8;                    // 8-row groups of the W tile
+  constexpr int NB = (NBG + 3) / 4;              // W DMA instructions per wave per K-step
+  constexpr int LPS = NA + NB;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  static_assert((STAGES - 2) * LPS <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 2 ? wave8 >> 2 : 0;
+  const int wave = wave8 & 3;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;              // logical 16-byte chunk this lane fetches: 4 float32 channels of A, 8 halves of W
+  unsigned char* gsm = smem + kg * (STAGES * STAGE_BYTES);
+
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int sp = 0;
+  if constexpr (SPLITK) { sp = bid % splits; bid /= splits; }
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int nk_all = (p.K + 31) >> 5;
+  const int wrow = nk_all * 64;                  // halves per packed weight row
+  int m0, m_end;
+  const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
+  if (p.rows_per_batch > 0) {
+    const int tpb = (p.rows_per_batch + BM - 1) / BM;
+    const int b = tile_m / tpb;
+    m0 = b * p.rows_per_batch + (tile_m % tpb) * BM;
+    m_end = (b + 1) * p.rows_per_batch;
+    wt += (long long)b * p.w_bstride;
+  } else {
+    m0 = tile_m * BM;
+    m_end = p.M;
+  }
+  const int n0 = tile_n * BN;
+  int k0 = 0, k1 = nk_all;
+  if constexpr (SPLITK) {
+    const int per = (nk_all + splits - 1) / splits;
+    k0 = sp * per;
+    k1 = min(nk_all, k0 + per);
+  }
+  const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
+
+  const float* a_ptr[NA];
+  int a_hi0[NA], a_wi0[NA];
+  unsigned a_okmask = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + (i * 4 + wave) * 8 + rsub;
+    const bool ok = m < m_end;
+    if (ok) a_okmask |= 1u << i;
+    const int mm = ok ? m : m0;
+    if (p.pointwise) {
+      a_ptr[i] = in + (long long)mm * p.in_ld;
+      a_hi0[i] = 0;
+      a_wi0[i] = 0;
+    } else {
+      const int wo = mm % p.Wo;
+      const int t = mm / p.Wo;
+      const int ho = t % p.Ho;
+      const int b = t / p.Ho;
+      a_hi0[i] = ho * p.stride - p.pad_t;
+      a_wi0[i] = wo * p.stride - p.pad_l;
+      a_ptr[i] = in + (((long long)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.in_ld;   // virtual when in the halo
+    }
+  }
+  const f16_t* b_ptr[NB];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + ((j * 4 + wave) % NBG) * 8 + rsub;
+    const bool ok = n < p.Cout;
+    if (ok) b_okmask |= 1u << j;
+    b_ptr[j] = wt + (long long)(ok ? n : 0) * wrow;
+  }
+  const void* zsrc = reinterpret_cast<const void*>(g_zero16_x3);
+  // im2col position of this lane's chunk in the next K-step to be issued, advanced by 32 channels per K-step without divisions
+  int i_cc = 0, i_kh = 0, i_kw = 0;
+  if (!p.pointwise) {
+    const int kk = ((k0 + kg) * 8 + lc) * 4;
+    const int tap = kk / p.Cin;
+    i_cc = kk - tap * p.Cin;
+    i_kh = tap / p.KW;
+    i_kw = tap - i_kh * p.KW;
+  }
+
+  auto issue = [&](int ks, int buf) {
+    unsigned char* sA = gsm + buf * STAGE_BYTES;
+    unsigned char* sB = sA + BM * 128;
+    const int kk = (ks * 8 + lc) * 4;            // first of this lane's four channels in the im2col K axis
+    const bool kok = kk < p.K;
+    if (p.pointwise) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = kok && ((a_okmask >> i) & 1u);
+        glds16(ok ? (const void*)(a_ptr[i] + kk) : zsrc, sA + (i * 4 + wave) * 1024);
+      }
+    } else {
+      const int off = (i_kh * p.W + i_kw) * p.in_ld + i_cc;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = kok && ((a_okmask >> i) & 1u) && (unsigned)(a_hi0[i] + i_kh) < (unsigned)p.H &&
+                        (unsigned)(a_wi0[i] + i_kw) < (unsigned)p.W;
+        glds16(ok ? (const void*)(a_ptr[i] + off) : zsrc, sA + (i * 4 + wave) * 1024);
+      }
+      i_cc += 32 * KG;
+      while (i_cc >= p.Cin) {
+        i_cc -= p.Cin;
+        if (++i_kw == p.KW) { i_kw = 0; ++i_kh; }
+      }
+    }
+    const int kw16 = (ks * 8 + lc) * 8;          // weight rows are zero-padded to whole K-steps: no K-tail test
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = (b_okmask >> j) & 1u;
+      glds16(ok ? (const void*)(b_ptr[j] + kw16) : zsrc, sB + ((j * 4 + wave) % NBG) * 1024);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkg = max(0, (k1 - k0 - kg + KG - 1) / KG);      // this group's K-steps
+  const int nit = (k1 - k0 + KG - 1) / KG;                     // barrier rounds
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nkg) issue(k0 + kg + s * KG, s);
+
+  const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
+  const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;      // tile row offsets are multiples of 16 rows
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it % STAGES;
+    const int ahead = min(nkg - 1 - it, STAGES - 2);
+    if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * LPS>();
+    else if (ahead == 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (KG == 2 && it >= nkg) continue;
+    if (it + STAGES - 1 < nkg) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
+
+    const unsigned char* cA = gsm + buf * STAGE_BYTES + a_row0 * 128;
+    const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
+    f16x8 bhi[TN], blo[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bhi[j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc0);
+      blo[j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc1);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc0);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc1);
+      f16x8 ahi, alo;
+      split8(x0, x1, ahi, alo);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {      // transposed (weights as the row operand): acc[r] = 4 CONSECUTIVE CHANNELS (n = 4 fq + r) of pixel row fr
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo[j], ahi, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[j], alo, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[j], ahi, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  if constexpr (KG == 2) {
+    __syncthreads();   // every wave is done with the operand stages: LDS carries the second group's accumulators to the first
+    static_assert(BM * BN * 4 <= KG * STAGES * STAGE_BYTES, "accumulator exchange must fit in the operand LDS");
+    f32x4* xch = reinterpret_cast<f32x4*>(smem) + wave * (TM * TN * 64) + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) xch[(i * TN + j) * 64] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 o = xch[(i * TN + j) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+      }
+  }
+
+  if constexpr (SPLITK) {
+    float* slab = slabs + (long long)sp * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int m = m0 + a_row0 + i * 16 + fr;
+        const int n = n0 + b_row0 + j * 16 + fq * 4;
+        if (m < m_end && n < p.Cout) *reinterpret_cast<f32x4*>(slab + (long long)m * p.Cout + n) = acc[i][j];
+      }
+  } else {
+    float* __restrict__ out = reinterpret_cast<float*>(p.out);
+    const float* __restrict__ res = reinterpret_cast<const float*>(p.res);
+    with_act(p.act, [&](auto A) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + b_row0 + j * 16 + fq * 4;
+        if (n >= p.Cout) continue;            // Cout % 4 == 0: a lane's four channels are in or out together
+        const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + a_row0 + i * 16 + fr;
+          if (m >= m_end) continue;
+          f32x4 y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = act_c<decltype(A)::value>(acc[i][j][r] * sc[r] + sh[r]);
+          if (res) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long long)m * p.res_ld + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] += rv[r];
+          }
+          *reinterpret_cast<f32x4*>(out + (long long)m * p.out_ld + n) = y;
+        }
+      }
+    });
+  }
+}
+
+struct Cfg { int bm, bn, stages, kg = 1; };
+// same variant ids as conv_igemm2.hip (the plan function is shared); a K-step here is 32 channels
+constexpr Cfg kCfg[] = {
+    {128, 128, 3}, {128, 128, 2}, {128, 64, 3}, {128, 64, 4}, {64, 64, 3}, {64, 64, 4}, {256, 32, 3}, {256, 32, 2}, {128, 32, 3}, {128, 32, 4},
+    {256, 16, 2}, {128, 16, 4}, {64, 128, 3}, {64, 64, 2}, {128, 64, 2}, {64, 128, 2}, {128, 32, 2}, {32, 64, 3}, {32, 128, 3},
+    {64, 64, 2, 2}, {64, 64, 3, 2}, {64, 128, 2, 2},
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
+template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1>
+int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
+  const size_t lds = (size_t)KG * STAGES * (BM + BN) * 128;
+  if (lds > 160 * 1024) return -1;
+  if (KG == 2 && splits > 1) return -4;
+  long long tiles_m = p.rows_per_batch > 0 ? (long long)p.B * cdiv(p.rows_per_batch, BM) : cdiv(p.M, BM);
+  long long tiles = tiles_m * cdiv(p.Cout, BN);
+  if (splits <= 1) {
+    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG>;
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1);
+  } else if constexpr (KG == 1) {
+    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, true>;
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, p, slabs, splits);
+  }
+  return 0;
+}
+
+// f32 [rows][K] -> packed halves [rows][ceil(K / 32) * 64]
+__global__ __launch_bounds__(256) void pack_w_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ out, long long rows, int K, int nk) {
+  const long long total = rows * nk * 32;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i & 31);
+    const long long t = i >> 5;
+    const int ks = (int)(t % nk);
+    const long long n = t / nk;
+    const int k = ks * 32 + r;
+    const float x = k < K ? w[n * K + k] : 0.f;
+    const f16_t hi = f2h(x);
+    const f16_t lo = (f16_t)(x - (float)hi);
+    const int pos = ((r & 15) >> 2) * 8 + (r & 3) + ((r >> 4) << 2);
+    f16_t* row = out + (n * nk + ks) * 64;
+    row[pos] = hi;
+    row[32 + pos] = lo;
+  }
+}
+
+}  // namespace
+
+int igemm_x3_num_variants() { return kNumCfg; }
+void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages) { *bm = kCfg[v].bm; *bn = kCfg[v].bn; *stages = kCfg[v].stages; }
+
+// Launch variant v (conv_igemm2.hip's ids).  Returns 0, or a negative value if the variant cannot run this problem.
+int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s) {
+  switch (v) {
+    case 0: return launch_x3<128, 128, 2, 2, 3>(p, slabs, splits, s);
+    case 1: return launch_x3<128, 128, 2, 2, 2>(p, slabs, splits, s);
+    case 2: return launch_x3<128, 64, 4, 1, 3>(p, slabs, splits, s);
+    case 3: return launch_x3<128, 64, 4, 1, 4>(p, slabs, splits, s);
+    case 4: return launch_x3<64, 64, 4, 1, 3>(p, slabs, splits, s);
+    case 5: return launch_x3<64, 64, 4, 1, 4>(p, slabs, splits, s);
+    case 6: return launch_x3<256, 32, 4, 1, 3>(p, slabs, splits, s);
+    case 7: return launch_x3<256, 32, 4, 1, 2>(p, slabs, splits, s);
+    case 8: return launch_x3<128, 32, 4, 1, 3>(p, slabs, splits, s);
+    case 9: return launch_x3<128, 32, 4, 1, 4>(p, slabs, splits, s);
+    case 10: return launch_x3<256, 16, 4, 1, 2>(p, slabs, splits, s);
+    case 11: return launch_x3<128, 16, 4, 1, 4>(p, slabs, splits, s);
+    case 12: return launch_x3<64, 128, 2, 2, 3>(p, slabs, splits, s);
+    case 13: return launch_x3<64, 64, 4, 1, 2>(p, slabs, splits, s);
+    case 14: return launch_x3<128, 64, 4, 1, 2>(p, slabs, splits, s);
+    case 15: return launch_x3<64, 128, 2, 2, 2>(p, slabs, splits, s);
+    case 16: return launch_x3<128, 32, 4, 1, 2>(p, slabs, splits, s);
+    case 17: return launch_x3<32, 64, 1, 4, 3>(p, slabs, splits, s);
+    case 18: return launch_x3<32, 128, 1, 4, 3>(p, slabs, splits, s);
+    case 19: return launch_x3<64, 64, 4, 1, 2, 2>(p, slabs, splits, s);
+    case 20: return launch_x3<64, 64, 4, 1, 3, 2>(p, slabs, splits, s);
+    case 21: return launch_x3<64, 128, 2, 2, 2, 2>(p, slabs, splits, s);
+    default: return -3;
+  }
+}
+
+extern "C" size_t cfp_pack_w_x3_elems(long long rows, int K) { return rows <= 0 || K <= 0 ? 0 : (size_t)rows * ((K + 31) / 32) * 64; }
+
+// Convolution / linear weights [rows][K] float32 (K = KH * KW * Cin in (kh, kw, ci) order) -> the pre-split operand of the f16x3 kernels:
+// [rows][ceil(K / 32)][hi(32) | lo(32)] IEEE halves in the kernels' lane order, zero padded to whole K-steps.  `rows` may be B * Cout
+// (per-image weights).
+extern "C" int cfp_pack_w_x3(const float* w, void* out, long long rows, int K, cfp_stream_t stream) {
+  CFP_REQUIRE(w && out, CFP_EINVAL, "cfp_pack_w_x3: null pointer");
+  CFP_REQUIRE(rows > 0 && K > 0 && aligned16(out), CFP_ESHAPE, "cfp_pack_w_x3: bad shape / alignment");
+  const int nk = (K + 31) / 32;
+  const long long total = rows * nk * 32;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_w_x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, reinterpret_cast<f16_t*>(out), rows, K, nk);
+  return cfp_check_launch("cfp_pack_w_x3");
+}

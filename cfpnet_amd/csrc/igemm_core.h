@@ -41,6 +41,11 @@ int igemm2_num_variants();
 void igemm2_variant_shape(int v, int* bm, int* bn, int* stages);
 int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
 
+// conv_igemm_x3.hip (float32 storage, f16x3 matrix math; `p.w` = the packed operand of cfp_pack_w_x3)
+int igemm_x3_num_variants();
+void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages);
+int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
+
 // conv3x3_direct.hip
 int conv3x3_num_variants();
 void conv3x3_variant_shape(int v, int* th, int* bn);

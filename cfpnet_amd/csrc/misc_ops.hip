@@ -224,8 +224,9 @@ template <typename T>
 __global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restrict__ partial, int nsplit, float inv_hw,
                                                             const float* __restrict__ wr, const float* __restrict__ br,
                                                             const float* __restrict__ we_t, const float* __restrict__ be,
-                                                            const T* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R) {
+                                                            const T* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R, int x3) {
   constexpr int VE = Vec<T>::N;
+  const int nk3 = (C + 31) >> 5;            // x3 (float32 weights only): wout is the pre-split f16x3 operand (cfp_pack_w_x3 layout)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* mean = sm;                         // [C]
   float* hid = sm + C;                      // [R] (padded to 64)
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restr
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
           for (int e = 0; e < VE; ++e) v[k][e] *= g[e];
+          if constexpr (VE == 4) { if (x3) { x3_store4(reinterpret_cast<f16_t*>(wout), (long long)b * Cout + n + k * nrl, nk3, cv * 4, v[k]); continue; } }
           Vec<T>::store(wout + ((long long)b * Cout + n + k * nrl) * C + cv * VE, v[k]);
         }
       }
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restr
         Vec<T>::load(w + (long long)n * C + cv * VE, v);
 #pragma unroll
         for (int e = 0; e < VE; ++e) v[e] *= g[e];
+        if constexpr (VE == 4) { if (x3) { x3_store4(reinterpret_cast<f16_t*>(wout), (long long)b * Cout + n, nk3, cv * 4, v); continue; } }
         Vec<T>::store(wout + ((long long)b * Cout + n) * C + cv * VE, v);
       }
     }
@@ -348,8 +351,9 @@ __global__ __launch_bounds__(1024) void se_gate_fold_kernel(const float* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void se_gate_fold2_kernel(const float* __restrict__ hpart, int K, float inv_hw, const float* __restrict__ br,
                                                             const float* __restrict__ we_t, const float* __restrict__ be,
-                                                            const float* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R, int rows_per_z) {
+                                                            const float* __restrict__ w, T* __restrict__ wout, int Cout, int C, int R, int rows_per_z, int x3) {
   constexpr int VE = Vec<T>::N;
+  const int nk3 = (C + 31) >> 5;            // x3 (float32 only): wout is the pre-split f16x3 operand (cfp_pack_w_x3 layout)
   __shared__ float hsum[4][64];
   __shared__ float hid[64];
   __shared__ float gpart[2][128];
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(256) void se_gate_fold2_kernel(const float* __restr
           if (n + k * NRL < n1) {
 #pragma unroll
             for (int e = 0; e < VE; ++e) v[k][e] *= g[e];
+            if constexpr (VE == 4) { if (x3) { x3_store4(reinterpret_cast<f16_t*>(wout), (long long)b * Cout + n + k * NRL, nk3, cv * 4, v[k]); continue; } }
             Vec<T>::store(wout + ((long long)b * Cout + n + k * NRL) * C + cv * VE, v[k]);
           }
         }
@@ -738,6 +743,8 @@ extern "C" int cfp_se_fold(const void* w_proj, void* w_out, const float* hidden,
 extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float* w_reduce, const float* b_reduce,
                                 const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out, int B, int Cout,
                                 int C, int R, int dtype, cfp_stream_t stream) {
+  const int x3 = dtype == CFP_F32X3 ? 1 : 0;      // float32 project weights in, per-image pre-split f16x3 operands out
+  if (x3) dtype = CFP_F32;
   CHECK_DTYPE("cfp_se_gate_fold");
   CFP_REQUIRE(partial && w_reduce && b_reduce && w_expand_t && b_expand && w_proj && w_out, CFP_EINVAL, "cfp_se_gate_fold: null pointer");
   CFP_REQUIRE(aligned16(partial) && aligned16(w_reduce) && aligned16(w_proj) && aligned16(w_out), CFP_EINVAL,
@@ -749,18 +756,20 @@ extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, 
   dim3 grid(cdiv(C, 256), B);
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(se_gate_fold_kernel<bf16_t>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
-                       b_expand, (const bf16_t*)w_proj, (bf16_t*)w_out, Cout, C, R);
+                       b_expand, (const bf16_t*)w_proj, (bf16_t*)w_out, Cout, C, R, 0);
   else if (dtype == CFP_F16)
     hipLaunchKernelGGL(se_gate_fold_kernel<f16_t>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
-                       b_expand, (const f16_t*)w_proj, (f16_t*)w_out, Cout, C, R);
+                       b_expand, (const f16_t*)w_proj, (f16_t*)w_out, Cout, C, R, 0);
   else
     hipLaunchKernelGGL(se_gate_fold_kernel<float>, grid, dim3(1024), lds, s, partial, nsplit, inv_hw, w_reduce, b_reduce, w_expand_t,
-                       b_expand, (const float*)w_proj, (float*)w_out, Cout, C, R);
+                       b_expand, (const float*)w_proj, (float*)w_out, Cout, C, R, x3);
   return cfp_check_launch("cfp_se_gate_fold");
 }
 
 extern "C" int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const float* b_reduce, const float* w_expand_t, const float* b_expand,
                                  const float* w_proj, void* w_out, int B, int Cout, int C, int R, int dtype, cfp_stream_t stream) {
+  const int x3 = dtype == CFP_F32X3 ? 1 : 0;
+  if (x3) dtype = CFP_F32;
   CHECK_DTYPE("cfp_se_gate_fold2");
   CFP_REQUIRE(hpart && b_reduce && w_expand_t && b_expand && w_proj && w_out, CFP_EINVAL, "cfp_se_gate_fold2: null pointer");
   CFP_REQUIRE(aligned16(w_proj) && aligned16(w_out), CFP_EINVAL, "cfp_se_gate_fold2: pointers must be 16-byte aligned");
@@ -776,13 +785,13 @@ extern "C" int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const 
   dim3 grid(slabs, B, cdiv(Cout, rows_per_z));
   if (dtype == CFP_BF16)
     hipLaunchKernelGGL(se_gate_fold2_kernel<bf16_t>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
-                       (bf16_t*)w_out, Cout, C, R, rows_per_z);
+                       (bf16_t*)w_out, Cout, C, R, rows_per_z, 0);
   else if (dtype == CFP_F16)
     hipLaunchKernelGGL(se_gate_fold2_kernel<f16_t>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
-                       (f16_t*)w_out, Cout, C, R, rows_per_z);
+                       (f16_t*)w_out, Cout, C, R, rows_per_z, 0);
   else
     hipLaunchKernelGGL(se_gate_fold2_kernel<float>, grid, dim3(256), 0, s, hpart, K, inv_hw, b_reduce, w_expand_t, b_expand, w_proj,
-                       (float*)w_out, Cout, C, R, rows_per_z);
+                       (float*)w_out, Cout, C, R, rows_per_z, x3);
   return cfp_check_launch("cfp_se_gate_fold2");
 }
 

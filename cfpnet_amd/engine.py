@@ -96,7 +96,11 @@ class Engine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, layer_names: Sequence[str], n_bins: int = 256,
                  min_val: float = 1e-3, max_val: float = 10.0, norm: str = "linear", change_embedding: bool = True,
                  no_skip_inside: bool = False, stem_act: bool = False, dtype=torch.bfloat16, device="cuda:0",
-                 zone_sample_num: int = 16, base_resolution=spec.BASE_RESOLUTION):
+                 zone_sample_num: int = 16, base_resolution=spec.BASE_RESOLUTION, x3: bool = False):
+        """`x3` (float32 storage only): every convolution / linear layer runs its matrix math split-precision on the 16-bit matrix cores
+        (A_hi W_hi + A_hi W_lo + A_lo W_hi in IEEE half, float32 accumulate; csrc/conv_igemm_x3.hip) instead of the float32 MFMA:
+        ~21 significant bits per product at 3/16 instead of 1/16 of the 16-bit matrix rate.  Activations, every other kernel and the
+        results' type are those of the float32 mode."""
         hip.load()   # fail loudly if the HIP extension is missing
         self.base_resolution = tuple(base_resolution)
         self.fusion = spec.fusion_table(self.base_resolution)    # decoder.py:82-94 generalised to other table sizes (configs[4])
@@ -108,6 +112,9 @@ class Engine:
         self.norm = {"linear": 0, "softmax": 1, "sigmoid": 2}[norm]
         self.change_embedding, self.no_skip_inside, self.stem_act = change_embedding, no_skip_inside, stem_act
         self.dtype, self.device = dtype, torch.device(device)
+        assert not x3 or dtype == torch.float32, "x3 is a matrix-math mode of float32 storage"
+        self.x3 = bool(x3)
+        self.cdt = hip.F32X3 if self.x3 else ops.DT[dtype]          # planning dtype (cfp_conv2d_ws_bytes)
         self.zone_sample_num = zone_sample_num
         # depth head: conv3x3 -> conv_out -> softmax -> expectation as ONE kernel (csrc/head_fused.hip) in the 16-bit modes;
         # head_hilo = (conv_out weights as hi + lo planes, ram fed to conv_out as hi + lo): the logits then carry neither the
@@ -187,6 +194,8 @@ class Engine:
             return ops.pack_w2(flat, self.dtype).to(self.device)
         if kh * kw == 1 and self.diffuse_cin and self.dtype == torch.float16:
             flat = ops.round_taps(flat.reshape(co, 1, kh * kw * cip), self.dtype).reshape(co, -1)     # error diffusion along the input channels
+        if self.x3:
+            return ops.pack_w_x3(self._dev(flat))      # pre-split hi | lo halves in the f16x3 kernels' lane order
         return self._dev(flat, self.dtype)
 
     def _fold_bn(self, sd, bn: Optional[str], bias: Optional[torch.Tensor], co: int, eps: float):
@@ -340,10 +349,10 @@ class Engine:
         assert a.rows == rows and a.ld == (ld or C), key
         return Act(a.buf, 0, C)
 
-    def _buf(self, plan, key: str, shape, dtype) -> torch.Tensor:
+    def _buf(self, plan, key: str, shape, dtype, zero: bool = False) -> torch.Tensor:
         bufs = plan["bufs"]
         if key not in bufs:
-            bufs[key] = torch.empty(shape, dtype=dtype, device=self.device)
+            bufs[key] = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
         assert tuple(bufs[key].shape) == tuple(shape), key
         return bufs[key]
 
@@ -364,16 +373,16 @@ class Engine:
             (pt, pb), (pl, pr) = pads
             Ho, Wo = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
         ops.conv2d(x, self.P[name + ".w"], self.P[name + ".s"], self.P[name + ".t"], out, B, H, W, k, k, stride, pt, pl,
-                   Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, self.P[name + ".w"].shape[-1]))
+                   Ho, Wo, act, residual, self._ws(B * Ho * Wo, out.C, k * k * x.C))
         return Ho, Wo
 
     def _lin(self, wname, x: Act, out: Act, rows, act=hip.ACT_NONE, residual=None, st: Optional[str] = None, ln=None):
         ops.linear(x, self.P[wname], self.P[st + ".s"] if st else None, self.P[st + ".t"] if st else None, out, rows, act, residual,
-                   None if ln is not None else self._ws(rows, out.C, self.P[wname].shape[-1]), ln)
+                   None if ln is not None else self._ws(rows, out.C, x.C), ln)
 
     def _ws(self, M: int, Cout: int, K: int) -> Optional[torch.Tensor]:
         """Split-K scratch shared by all layers (kernels on one stream run in order)."""
-        need = ops.conv2d_ws_bytes(M, Cout, K, ops.DT[self.dtype])
+        need = ops.conv2d_ws_bytes(M, Cout, K, self.cdt)
         if need == 0:
             return None
         ws = self._lane_ws.get(self._lane)
@@ -458,9 +467,12 @@ class Engine:
                     self._dbg(f"enc{bi}.dw", mid2)
                 # SE tail (mean -> FC -> SiLU -> FC -> sigmoid) in one launch; the gate multiplies the project conv's
                 # input channels, so it is folded into per-image project weights instead of a pass over mid2
-                wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
+                if self.x3:      # per-image pre-split operands; the K padding of the rows is zeroed once and never written
+                    wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, (b.mid + 31) // 32 * 64), torch.float16, zero=True)
+                else:
+                    wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
                 ops.se_gate_fold(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], self.P[q + ".se.we_t"],
-                                 self.P[q + ".se.be"], self.P[q + ".pwl.w"], wb, B, b.cout, b.mid, b.se_rd)
+                                 self.P[q + ".se.be"], self.P[q + (".pwl.w32" if self.x3 else ".pwl.w")], wb, B, b.cout, b.mid, b.se_rd)
                 ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
                            res, None, per_image_weights=True)
             self._dbg(f"enc{bi}", out)

@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CFP_HIP_LIB") or os.path.join(_HERE, "libcfpnet_hip.so")      # CFP_HIP_LIB: A/B runs against another build
 
 F32, BF16, F16 = 0, 1, 2
+F32X3 = 3      # float32 storage + f16x3 matrix math: a planning / packing dtype (include/cfpnet_hip.h)
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
 TOF_SAMPLE_UNIFORM, TOF_SAMPLE_ICDF = 0, 1
 HEAD_WOUT_HILO, HEAD_RAM_HILO = 1, 2
-CONV_PER_IMAGE, CONV_W2, CONV_IN_FLIGHT = 1, 2, 4
+CONV_PER_IMAGE, CONV_W2, CONV_IN_FLIGHT, CONV_X3 = 1, 2, 4, 8
 
 _p, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 
@@ -29,6 +30,8 @@ SIGNATURES = {
     "cfp_conv2d_nhwc_ex": (_i, [_p, _i, _p, _p, _p, _p, _i, _p, _i] + [_i] * 14 + [_p, _p, _f, _i, _p, _sz, _p]),
     "cfp_conv2d_nhwc_moments": (_i, [_p, _i, _p, _p, _p, _i] + [_i] * 13 + [_p, _sz, _p, _sz, _p, _p, _p]),
     "cfp_conv2d_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "cfp_pack_w_x3_elems": (_sz, [_ll, _i]),
+    "cfp_pack_w_x3": (_i, [_p, _p, _ll, _i, _p]),
     "cfp_conv2d_plan": (_i, [_i] * 8 + [_p, _p]),
     "cfp_debug_set": (_i, [_i, _i]),
     "cfp_conv2d_variant": (_i, [_i, _i]),

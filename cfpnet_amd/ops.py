@@ -71,13 +71,17 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
     assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
     K = KH * KW * x.C
     wshape = (B, out.C, K) if per_image_weights else (out.C, K)
-    w2 = (not per_image_weights) and KH * KW == 1 and tuple(w.shape) == (out.C, 2 * ((K + 63) // 64) * 64)     # two-term rows [hi | lo]: pack_w2
-    assert w.dtype == x.buf.dtype and (w2 or tuple(w.shape) == wshape) and w.is_contiguous(), (w.shape, wshape)
+    x3 = x.buf.dtype == torch.float32 and w.dtype == torch.float16      # pre-split f16x3 operand (pack_w_x3) on float32 tensors
+    if x3:
+        wshape = wshape[:-1] + ((K + 31) // 32 * 64,)
+    w2 = (not x3) and (not per_image_weights) and KH * KW == 1 and tuple(w.shape) == (out.C, 2 * ((K + 63) // 64) * 64)     # two-term rows [hi | lo]: pack_w2
+    assert (x3 or w.dtype == x.buf.dtype) and (w2 or tuple(w.shape) == wshape) and w.is_contiguous(), (w.shape, wshape)
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     hip.call("cfp_conv2d_nhwc_ex", x.ptr, x.ld, w.data_ptr(), hip.ptr(scale), hip.ptr(shift),
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
              B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
-             hip.ptr(g), hip.ptr(b), float(eps), int(per_image_weights) | (hip.CONV_W2 if w2 else 0) | (hip.CONV_IN_FLIGHT if PLAN_IN_FLIGHT else 0),
+             hip.ptr(g), hip.ptr(b), float(eps),
+             int(per_image_weights) | (hip.CONV_W2 if w2 else 0) | (hip.CONV_IN_FLIGHT if PLAN_IN_FLIGHT else 0) | (hip.CONV_X3 if x3 else 0),
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 
@@ -106,7 +110,10 @@ DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
 
 def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
     t = {hip.BF16: "bf16", hip.F16: "f16"}.get(dt, "f32")
-    if variant >= 300:
+    if variant >= 400:
+        bm, bn, st = GEN2_TILES[variant - 400]
+        n = f"igemm_x3<{bm}x{bn},s{st}" + (",kg2>" if variant - 400 >= 19 else ">")
+    elif variant >= 300:
         n = f"conv3x3_halo<{t}>"
     elif variant >= 200:
         th, bn = DIRECT3_TILES[variant - 200]
@@ -154,10 +161,13 @@ def se_fold(w_proj: torch.Tensor, w_out: torch.Tensor, hidden, we_t, be, B, Cout
 
 
 def se_gate_fold(partial, nsplit, inv_hw, wr, br, we_t, be, w_proj: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R):
-    assert w_proj.shape == (Cout, C) and w_out.shape == (B, Cout, C) and w_proj.dtype == w_out.dtype
+    """`w_out` float16 with float32 `w_proj`: the per-image pre-split f16x3 operands [B, Cout, ceil(C/32)*64] (zero-initialised by the caller:
+    the K padding is never written)."""
+    x3 = w_proj.dtype == torch.float32 and w_out.dtype == torch.float16
+    assert w_proj.shape == (Cout, C) and w_out.shape == ((B, Cout, (C + 31) // 32 * 64) if x3 else (B, Cout, C)) and (x3 or w_proj.dtype == w_out.dtype)
     assert we_t.shape == (R, C) and wr.shape == (R, C) and partial.numel() >= B * nsplit * C
     hip.call("cfp_se_gate_fold", partial.data_ptr(), nsplit, float(inv_hw), wr.data_ptr(), br.data_ptr(), we_t.data_ptr(), be.data_ptr(),
-             w_proj.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_proj.dtype], _s())
+             w_proj.data_ptr(), w_out.data_ptr(), B, Cout, C, R, hip.F32X3 if x3 else DT[w_proj.dtype], _s())
 
 
 def dwconv3x3_se_parts(B: int, Ho: int, Wo: int, C: int, stride: int, dt: int) -> int:
@@ -173,11 +183,13 @@ def dwconv3x3_se(x: Act, w, scale, shift, out: Act, w_reduce: torch.Tensor, hpar
              w_reduce.data_ptr(), R, hpart.data_ptr(), B, H, W, x.C, stride, pad_t, pad_l, Ho, Wo, act, x.dt, _s())
 
 
-def se_gate_fold2(hpart, K, inv_hw, br, we_t, be, w_proj32: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R):
-    assert w_proj32.shape == (Cout, C) and w_proj32.dtype == torch.float32 and w_out.shape == (B, Cout, C)
+def se_gate_fold2(hpart, K, inv_hw, br, we_t, be, w_proj32: torch.Tensor, w_out: torch.Tensor, B, Cout, C, R, x3: bool = False):
+    """`x3`: w_out is the per-image pre-split f16x3 operand [B, Cout, ceil(C/32)*64] float16 (zero-initialised by the caller)."""
+    assert w_proj32.shape == (Cout, C) and w_proj32.dtype == torch.float32
+    assert w_out.shape == ((B, Cout, (C + 31) // 32 * 64) if x3 else (B, Cout, C)) and (not x3 or w_out.dtype == torch.float16)
     assert we_t.shape == (R, C) and hpart.dtype == torch.float32 and hpart.numel() >= B * K * R
     hip.call("cfp_se_gate_fold2", hpart.data_ptr(), K, float(inv_hw), br.data_ptr(), we_t.data_ptr(), be.data_ptr(),
-             w_proj32.data_ptr(), w_out.data_ptr(), B, Cout, C, R, DT[w_out.dtype], _s())
+             w_proj32.data_ptr(), w_out.data_ptr(), B, Cout, C, R, hip.F32X3 if x3 else DT[w_out.dtype], _s())
 
 
 def dwconv_large(x: Act, w, scale, shift, out: Act, B, H, W, k, act):
@@ -200,6 +212,16 @@ def _bracket16(w: torch.Tensor, dtype):
     up = torch.where(r >= w, r, nxt_up)
     down = torch.where(r <= w, r, nxt_dn)
     return down, up
+
+
+def pack_w_x3(w2d: torch.Tensor) -> torch.Tensor:
+    """[rows, K] float32 on the GPU -> the pre-split f16x3 operand [rows, ceil(K/32)*64] float16 (cfp_pack_w_x3): per 32-channel K-step
+    [hi(32) | lo(32)] in the kernels' lane order, zero padded."""
+    assert w2d.is_cuda and w2d.dtype == torch.float32 and w2d.dim() == 2 and w2d.is_contiguous()
+    rows, k = w2d.shape
+    out = torch.empty(rows, (k + 31) // 32 * 64, dtype=torch.float16, device=w2d.device)
+    hip.call("cfp_pack_w_x3", w2d.data_ptr(), out.data_ptr(), rows, k, _s())
+    return out
 
 
 def pack_w2(w2d: torch.Tensor, dtype) -> torch.Tensor:

@@ -32,6 +32,9 @@ typedef void* cfp_stream_t; /* hipStream_t */
 
 enum { CFP_OK = 0, CFP_EINVAL = -1, CFP_ESHAPE = -2, CFP_EHIP = -3 };
 enum { CFP_F32 = 0, CFP_BF16 = 1, CFP_F16 = 2 };
+/* CFP_F32X3: float32 STORAGE with split-precision ("f16x3") matrix math -- accepted where a call plans or packs for that mode
+ * (cfp_conv2d_plan, cfp_conv2d_ws_bytes, cfp_se_gate_fold's output format); kernels that do no matrix math take CFP_F32 tensors as they are. */
+enum { CFP_F32X3 = 3 };
 enum { CFP_TOF_SAMPLE_UNIFORM = 0, CFP_TOF_SAMPLE_ICDF = 1 };   /* sample_point_from_hist_parallel: --sample_uniform / default */
 enum { CFP_ACT_NONE = 0, CFP_ACT_RELU = 1, CFP_ACT_LRELU = 2, CFP_ACT_SILU = 3, CFP_ACT_GELU = 4, CFP_ACT_SIGMOID = 5 };
 
@@ -68,7 +71,14 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
  *     the K loop over both halves against the same activations, so the layer sees its weights with ~22 (fp16) / ~16 (bf16)
  *     significant bits instead of 11 / 8.  Weight rounding of the pointwise layers is 0.8e-3 of the fp16 engine's 0.9e-3
  *     relative-L1 error (profiles/r2_precision_budget.md). */
-enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2, CFP_CONV_IN_FLIGHT = 4 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument.
+/*   - per_image_weights & CFP_CONV_X3 (dtype CFP_F32): split-precision matrix math on float32 tensors.  Every value is taken as
+ *     hi + lo (two IEEE halves, ~21 significant bits) and the product as A_hi W_hi + A_hi W_lo + A_lo W_hi on
+ *     v_mfma_f32_16x16x32_f16 with float32 accumulation: 3/16 of the 16-bit matrix rate instead of the 1/16 of the float32 MFMA,
+ *     product error ~2^-21.  `w` is then the PRE-SPLIT operand written by cfp_pack_w_x3 ([Cout][ceil(K/32)][hi(32) | lo(32)] halves;
+ *     with CFP_CONV_PER_IMAGE: B such matrices, as cfp_se_gate_fold writes them for dtype CFP_F32X3).  This is the mode whose results
+ *     stay inside the reference tolerance (1e-3 relative L1 on the depth map, /root/reference/src/models/deltar.py:34-67 in float32)
+ *     for every weight family -- the default of the drop-in boundary. */
+enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2, CFP_CONV_IN_FLIGHT = 4, CFP_CONV_X3 = 8 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument.
  * CFP_CONV_IN_FLIGHT: a hint -- this launch will run beside launches of other batches (several captured forwards in flight): the tile is then
  * chosen for the resources it holds rather than for its own latency (larger tiles).  Results do not depend on it: every tile walks K in the same order. */
 int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
@@ -78,6 +88,13 @@ int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* sc
                        const float* ln_gamma, const float* ln_beta, float ln_eps, int per_image_weights,
                        void* ws, size_t ws_bytes, cfp_stream_t stream);
 
+/* Weights [rows][K] float32 (K = KH*KW*Cin in (kh, kw, ci) order; rows = Cout, or B*Cout for per-image weights) -> the pre-split
+ * operand of the CFP_CONV_X3 kernels: [rows][ceil(K/32)][hi(32) | lo(32)] IEEE halves in the kernels' lane order, zero padded to whole
+ * 32-channel K-steps.  cfp_pack_w_x3_elems = halves in that buffer.  Replaces nothing in the reference (a weight re-layout, like the
+ * [Cout][KH][KW][Cin] packing of every other mode); the layers are the nn.Conv2d / nn.Linear calls listed at cfp_conv2d_nhwc. */
+size_t cfp_pack_w_x3_elems(long long rows, int K);
+int cfp_pack_w_x3(const float* w, void* out, long long rows, int K, cfp_stream_t stream);
+
 /* Scratch cfp_conv2d_nhwc wants for (M = B*Ho*Wo, Cout, K = KH*KW*Cin): non-zero only for layers it
  * runs split-K (few output tiles, long K: the GSA sr convs, the 1/32-scale pointwise convs).  With
  * ws == NULL or too small the layer runs un-split (same result up to f32 re-association). */
@@ -86,7 +103,7 @@ size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype);
 /* Kernel plan cfp_conv2d_nhwc uses for a problem (per-kernel accounting in bench.py and
  * tools/conv_bench.py).  *variant: 0..3 = first-generation tiles 256x16 / 256x32 / 128x64 /
  * 128x128 (f32); 100 + v = second-generation (bf16, LDS-DMA staged) variant v; 200 + v = direct 3x3
- * (LDS halo tile) variant v.  *splits = K-splits.  KH/stride describe the filter (K = KH*KH*Cin);
+ * (LDS halo tile) variant v; 400 + v = f16x3 variant v (dtype CFP_F32X3: float32 storage, CFP_CONV_X3).  *splits = K-splits.  KH/stride describe the filter (K = KH*KH*Cin);
  * rows_per_batch > 0 describes a per_image_weights call (B images of rows_per_batch rows). */
 int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                     int* splits);

@@ -151,6 +151,140 @@ def test_conv2d_gen2_every_tile_variant(variant, dtype):
         lib.cfp_debug_set(1, -1)
 
 
+# ---- float32 storage with split-precision (f16x3) matrix math: csrc/conv_igemm_x3.hip ------------------------------------------
+X3_TOL = 4e-6       # relative to the largest |reference| entry; the float32 MFMA kernel measures ~1e-6 on the same problems
+
+
+def _x3_problem(case, seed=1, xscale=1.0):
+    """float64 reference + device operands of a conv case for the f16x3 kernels (weights pre-split by cfp_pack_w_x3)."""
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    x = rnd(B, Cin, H, W, seed=seed) * xscale
+    w = rnd(Cout, Cin, k, k, seed=seed + 1, scale=1.0 / math.sqrt(Cin * k * k))
+    scale = rnd(Cout, seed=seed + 2).abs() + 0.5
+    shift = rnd(Cout, seed=seed + 3) * xscale
+    Ho = (H + pt + pb - k) // s + 1
+    Wo = (W + pl + pr - k) // s + 1
+    res = rnd(B, Cout, Ho, Wo, seed=seed + 4) * xscale
+    ref = F.conv2d(F.pad(x.double(), (pl, pr, pt, pb)), w.double(), None, s)
+    ref = F.silu(ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]) + res.double()
+    xa = to_act(nhwc(x), torch.float32, ld=Cin + 16, c0=8)
+    w32 = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(DEV)
+    ra = to_act(nhwc(res), torch.float32)
+    return ref, xa, w32, ops.pack_w_x3(w32), scale.to(DEV), shift.to(DEV), ra, Ho, Wo
+
+
+def _x3_close(got, ref, what, tol=X3_TOL):
+    err = float((got.double() - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+    assert err <= tol, f"{what}: max err / max |ref| = {err:.3e}"
+    return err
+
+
+def test_pack_w_x3_layout():
+    """hi + lo of the packed operand reproduce the float32 weights to 2^-21, in the documented lane order, zero padded."""
+    co, K = 5, 72
+    w = (rnd(co, K, seed=3) * 0.1).to(DEV)
+    pk = ops.pack_w_x3(w).float().cpu().reshape(co, -1, 2, 32)
+    assert pk.shape[1] == 3
+    r = torch.arange(32)
+    pos = ((r % 16) // 4) * 8 + r % 4 + 4 * (r // 16)
+    back = torch.zeros(co, 96)
+    for ks in range(3):
+        back[:, ks * 32 + r] = pk[:, ks, 0, pos] + pk[:, ks, 1, pos]
+    assert float((back[:, :K] - w.cpu()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    assert float(back[:, K:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_x3(case):
+    """Every conv case through the automatic f16x3 plan (with and without its split-K workspace) against a float64 reference:
+    as tight as the float32 MFMA kernel, three decimal orders inside the 1e-3 gate."""
+    B, H, W, Cin, Cout, k, s, (pt, pl, pb, pr) = case
+    ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+    nws = ops.conv2d_ws_bytes(B * Ho * Wo, Cout, k * k * Cin, hip.F32X3)
+    for ws in ([torch.empty(max(nws // 4, 1), device=DEV), None] if nws else [None]):
+        out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
+        out = ops.Act(out.buf, 16, Cout)
+        ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pt, pl, Ho, Wo, hip.ACT_SILU, ra, ws)
+        torch.cuda.synchronize()
+        _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 conv {case} (ws {nws if ws is not None else 0})")
+        assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("variant", GEN2_VARIANTS)
+def test_conv2d_x3_every_tile_variant(variant):
+    """Every f16x3 tile configuration on every conv case, forced through the debug knob (400 + v), un-split and with 4 K-splits."""
+    lib = hip.load()
+    try:
+        lib.cfp_debug_set(0, 400 + variant)
+        for case in CONV_CASES:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            for splits in ((1,) if variant in GEN2_KGROUPS else (1, 4)):
+                lib.cfp_debug_set(1, splits)
+                out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
+                out = ops.Act(out.buf, 16, Cout)
+                ws = torch.empty(splits * B * Ho * Wo * Cout, device=DEV)
+                ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, ws)
+                torch.cuda.synchronize()
+                _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 v{variant} splits {splits} conv {case}")
+                assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+    finally:
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(1, -1)
+
+
+@pytest.mark.parametrize("xscale", [1e-2, 1e-4, 3e3])
+def test_conv2d_x3_small_and_large_magnitudes(xscale):
+    """Activations far from 1: at 1e-2 the lo halves are IEEE-half SUBNORMALS (the matrix core must take them as they are), at 1e-4 the
+    hi halves are; at 3e3 sums approach the half range.  The error stays relative to the data, not to 1."""
+    case = (2, 15, 20, 136, 232, 1, 1, (0, 0, 0, 0))
+    B, H, W, Cin, Cout, k, s, pads = case
+    ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case, xscale=xscale)
+    out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+    ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, 0, 0, Ho, Wo, hip.ACT_SILU, ra, None)
+    torch.cuda.synchronize()
+    # below ~6e-5 a half has fewer than 11 bits: the absolute error floor is 2^-25 per term (harmless next to O(1) activations)
+    _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 magnitudes {xscale}", tol=4e-6 if xscale >= 1e-2 else 2e-4)
+
+
+def test_conv2d_x3_per_image_weights_and_layernorm():
+    """Per-image pre-split weights (the squeeze-excite fold) and the LayerNorm that follows as a second kernel."""
+    B, HW, Cin, Cout = 3, 300, 232, 128
+    x = rnd(B * HW, Cin, seed=1)
+    w = rnd(B, Cout, Cin, seed=2, scale=1 / math.sqrt(Cin))
+    xa = to_act(x, torch.float32)
+    wx = ops.pack_w_x3(w.reshape(B * Cout, Cin).to(DEV)).reshape(B, Cout, -1)
+    out = ops.new_act(B * HW, Cout, torch.float32, DEV)
+    ops.conv2d(xa, wx, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None, per_image_weights=True)
+    ref = torch.einsum("bmk,bnk->bmn", x.reshape(B, HW, Cin).double(), w.double()).reshape(B * HW, Cout)
+    _x3_close(out.torch().cpu(), ref, "x3 per-image weights")
+    g, bt = rnd(Cout, seed=5).abs() + 0.5, rnd(Cout, seed=6)
+    res = rnd(HW, Cout, seed=7)
+    w1 = w[0]
+    out2 = ops.new_act(HW, Cout, torch.float32, DEV)
+    ops.linear(xa, ops.pack_w_x3(w1.contiguous().to(DEV)), None, None, out2, HW, hip.ACT_RELU, to_act(res, torch.float32), None,
+               (g.to(DEV), bt.to(DEV), 1e-5))
+    y = F.relu(x[:HW].double() @ w1.double().t())
+    ref2 = F.layer_norm(y, (Cout,), g.double(), bt.double(), 1e-5) + res.double()
+    _x3_close(out2.torch().cpu(), ref2, "x3 + LayerNorm + residual", tol=2e-5)
+
+
+def test_se_gate_fold_writes_x3_operands():
+    """cfp_se_gate_fold with dtype CFP_F32X3: the per-image folded project weights arrive pre-split, equal to packing the float32 fold."""
+    B, Cout, C, R, ns = 2, 40, 136, 8, 3
+    part = rnd(B * ns * C, seed=1).abs().to(DEV)
+    wr, br = rnd(R, C, seed=2, scale=0.1).to(DEV), rnd(R, seed=3).to(DEV)
+    we_t, be = rnd(R, C, seed=4).to(DEV), rnd(C, seed=5).to(DEV)
+    w = rnd(Cout, C, seed=6, scale=0.1).to(DEV)
+    w32 = torch.empty(B, Cout, C, device=DEV)
+    ops.se_gate_fold(part, ns, 0.01, wr, br, we_t, be, w, w32, B, Cout, C, R)
+    wx = torch.zeros(B, Cout, (C + 31) // 32 * 64, dtype=torch.float16, device=DEV)
+    ops.se_gate_fold(part, ns, 0.01, wr, br, we_t, be, w, wx, B, Cout, C, R)
+    want = ops.pack_w_x3(w32.reshape(B * Cout, C)).reshape(B, Cout, -1)
+    torch.cuda.synchronize()
+    assert torch.equal(wx, want)
+
+
 DIRECT3_CASES = [
     (1, 12, 16, 40, 16, 3, 1, (1, 1, 1, 1)),      # Cin < 64 (one partly filled channel chunk), Cout 16
     (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)),    # 7 channel chunks, tail chunk of 8 channels, 2 N-tiles

@@ -11,8 +11,17 @@ layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 inp = synthetic.to_device(synthetic.make_inputs(B), "cuda:0")
-for dt in ((torch.bfloat16,) if os.environ.get('MODE_BENCH_BF16_ONLY') else (torch.float32, torch.float16, torch.bfloat16)):
-    eng = Engine(sd, layer_names=layers, dtype=dt)
+_ALL = {"f32": torch.float32, "x3": "x3", "f16": torch.float16, "bf16": torch.bfloat16}
+_sel = os.environ.get("MODE_BENCH_DTYPES")    # e.g. "f32" or "f32,f16"
+for dt in ((torch.bfloat16,) if os.environ.get('MODE_BENCH_BF16_ONLY') else tuple(_ALL[k] for k in _sel.split(",")) if _sel else tuple(_ALL.values())):
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True) if dt == "x3" else Engine(sd, layer_names=layers, dtype=dt)
+    if os.environ.get("MODE_BENCH_CHECK"):      # relative L1 of the depth map against the float32 engine's
+        e32 = Engine(sd, layer_names=layers, dtype=torch.float32)
+        p32 = e32.forward(inp)[1].float()
+        pm = eng.forward(inp)[1].float()
+        rel = ((pm - p32).abs().flatten(1).sum(1) / p32.abs().flatten(1).sum(1))
+        print(json.dumps({"dtype": str(dt), "rel_l1_vs_f32_engine_per_image": [float(v) for v in rel]}))
+        del e32
     mx = int(os.environ.get("MODE_BENCH_MAX_INFLIGHT", "4"))
     (kind, n), times = eng.capture_best(inp, reps=12, candidates=(("lanes", 1),) + tuple(("inflight", k) for k in range(2, mx + 1)))
     best = min(times.values())
