@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256) void colmoments_final_kernel(const float* __re
   mean[c] = a.mean; var[c] = v; invstd[c] = is;
   scale[c] = g * is; shift[c] = b0 - a.mean * g * is;
   const float unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * a.mean;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * unbias;
+  // a batch whose statistics are not finite (an fp16 activation overflow: the step the optimizer then skips, cfp_grad_clip_factor) must
+  // not poison the running statistics -- they outlive the step and are folded into every later validation engine
+  const bool finite = fabsf(a.mean) <= 3.0e38f && fabsf(v) <= 3.0e38f;      // false for inf and NaN
+  if (running_mean && finite) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * a.mean;
+  if (running_var && finite) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * unbias;
 }
 
 // MODE 0 -> mean; MODE 1 -> var (biased) ; MODE 2/3 -> dbeta (which 0), dgamma (which 1).

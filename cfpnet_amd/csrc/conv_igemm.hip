@@ -442,8 +442,13 @@ int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cou
 static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split, bool tput) {
   Plan2 pl = plan2(M, N, 2 * (cdiv(K, 32) * 32), rpb, B, allow_split, false, tput);
   // short-K, many-row problems (the rules' "first-generation" answer) and the direct 3x3 kernel have no f16x3 form: row-heavy tiles
-  if (pl.gen1 || pl.direct >= 0) pl.variant = N <= 16 ? 10 : N <= 32 ? 16 : N <= 64 ? 14 : 1;
+  if (pl.gen1 || pl.direct >= 0) pl.variant = N <= 16 ? 10 : N <= 32 ? 16 : N <= 64 ? 14 : K <= 64 ? 16 : 1;
   pl.gen1 = false; pl.direct = -1;
+  // tools/conv_bench_x3.py (alone and four copies side by side, profiles/r4_conv_bench_x3_*.txt): the 128 x 128 tile as four row waves
+  // (every A fragment converted once) beats the 2 x 2 layout everywhere (head conv 562 vs 614 us alone, 537 vs 569 in flight), and in
+  // flight it also beats the 64 x 128 tile on the long-K decoder convs (9600 x 256 x 3528: 53 vs 58 us, 38400 x 224 x 504: 36 vs 43)
+  if (pl.variant == 0 || pl.variant == 1) pl.variant = 26;
+  if (tput && pl.variant == 15 && M >= 9000 && N >= 128 && N <= 256 && K >= 500) pl.variant = 26;
   if (pl.variant < 0 || pl.variant >= igemm_x3_num_variants()) pl.variant = 13;
   return pl;
 }

@@ -14,7 +14,8 @@
 //   * a K-step is 32 input channels.  An A row in LDS is the 32 FLOAT32 values as they sit in the NHWC tensor (eight 16-byte chunks);
 //     lane (fr, fq) reads chunks fq and fq + 4 (the two reads of the 16-bit kernel, so the same banks) = channels 4 fq .. 4 fq + 3 and
 //     16 + 4 fq .. 16 + 4 fq + 3, and splits its eight values into the hi / lo operands in registers: 4 x v_cvt_pkrtz_f16_f32,
-//     8 x v_fma_mix_f32 (x - hi, exact), 4 x v_cvt_pk_f16_f32 per fragment.  Tiles with WN = 1 convert every A element exactly once.
+//     8 x v_cvt_f32_f16 + 4 x v_pk_add_f32 (x - hi, exact), 4 x v_cvt_pk_f16_f32 per fragment (~20 vector instructions beside the
+//     fragment's 3 TN MFMAs).  Tiles with WN = 1 convert every A element exactly once.
 //   * the weights are PRE-SPLIT by cfp_pack_w_x3 (or by the squeeze-excite fold kernels, per image): row n holds, per K-step, 64 halves
 //     [hi(32) | lo(32)] in the lane order above (position 8 fq + e <-> channel 4 fq + e for e < 4, 16 + 4 fq + e - 4 for e >= 4), zero
 //     padded to whole K-steps -- the B fragments are plain 16-byte LDS reads.
@@ -297,6 +298,8 @@ constexpr Cfg kCfg[] = {
     {128, 128, 3}, {128, 128, 2}, {128, 64, 3}, {128, 64, 4}, {64, 64, 3}, {64, 64, 4}, {256, 32, 3}, {256, 32, 2}, {128, 32, 3}, {128, 32, 4},
     {256, 16, 2}, {128, 16, 4}, {64, 128, 3}, {64, 64, 2}, {128, 64, 2}, {64, 128, 2}, {128, 32, 2}, {32, 64, 3}, {32, 128, 3},
     {64, 64, 2, 2}, {64, 64, 3, 2}, {64, 128, 2, 2},
+    // f16x3 only (ids >= 22): larger row tiles (fewer L2 -> LDS bytes per MFMA) and the other wave layouts of the common shapes
+    {256, 128, 2}, {256, 64, 2}, {64, 64, 2}, {128, 64, 2}, {128, 128, 2}, {64, 128, 2},
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -370,6 +373,12 @@ int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t
     case 19: return launch_x3<64, 64, 4, 1, 2, 2>(p, slabs, splits, s);
     case 20: return launch_x3<64, 64, 4, 1, 3, 2>(p, slabs, splits, s);
     case 21: return launch_x3<64, 128, 2, 2, 2, 2>(p, slabs, splits, s);
+    case 22: return launch_x3<256, 128, 2, 2, 2>(p, slabs, splits, s);
+    case 23: return launch_x3<256, 64, 4, 1, 2>(p, slabs, splits, s);
+    case 24: return launch_x3<64, 64, 2, 2, 2>(p, slabs, splits, s);
+    case 25: return launch_x3<128, 64, 2, 2, 2>(p, slabs, splits, s);
+    case 26: return launch_x3<128, 128, 4, 1, 2>(p, slabs, splits, s);
+    case 27: return launch_x3<64, 128, 4, 1, 2>(p, slabs, splits, s);
     default: return -3;
   }
 }

@@ -53,8 +53,16 @@ class _Store(nn.Module):
 
 class Deltar(_Store):
     def __init__(self, n_bins: int = 100, min_val: float = 0.1, max_val: float = 10, norm: str = "linear", *,
-                 args=None, dtype=torch.bfloat16, stem_act: bool = False, init: str = "deterministic",
+                 args=None, dtype="f32x3", stem_act: bool = False, init: str = "deterministic",
                  base_resolution=spec.BASE_RESOLUTION, prob_dtype=torch.float32):
+        """`dtype` (not in the reference) picks the numerics of the HIP path:
+          "f32x3" (DEFAULT)  float32 storage, split-precision (f16 x 3) matrix math: the mode whose depth maps stay within the reference
+                             tolerance (1e-3 relative L1 against the reference's float32 forward, deltar.py:34-67) on every weight family
+                             -- measured ~2e-6 (tests/test_forward_gpu.py::test_f32x3_meets_the_gate_on_every_image_of_every_weight_family);
+                             `prob` comes out of the kernels in float32 like the reference's.  Training-mode forwards run in float32.
+          torch.float32      float32 storage and float32 matrix cores: the bit-level parity mode (1/16 of the 16-bit matrix rate)
+          torch.float16 / torch.bfloat16   16-bit storage, opt-in SPEED modes: 2.4 x the default's throughput, but outside the tolerance
+                             on ill-conditioned (confident-head) networks -- fp16 0.8e-3 ... 1.2e-2, bf16 ~6e-3."""
         super().__init__()
         a = args if args is not None else _global_args
         self.num_classes = n_bins
@@ -69,6 +77,9 @@ class Deltar(_Store):
         for ln in self.layer_names:
             if ln not in ("hist2image", "image", "combine1"):
                 raise NotImplementedError(ln)      # fusion.py:37
+        self.x3 = isinstance(dtype, str) and dtype.lower() in ("f32x3", "x3")
+        if isinstance(dtype, str):
+            dtype = {"f32x3": torch.float32, "x3": torch.float32, "f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dtype.lower()]
         self.compute_dtype = dtype
         # the reference returns `prob` in float32 (deltar.py:51,64-67); the engine writes it in its storage type (2 bytes per element at
         # batch 8 = 315 MB instead of 630 MB).  At THIS boundary the reference's type is the default (one cast); prob_dtype=None hands
@@ -88,6 +99,14 @@ class Deltar(_Store):
         self._version_counter = 0
         self.train_graphs = True          # .train() forward / backward replayed as HIP graphs (captured per batch geometry)
         self._train_captures: Dict = {}
+        # .eval() forwards are replayed as HIP graphs too, captured per input geometry (what evaluate_time.py:73-82 of the reference times is
+        # `model(input_data)`; eager, a forward is ~260 launches and host-bound).  The results live in a RING of `eval_out_ring` output
+        # sets: the tensors a forward returns stay valid until `eval_out_ring` forwards later (the reference's loops consume a batch's
+        # outputs before the next forward: evaluate_all.py:42-60, train.py validate).  eval_graphs = False: eager launches, fresh tensors.
+        self.eval_graphs = True
+        self.eval_out_ring = 2
+        self._eval_caps: Dict = {}
+        self._sig_cache = None
 
     # -- reference API ------------------------------------------------------------------
     def _get_name(self):
@@ -125,8 +144,9 @@ class Deltar(_Store):
             self._engine = Engine(sd, layer_names=self.layer_names, n_bins=self.num_classes, min_val=self.min_val,
                                   max_val=self.max_val, norm=self.norm, change_embedding=self.change_embedding,
                                   no_skip_inside=self.no_skip_inside, stem_act=self.stem_act, dtype=self.compute_dtype,
-                                  device=dev, zone_sample_num=self.zone_sample_num, base_resolution=self.base_resolution)
+                                  device=dev, zone_sample_num=self.zone_sample_num, base_resolution=self.base_resolution, x3=self.x3)
             self._engine_version = self._version_counter
+            self._eval_caps = {}          # graphs of the previous engine read its packed parameters
         return self._engine
 
     def draw_pos_offsets(self, H: int, W: int) -> Dict[str, tuple]:
@@ -149,10 +169,58 @@ class Deltar(_Store):
         pos_offsets = kwargs.get("pos_offsets")
         if pos_offsets is None:
             pos_offsets = self.draw_pos_offsets(input_data["rgb"].shape[-2], input_data["rgb"].shape[-1])
-        edges, pred, prob = eng.forward(input_data, return_prob=kwargs.get("return_prob", True), pos_offsets=pos_offsets)
+        return_prob = kwargs.get("return_prob", True)
+        if self.eval_graphs:
+            edges, pred, prob = self._forward_eval_graph(eng, input_data, pos_offsets, return_prob)
+        else:
+            edges, pred, prob = eng.forward(input_data, return_prob=return_prob, pos_offsets=pos_offsets)
+        # the reference returns `prob` in float32 (deltar.py:51,64-67).  The default mode (f32x3) and the float32 mode write it in that
+        # type themselves; only the opt-in 16-bit speed modes store 2 bytes per element and pay this cast (prob_dtype=None: as stored)
         if prob is not None and self.prob_dtype is not None and prob.dtype != self.prob_dtype:
             prob = prob.to(self.prob_dtype)
         return edges, pred, prob, None
+
+    def _forward_eval_graph(self, eng, input_data: Dict, pos_offsets, return_prob: bool):
+        """Eval forward as a HIP-graph replay.  Two kinds of graph per input geometry and output-ring slot: one that reads PRIVATE copies
+        of the inputs (any caller: three device copies, then the replay) and -- from the second consecutive call with the very same
+        device tensors on -- one that reads the CALLER'S tensors in place: that replay is pure host logic + one graph launch, no torch
+        kernel, and sees whatever the tensors hold at that moment (the reference's latency loop, evaluate_time.py:73-82)."""
+        rgb, add = input_data["rgb"], input_data["additional"]
+        pinfo = add["patch_info"]
+        if self._sig_cache is None or self._sig_cache[0] is not pinfo:      # the same dict object again (kept alive here): same integers
+            self._sig_cache = (pinfo, _patch_signature(pinfo))
+        key = (tuple(rgb.shape), tuple(add["hist_data"].shape), self._sig_cache[1], bool(return_prob),
+               tuple(sorted((k, tuple(int(x) for x in v)) for k, v in pos_offsets.items())))
+        st = self._eval_caps.get(key)
+        if st is None:
+            if len(self._eval_caps) >= 4:                      # a handful of geometries at most: each pins its output ring
+                self._eval_caps.pop(next(iter(self._eval_caps)))
+            st = self._eval_caps[key] = {"calls": 0, "last": None, "owned": {}, "adopted": {}}
+        m = add["mask"]
+        ptrs = None
+        if (rgb.is_cuda and rgb.device == eng.device and rgb.dtype == torch.float32 and rgb.is_contiguous() and add["hist_data"].device == eng.device
+                and add["hist_data"].dtype == torch.float32 and add["hist_data"].is_contiguous() and m.device == eng.device
+                and m.dtype in (torch.bool, torch.uint8) and m.is_contiguous()):
+            ptrs = (rgb.data_ptr(), add["hist_data"].data_ptr(), m.data_ptr())
+        slot = st["calls"] % max(1, int(self.eval_out_ring))
+        st["calls"] += 1
+        same = ptrs is not None and ptrs == st["last"]
+        st["last"] = ptrs
+        if same:
+            h = st["adopted"].get((ptrs, slot))
+            if h is None:
+                if len(st["adopted"]) >= 2 * max(1, int(self.eval_out_ring)):
+                    st["adopted"].clear()
+                eng.capture(input_data, return_prob=return_prob, pos_offsets=pos_offsets, adopt_inputs=True)
+                h = st["adopted"][(ptrs, slot)] = eng._graph
+            eng._graph, eng._slots = h, None
+            return eng.replay()
+        h = st["owned"].get(slot)
+        if h is None:
+            eng.capture(input_data, return_prob=return_prob, pos_offsets=pos_offsets)
+            h = st["owned"][slot] = eng._graph
+        eng._graph, eng._slots = h, None
+        return eng.replay(input_data)
 
 
 _OFFSET_NAMES = ("cross_atten3", "cross_atten2", "cross_atten1")
@@ -300,8 +368,9 @@ Deltar._forward_train = _forward_train
 
 
 def make_model(args, dtype=None):
-    """`src/utils/utils.py:7-11`.  `dtype` (not in the reference) picks the engine's storage format: torch.bfloat16
-    (default), torch.float16 or torch.float32."""
+    """`src/utils/utils.py:7-11`.  `dtype` (not in the reference) picks the numerics of the HIP path: "f32x3" (default: float32 storage,
+    split-precision matrix math -- inside the reference tolerance on every weight family), torch.float32 (bit-level parity mode),
+    torch.float16 / torch.bfloat16 (16-bit storage: opt-in speed modes).  See `Deltar.__init__`."""
     if args.model_name == "deltar":
         kw = {} if dtype is None else {"dtype": dtype}
         return Deltar(n_bins=args.n_bins, min_val=args.min_depth, max_val=args.max_depth, norm=args.norm, args=args, **kw)

@@ -95,12 +95,17 @@ def _shared_stream(device, role):
 class Engine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, layer_names: Sequence[str], n_bins: int = 256,
                  min_val: float = 1e-3, max_val: float = 10.0, norm: str = "linear", change_embedding: bool = True,
-                 no_skip_inside: bool = False, stem_act: bool = False, dtype=torch.bfloat16, device="cuda:0",
-                 zone_sample_num: int = 16, base_resolution=spec.BASE_RESOLUTION, x3: bool = False):
+                 no_skip_inside: bool = False, stem_act: bool = False, dtype=None, device="cuda:0",
+                 zone_sample_num: int = 16, base_resolution=spec.BASE_RESOLUTION, x3: Optional[bool] = None):
         """`x3` (float32 storage only): every convolution / linear layer runs its matrix math split-precision on the 16-bit matrix cores
         (A_hi W_hi + A_hi W_lo + A_lo W_hi in IEEE half, float32 accumulate; csrc/conv_igemm_x3.hip) instead of the float32 MFMA:
         ~21 significant bits per product at 3/16 instead of 1/16 of the 16-bit matrix rate.  Activations, every other kernel and the
-        results' type are those of the float32 mode."""
+        results' type are those of the float32 mode.  With neither `dtype` nor `x3` given the engine is built in that mode (float32
+        storage, x3): the one inside the reference tolerance on every weight family.  torch.float16 / torch.bfloat16 are the opt-in
+        16-bit speed modes, torch.float32 without `x3` the bit-level parity mode."""
+        if dtype is None:
+            dtype, x3 = torch.float32, (True if x3 is None else x3)
+        x3 = bool(x3)
         hip.load()   # fail loudly if the HIP extension is missing
         self.base_resolution = tuple(base_resolution)
         self.fusion = spec.fusion_table(self.base_resolution)    # decoder.py:82-94 generalised to other table sizes (configs[4])
@@ -435,7 +440,7 @@ class Engine:
                     part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
                     ops.mbconv_expand_dw(x, self.P[q + ".pw.wimg"], self.P[q + ".pw.s"], self.P[q + ".pw.t"], self.P[q + ".dw.w"],
                                          self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w)
-                elif self.se2 and ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype]) > 0:
+                elif self.se2 and b.se_rd <= 64 and ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype]) > 0:
                     # round 3: the depthwise kernel applies the reduce FC to its own channel sums (it is linear in them), the tail kernel
                     # adds the K partial vectors, finishes the gate and folds it into float32 project weights in one full-chip launch
                     mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
@@ -724,7 +729,7 @@ class Engine:
 
     # ------------------------------------------------------------------------------ HIP graph
     def capture(self, input_data: dict, *, return_prob: bool = True, pos_offsets: Optional[dict] = None, lanes: int = 1,
-                inflight: int = 1):
+                inflight: int = 1, adopt_inputs: bool = False):
         """Record the whole forward for this input shape into HIP graphs.  The launch list is static (all
         data-dependent geometry is host-side integers), so replaying costs one graph launch instead of ~280 kernel
         launches.  With `lanes` > 1 every batch lane gets its OWN graph, captured on and replayed from its own stream
@@ -733,7 +738,11 @@ class Engine:
 
         `inflight` > 1 instead keeps that many WHOLE batches in flight: one linear graph per slot, each with its own
         inputs, scratch and outputs, on streams probed to run concurrently (`concurrent_streams`).  Use `replay_async`
-        to feed the slots round-robin; `replay` still gives the plain one-call-one-result behaviour."""
+        to feed the slots round-robin; `replay` still gives the plain one-call-one-result behaviour.
+
+        `adopt_inputs` (single graph only): the graph reads the CALLER'S device tensors in place instead of private copies (they must be
+        float32 / uint8-or-bool, contiguous, on this device and must stay alive): `replay()` without arguments then sees whatever they
+        hold at that moment, with no copy in front of it (`Deltar.forward` uses this when it is called with the same tensors again)."""
         dev = self.device
         add = input_data["additional"]
         B = input_data["rgb"].shape[0]
@@ -743,10 +752,18 @@ class Engine:
         self._slot_next = 0
         if inflight > 1:
             return self._capture_inflight(input_data, inflight, return_prob, pos_offsets)
-        static = {"rgb": input_data["rgb"].to(device=dev, dtype=torch.float32).contiguous().clone(),
-                  "additional": {"hist_data": add["hist_data"].to(device=dev, dtype=torch.float32).contiguous().clone(),
-                                 "mask": add["mask"].to(device=dev).to(torch.uint8).contiguous().clone(),
-                                 "rect_data": add.get("rect_data"), "patch_info": add["patch_info"]}}
+        if adopt_inputs:
+            assert lanes == 1, "adopt_inputs: single-graph capture only"
+            m = add["mask"]
+            for t, dts in ((input_data["rgb"], (torch.float32,)), (add["hist_data"], (torch.float32,)), (m, (torch.uint8, torch.bool))):
+                assert t.device == dev and t.dtype in dts and t.is_contiguous(), "adopt_inputs: device tensors in the kernels' own types"
+            static = {"rgb": input_data["rgb"], "additional": {"hist_data": add["hist_data"], "mask": m.view(torch.uint8) if m.dtype == torch.bool else m,
+                                                               "rect_data": add.get("rect_data"), "patch_info": add["patch_info"]}}
+        else:
+            static = {"rgb": input_data["rgb"].to(device=dev, dtype=torch.float32).contiguous().clone(),
+                      "additional": {"hist_data": add["hist_data"].to(device=dev, dtype=torch.float32).contiguous().clone(),
+                                     "mask": add["mask"].to(device=dev).to(torch.uint8).contiguous().clone(),
+                                     "rect_data": add.get("rect_data"), "patch_info": add["patch_info"]}}
         edges = torch.empty(B, self.n_bins + 1, dtype=torch.float32, device=dev)
         pred = torch.empty(B, 1, H // 2, W // 2, dtype=torch.float32, device=dev)
         prob = torch.empty(B, self.n_bins, H // 2, W // 2, dtype=self.dtype, device=dev) if return_prob else None
@@ -789,7 +806,8 @@ class Engine:
         """Which of the two kernel plans the convolutions launched from now on follow: the default one, fitted on isolated timings, or the
         one for several batches in flight (larger tiles: a launch's cost is then the resources it holds, not its own latency; the
         CFP_CONV_IN_FLIGHT hint of cfp_conv2d_nhwc_ex).  `capture(inflight=n)` switches to the second while it records its slots.  Results
-        do not depend on the plan (every tile walks K in the same order)."""
+        are bit-identical WITHIN a plan; across the two plans a convolution may run through another kernel (halo / implicit GEMM, another
+        tile), i.e. another float32 summation order -- re-association noise, far below the storage rounding of the 16-bit modes."""
         ops.PLAN_IN_FLIGHT = bool(throughput) and os.environ.get("CFP_TPUT_PLAN", "1") != "0"
 
     def _capture_inflight(self, input_data, inflight, return_prob, pos_offsets):
@@ -923,7 +941,11 @@ class Engine:
         if input_data is not None:
             static["rgb"].copy_(input_data["rgb"], non_blocking=True)
             static["additional"]["hist_data"].copy_(input_data["additional"]["hist_data"], non_blocking=True)
-            static["additional"]["mask"].copy_(input_data["additional"]["mask"].to(torch.uint8), non_blocking=True)
+            m = input_data["additional"]["mask"]
+            if m.dtype == torch.bool and m.is_cuda:      # same bytes as uint8: a plain device copy, no conversion kernel
+                static["additional"]["mask"].view(torch.bool).copy_(m, non_blocking=True)
+            else:
+                static["additional"]["mask"].copy_(m.to(torch.uint8), non_blocking=True)
         if len(graphs) == 1:
             st = self._lane_streams[0][0]
             st.wait_stream(cur)
@@ -1014,7 +1036,9 @@ class Engine:
         def up(i, src: Act, hs_, ws_, hd, wd):
             M = B * hd * wd
             t1 = self._act(plan, f"up{i}.a", M, c[i])
-            if self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None:
+            # the fused kernel's own preconditions (cfp_upsample_cat_conv3x3 returns CFP_ESHAPE otherwise): 32-bit byte offsets, H, W > 1
+            fits = hd > 1 and wd > 1 and B * hd * wd * cat[i].ld * 2 < 2 ** 31 - 65536 and hs_ * ws_ * src.ld * 2 < 2 ** 31 - 65536
+            if self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None and fits:
                 # cfp_upsample_cat_conv3x3: bilinear + concat computed inside the conv's halo loader (bit-identical to the pair below)
                 n = f"decoder.up{i}.a"
                 ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".w"], self.P[n + ".s"], self.P[n + ".t"],

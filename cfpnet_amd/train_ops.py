@@ -292,6 +292,14 @@ class WgradQueue:
             from . import hip
             arr = (hip.WgradJob * len(self.jobs))(*self.jobs)
             hip.call("cfp_wgrad_reduce_jobs", ctypes.addressof(arr), len(self.jobs), hip.current_stream())
+            # the reduction may run on another stream than the one the slabs were allocated on (side-stream weight gradients flushed on
+            # main at the end of the backward and the reverse): tell the caching allocator, or it may hand a block back to its own stream
+            # while this launch is still pending
+            cur = torch.cuda.current_stream()
+            for item in self.keep:
+                for t in (item if isinstance(item, (tuple, list)) else (item,)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
         self.jobs, self.keep = [], []
 
 

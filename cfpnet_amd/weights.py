@@ -159,3 +159,36 @@ def make_state_dict(manifest: Iterable[Tuple[str, Tuple[int, ...], str]], family
 def make_torch_state_dict(manifest, family: str = "uniform"):
     import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in make_state_dict(manifest, family).items()}
+
+
+def trained_like_state_dict(layer_names, steps: int = 300, batch: int = 4, device="cuda:0", lr: float = 3e-4, seed: int = 7, dtype=None):
+    """The closest stand-in for the authors' `best.pt` (/root/reference/README.md:22) that can be made offline: the reference's own
+    initialisation (the `kaiming` family) after `steps` real optimisation steps of `trainer.Trainer` (train.py:104-135: training forward,
+    SILog, backward, AdamW / OneCycle) on synthetic 416x544 crops whose target depth FOLLOWS the ToF zones (zone means of the histogram
+    samples, bilinearly spread over the crop) -- so the network learns depth completion from its inputs: a confident (peaked) 256-way head,
+    BatchNorm running statistics that are real moving averages, weights that have left their initial distribution.  Runs on the GPU
+    (there is no CPU training path); returns a reference-layout state dict on the CPU."""
+    import torch
+    import torch.nn.functional as F
+    from . import spec, synthetic
+    from .trainer import Trainer
+    sd = make_torch_state_dict(spec.model_manifest(layer_names), family="kaiming")
+    H, W, zn, zpx = 416, 544, 6, 64
+    data = []
+    for i in range(6):
+        inp = synthetic.make_inputs(batch, H, W, zn, zpx, seed=seed + 31 * i, drop_hist=0.1 * (i % 3))
+        hist = inp["additional"]["hist_data"].float()                       # [B, Z, 16] sample points of each zone's depth distribution
+        zmean = hist.mean(-1).reshape(batch, 1, zn, zn)
+        zmean = torch.where(inp["additional"]["mask"].reshape(batch, 1, zn, zn), zmean, zmean.mean((2, 3), keepdim=True))
+        tgt = F.interpolate(zmean, size=(H, W), mode="bilinear", align_corners=False).clamp(0.1, 9.5)
+        data.append((synthetic.to_device(inp, device), tgt.to(device)))
+    tr = Trainer(sd, list(layer_names), lr=lr, total_steps=steps, dtype=dtype or torch.float32, device=device)
+    tr.capture(*data[0])
+    for i in range(steps):
+        loss, _, _ = tr.step(*data[i % len(data)])
+    torch.cuda.synchronize()
+    out = tr.state_dict()
+    out["__loss__"] = float(loss)
+    del tr
+    torch.cuda.empty_cache()
+    return out

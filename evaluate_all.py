@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Evaluation with the reference's CLI and protocol (`/root/reference/evaluate_all.py:44-167`):
 
-    python evaluate_all.py @configs/cfpnet_combine1.txt --selected_epoch best [--synthetic 64] [--dtype f16] [--bs 8]
+    python evaluate_all.py @configs/cfpnet_combine1.txt --selected_epoch best [--synthetic 64] [--dtype f32x3|f32|f16|bf16] [--bs 8]
 
 Per batch: ToF simulation from the ground-truth depth (GPU, `cfp_tof_hist_sim`), model forward (HIP engine), then
 `np.clip` -> bilinear to full resolution -> `min_depth < gt < max_depth` mask -> the nine `compute_errors` metrics, all in
@@ -38,7 +38,7 @@ def main(argv=None):
 
     argv = list(argv if argv is not None else sys.argv[1:])
     n_syn = _pop(argv, "--synthetic", 0, int)
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[_pop(argv, "--dtype", "f16")]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32x3": "f32x3"}[_pop(argv, "--dtype", "f32x3")]
     bs = _pop(argv, "--batch", 8, int)
     args = config.parse_args(argv) if argv else config.defaults()
     device = torch.device("cuda:0")

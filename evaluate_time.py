@@ -39,12 +39,10 @@ def main(argv=None):
     model = model.to(device).eval()
     H, W = 480, 640
     inp = synthetic.to_device(synthetic.make_inputs(1, H, W, 8, 56, seed=synthetic.SEED), device)
-    eng = model.engine(device)
-    if use_graph:
-        eng.capture(inp)
-        run = lambda: eng.replay()
-    else:
-        run = lambda: model(inp)
+    # what is timed is `model(input_data)`, the call the reference times (evaluate_time.py:73-82): Deltar.forward replays the forward as a
+    # HIP graph that reads these very tensors (same tensors every iteration: no copy, no torch kernel); --eager launches kernel by kernel
+    model.eval_graphs = use_graph
+    run = lambda: model(inp)
     with torch.no_grad():
         for _ in range(100):
             run()

@@ -206,6 +206,56 @@ def test_fp16_meets_the_gate_on_three_seeds_of_every_weight_family(family):
     print(f"fp16 {family}: worst image of 24 = {worst:.3e}")
 
 
+_TRAINED = {}
+
+
+def trained_like(layers):
+    """One trained-like state dict per test session (300 real optimisation steps on the GPU, weights.trained_like_state_dict)."""
+    if "sd" not in _TRAINED:
+        sd = weights.trained_like_state_dict(layers, steps=300)
+        print(f"trained-like family: SILog after 300 steps {sd.pop('__loss__'):.4f}")
+        _TRAINED["sd"] = sd
+    return _TRAINED["sd"]
+
+
+@pytest.mark.parametrize("family", ["uniform", "kaiming", "kaiming_peaked", "trained"])
+def test_f32x3_meets_the_gate_on_every_image_of_every_weight_family(family):
+    """THE parity gate of the default mode (float32 storage, f16x3 matrix math: Engine(dtype=float32, x3=True), what `Deltar` and
+    `make_model` build unless told otherwise): configs[1] -- batch 8, 480x640, 8x8 zones -- through the captured graph, two input seeds
+    (with and without dropped zones) x four weight families, relative L1 of the depth map against the CPU oracle <= 1e-3 (north_star)
+    on EVERY image, no family-specific bound:
+      uniform         the key-addressed family of the golden fixtures;
+      kaiming         the reference's own initialisation (deltar.py:23-32, fusion.py:22-23) with calibrated BatchNorm statistics;
+      kaiming_peaked  the same with a confident head (conv_out x 6) -- the family on which every 16-bit STORAGE mode is outside the gate
+                      (one fp16 rounding of the input image alone moves it by 2.4e-3, test below);
+      trained         300 real optimisation steps from the reference's initialisation (weights.trained_like_state_dict): the closest
+                      offline stand-in for the authors' checkpoint."""
+    layers = spec.COMBINE1_LAYERS
+    if family == "trained":
+        sd = trained_like(layers)
+    else:
+        sd = weights.make_torch_state_dict(spec.model_manifest(layers), family=family)
+        if family != "uniform":
+            sd = calibrate_bn(sd, layers)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True)
+    worst = 0.0
+    for si, seed in enumerate((synthetic.SEED, 4242)):
+        inp = synthetic.make_inputs(8, 480, 640, 8, 56, seed=seed, drop_hist=(0.0, 0.34)[si])
+        _, p0, pr0 = O.forward(sd, inp, layer_names=layers)
+        dinp = synthetic.to_device(inp, "cuda:0")
+        if si == 0:
+            eng.capture(dinp)
+        _, p1, _ = eng.replay(dinp)
+        torch.cuda.synchronize()
+        per_image = [rel_l1(p1[b].cpu().numpy(), p0[b].numpy()) for b in range(8)]
+        print(f"f32x3 {family} seed {seed}: rel-L1 {rel_l1(p1.cpu().numpy(), p0.numpy()):.3e}, worst image {max(per_image):.3e}, "
+              f"pred std {float(p0.std()):.3f}, mean max-prob {float(pr0.max(1)[0].mean()):.3f}")
+        worst = max(worst, max(per_image))
+        assert max(per_image) <= TOL_F32, (family, seed, per_image)
+    print(f"f32x3 {family}: worst image of 16 = {worst:.3e}")
+
+
 def test_ill_conditioned_network_is_reported_not_gated():
     """The reference's initialisation with a CONFIDENT head (conv_out x 6: a peaked 256-way softmax like a trained model's): the float32
     engine with nothing but its INPUT IMAGE rounded once to fp16 already differs from itself by > 1e-3 -- no 16-bit storage format can
@@ -284,6 +334,96 @@ def test_deltar_module_boundary():
     ones = [p for p in model.get_1x_lr_params()]
     tens = [p for p in model.get_10x_lr_params()]
     assert len(ones) + len(tens) == len(list(model.parameters()))
+
+
+def _boundary_model():
+    from cfpnet_amd import config
+    from cfpnet_amd.deltar import make_model
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = config.parse_args(["@" + os.path.join(root, "configs", "cfpnet_combine1.txt")])
+    return make_model(args).eval().to("cuda:0")
+
+
+def test_default_boundary_mode_is_the_compliant_one():
+    """`make_model(args)` with no dtype builds the f32x3 engine: float32 storage, split-precision matrix math, float32 `prob` straight
+    from the kernels (no cast at the boundary), results equal to the eager Engine in that mode and inside the gate against the oracle."""
+    model = _boundary_model()
+    assert model.x3 and model.compute_dtype == torch.float32
+    inp = synthetic.make_inputs(2, seed=11, drop_hist=0.2)
+    dinp = synthetic.to_device(inp, "cuda:0")
+    edges, pred, prob, _ = model(dinp)
+    eng = model.engine("cuda:0")
+    assert eng.x3 and eng.dtype == torch.float32 and prob.dtype == torch.float32
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    _, p0, pr0 = O.forward(sd, inp, layer_names=spec.COMBINE1_LAYERS)
+    per_image = [rel_l1(pred[b].cpu().numpy(), p0[b].numpy()) for b in range(2)]
+    print(f"default boundary mode vs oracle: {per_image}")
+    assert max(per_image) <= TOL_F32
+    assert float((prob.cpu() - pr0).abs().max()) < 1e-4
+
+
+def test_eval_forward_replays_graphs_with_the_reference_semantics():
+    """`model(input_data)` in eval mode is a graph replay: (a) other tensors of the same geometry give that input's result (private-copy
+    graph), (b) the same tensors again -- contents changed IN PLACE -- give the new contents' result (the adopted-input graph reads the
+    caller's tensors), (c) a result stays valid while the next forward runs (output ring of two), (d) all equal the eager engine."""
+    model = _boundary_model()
+    ref = _boundary_model()
+    ref.eval_graphs = False
+    a = synthetic.to_device(synthetic.make_inputs(2, seed=1), "cuda:0")
+    b = synthetic.to_device(synthetic.make_inputs(2, seed=2, drop_hist=0.3), "cuda:0")
+    want_a, want_b = ref(a)[1].clone(), ref(b)[1].clone()
+    pa = model(a)[1]
+    pb = model(b)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(pa, want_a) and torch.equal(pb, want_b)          # (a) + (c): pa still holds a's result after b's forward
+    pb2 = model(b)[1]                                                     # second consecutive call with b's tensors: adopted-input graph
+    pb3 = model(b)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(pb2, want_b) and torch.equal(pb3, want_b)
+    b["rgb"].copy_(a["rgb"]); b["additional"]["hist_data"].copy_(a["additional"]["hist_data"]); b["additional"]["mask"].copy_(a["additional"]["mask"])
+    pb4 = model(b)[1]                                                     # (b): same tensors, new contents, no re-capture
+    torch.cuda.synchronize()
+    assert torch.equal(pb4, want_a)
+    assert len(model._eval_caps) == 1
+
+
+def test_eval_forward_launches_no_torch_kernel_and_costs_what_the_engine_costs():
+    """The call the reference times (evaluate_time.py:73-82) is `model(input_data)`.  Called again with the same device tensors it must be
+    host logic + one graph launch: no ATen operator runs (torch.profiler sees none), and its latency at batch 8 is within 5 % of a bare
+    `Engine.replay()` of the same mode."""
+    import time
+    from torch.profiler import profile, ProfilerActivity
+    model = _boundary_model()
+    inp = synthetic.to_device(synthetic.make_inputs(8), "cuda:0")
+    with torch.no_grad():
+        for _ in range(6):
+            out = model(inp)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            for _ in range(3):
+                model(inp)
+        torch.cuda.synchronize()
+        ops_seen = sorted({e.name for e in prof.events() if e.name.startswith("aten::")})
+        print("ATen operators in a steady-state eval forward:", ops_seen)
+        assert ops_seen == [], ops_seen
+
+        def timed(fn, n=60):
+            for _ in range(10):
+                fn()
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            return sum(ts[1:-2]) / (n - 3) * 1e3
+        t_model = timed(lambda: model(inp))
+        eng = Engine({k: v.detach().cpu() for k, v in model.state_dict().items()}, layer_names=model.layer_names, dtype=torch.float32, x3=True,
+                     change_embedding=model.change_embedding, no_skip_inside=model.no_skip_inside)
+        eng.capture(inp)
+        t_eng = timed(lambda: eng.replay())
+    print(f"latency at batch 8: model(input_data) {t_model:.3f} ms, Engine.replay {t_eng:.3f} ms")
+    assert t_model <= 1.05 * t_eng + 0.02
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 3e-3)])

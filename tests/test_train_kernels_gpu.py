@@ -128,6 +128,35 @@ def test_batchnorm_training_forward_backward(rows, C, act, dtype):
     assert float((dbeta.cpu() - beta.grad).abs().max()) <= 3e-5 * float(beta.grad.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+@pytest.mark.parametrize("via_partials", [False, True])
+def test_batchnorm_running_statistics_survive_a_non_finite_batch(bad, via_partials):
+    """An activation overflow in an fp16 forward (the step cfp_grad_clip_factor then makes the optimizer skip) must not reach the
+    running statistics: they outlive the step and every later validation engine folds them.  The poisoned channel keeps its running
+    mean / variance, the clean channels are updated as usual -- through the statistics pass and through the conv-epilogue partials."""
+    rows, C, mom = 512, 16, 0.1
+    x = rnd(rows, C, seed=1)
+    x[7, 3] = bad
+    rm, rv = rnd(C, seed=4), rnd(C, seed=5).abs() + 0.5
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    bn = train_ops.BatchNormTrain(C, DEV, eps=1e-3, momentum=mom)
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    if via_partials:      # two row tiles of 256 rows: (mean, M2) per tile as the conv epilogue leaves them
+        xt = x.reshape(2, 256, C)
+        m = xt.mean(1)
+        part = torch.stack([m, ((xt - m[:, None]) ** 2).sum(1)], 1).contiguous().to(DEV)      # [2][2][C]
+        bn.forward(x.to(DEV), g, b, rmd, rvd, hip.ACT_NONE, mom=(part, 2, 256))
+    else:
+        bn.forward(x.to(DEV), g, b, rmd, rvd, hip.ACT_NONE)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(rmd).all()) and bool(torch.isfinite(rvd).all())
+    assert float(rmd[3]) == float(rm[3]) and float(rvd[3]) == float(rv[3])
+    keep = [c for c in range(C) if c != 3]
+    want_m = (1 - mom) * rm + mom * x.mean(0)
+    want_v = (1 - mom) * rv + mom * x.var(0, unbiased=True)
+    assert torch.allclose(rmd.cpu()[keep], want_m[keep], rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu()[keep], want_v[keep], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 30, 40, 112, 448, 1, 1), (2, 60, 80, 40, 160, 3, 1), (1, 120, 160, 8, 40, 3, 2), (3, 13, 17, 136, 816, 1, 1),
                                   (1, 9, 11, 232, 1392, 1, 1), (16, 26, 34, 448, 112, 1, 1), (2, 104, 136, 16, 16, 3, 1), (1, 1, 70, 8, 32, 1, 1)])

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Sweep of the f16x3 implicit-GEMM tiles (csrc/conv_igemm_x3.hip) over the conv / linear launches of one float32-storage forward:
+every distinct problem with the automatic plan and with every tile variant (x K-splits) forced through cfp_debug_set(0, 400 + v),
+alone or with --inflight copies side by side.  Writes gpurun_out/conv_bench_x3.json (rows sorted by time x count).
+    python tools/conv_bench_x3.py [--inflight 4] [--quick]"""
+import argparse, ctypes, json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cfpnet_amd import hip, spec, synthetic, weights
+from cfpnet_amd.engine import Engine, concurrent_streams
+from _gtime import graph_time_us, graph_time_us_concurrent
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--reps", type=int, default=12)
+ap.add_argument("--inflight", type=int, default=1)
+ap.add_argument("--quick", action="store_true", help="plan only, no sweep")
+ap.add_argument("--out", default="gpurun_out/conv_bench_x3.json")
+a = ap.parse_args()
+
+layers = spec.COMBINE1_LAYERS
+sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True)
+inp = synthetic.to_device(synthetic.make_inputs(a.batch), "cuda:0")
+for _ in range(2):
+    eng.forward(inp)
+torch.cuda.synchronize()
+lib = hip.load()
+calls, real = [], hip.call
+
+
+def rec(name, *args):
+    if name == "cfp_conv2d_nhwc_ex":
+        calls.append(args)
+    real(name, *args)
+
+
+hip.call = rec
+eng.forward(inp)
+torch.cuda.synchronize()
+hip.call = real
+uniq = {}
+for args in calls:
+    B, H, W, Cin, Cout, KH, KW, st, pt, pl, Ho, Wo = args[9:21]
+    key = (B, H, W, Cin, Cout, KH, st, Ho, Wo, bool(args[23]), int(args[26]) & 1, bool(args[5]))
+    uniq.setdefault(key, [args, 0])[1] += 1
+STREAMS = concurrent_streams("cuda:0", want=a.inflight) if a.inflight > 1 else None
+
+
+def timeit(args, reps):
+    fn = lambda: real("cfp_conv2d_nhwc_ex", *args[:-1], hip.current_stream())
+    if STREAMS:
+        return graph_time_us_concurrent(fn, STREAMS, calls=max(4, reps // 2), replays=3)
+    return graph_time_us(fn, calls=max(4, reps // 2), replays=4)
+
+
+NV = 28
+rows, tot_auto, tot_best = [], 0.0, 0.0
+for key, (args, cnt) in uniq.items():
+    B, H, W, Cin, Cout, KH, st, Ho, Wo, ln, piw, has_res = key
+    M, K = B * Ho * Wo, KH * KH * Cin
+    t_auto = timeit(args, a.reps)
+    best, sweep = (t_auto, "auto"), {}
+    if not a.quick:
+        for v in range(NV):
+            for sp in ((1, 2, 4, 8) if (M * Cout < 2_000_000 and K >= 512 and not piw and v < 19) else (1,)):
+                lib.cfp_debug_set(0, 400 + v); lib.cfp_debug_set(1, sp)
+                try:
+                    t = timeit(args, max(5, a.reps // 2))
+                except RuntimeError:
+                    continue
+                sweep[f"{v}/{sp}"] = t
+                if t < best[0]:
+                    best = (t, f"v{v}/s{sp}")
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
+    pv, ps = ctypes.c_int(0), ctypes.c_int(0)
+    lib.cfp_conv2d_plan(M, Cout, K, KH, st, hip.F32X3, Ho * Wo if piw else 0, B, ctypes.byref(pv), ctypes.byref(ps))
+    rows.append(dict(M=M, N=Cout, K=K, k=KH, stride=st, ln=ln, piw=piw, res=has_res, count=cnt, auto_us=t_auto, best_us=best[0], best=best[1],
+                     plan=f"v{pv.value - 400}/s{ps.value}", gflop=2.0 * M * Cout * K / 1e9, sweep=sweep))
+    tot_auto += cnt * t_auto; tot_best += cnt * best[0]
+rows.sort(key=lambda r: -r["auto_us"] * r["count"])
+print(f"{'M':>7} {'N':>5} {'K':>5} k s  x  {'auto':>8} {'best':>8}  plan      best       TF/s(x1, auto)")
+for r in rows:
+    print(f"{r['M']:7d} {r['N']:5d} {r['K']:5d} {r['k']} {r['stride']} {r['count']:2d} {r['auto_us']:8.1f} {r['best_us']:8.1f}  {r['plan']:9s} {r['best']:10s} "
+          f"{r['gflop'] / r['auto_us'] * 1e-3:7.1f}" + (" LN" if r["ln"] else "") + (" PIW" if r["piw"] else ""))
+print(f"total per forward: auto {tot_auto / 1e3:.3f} ms, best-of-sweep {tot_best / 1e3:.3f} ms, launches {len(calls)}")
+os.makedirs(os.path.dirname(a.out), exist_ok=True)
+json.dump(rows, open(a.out, "w"))

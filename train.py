@@ -264,7 +264,9 @@ def main(argv=None):
             if epoch is not None:                                    # train.py:150-155: checkpoint {model, optimizer, epoch} + bare weights
                 torch.save(weights_now, os.path.join(d, f"{epoch}_{m['rmse']:.3f}.pt"))
                 if steps_here > 0:                                   # the optimizer state exists once a step ran in this process
-                    save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, epoch, at_step)
+                    # the `epoch` FIELD is the last fully completed epoch (a mid-epoch validation has not finished `epoch` yet): a
+                    # reference-style consumer that resumes at epoch + 1 must not skip the rest of this one
+                    save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, at_step // steps_per_epoch - 1, at_step)
             if m["rmse"] < best_rmse:
                 torch.save(weights_now, os.path.join(d, "best.pt"))
         best_rmse = min(best_rmse, m["rmse"])
