@@ -209,3 +209,28 @@ def test_one_rank_rccl_process_group_runs_the_overlapped_step(tmp_path):
         assert torch.equal(r[mode]["grad"], r["no_dist"]["grad"]), mode
         assert torch.equal(r[mode]["param"], r["no_dist"]["param"]), mode
     assert float(r["no_dist"]["grad"].abs().max()) > 0
+
+
+def test_the_driver_command_for_two_ranks_runs_end_to_end(tmp_path):
+    """The exact command the driver runs at N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), here with
+    two ranks on this box's one GPU over gloo (RCCL cannot put two ranks on one device), started as a FRESH child process before
+    anything in it touches the GPU: inference replicas with in-flight slots, teardown, then the data-parallel training leg with its
+    gradient all-reduce -- the whole sequence, parsed from the one JSON line rank 0 prints."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--train-batch", "4"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 only, ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"]["world_size"] == 2 and d["ranks_seen"]["backend"] == "gloo"
+    assert abs(d["value"] - 2 * d["per_gpu"]) < 1e-6 * d["value"]      # whole job = sum over the ranks
+    assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
+    t = d["training"]
+    assert t["config"]["n_gpus"] == 2 and t["config"]["global_batch"] == 8
+    assert "allreduce_ms" in t and "overlap_frac" in t and t["ms_per_step"] > 0
+    assert t["loss_first_step"] == t["loss_first_step"]          # finite, not NaN
