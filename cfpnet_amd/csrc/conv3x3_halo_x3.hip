@@ -1,0 +1,339 @@
+// 3x3 stride-1 convolution for FLOAT32 STORAGE with split-precision (f16x3) matrix math, whole-depth input halo in LDS.
+//
+// Reference ops: the 3x3 convolutions of the decoder and the depth head (decoder.py:13,43-58,70-80 UpSampleBN / conv0, transformer.py:197-200
+// DAPM convs) and of the RGB encoder's stem-side blocks (encoder.py:57-69) -- in the DEFAULT numerics of the drop-in boundary (float32
+// tensors, A_hi W_hi + A_hi W_lo + A_lo W_hi on v_mfma_f32_16x16x32_f16; conv_igemm_x3.hip has the arithmetic and its error).
+//
+// Why: with several batches in flight the f16x3 implicit GEMMs are bound by the L2 -> LDS path (tools/igemm_x3_probe.py: the head conv's
+// operand DMA alone takes 357 of its 625 us, at the ~60 GB/s per CU that path delivers; tools/conv_bench_x3.py: most launches sit at
+// 60-100 % of that bound).  The 3x3 convolutions move 24 of the 35 GB per forward through it, nine times their input: the im2col A operand
+// is fetched once per tap.  Here, as in conv3x3_halo.hip (the 16-bit kernel this one is modelled on):
+//   * a workgroup owns TH x 16 output pixels (TH = 16 or 8) and NT x WN x 16 output channels; the (TH + 2) x 18 input halo with ALL Cin
+//     channels is loaded ONCE, register-staged, and SPLIT ONCE on the way into LDS -- every element is converted a single time, where the
+//     implicit GEMM converts it in the K loop of every wave, tap and N-tile that meets it.  LDS image of a pixel: per 8 channels
+//     [hi(c0..c3) | hi(c4..c7) | lo(c0..c3) | lo(c4..c7)] (32 bytes), pixel pitch an ODD number of 16-byte slots;
+//   * K runs over (tap, channel) in the weight tensor's own order, 32 per step, against the SAME pre-split weight operand the implicit GEMM
+//     takes (cfp_pack_w_x3: MFMA slot (fq, e) <-> k = 4 fq + e, 16 + 4 fq + e - 4): lane (pixel fr, fq) needs the channel quads 8 ks + fq and
+//     8 ks + 4 + fq of the flattened (tap, channel / 4) axis -- two positions per lane advanced by compare-and-subtract, four ds_read_b64
+//     per fragment (hi / lo of each quad).  Lanes fq and fq ^ 1 read the two quads of one 8-channel group: the 32 lanes of a ds_read_b64
+//     group cover 16 pixels x 16 contiguous bytes at an odd slot pitch = all 64 banks once (MI355X_MICROARCH.md, LDS table);
+//   * the weights are the only streamed operand (LDS-DMA, 128-byte rows [hi(32) | lo(32)], XOR-swizzled, STAGES deep, one raw barrier per
+//     K-step) -- no conversion and no float32 operand in the K loop at all;
+//   * a wave computes 4 pixel rows x NT 16-channel tiles, accumulators transposed (a lane owns 4 consecutive channels of one pixel):
+//     folded BatchNorm / bias, activation, optional skip, 16-byte float32 stores.
+// L2 -> LDS bytes per workgroup: halo + all weights of its channel block, e.g. conv0 (32 -> 128 channels at 240 x 320 x 8): 0.45 GB per
+// launch against the implicit GEMM's 1.42 GB; up4's first conv (80 -> 32): 0.47 against 2.26.
+#include "igemm_core.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16hx[4] = {0u, 0u, 0u, 0u};
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct HaloX3P {
+  int PP;          // halo pixel pitch in bytes: Cin * 4 rounded up to an odd number of 16-byte slots
+  int QPP;         // channel quads per pixel = Cin / 4 (even: Cin % 8 == 0)
+  int tiles_x, tiles_y;
+  int n_blocks;    // workgroups per pixel tile (each owns NT * WN * 16 output channels and re-reads the halo from L2)
+  FastDiv dq;      // piece -> (pixel, quad)
+};
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P hp) {
+  constexpr int WM = 4 / WN;
+  constexpr int TH = 4 * WM;                 // output rows per workgroup (a wave owns 4)
+  constexpr int HC = 18;                     // halo columns
+  constexpr int HPIX = (TH + 2) * HC;
+  constexpr int NPAD = NT * WN * 16;         // weight rows staged per K-step
+  constexpr int NBG = NPAD / 8;
+  constexpr int NB = (NBG + 3) / 4;
+  constexpr int WSTAGE = NPAD * 128;
+  constexpr int LB = 6;                      // halo pieces per thread and loader pass
+  static_assert((STAGES - 2) * NB <= 63, "vmcnt field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;
+  unsigned char* sX = smem + STAGES * WSTAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_base = (bid % hp.n_blocks) * NPAD; bid /= hp.n_blocks;      // channel blocks of one tile are neighbours: they share the halo in L2
+  const int tx_ = bid % hp.tiles_x; bid /= hp.tiles_x;
+  const int ty_ = bid % hp.tiles_y;
+  const int b = bid / hp.tiles_y;
+  const int x0 = tx_ * 16, y0 = ty_ * TH;
+
+  const float* __restrict__ in = reinterpret_cast<const float*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
+  const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
+  const void* zsrc = reinterpret_cast<const void*>(g_zero16hx);
+  const int nk = (p.K + 31) >> 5;
+  const int wrow = nk * 64;
+
+  // ---- weight stages: lane (row rsub of an 8-row group, logical 16-byte chunk lc of the 128-byte K-step row) -----------------------
+  const f16_t* b_ptr[NB];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n_base + ((j * 4 + wave) % NBG) * 8 + rsub;
+    const bool ok = n < p.Cout;
+    if (ok) b_okmask |= 1u << j;
+    b_ptr[j] = wt + (long long)(ok ? n : 0) * wrow;
+  }
+  auto issue = [&](int ks, int buf) {
+    unsigned char* s = sW + buf * WSTAGE;
+    const int kk = (ks * 8 + lc) * 8;          // rows are zero-padded to whole K-steps
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = (b_okmask >> j) & 1u;
+      glds16(ok ? (const void*)(b_ptr[j] + kk) : zsrc, s + ((j * 4 + wave) % NBG) * 1024);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  // ---- the halo: 16-byte float32 pieces (one channel quad of one pixel), all of the thread's loads of a pass in flight, then split and
+  //      stored as [hi4 | .. | lo4 | ..] of the quad's 8-channel group ----------------------------------------------------------------
+  {
+    const int nitems = HPIX * hp.QPP;
+    for (int base = 0; base < nitems; base += 256 * LB) {
+      f32x4 v[LB];
+      int dst[LB];
+#pragma unroll
+      for (int n = 0; n < LB; ++n) {
+        const int i = base + tid + n * 256;
+        unsigned upx, uq;
+        fd_rowcol((unsigned)i, hp.dq, upx, uq);
+        const int px = (int)upx, q = (int)uq;
+        const int hy = px / HC, hx = px - hy * HC;
+        const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+        const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        dst[n] = i < nitems ? px * hp.PP + (q >> 1) * 32 + (q & 1) * 8 : -1;
+        v[n] = ok ? *reinterpret_cast<const f32x4*>(in + (y * p.W + x) * p.in_ld + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};      // one image < 2^31 elements (host check)
+      }
+#pragma unroll
+      for (int n = 0; n < LB; ++n) {
+        if (dst[n] < 0) continue;
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = f2h(v[n][e]);                              // round-to-nearest, saturating
+          lo[e] = (f16_t)(v[n][e] - (float)hi[e]);           // exact difference, rounded once: |x - hi - lo| <= 2^-22 |x|
+        }
+        *reinterpret_cast<f16x4*>(sX + dst[n]) = hi;
+        *reinterpret_cast<f16x4*>(sX + dst[n] + 16) = lo;
+      }
+    }
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // positions of this lane's two channel quads (k4 = 8 ks + fq and 8 ks + 4 + fq) in the flattened (tap, quad) axis: quad inside the pixel,
+  // byte offset of the tap inside the halo
+  const int nq_all = 9 * hp.QPP;
+  int cq[2], dx[2], off[2], k4[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    k4[h] = fq + 4 * h;
+    int tap = k4[h] / hp.QPP;
+    cq[h] = k4[h] - tap * hp.QPP;
+    const int ty = tap / 3;
+    dx[h] = tap - ty * 3;
+    off[h] = (ty * HC + dx[h]) * hp.PP;
+  }
+  const unsigned char* xrow = sX + ((wm * 4) * HC + fr) * hp.PP;      // tap (0, 0) of output pixel (row wm * 4, column fr)
+  const int growb = HC * hp.PP;
+  const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks % STAGES;
+    const int ahead = min(nk - 1 - ks, STAGES - 2);
+    if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * NB>();
+    else if (ahead == 1) wait_vmcnt<NB>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores (first time round) and the fragment reads of the previous step
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + STAGES - 1 < nk) issue(ks + STAGES - 1, (ks + STAGES - 1) % STAGES);
+    const unsigned char* cW = sW + buf * WSTAGE + (wn * NT * 16) * 128;
+    f16x8 whi[NT], wlo[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      whi[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc0);
+      wlo[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc1);
+    }
+    // quads past the ninth tap meet zero weights: read any finite data (the tile's first piece)
+    const int xo0 = k4[0] < nq_all ? off[0] + (cq[0] >> 1) * 32 + (cq[0] & 1) * 8 : 0;
+    const int xo1 = k4[1] < nq_all ? off[1] + (cq[1] >> 1) * 32 + (cq[1] & 1) * 8 : 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned char* xb = xrow + g * growb;
+      const f16x4 h0 = *reinterpret_cast<const f16x4*>(xb + xo0), l0 = *reinterpret_cast<const f16x4*>(xb + xo0 + 16);
+      const f16x4 h1 = *reinterpret_cast<const f16x4*>(xb + xo1), l1 = *reinterpret_cast<const f16x4*>(xb + xo1 + 16);
+      const f16x8 xhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const f16x8 xlo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {      // acc[r] = channel 4 fq + r of tile j, pixel fr
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xhi, acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xlo, acc[g][j], 0, 0, 0);
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xhi, acc[g][j], 0, 0, 0);
+      }
+    }
+    // next K-step: eight quads further for both positions
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      k4[h] += 8;
+      cq[h] += 8;
+      while (cq[h] >= hp.QPP) {
+        cq[h] -= hp.QPP;
+        off[h] += hp.PP;
+        if (++dx[h] == 3) { dx[h] = 0; off[h] += (HC - 3) * hp.PP; }
+      }
+    }
+  }
+
+  // ---- epilogue: folded BatchNorm / bias, activation, optional skip; 16-byte float32 stores from the accumulators ----------------------
+  float* __restrict__ out = reinterpret_cast<float*>(p.out) + (long long)b * p.Ho * p.Wo * p.out_ld;
+  const float* __restrict__ res = p.res ? reinterpret_cast<const float*>(p.res) + (long long)b * p.Ho * p.Wo * p.res_ld : nullptr;
+  const int x = x0 + fr;
+  with_act(p.act, [&](auto A) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n_base + (wn * NT + j) * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int y = y0 + wm * 4 + g;
+        if (!(y < p.Ho && x < p.Wo)) continue;
+        const long long pix = (long long)y * p.Wo + x;
+        f32x4 yv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = act_c<decltype(A)::value>(acc[g][j][r] * sc[r] + sh[r]);
+        if (res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(res + pix * p.res_ld + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[r] += rv[r];
+        }
+        *reinterpret_cast<f32x4*>(out + pix * p.out_ld + n) = yv;
+      }
+    }
+  });
+}
+
+struct HCfg { int nt, wn; };
+constexpr HCfg kHCfg[] = {
+    {1, 1},  // 0: Cout <= 16, 16 x 16 pixels
+    {2, 1},  // 1: <= 32
+    {4, 1},  // 2: <= 64
+    {2, 2},  // 3: <= 64, 8 x 16 pixels
+    {4, 2},  // 4: <= 128
+    {5, 2},  // 5: <= 160
+    {7, 2},  // 6: <= 224
+    {1, 2},  // 7: <= 32, 8 x 16 pixels
+    {8, 1},  // 8: <= 128, 16 x 16 pixels
+    {5, 1},  // 9: <= 80
+};
+constexpr int kNumHCfg = sizeof(kHCfg) / sizeof(kHCfg[0]);
+
+template <int NT, int WN>
+int launch_hx(const ConvP& p, hipStream_t s) {
+  constexpr int TH = 4 * (4 / WN);
+  constexpr int NPAD = NT * WN * 16;
+  constexpr int STAGES = 2;
+  HaloX3P hp;
+  hp.n_blocks = cdiv(p.Cout, NPAD);
+  hp.QPP = p.Cin / 4;
+  hp.dq = make_fastdiv((unsigned)hp.QPP);
+  if ((long long)p.H * p.W * p.in_ld >= (1ll << 31)) return -1;
+  int slots = hp.QPP;
+  if ((slots & 1) == 0) ++slots;
+  hp.PP = slots * 16;
+  hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
+  const size_t halo = (size_t)(TH + 2) * 18 * hp.PP;
+  const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
+  const size_t lds = (size_t)STAGES * NPAD * 128 + halo;
+  if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
+  auto k = conv3x3_halo_x3_kernel<NT, WN, STAGES>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);
+  return 0;
+}
+
+}  // namespace
+
+int conv3x3_halo_x3_num_variants() { return kNumHCfg; }
+
+// The problems this kernel takes: 3x3, stride 1, undilated, float32 tensors with pre-split weights, Cin a multiple of 8, shared weights.
+bool conv3x3_halo_x3_takes(const ConvP& p) {
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.dil == 1 && p.Cin % 8 == 0 && p.Cin >= 8 && p.Cout % 4 == 0 && p.rows_per_batch == 0 &&
+         p.ln_gamma == nullptr && (long long)p.H * p.W * p.in_ld < (1ll << 31);
+}
+
+// Smallest LDS footprint (bytes) of variant v for this problem, or 0 if it cannot hold the halo.
+size_t conv3x3_halo_x3_lds(int v, const ConvP& p) {
+  if (v < 0 || v >= kNumHCfg) return 0;
+  const int th = 4 * (4 / kHCfg[v].wn), npad = kHCfg[v].nt * kHCfg[v].wn * 16;
+  int slots = p.Cin / 4;
+  if ((slots & 1) == 0) ++slots;
+  const size_t lds = (size_t)2 * npad * 128 + (size_t)(th + 2) * 18 * slots * 16;
+  return lds <= 160 * 1024 ? lds : 0;
+}
+
+// v < 0: automatic tile (widest channel block that fits, 16 x 16 pixels while two workgroups still share a CU).
+int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
+  if (v < 0) {
+    const int c = p.Cout;
+    const int cands16[] = {0, 1, 2, 9, 8};          // 16 x 16 pixel tiles by channel capacity 16 / 32 / 64 / 80 / 128
+    const int cands8[] = {7, 3, 4, 5, 6};           // 8 x 16 pixel tiles: 32 / 64 / 128 / 160 / 224
+    const int cap16[] = {16, 32, 64, 80, 128}, cap8[] = {32, 64, 128, 160, 224};
+    int best = -1;
+    const long long px = (long long)p.B * p.Ho * p.Wo;
+    // measured exceptions to "widest block, 16 x 16 pixels": thin outputs at a quarter of the full resolution fill the chip better with
+    // 8 x 16 pixel tiles (153600 px x 32 ch: 17.2 vs 19.6 us in flight); 224 channels as two 128-channel blocks (33 vs 39 us)
+    if (c <= 32 && px < 300000 && conv3x3_halo_x3_lds(7, p)) best = 7;
+    if (c > 160 && c <= 256 && conv3x3_halo_x3_lds(4, p)) best = 4;
+    for (int i = 0; i < 5 && best < 0; ++i)
+      if (c <= cap16[i] && conv3x3_halo_x3_lds(cands16[i], p) && conv3x3_halo_x3_lds(cands16[i], p) <= 80 * 1024) best = cands16[i];
+    for (int i = 0; i < 5 && best < 0; ++i)
+      if (c <= cap8[i] && conv3x3_halo_x3_lds(cands8[i], p)) best = cands8[i];
+    if (best < 0) {      // wider than any block: several channel blocks per tile
+      best = conv3x3_halo_x3_lds(4, p) ? 4 : (conv3x3_halo_x3_lds(3, p) ? 3 : -1);
+    }
+    if (best < 0) return -1;
+    v = best;
+  }
+  switch (v) {
+    case 0: return launch_hx<1, 1>(p, s);
+    case 1: return launch_hx<2, 1>(p, s);
+    case 2: return launch_hx<4, 1>(p, s);
+    case 3: return launch_hx<2, 2>(p, s);
+    case 4: return launch_hx<4, 2>(p, s);
+    case 5: return launch_hx<5, 2>(p, s);
+    case 6: return launch_hx<7, 2>(p, s);
+    case 7: return launch_hx<1, 2>(p, s);
+    case 8: return launch_hx<8, 1>(p, s);
+    case 9: return launch_hx<5, 1>(p, s);
+    default: return -3;
+  }
+}

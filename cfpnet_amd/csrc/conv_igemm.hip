@@ -315,6 +315,15 @@ int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whol
 // 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
 // stride 2 (tools/conv_bench.py --halo, us with / without): stem 614400 x 40 x 72 25.5-27 / 29, 153600 x 64 x 144 23.4 / 26, 38400 x 160 x 360 20.8 / 23.4
+int g_halo_x3 = 1;              // cfp_debug_set key 24: 0 = the f16x3 3x3 convolutions never take the halo kernel
+// where conv3x3_halo_x3.hip replaces the f16x3 implicit GEMM: many pixels (the halo and the weights of a channel block are fetched once
+// per workgroup instead of nine times / once per 128 rows) and an input depth whose halo fits LDS
+// (tools/conv_bench_x3.py --halo, us halo / implicit GEMM, alone and with four copies side by side; profiles/r4_conv_bench_x3_halo_*.txt):
+// it wins where the input is SHALLOW -- 614400 px: 32 -> 128 ch 152 / 188 in flight (167 / 207 alone), 40 -> 16 63 / 83, 32 -> 32 60 / 73,
+// 16 -> 16 23 / 41; 153600 px 40 -> 160 62 / 97; 38400 px 56 -> 224 33 / 41 -- and loses from 64 input channels up (the head's 128 -> 128:
+// 692 / 573, 153600 px 168 -> 64: 182 / 136, 38400 px 128 -> 64: 39 / 23): a deep halo leaves one workgroup per CU, whose load phase
+// (95-124 KB through registers) nothing overlaps, where the implicit GEMM pipelines its operand stream over K.
+static bool halo_x3_wins(long long M, int Cin, int Cout, bool tput) { return M >= 30000 && Cin <= 56; }
 static bool halo_wins_s2(long long M, int Cout) { return g_halo == 2 || (g_halo == 1 && g_halo_s2 && M >= 30000 && Cout <= 160); }
 static bool halo_wins(long long M, int Cout, bool tput) {
   if (g_halo == 2) return true;
@@ -340,6 +349,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 23: cfp_dwl_wgrad_debug_set(value); return CFP_OK;
     case 18: g_halo_s2 = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
+    case 24: g_halo_x3 = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
@@ -456,6 +466,12 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
 extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                                int* splits) {
   if (dtype == CFP_F32X3) {
+    if (KH == 3 && stride == 1 && K % 9 == 0 && (K / 9) % 8 == 0 && rows_per_batch <= 0 && g_halo_x3 && g_force_variant < 0 &&
+        halo_x3_wins(M, K / 9, Cout, g_tput != 0)) {
+      if (variant) *variant = 500;          // conv3x3_halo_x3.hip (the tile is chosen from Cout and the LDS the halo takes)
+      if (splits) *splits = 1;
+      return CFP_OK;
+    }
     Plan2 pl = plan_x3(M, Cout, K, rows_per_batch, B, rows_per_batch <= 0, g_tput != 0);
     if (variant) *variant = 400 + pl.variant;
     if (splits) *splits = pl.splits;
@@ -557,6 +573,15 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
                 "cfp_conv2d_nhwc: problem too large for the f16x3 kernel");
     CFP_REQUIRE(aligned16(scale) && aligned16(shift), CFP_EINVAL, "cfp_conv2d_nhwc: scale / shift must be 16-byte aligned (read as 4-float vectors)");
     const int rpb = per_image_weights ? Ho * Wo : 0;
+    // 3x3 stride-1 layers with the whole-depth halo in LDS (conv3x3_halo_x3.hip): cfp_debug_set(0, 500 + v) forces its tile v, 500 + 99 its
+    // automatic tile, 400 + v keeps the implicit GEMM
+    if (!per_image_weights && !ln_gamma && conv3x3_halo_x3_takes(p) &&
+        (g_force_variant >= 500 || (g_force_variant < 0 && g_halo_x3 && halo_x3_wins(p.M, Cin, Cout, tput)))) {
+      const int hv = g_force_variant >= 500 && g_force_variant < 599 ? g_force_variant - 500 : -1;
+      int rc = conv3x3_halo_x3_launch(hv, p, s);
+      if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
+      CFP_REQUIRE(g_force_variant < 500, CFP_EHIP, "cfp_conv2d_nhwc: the forced f16x3 halo variant cannot run this problem");
+    }
     Plan2 pl = plan_x3(p.M, Cout, p.K, rpb, B, rpb == 0, tput);
     if (g_force_variant >= 400 && g_force_variant - 400 < igemm_x3_num_variants()) pl.variant = g_force_variant - 400;
     if (g_force_splits >= 1) pl.splits = g_force_splits;

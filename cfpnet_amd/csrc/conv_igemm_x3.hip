@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (KG == 2 && it >= nkg) continue;
-    if (it + STAGES - 1 < nkg) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
+    if (it + STAGES - 1 < nkg && !(p.probe & 1)) issue(k0 + kg + (it + STAGES - 1) * KG, (it + STAGES - 1) % STAGES);
+    if (p.probe & 2) continue;      // timing probes (cfp_debug_set key 16; results are garbage): 1 = no DMA after the prologue, 2 = no reads / MFMAs,
+                                    // 4 = no hi / lo split (one MFMA per block), 8 = split but one MFMA per block
 
     const unsigned char* cA = gsm + buf * STAGE_BYTES + a_row0 * 128;
     const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
@@ -221,7 +223,20 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc0);
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc1);
       f16x8 ahi, alo;
+      if (p.probe & 4) {
+        ahi = __builtin_bit_cast(f16x8, x0); alo = __builtin_bit_cast(f16x8, x1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[j], ahi, acc[i][j], 0, 0, 0);
+        continue;
+      }
       split8(x0, x1, ahi, alo);
+      if (p.probe & 8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[j], ahi, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][0][e & 3] += (float)alo[e];
+        continue;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {      // transposed (weights as the row operand): acc[r] = 4 CONSECUTIVE CHANNELS (n = 4 fq + r) of pixel row fr
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo[j], ahi, acc[i][j], 0, 0, 0);

@@ -46,6 +46,12 @@ int igemm_x3_num_variants();
 void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages);
 int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
 
+// conv3x3_halo_x3.hip (float32 storage, f16x3 matrix math, whole-depth halo in LDS; the weights are cfp_pack_w_x3's operand)
+int conv3x3_halo_x3_num_variants();
+bool conv3x3_halo_x3_takes(const ConvP& p);
+size_t conv3x3_halo_x3_lds(int v, const ConvP& p);
+int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s);
+
 // conv3x3_direct.hip
 int conv3x3_num_variants();
 void conv3x3_variant_shape(int v, int* th, int* bn);

@@ -103,7 +103,8 @@ size_t cfp_conv2d_ws_bytes(int M, int Cout, int K, int dtype);
 /* Kernel plan cfp_conv2d_nhwc uses for a problem (per-kernel accounting in bench.py and
  * tools/conv_bench.py).  *variant: 0..3 = first-generation tiles 256x16 / 256x32 / 128x64 /
  * 128x128 (f32); 100 + v = second-generation (bf16, LDS-DMA staged) variant v; 200 + v = direct 3x3
- * (LDS halo tile) variant v; 400 + v = f16x3 variant v (dtype CFP_F32X3: float32 storage, CFP_CONV_X3).  *splits = K-splits.  KH/stride describe the filter (K = KH*KH*Cin);
+ * (LDS halo tile) variant v; 400 + v = f16x3 implicit-GEMM variant v, 500 = the f16x3 whole-depth-halo 3x3 kernel (dtype CFP_F32X3: float32
+ * storage, CFP_CONV_X3).  *splits = K-splits.  KH/stride describe the filter (K = KH*KH*Cin);
  * rows_per_batch > 0 describes a per_image_weights call (B images of rows_per_batch rows). */
 int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                     int* splits);

@@ -285,6 +285,63 @@ def test_se_gate_fold_writes_x3_operands():
     assert torch.equal(wx, want)
 
 
+X3_HALO_CASES = [
+    (1, 12, 16, 40, 16, 3, 1, (1, 1, 1, 1)),      # 40 -> 16, exact 16-column tiles, K = 360 ends inside a 32-deep step
+    (2, 21, 35, 16, 16, 3, 1, (1, 1, 1, 1)),      # ragged rows and columns
+    (1, 19, 30, 8, 32, 3, 1, (1, 1, 1, 1)),       # one channel group per pixel: a K-step spans four taps
+    (2, 17, 18, 40, 160, 3, 1, (1, 1, 1, 1)),     # stage 3 expand
+    (1, 9, 33, 56, 224, 3, 1, (1, 1, 1, 1)),      # stage 4 expand
+    (1, 16, 16, 64, 64, 3, 1, (1, 1, 1, 1)),
+    (1, 25, 20, 32, 128, 3, 1, (0, 2, 2, 0)),     # asymmetric padding (conv0's channel counts)
+    (3, 8, 8, 24, 40, 3, 1, (1, 1, 1, 1)),        # channel counts that fill no tile exactly
+    (1, 5, 70, 48, 96, 3, 1, (1, 1, 1, 1)),       # fewer rows than a tile
+    (1, 18, 34, 128, 128, 3, 1, (1, 1, 1, 1)),    # the depth head's conv (8 x 16 pixel tiles only: the halo is 95 KB)
+    (1, 10, 20, 168, 64, 3, 1, (1, 1, 1, 1)),     # up3's first conv: the deepest halo that fits
+    (2, 11, 13, 80, 32, 3, 1, (1, 1, 1, 1)),      # up4's first conv
+]
+X3_HALO_CAP = [16, 32, 64, 64, 128, 160, 224, 32, 128, 80]      # output channels per workgroup of each tile (csrc/conv3x3_halo_x3.hip kHCfg)
+
+
+@pytest.mark.parametrize("variant", list(range(10)) + [99])
+def test_conv3x3_halo_x3_every_variant(variant):
+    """The f16x3 whole-depth-halo 3x3 kernel (float32 tensors, halo split once into LDS, the implicit GEMM's pre-split weights), every tile
+    forced through the debug knob (500 + v; 599 = its automatic tile) against a float64 reference, and equal to the f16x3 implicit GEMM to
+    float32 re-association."""
+    lib = hip.load()
+    ran = 0
+    try:
+        for case in X3_HALO_CASES:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            lib.cfp_debug_set(0, 500 + variant)
+            out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
+            out = ops.Act(out.buf, 16, Cout)
+            try:
+                ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            except RuntimeError as e:
+                assert "cannot run this problem" in str(e) and variant != 99      # halo too deep for this tile's LDS
+                continue
+            torch.cuda.synchronize()
+            ran += 1
+            _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 halo v{variant} conv {case}")
+            assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+            lib.cfp_debug_set(0, 413)
+            out2 = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+            ops.conv2d(xa, wx, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            assert float((out2.torch() - out.torch()).abs().max()) <= 2e-6 * float(ref.abs().max())
+    finally:
+        lib.cfp_debug_set(0, -1)
+    assert ran >= (len(X3_HALO_CASES) if variant == 99 else 5)
+
+
+def test_conv3x3_halo_x3_is_what_the_plan_picks_for_many_pixel_layers():
+    v, sp = ops.conv2d_plan(8 * 240 * 320, 128, 9 * 32, hip.F32X3, 0, 8, 3, 1)
+    assert v == 500 and sp == 1
+    v, _ = ops.conv2d_plan(8 * 15 * 20, 256, 9 * 392, hip.F32X3, 0, 8, 3, 1)
+    assert 400 <= v < 500
+
+
 DIRECT3_CASES = [
     (1, 12, 16, 40, 16, 3, 1, (1, 1, 1, 1)),      # Cin < 64 (one partly filled channel chunk), Cout 16
     (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)),    # 7 channel chunks, tail chunk of 8 channels, 2 N-tiles
