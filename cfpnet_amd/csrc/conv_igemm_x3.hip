@@ -53,10 +53,12 @@ __device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& 
   }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1>
-__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __restrict__ slabs, int splits) {
-  static_assert(WM * WN == 4, "four waves per group");
-  static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
+// The K loop: accumulates C[m0.., n0..] over K-steps [k0, k1) into acc.  smem: KG * STAGES * (BM + BN) * 128 bytes.  All 256 * KG threads call it.
+// INTERLEAVE: fragment i of wave-row wm covers tile rows (i * WM + wm) * 16 .. + 15 instead of (wm * TM + i) * 16 .. (the fused bin head wants
+// the 64 rows of one i contiguous).
+template <int BM, int BN, int WM, int WN, int STAGES, int KG, bool INTERLEAVE = false>
+__device__ __forceinline__ void x3_mainloop(const ConvP& p, const f16_t* __restrict__ wt, int m0, int m_end, int n0, int k0, int k1,
+                                            unsigned char* smem, f32x4 (&acc)[BM / WM / 16][BN / WN / 16]) {
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
   constexpr int NA = BM / 32;                    // A DMA instructions per wave per K-step
@@ -65,8 +67,6 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   constexpr int LPS = NA + NB;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   static_assert((STAGES - 2) * LPS <= 63, "vmcnt field");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,34 +77,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   const int rsub = lane >> 3;
   const int lc = (lane & 7) ^ rsub;              // logical 16-byte chunk this lane fetches: 4 float32 channels of A, 8 halves of W
   unsigned char* gsm = smem + kg * (STAGES * STAGE_BYTES);
-
-  const int tiles_n = (p.Cout + BN - 1) / BN;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int sp = 0;
-  if constexpr (SPLITK) { sp = bid % splits; bid /= splits; }
-  const int tile_n = bid % tiles_n;
-  const int tile_m = bid / tiles_n;
   const int nk_all = (p.K + 31) >> 5;
   const int wrow = nk_all * 64;                  // halves per packed weight row
-  int m0, m_end;
-  const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
-  if (p.rows_per_batch > 0) {
-    const int tpb = (p.rows_per_batch + BM - 1) / BM;
-    const int b = tile_m / tpb;
-    m0 = b * p.rows_per_batch + (tile_m % tpb) * BM;
-    m_end = (b + 1) * p.rows_per_batch;
-    wt += (long long)b * p.w_bstride;
-  } else {
-    m0 = tile_m * BM;
-    m_end = p.M;
-  }
-  const int n0 = tile_n * BN;
-  int k0 = 0, k1 = nk_all;
-  if constexpr (SPLITK) {
-    const int per = (nk_all + splits - 1) / splits;
-    k0 = sp * per;
-    k1 = min(nk_all, k0 + per);
-  }
   const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
 
   const float* a_ptr[NA];
@@ -183,7 +157,6 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     }
   };
 
-  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -195,7 +168,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nkg) issue(k0 + kg + s * KG, s);
 
-  const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
+  const int b_row0 = wn * (BN / WN);
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;      // tile row offsets are multiples of 16 rows
   for (int it = 0; it < nit; ++it) {
     const int buf = it % STAGES;
@@ -210,8 +183,32 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     if (p.probe & 2) continue;      // timing probes (cfp_debug_set key 16; results are garbage): 1 = no DMA after the prologue, 2 = no reads / MFMAs,
                                     // 4 = no hi / lo split (one MFMA per block), 8 = split but one MFMA per block
 
-    const unsigned char* cA = gsm + buf * STAGE_BYTES + a_row0 * 128;
+    const unsigned char* cA = gsm + buf * STAGE_BYTES;
     const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
+    if constexpr (TN > 2 * TM) {
+      // wide wave tiles (the fused bin head: 16 column tiles): the A fragments are split first and stay, the weight fragments stream
+      // through eight registers at a time
+      f16x8 ahi[TM], alo[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = (INTERLEAVE ? (i * WM + wm) : (wm * TM + i)) * 16 + fr;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc1);
+        split8(x0, x1, ahi[i], alo[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc0);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ahi[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, alo[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ahi[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     f16x8 bhi[TN], blo[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -220,8 +217,9 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc0);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(cA + (i * 16 + fr) * 128 + pc1);
+      const int r = (INTERLEAVE ? (i * WM + wm) : (wm * TM + i)) * 16 + fr;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc0);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc1);
       f16x8 ahi, alo;
       if (p.probe & 4) {
         ahi = __builtin_bit_cast(f16x8, x0); alo = __builtin_bit_cast(f16x8, x1);
@@ -246,6 +244,54 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     }
   }
   wait_vmcnt<0>();
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __restrict__ slabs, int splits) {
+  static_assert(WM * WN == 4, "four waves per group");
+  static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 2 ? wave8 >> 2 : 0;
+  const int wave = wave8 & 3;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int sp = 0;
+  if constexpr (SPLITK) { sp = bid % splits; bid /= splits; }
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int nk_all = (p.K + 31) >> 5;
+  int m0, m_end;
+  const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
+  if (p.rows_per_batch > 0) {
+    const int tpb = (p.rows_per_batch + BM - 1) / BM;
+    const int b = tile_m / tpb;
+    m0 = b * p.rows_per_batch + (tile_m % tpb) * BM;
+    m_end = (b + 1) * p.rows_per_batch;
+    wt += (long long)b * p.w_bstride;
+  } else {
+    m0 = tile_m * BM;
+    m_end = p.M;
+  }
+  const int n0 = tile_n * BN;
+  int k0 = 0, k1 = nk_all;
+  if constexpr (SPLITK) {
+    const int per = (nk_all + splits - 1) / splits;
+    k0 = sp * per;
+    k1 = min(nk_all, k0 + per);
+  }
+  f32x4 acc[TM][TN];
+  x3_mainloop<BM, BN, WM, WN, STAGES, KG>(p, wt, m0, m_end, n0, k0, k1, smem, acc);
+  const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
   if constexpr (KG == 2) {
     __syncthreads();   // every wave is done with the operand stages: LDS carries the second group's accumulators to the first
     static_assert(BM * BN * 4 <= KG * STAGES * STAGE_BYTES, "accumulator exchange must fit in the operand LDS");
@@ -339,6 +385,73 @@ int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
   return 0;
 }
 
+// ---- fused bin head (f16x3): conv_out 1x1 (Cin -> 256 logits) + softmax over the bins + expectation with the bin centres, float32 prob
+// written NCHW (deltar.py:45-62: conv_out = Conv2d(128, n_bins, 1) + Softmax(dim=1), pred = sum(prob * centers)).  The 128 x 256 logit tile
+// never leaves the registers (transposed accumulators: a lane holds 64 of its pixel's 256 logits, the other three quarters sit in lanes
+// fr + 16, + 32, + 48); the probabilities of 64 pixels at a time cross LDS so that the NCHW store is 16-byte vectors along the pixel axis,
+// 256 contiguous bytes per bin.  Saves the logits' round trip (629 MB written + read at batch 8) and a launch.
+constexpr int HB_M = 128, HB_N = 256, HB_PP = 64 + 4;      // HB_PP: floats per bin row of the 64-pixel probability tile in LDS
+
+__global__ __launch_bounds__(256) void bin_head_x3_kernel(ConvP p, const float* __restrict__ bias, const float* __restrict__ centers,
+                                                          float* __restrict__ prob, float* __restrict__ pred, int HW) {
+  constexpr int TM = 2, TN = 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * HB_M;
+  f32x4 acc[TM][TN];
+  x3_mainloop<HB_M, HB_N, 4, 1, 2, 1, true>(p, reinterpret_cast<const f16_t*>(p.w), m0, p.M, 0, 0, (p.K + 31) >> 5, smem, acc);
+  float* sP = reinterpret_cast<float*>(smem);      // [256][HB_PP]
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    __syncthreads();      // the operand stages (first round) / the previous round's probability tile are done with
+    const int m = m0 + i * 64 + wave * 16 + fr;      // this lane's pixel (INTERLEAVE row map)
+    const int bidx = min(m, p.M - 1) / HW;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 bs = *reinterpret_cast<const f32x4*>(bias + j * 16 + fq * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[i][j][r] += bs[r]; mx = fmaxf(mx, acc[i][j][r]); }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[i][j][r] = __expf(acc[i][j][r] - mx); s += acc[i][j][r]; }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float inv = 1.f / s;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const f32x4 cen = *reinterpret_cast<const f32x4*>(centers + (long long)bidx * HB_N + j * 16 + fq * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[i][j][r] *= inv; dot = fmaf(acc[i][j][r], cen[r], dot); }
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (fq == 0 && m < p.M) pred[m] = dot;
+    if (prob == nullptr) continue;
+    const int pl = wave * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[(j * 16 + fq * 4 + r) * HB_PP + pl] = acc[i][j][r];
+    __syncthreads();
+    for (int q = tid; q < HB_N * 16; q += 256) {
+      const int n = q >> 4, ch = q & 15;
+      const int mm = m0 + i * 64 + ch * 4;
+      if (mm >= p.M) continue;
+      const int b = mm / HW, hw = mm - b * HW;      // HW % 4 == 0: four pixels stay inside one image
+      *reinterpret_cast<f32x4*>(prob + ((long long)b * HB_N + n) * HW + hw) = *reinterpret_cast<const f32x4*>(sP + n * HB_PP + ch * 4);
+    }
+  }
+}
+
 // f32 [rows][K] -> packed halves [rows][ceil(K / 32) * 64]
 __global__ __launch_bounds__(256) void pack_w_x3_kernel(const float* __restrict__ w, f16_t* __restrict__ out, long long rows, int K, int nk) {
   const long long total = rows * nk * 32;
@@ -411,4 +524,22 @@ extern "C" int cfp_pack_w_x3(const float* w, void* out, long long rows, int K, c
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_w_x3_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, reinterpret_cast<f16_t*>(out), rows, K, nk);
   return cfp_check_launch("cfp_pack_w_x3");
+}
+
+// cfp_bin_head_fused for dtype CFP_F32X3 (head.hip dispatches here): x float32 [B*HW, x_ld], w = cfp_pack_w_x3 of conv_out's [256, Cin].
+int bin_head_x3_launch(const void* x, int x_ld, const void* w, const float* bias, const float* centers, float* prob, float* pred, int B, int HW,
+                       int Cin, hipStream_t s) {
+  ConvP p;
+  p.in = x; p.w = w; p.out = nullptr; p.res = nullptr; p.scale = nullptr; p.shift = nullptr;
+  p.in_ld = x_ld; p.out_ld = 0; p.res_ld = 0;
+  p.B = 1; p.H = 1; p.W = B * HW; p.Cin = Cin; p.Ho = 1; p.Wo = B * HW; p.Cout = HB_N;
+  p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
+  p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.f16 = 0; p.k2 = 0; p.dil = 1; p.mom = nullptr; p.probe = 0;
+  p.up_src = nullptr; p.up_ld = p.up_C = p.up_H = p.up_W = 0; p.up_sy = p.up_sx = 0.f;
+  size_t lds = (size_t)2 * (HB_M + HB_N) * 128;
+  static_assert((size_t)HB_N * HB_PP * 4 <= (size_t)2 * (HB_M + HB_N) * 128, "probability tile must fit in the operand LDS");
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)bin_head_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+  hipLaunchKernelGGL(bin_head_x3_kernel, dim3(cdiv(p.M, HB_M)), dim3(256), lds, s, p, bias, centers, prob, pred, HW);
+  return 0;
 }

@@ -274,7 +274,16 @@ __global__ __launch_bounds__(256) void bin_head_fused_kernel(ConvP p, const floa
 
 extern "C" int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
                                   void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_bin_head_fused: bf16/f16 only (use cfp_conv2d_nhwc + cfp_bin_softmax for f32)");
+  if (dtype == CFP_F32X3) {      // float32 tensors, f16x3 matrix math, float32 prob: conv_igemm_x3.hip
+    CFP_REQUIRE(x && w && bias && centers && pred, CFP_EINVAL, "cfp_bin_head_fused: null pointer");
+    CFP_REQUIRE(B > 0 && HW > 0 && HW % 4 == 0 && Cin > 0 && Cin % 4 == 0 && x_ld % 4 == 0 && x_ld >= Cin && (long long)B * HW < (1ll << 31), CFP_ESHAPE,
+                "cfp_bin_head_fused: bad shape (HW and Cin must be multiples of 4)");
+    CFP_REQUIRE(aligned16(x) && aligned16(w) && aligned16(prob) && aligned16(bias) && aligned16(centers), CFP_EINVAL, "cfp_bin_head_fused: pointers must be 16-byte aligned");
+    int rc = bin_head_x3_launch(x, x_ld, w, bias, centers, (float*)prob, pred, B, HW, Cin, reinterpret_cast<hipStream_t>(stream));
+    CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_bin_head_fused: f16x3 kernel launch failed");
+    return cfp_check_launch("cfp_bin_head_fused");
+  }
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_bin_head_fused: bf16/f16 or CFP_F32X3 (use cfp_conv2d_nhwc + cfp_bin_softmax for plain f32)");
   CFP_REQUIRE(x && w && bias && centers && pred, CFP_EINVAL, "cfp_bin_head_fused: null pointer");
   CFP_REQUIRE(B > 0 && HW > 0 && HW % 8 == 0 && Cin > 0 && Cin % 8 == 0 && x_ld % 8 == 0 && x_ld >= Cin &&
                   (long long)B * HW < (1ll << 31), CFP_ESHAPE, "cfp_bin_head_fused: bad shape (HW and Cin must be multiples of 8)");

@@ -45,6 +45,8 @@ int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s
 int igemm_x3_num_variants();
 void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages);
 int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
+int bin_head_x3_launch(const void* x, int x_ld, const void* w, const float* bias, const float* centers, float* prob, float* pred, int B, int HW,
+                       int Cin, hipStream_t s);
 
 // conv3x3_halo_x3.hip (float32 storage, f16x3 matrix math, whole-depth halo in LDS; the weights are cfp_pack_w_x3's operand)
 int conv3x3_halo_x3_num_variants();

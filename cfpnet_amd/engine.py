@@ -1106,7 +1106,7 @@ class Engine:
             # conv3x3 + conv_out + softmax + expectation in one kernel: neither ram nor the logits reach HBM
             ops.depth_head_fused(unet, self.P[h + ".conv3x3.w"], self.P[h + ".conv3x3.s"], self.P[h + ".conv3x3.t"], self.P["conv_out.wp"],
                                  self.P["conv_out.t"], centers, prob, pred, B, hs[0], wsz[0], ram_out=ram, ram_hilo=self.head_hilo[1])
-        elif self.half and self.n_bins == 256 and HWh % 8 == 0:
+        elif (self.half or self.x3) and self.n_bins == 256 and HWh % 8 == 0 and os.environ.get("CFP_BIN_HEAD_FUSED", "1") != "0":
             # 1x1 conv + softmax + expectation in one kernel: the logits never reach HBM
             ops.bin_head_fused(ram, self.P["conv_out.w"], self.P["conv_out.t"], centers, prob, pred, B, HWh)
         else:

@@ -431,8 +431,12 @@ def bin_softmax(logits: Act, centers, prob, pred, B, HW, nbins):
 
 
 def bin_head_fused(x: Act, w, bias, centers, prob, pred, B, HW):
+    """conv_out (1x1, -> 256 logits) + softmax + expectation in one launch.  16-bit tensors with 16-bit weights [256, C], or float32
+    tensors with the pre-split f16x3 operand of pack_w_x3 (float32 prob)."""
+    x3 = x.buf.dtype == torch.float32 and w.dtype == torch.float16
+    assert not x3 or (tuple(w.shape) == (256, (x.C + 31) // 32 * 64) and (prob is None or prob.dtype == torch.float32))
     hip.call("cfp_bin_head_fused", x.ptr, x.ld, w.data_ptr(), bias.data_ptr(), centers.data_ptr(), hip.ptr(prob),
-             pred.data_ptr(), B, HW, x.C, x.dt, _s())
+             pred.data_ptr(), B, HW, x.C, hip.F32X3 if x3 else x.dt, _s())
 
 
 def permute_wout(w: torch.Tensor, dtype, hilo: bool = True, diffuse: bool = False) -> torch.Tensor:

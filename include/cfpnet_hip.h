@@ -377,7 +377,9 @@ int cfp_depth_head_fused(const void* x, int x_ld, const void* w3, const float* s
 
 /* Fused bin head: logits = x @ w^T + bias never leave the chip:
  *   1x1 conv (Cin -> 256) on the matrix cores, row softmax, expectation, optional prob write.
- * Replaces conv_out (deltar.py:18-19,51) + deltar.py:61.  bf16 only; nbins == 256. */
+ * Replaces conv_out (deltar.py:18-19,51) + deltar.py:61.  nbins == 256.  dtype CFP_BF16 / CFP_F16: 16-bit x, w [256][Cin] and prob;
+ * dtype CFP_F32X3 (the default numerics of the drop-in boundary): float32 x, `w` = cfp_pack_w_x3 of the [256][Cin] weights, float32 prob
+ * -- the reference's own output type -- written by the kernel; HW % 4 == 0. */
 int cfp_bin_head_fused(const void* x, int x_ld, const void* w, const float* bias, const float* centers,
                        void* prob, float* pred, int B, int HW, int Cin, int dtype, cfp_stream_t stream);
 

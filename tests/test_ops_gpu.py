@@ -1035,6 +1035,28 @@ def test_bin_head_fused(HW, dtype):
     assert torch.equal(pred, pred2)
 
 
+@pytest.mark.parametrize("HW", [8 * 8, 30 * 40 + 4, 240 * 320])
+def test_bin_head_fused_x3(HW):
+    """The fused bin head in the default numerics (float32 tensors, f16x3 matrix math, float32 prob written by the kernel) against the
+    float64 chain conv_out -> softmax -> expectation; ragged last tile, a row count that is not a multiple of the 64-pixel store rounds."""
+    B, Cin, nb = 2, 128, 256
+    x = rnd(B * HW, Cin, seed=1)
+    w = rnd(nb, Cin, seed=2, scale=0.25)
+    bias = rnd(nb, seed=3)
+    centers = torch.sort(torch.rand(B, nb, generator=torch.Generator().manual_seed(2)) * 10, dim=1)[0]
+    wx = ops.pack_w_x3(w.contiguous().to(DEV))
+    prob = torch.zeros(B, nb, HW, dtype=torch.float32, device=DEV)
+    pred = torch.empty(B, HW, device=DEV)
+    ops.bin_head_fused(to_act(x, torch.float32), wx, bias.to(DEV), centers.to(DEV), prob, pred, B, HW)
+    p = torch.softmax((x.double() @ w.double().t() + bias.double()).reshape(B, HW, nb), dim=2)
+    assert float((prob.double().cpu() - p.permute(0, 2, 1)).abs().max()) < 2e-6
+    want = (p * centers.double()[:, None, :]).sum(2)
+    assert float((pred.double().cpu() - want).abs().max() / want.abs().max()) < 3e-6
+    pred2 = torch.empty(B, HW, device=DEV)
+    ops.bin_head_fused(to_act(x, torch.float32), wx, bias.to(DEV), centers.to(DEV), None, pred2, B, HW)
+    assert torch.equal(pred, pred2)
+
+
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("rows,Cin,Cout", [(700, 136, 816), (9600, 56, 224), (70000, 32, 96), (300, 1392, 232), (5000, 64, 64)])
 def test_pointwise_two_term_weights(rows, Cin, Cout, dtype):
