@@ -315,6 +315,8 @@ int g_halo = 1;                 // cfp_debug_set key 12: 0 = never take the whol
 // 28 / 43; K = 144: 24 / 31; x 32 ch: 28 / 40; 153600 px x 160 ch: 38 / 50; 614400 x 128: 81 / 84) and where it does not (153600 px
 // x 32 / 64 ch: 18-25 / 16-24, 38400 px: 13-23 / 11-23): the thin-output layers at full resolution and the wide expand convs.
 // stride 2 (tools/conv_bench.py --halo, us with / without): stem 614400 x 40 x 72 25.5-27 / 29, 153600 x 64 x 144 23.4 / 26, 38400 x 160 x 360 20.8 / 23.4
+extern int g_bin_head_x3_rows;  // conv_igemm_x3.hip
+int g_x3_ln_fused = 1;          // cfp_debug_set key 26: 0 = the f16x3 GEMMs run a following LayerNorm as a second kernel
 int g_halo_x3 = 1;              // cfp_debug_set key 24: 0 = the f16x3 3x3 convolutions never take the halo kernel
 // where conv3x3_halo_x3.hip replaces the f16x3 implicit GEMM: many pixels (the halo and the weights of a channel block are fetched once
 // per workgroup instead of nine times / once per 128 rows) and an input depth whose halo fits LDS
@@ -350,6 +352,8 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 18: g_halo_s2 = value; return CFP_OK;
     case 12: g_halo = value; return CFP_OK;
     case 24: g_halo_x3 = value; return CFP_OK;
+    case 25: g_bin_head_x3_rows = value; return CFP_OK;
+    case 26: g_x3_ln_fused = value; return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;
@@ -588,7 +592,15 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (pl.splits > 1 && pl.variant >= 19) pl.variant = 4;
     if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * cdiv(p.K, 32) * 64; pl.splits = 1; }
     if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) pl.splits = 1;
-    if (ln_gamma) p.res = nullptr;      // LayerNorm as a second kernel (the residual is added after it)
+    // LayerNorm over Cout in the epilogue when a four-row-wave tile spans exactly Cout channels; otherwise as a second kernel
+    int ln_v = -1;
+    if (ln_gamma && rpb == 0 && g_x3_ln_fused) ln_v = Cout == 128 ? (p.M >= 30000 ? 26 : 27) : Cout == 64 ? (p.M >= 100000 ? 14 : 13) : Cout == 32 ? 16 : Cout == 16 ? 11 : -1;
+    if (ln_v >= 0) {
+      CFP_REQUIRE(aligned16(ln_gamma) && aligned16(ln_beta), CFP_EINVAL, "cfp_conv2d_nhwc: LayerNorm parameters must be 16-byte aligned");
+      pl.variant = ln_v; pl.splits = 1; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;
+    } else if (ln_gamma) {
+      p.res = nullptr;      // the residual is added after the LayerNorm kernel
+    }
     int rc = igemm_x3_launch(pl.variant, p, (float*)ws, pl.splits, s);
     CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: f16x3 kernel launch failed");
     if (pl.splits > 1) {
@@ -597,7 +609,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
       hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
     }
     int e = cfp_check_launch("cfp_conv2d_nhwc");
-    if (e != CFP_OK || !ln_gamma) return e;
+    if (e != CFP_OK || !ln_gamma || ln_v >= 0) return e;
     return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
   }
 

@@ -327,6 +327,55 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   } else {
     float* __restrict__ out = reinterpret_cast<float*>(p.out);
     const float* __restrict__ res = reinterpret_cast<const float*>(p.res);
+    if constexpr (WN == 1 && KG == 1) {
+      if (p.ln_gamma != nullptr) {
+        // LayerNorm over the output channels fused in (host: BN == Cout, so the tile holds whole rows): out = LN(act(conv * scale + shift)) *
+        // gamma + beta + residual (transformer.py:63,68-70).  A pixel's BN channels sit in TN x 4 registers of the four lanes fr, fr + 16,
+        // fr + 32, fr + 48: the two-pass statistics (mean, then squared deviations, as cfp_layernorm) cost two cross-lane steps each.
+        with_act(p.act, [&](auto A) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int m = m0 + a_row0 + i * 16 + fr;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int n = j * 16 + fq * 4;
+              const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+              const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { acc[i][j][r] = act_c<decltype(A)::value>(acc[i][j][r] * sc[r] + sh[r]); sum += acc[i][j][r]; }
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.f / (float)BN);
+            float qq = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean; qq = fmaf(d, d, qq); }
+            qq += __shfl_xor(qq, 16, 64);
+            qq += __shfl_xor(qq, 32, 64);
+            const float rstd = rsqrtf(qq * (1.f / (float)BN) + p.ln_eps);
+            if (m >= m_end) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int n = j * 16 + fq * 4;
+              const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + n), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + n);
+              f32x4 y;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) y[r] = (acc[i][j][r] - mean) * rstd * g[r] + bt[r];
+              if (res) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long long)m * p.res_ld + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] += rv[r];
+              }
+              *reinterpret_cast<f32x4*>(out + (long long)m * p.out_ld + n) = y;
+            }
+          }
+        });
+        return;
+      }
+    }
     with_act(p.act, [&](auto A) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -390,11 +439,14 @@ int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
 // never leaves the registers (transposed accumulators: a lane holds 64 of its pixel's 256 logits, the other three quarters sit in lanes
 // fr + 16, + 32, + 48); the probabilities of 64 pixels at a time cross LDS so that the NCHW store is 16-byte vectors along the pixel axis,
 // 256 contiguous bytes per bin.  Saves the logits' round trip (629 MB written + read at batch 8) and a launch.
-constexpr int HB_M = 128, HB_N = 256, HB_PP = 64 + 4;      // HB_PP: floats per bin row of the 64-pixel probability tile in LDS
+constexpr int HB_N = 256, HB_PP = 64 + 4;      // HB_PP: floats per bin row of the 64-pixel probability tile in LDS
 
+// HB_M = 64: 80 KB of LDS, two workgroups per CU -- one's softmax / store phase overlaps the other's K loop (measured against HB_M = 128,
+// one workgroup per CU with a third fewer weight re-reads: tools/head_bench.py --x3)
+template <int HB_M>
 __global__ __launch_bounds__(256) void bin_head_x3_kernel(ConvP p, const float* __restrict__ bias, const float* __restrict__ centers,
                                                           float* __restrict__ prob, float* __restrict__ pred, int HW) {
-  constexpr int TM = 2, TN = 16;
+  constexpr int TM = HB_M / 64, TN = 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,7 +499,8 @@ __global__ __launch_bounds__(256) void bin_head_x3_kernel(ConvP p, const float* 
       const int mm = m0 + i * 64 + ch * 4;
       if (mm >= p.M) continue;
       const int b = mm / HW, hw = mm - b * HW;      // HW % 4 == 0: four pixels stay inside one image
-      *reinterpret_cast<f32x4*>(prob + ((long long)b * HB_N + n) * HW + hw) = *reinterpret_cast<const f32x4*>(sP + n * HB_PP + ch * 4);
+      // written once, read by nobody on this chip soon (630 MB at batch 8): streaming store, leaves L2 / the Infinity Cache to the operands
+      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(sP + n * HB_PP + ch * 4), reinterpret_cast<f32x4*>(prob + ((long long)b * HB_N + n) * HW + hw));
     }
   }
 }
@@ -526,6 +579,7 @@ extern "C" int cfp_pack_w_x3(const float* w, void* out, long long rows, int K, c
   return cfp_check_launch("cfp_pack_w_x3");
 }
 
+int g_bin_head_x3_rows = 64;      // cfp_debug_set key 25: pixel rows per workgroup of the fused f16x3 bin head (64 / 128)
 // cfp_bin_head_fused for dtype CFP_F32X3 (head.hip dispatches here): x float32 [B*HW, x_ld], w = cfp_pack_w_x3 of conv_out's [256, Cin].
 int bin_head_x3_launch(const void* x, int x_ld, const void* w, const float* bias, const float* centers, float* prob, float* pred, int B, int HW,
                        int Cin, hipStream_t s) {
@@ -536,10 +590,16 @@ int bin_head_x3_launch(const void* x, int x_ld, const void* w, const float* bias
   p.KH = 1; p.KW = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0; p.M = B * HW; p.K = Cin; p.act = 0; p.pointwise = 1;
   p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_eps = 0.f; p.rows_per_batch = 0; p.w_bstride = 0; p.f16 = 0; p.k2 = 0; p.dil = 1; p.mom = nullptr; p.probe = 0;
   p.up_src = nullptr; p.up_ld = p.up_C = p.up_H = p.up_W = 0; p.up_sy = p.up_sx = 0.f;
-  size_t lds = (size_t)2 * (HB_M + HB_N) * 128;
-  static_assert((size_t)HB_N * HB_PP * 4 <= (size_t)2 * (HB_M + HB_N) * 128, "probability tile must fit in the operand LDS");
+  static_assert((size_t)HB_N * HB_PP * 4 <= (size_t)2 * (64 + HB_N) * 128, "probability tile must fit in the operand LDS");
   static bool attr = false;
-  if (!attr) { if (hipFuncSetAttribute((const void*)bin_head_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
-  hipLaunchKernelGGL(bin_head_x3_kernel, dim3(cdiv(p.M, HB_M)), dim3(256), lds, s, p, bias, centers, prob, pred, HW);
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)bin_head_x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    if (hipFuncSetAttribute((const void*)bin_head_x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    attr = true;
+  }
+  if (g_bin_head_x3_rows == 128)
+    hipLaunchKernelGGL(bin_head_x3_kernel<128>, dim3(cdiv(p.M, 128)), dim3(256), (size_t)2 * (128 + HB_N) * 128, s, p, bias, centers, prob, pred, HW);
+  else
+    hipLaunchKernelGGL(bin_head_x3_kernel<64>, dim3(cdiv(p.M, 64)), dim3(256), (size_t)2 * (64 + HB_N) * 128, s, p, bias, centers, prob, pred, HW);
   return 0;
 }

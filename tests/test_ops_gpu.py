@@ -258,15 +258,29 @@ def test_conv2d_x3_per_image_weights_and_layernorm():
     ops.conv2d(xa, wx, None, None, out, B, 1, HW, 1, 1, 1, 0, 0, 1, HW, hip.ACT_NONE, None, None, per_image_weights=True)
     ref = torch.einsum("bmk,bnk->bmn", x.reshape(B, HW, Cin).double(), w.double()).reshape(B * HW, Cout)
     _x3_close(out.torch().cpu(), ref, "x3 per-image weights")
-    g, bt = rnd(Cout, seed=5).abs() + 0.5, rnd(Cout, seed=6)
-    res = rnd(HW, Cout, seed=7)
-    w1 = w[0]
-    out2 = ops.new_act(HW, Cout, torch.float32, DEV)
-    ops.linear(xa, ops.pack_w_x3(w1.contiguous().to(DEV)), None, None, out2, HW, hip.ACT_RELU, to_act(res, torch.float32), None,
-               (g.to(DEV), bt.to(DEV), 1e-5))
-    y = F.relu(x[:HW].double() @ w1.double().t())
-    ref2 = F.layer_norm(y, (Cout,), g.double(), bt.double(), 1e-5) + res.double()
-    _x3_close(out2.torch().cpu(), ref2, "x3 + LayerNorm + residual", tol=2e-5)
+    # LayerNorm fused into the epilogue (Cout 128 / 64 / 32 / 16: a four-row-wave tile spans the row) and as a second kernel (knob 26 = 0)
+    lib = hip.load()
+    for Co, rows in ((128, 300), (128, 40000), (64, 300), (64, 130000), (32, 5000), (16, 777)):
+        xr = rnd(rows, Cin, seed=11)
+        w1 = rnd(Co, Cin, seed=12, scale=1 / math.sqrt(Cin))
+        g, bt = rnd(Co, seed=5).abs() + 0.5, rnd(Co, seed=6)
+        sc, sh = rnd(Co, seed=8).abs() + 0.5, rnd(Co, seed=9)
+        res = rnd(rows, Co, seed=7)
+        y = F.relu((xr.double() @ w1.double().t()) * sc.double() + sh.double())
+        ref2 = F.layer_norm(y, (Co,), g.double(), bt.double(), 1e-5) + res.double()
+        got = []
+        for fused in (1, 0):
+            lib.cfp_debug_set(26, fused)
+            try:
+                out2 = ops.new_act(rows, Co, torch.float32, DEV, ld=Co + 8)
+                ops.linear(to_act(xr, torch.float32), ops.pack_w_x3(w1.contiguous().to(DEV)), sc.to(DEV), sh.to(DEV), out2, rows, hip.ACT_RELU,
+                           to_act(res, torch.float32), None, (g.to(DEV), bt.to(DEV), 1e-5))
+                torch.cuda.synchronize()
+            finally:
+                lib.cfp_debug_set(26, 1)
+            _x3_close(out2.torch().cpu(), ref2, f"x3 + LayerNorm + residual (Cout {Co}, rows {rows}, fused {fused})", tol=2e-5)
+            got.append(out2.torch().clone())
+        assert float((got[0] - got[1]).abs().max()) <= 1e-5 * float(ref2.abs().max())
 
 
 def test_se_gate_fold_writes_x3_operands():
