@@ -354,6 +354,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 24: g_halo_x3 = value; return CFP_OK;
     case 25: g_bin_head_x3_rows = value; return CFP_OK;
     case 26: g_x3_ln_fused = value; return CFP_OK;
+    case 27: conv3x3_halo_debug_odd_pitch(value); return CFP_OK;
     case 13: conv3x3_halo_debug_stages(value); return CFP_OK;
     case 0: g_force_variant = value; return CFP_OK;
     case 1: g_force_splits = value; return CFP_OK;

@@ -62,6 +62,7 @@ int conv3x3_launch(int v, const ConvP& p, hipStream_t s);
 // conv3x3_halo.hip
 int conv3x3_halo_num_variants();
 void conv3x3_halo_debug_stages(int v);
+void conv3x3_halo_debug_odd_pitch(int v);
 bool conv3x3_halo_takes(const ConvP& p);
 int conv3x3_halo_launch(int v, const ConvP& p, hipStream_t s);
 

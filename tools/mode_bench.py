@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfpnet_amd import spec, synthetic, weights
 from cfpnet_amd.engine import Engine
 
+for kv in filter(None, os.environ.get("CFP_DEBUG_SET", "").split(",")):      # e.g. CFP_DEBUG_SET=27=1: debug knobs for A/B runs
+    k, v = kv.split("=")
+    from cfpnet_amd import hip as _hip
+    _hip.load().cfp_debug_set(int(k), int(v))
 layers = spec.COMBINE1_LAYERS
 sd = weights.make_torch_state_dict(spec.model_manifest(layers))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
