@@ -10,8 +10,10 @@
 // is fetched once per tap.  Here, as in conv3x3_halo.hip (the 16-bit kernel this one is modelled on):
 //   * a workgroup owns TH x 16 output pixels (TH = 16 or 8) and NT x WN x 16 output channels; the (TH + 2) x 18 input halo with ALL Cin
 //     channels is loaded ONCE, register-staged, and SPLIT ONCE on the way into LDS -- every element is converted a single time, where the
-//     implicit GEMM converts it in the K loop of every wave, tap and N-tile that meets it.  LDS image of a pixel: per 8 channels
-//     [hi(c0..c3) | hi(c4..c7) | lo(c0..c3) | lo(c4..c7)] (32 bytes), pixel pitch an ODD number of 16-byte slots;
+//     implicit GEMM converts it in the K loop of every wave, tap and N-tile that meets it.  LDS image: a HI plane and a LO plane, each
+//     [pixel][Cin] halves with a pixel pitch of an ODD number of 16-byte slots (the planes are far apart on purpose: hi and lo of a quad
+//     16 bytes apart were fused by hipcc into ds_read2_b64, which is banked mod 32 in 4 x 16-lane groups and ran at 32-47 % conflict
+//     cycles -- profiles/r4e_x3_pmc_sq.json);
 //   * K runs over (tap, channel) in the weight tensor's own order, 32 per step, against the SAME pre-split weight operand the implicit GEMM
 //     takes (cfp_pack_w_x3: MFMA slot (fq, e) <-> k = 4 fq + e, 16 + 4 fq + e - 4): lane (pixel fr, fq) needs the channel quads 8 ks + fq and
 //     8 ks + 4 + fq of the flattened (tap, channel / 4) axis -- two positions per lane advanced by compare-and-subtract, four ds_read_b64
@@ -37,7 +39,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 struct HaloX3P {
-  int PP;          // halo pixel pitch in bytes: Cin * 4 rounded up to an odd number of 16-byte slots
+  int PP;          // halo pixel pitch in bytes PER PLANE: Cin * 2 rounded up to an odd number of 16-byte slots
+  int LO;          // byte offset of the lo plane = halo pixels * PP
   int QPP;         // channel quads per pixel = Cin / 4 (even: Cin % 8 == 0)
   int tiles_x, tiles_y;
   int n_blocks;    // workgroups per pixel tile (each owns NT * WN * 16 output channels and re-reads the halo from L2)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
         const int hy = px / HC, hx = px - hy * HC;
         const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
         const bool ok = i < nitems && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        dst[n] = i < nitems ? px * hp.PP + (q >> 1) * 32 + (q & 1) * 8 : -1;
+        dst[n] = i < nitems ? px * hp.PP + q * 8 : -1;
         v[n] = ok ? *reinterpret_cast<const f32x4*>(in + (y * p.W + x) * p.in_ld + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};      // one image < 2^31 elements (host check)
       }
 #pragma unroll
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
           lo[e] = (f16_t)(v[n][e] - (float)hi[e]);           // exact difference, rounded once: |x - hi - lo| <= 2^-22 |x|
         }
         *reinterpret_cast<f16x4*>(sX + dst[n]) = hi;
-        *reinterpret_cast<f16x4*>(sX + dst[n] + 16) = lo;
+        *reinterpret_cast<f16x4*>(sX + hp.LO + dst[n]) = lo;
       }
     }
   }
@@ -180,14 +183,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
       whi[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc0);
       wlo[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc1);
     }
-    // quads past the ninth tap meet zero weights: read any finite data (the tile's first piece)
-    const int xo0 = k4[0] < nq_all ? off[0] + (cq[0] >> 1) * 32 + (cq[0] & 1) * 8 : 0;
-    const int xo1 = k4[1] < nq_all ? off[1] + (cq[1] >> 1) * 32 + (cq[1] & 1) * 8 : 0;
+    // quads past the ninth tap meet zero weights: read any finite data -- the tile's first piece, the same address in every such lane
+    // (identical addresses broadcast; per-lane addresses would collide with the live lanes of the read group)
+    const bool live0 = k4[0] < nq_all, live1 = k4[1] < nq_all;
+    const int xo0 = off[0] + cq[0] * 8, xo1 = off[1] + cq[1] * 8;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const unsigned char* xb = xrow + g * growb;
-      const f16x4 h0 = *reinterpret_cast<const f16x4*>(xb + xo0), l0 = *reinterpret_cast<const f16x4*>(xb + xo0 + 16);
-      const f16x4 h1 = *reinterpret_cast<const f16x4*>(xb + xo1), l1 = *reinterpret_cast<const f16x4*>(xb + xo1 + 16);
+      const unsigned char* xb0 = live0 ? xrow + g * growb + xo0 : sX;
+      const unsigned char* xb1 = live1 ? xrow + g * growb + xo1 : sX;
+      const f16x4 h0 = *reinterpret_cast<const f16x4*>(xb0), l0 = *reinterpret_cast<const f16x4*>(xb0 + hp.LO);
+      const f16x4 h1 = *reinterpret_cast<const f16x4*>(xb1), l1 = *reinterpret_cast<const f16x4*>(xb1 + hp.LO);
       const f16x8 xhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
       const f16x8 xlo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
 #pragma unroll
@@ -265,11 +270,12 @@ int launch_hx(const ConvP& p, hipStream_t s) {
   hp.QPP = p.Cin / 4;
   hp.dq = make_fastdiv((unsigned)hp.QPP);
   if ((long long)p.H * p.W * p.in_ld >= (1ll << 31)) return -1;
-  int slots = hp.QPP;
+  int slots = hp.QPP / 2;          // 16-byte slots of one plane's pixel (QPP is even)
   if ((slots & 1) == 0) ++slots;
   hp.PP = slots * 16;
+  hp.LO = (TH + 2) * 18 * hp.PP;
   hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
-  const size_t halo = (size_t)(TH + 2) * 18 * hp.PP;
+  const size_t halo = (size_t)2 * hp.LO;
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
   const size_t lds = (size_t)STAGES * NPAD * 128 + halo;
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
@@ -294,9 +300,9 @@ bool conv3x3_halo_x3_takes(const ConvP& p) {
 size_t conv3x3_halo_x3_lds(int v, const ConvP& p) {
   if (v < 0 || v >= kNumHCfg) return 0;
   const int th = 4 * (4 / kHCfg[v].wn), npad = kHCfg[v].nt * kHCfg[v].wn * 16;
-  int slots = p.Cin / 4;
+  int slots = p.Cin / 8;
   if ((slots & 1) == 0) ++slots;
-  const size_t lds = (size_t)2 * npad * 128 + (size_t)(th + 2) * 18 * slots * 16;
+  const size_t lds = (size_t)2 * npad * 128 + (size_t)2 * (th + 2) * 18 * slots * 16;
   return lds <= 160 * 1024 ? lds : 0;
 }
 
