@@ -34,25 +34,6 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_ba
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// eight float32 -> (hi, lo) half operands.  hi by truncation (v_cvt_pkrtz never rounds a finite value up to infinity), x - hi is exact in
-// float32, lo rounds it to nearest-even: |x - hi - lo| <= 2^-11 |x - hi| <= 2^-21 |x|.
-__device__ __forceinline__ void split8(const f32x4& x0, const f32x4& x1, f16x8& hi, f16x8& lo) {
-  typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const f32x4& x = h == 0 ? x0 : x1;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const h2_t t = __builtin_amdgcn_cvt_pkrtz(x[2 * q], x[2 * q + 1]);
-      const f16x2 t2 = __builtin_bit_cast(f16x2, t);
-      const float r0 = __builtin_fmaf((float)t2[0], -1.f, x[2 * q]);
-      const float r1 = __builtin_fmaf((float)t2[1], -1.f, x[2 * q + 1]);
-      hi[4 * h + 2 * q] = t2[0]; hi[4 * h + 2 * q + 1] = t2[1];
-      lo[4 * h + 2 * q] = (_Float16)r0; lo[4 * h + 2 * q + 1] = (_Float16)r1;
-    }
-  }
-}
-
 // The K loop: accumulates C[m0.., n0..] over K-steps [k0, k1) into acc.  smem: KG * STAGES * (BM + BN) * 128 bytes.  All 256 * KG threads call it.
 // INTERLEAVE: fragment i of wave-row wm covers tile rows (i * WM + wm) * 16 .. + 15 instead of (wm * TM + i) * 16 .. (the fused bin head wants
 // the 64 rows of one i contiguous).

@@ -391,12 +391,31 @@ int launch_lkpm(const LkpmP<H>& p, hipStream_t s) {
 
 }  // namespace
 
+int loftr_tail_x3_launch(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld, void* out, int out_ld,
+                         const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2, const float* ln1_g, const float* ln1_b,
+                         const float* ln2_g, const float* ln2_b, float ln_eps, int NB, int Hq, int Wq, int qth, int qtw, float v_length,
+                         float eps, int heads, int D, hipStream_t s);      // loftr_tail_x3.hip
+
 extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
                               void* out, int out_ld, const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
                               const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
                               int NB, int Hq, int Wq, int qth, int qtw, float v_length, float eps, int heads, int D,
                               int dtype, cfp_stream_t stream) {
-  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_loftr_tail: bf16/f16 only (the f32 parity mode uses the unfused kernels)");
+  if (dtype == CFP_F32X3) {      // float32 tensors, f16x3 matrix math, weights = cfp_pack_w_x3 operands: loftr_tail_x3.hip
+    CFP_REQUIRE((q || w_q) && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
+                "cfp_loftr_tail: null pointer (q or w_q must be given)");
+    CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && v_length > 0.f && (long long)NB * Hq * Wq < (1ll << 31), CFP_ESHAPE, "cfp_loftr_tail: bad grid");
+    CFP_REQUIRE((D == 32 || D == 64 || D == 128) && (heads == 4 || heads == 8), CFP_ESHAPE, "cfp_loftr_tail: D must be 32/64/128 and heads 4/8");
+    CFP_REQUIRE((w_q || (q_ld >= D && q_ld % 4 == 0)) && x_ld >= D && out_ld >= D && x_ld % 4 == 0 && out_ld % 4 == 0, CFP_ESHAPE,
+                "cfp_loftr_tail: pitches must be >= D and multiples of 4");
+    CFP_REQUIRE(aligned16(q) && aligned16(w_q) && aligned16(x) && aligned16(out) && aligned16(w_merge) && aligned16(w_mlp0) && aligned16(w_mlp2) &&
+                    aligned16(kv), CFP_EINVAL, "cfp_loftr_tail: pointers must be 16-byte aligned");
+    int rc3 = loftr_tail_x3_launch(q, q_ld, kv, ksum, x, x_ld, out, out_ld, w_q, w_merge, w_mlp0, w_mlp2, ln1_g, ln1_b, ln2_g, ln2_b, ln_eps, NB, Hq, Wq,
+                                   qth, qtw, v_length, eps, heads, D, reinterpret_cast<hipStream_t>(stream));
+    CFP_REQUIRE(rc3 == 0, CFP_EHIP, "cfp_loftr_tail: f16x3 launch failed");
+    return cfp_check_launch("cfp_loftr_tail");
+  }
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_loftr_tail: bf16 / f16 or CFP_F32X3 (the plain f32 parity mode uses the unfused kernels)");
   CFP_REQUIRE((q || w_q) && kv && ksum && x && out && w_merge && w_mlp0 && w_mlp2 && ln1_g && ln1_b && ln2_g && ln2_b, CFP_EINVAL,
               "cfp_loftr_tail: null pointer (q or w_q must be given)");
   CFP_REQUIRE(NB > 0 && Hq > 0 && Wq > 0 && qth > 0 && qtw > 0 && v_length > 0.f, CFP_ESHAPE, "cfp_loftr_tail: bad grid");

@@ -524,7 +524,8 @@ class Engine:
         d = D // heads
         x = xb.slice(0, D)
         qb = self._act(plan, f"{tag}.qkv", rows_q, 3 * D)
-        tail_q = self.half and self.tail_q        # the fused tail projects q for its own rows: no q GEMM, no q tensor
+        fused_tail = self.half or (self.x3 and os.environ.get("CFP_X3_TAIL", "1") != "0")      # apply + merge + norm1 + mlp + norm2 + residual in one kernel
+        tail_q = fused_tail and self.tail_q       # the fused tail projects q for its own rows: no q GEMM, no q tensor
         if pre is not None and tail_q:
             kv, ks = pre                              # key/value state computed ahead of time (hist2image: _kv_state on the side stream)
             ops.loftr_tail(None, kv, ks, x, out, self.P[p + ".q1"], self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
@@ -550,7 +551,7 @@ class Engine:
         ws = self._f32(plan, f"{tag}.kvws", nws)
         ops.attn_kv_reduce(kA, vA, kv, ks, ws, kvmode["NB"], kvmode["Hk"], kvmode["Wk"], kvmode["th"], kvmode["tw"],
                            kvmode["clip"], kvmode["count_pad"], kvmode["v_length"], heads, d)
-        if self.half:
+        if fused_tail:
             # apply + merge + norm1 + mlp + norm2 + residual in one kernel: the intermediates stay in LDS
             ops.loftr_tail(None if tail_q else qb.slice(0, D), kv, ks, x, out, self.P[p + ".q1"] if tail_q else None,
                            self.P[p + ".merge"], self.P[p + ".mlp0"], self.P[p + ".mlp2"],
@@ -1010,7 +1011,7 @@ class Engine:
         with torch.cuda.stream(side):                # ToF branch: 10 tiny launches, hidden under the RGB encoder
             hfeat = self._hist_encoder(plan, hist, B * Z * N, taps)
             plan["x2i_kv"] = {}
-            if self.half and self.tail_q and self._hist_pe_fused and os.environ.get("CFP_X2I_HOIST", "1") == "1":
+            if (self.half or (self.x3 and os.environ.get("CFP_X3_TAIL", "1") != "0")) and self.tail_q and self._hist_pe_fused and os.environ.get("CFP_X2I_HOIST", "1") == "1":
                 # the key/value states of all hist2image layers depend on the ToF embeddings only: beside the RGB encoder too
                 for fname, feat in (("cross_atten3", hfeat[2]), ("cross_atten2", hfeat[1]), ("cross_atten1", hfeat[0])):
                     D = self.fusion[fname][0]

@@ -361,14 +361,16 @@ def loftr_tail(q: Optional[Act], kv, ksum, x: Act, out: Act, w_q, w_merge, w_mlp
                heads, eps=1e-6, ln_eps=1e-5):
     """`q` given: the projected queries; `q` None and `w_q` [D, D] given: the kernel projects q = x @ w_q^T for its own rows."""
     D = x.C
+    x3 = x.buf.dtype == torch.float32 and w_merge.dtype == torch.float16      # float32 tensors + pre-split f16x3 operands (pack_w_x3)
     assert (q is None) != (w_q is None), "loftr_tail: give either q or w_q"
-    assert out.C == D and w_merge.shape == (D, D) and w_mlp0.shape == (2 * D, 2 * D) and w_mlp2.shape == (D, 2 * D)
+    k1, k2 = (2 * D, 4 * D) if x3 else (D, 2 * D)                             # packed rows hold 64 halves per 32 channels
+    assert out.C == D and w_merge.shape == (D, k1) and w_mlp0.shape == (2 * D, k2) and w_mlp2.shape == (D, k2)
     assert q is None or q.C == D
-    assert w_q is None or w_q.shape == (D, D)
+    assert w_q is None or w_q.shape == (D, k1)
     hip.call("cfp_loftr_tail", q.ptr if q is not None else None, q.ld if q is not None else 0, kv.data_ptr(), ksum.data_ptr(), x.ptr, x.ld,
              out.ptr, out.ld, w_q.data_ptr() if w_q is not None else None, w_merge.data_ptr(),
              w_mlp0.data_ptr(), w_mlp2.data_ptr(), ln1[0].data_ptr(), ln1[1].data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr(),
-             float(ln_eps), NB, Hq, Wq, qth, qtw, float(v_length), float(eps), heads, D, x.dt, _s())
+             float(ln_eps), NB, Hq, Wq, qth, qtw, float(v_length), float(eps), heads, D, hip.F32X3 if x3 else x.dt, _s())
 
 
 def resize_bilinear(src: Act, Hs, Ws, srect, dst: Act, Hd, Wd, drect, B, zone_valid=None, zn=0, p1=0, p2=0,

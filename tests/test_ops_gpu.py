@@ -1049,6 +1049,50 @@ def test_bin_head_fused(HW, dtype):
     assert torch.equal(pred, pred2)
 
 
+@pytest.mark.parametrize("D,heads,NB,Hq,Wq,qth,qtw", [(128, 8, 2, 5, 7, 2, 3), (64, 8, 1, 16, 12, 7, 7), (32, 8, 2, 11, 9, 11, 9), (128, 4, 3, 4, 6, 1, 1),
+                                                      (64, 4, 1, 9, 30, 3, 10), (32, 4, 1, 70, 3, 5, 3)])
+def test_loftr_tail_x3(D, heads, NB, Hq, Wq, qth, qtw):
+    """The fused LoFTR tail in the default numerics (float32 tensors, f16x3 GEMMs from pre-split weights): q projection (given or computed),
+    apply, merge, norm1, mlp, norm2, + x against the float64 chain; ragged last row tile, key groups of every shape."""
+    d = D // heads
+    rows = NB * Hq * Wq
+    ggy, ggx = -(-Hq // qth), -(-Wq // qtw)
+    G = NB * ggy * ggx
+    S = float(qth * qtw)
+    xf = rnd(rows, D, seed=2)
+    wq = rnd(D, D, seed=12, scale=1.0 / math.sqrt(D))
+    kvf = rnd(G, heads, d, d, seed=3, scale=0.3)
+    ksf = rnd(G, heads, d, seed=4).abs() + 0.5
+    wm = rnd(D, D, seed=5, scale=1.0 / math.sqrt(D))
+    w0 = rnd(2 * D, 2 * D, seed=6, scale=1.0 / math.sqrt(2 * D))
+    w2 = rnd(D, 2 * D, seed=7, scale=1.0 / math.sqrt(2 * D))
+    g1, b1, g2, b2 = rnd(D, seed=8).abs() + 0.5, rnd(D, seed=9), rnd(D, seed=10).abs() + 0.5, rnd(D, seed=11)
+    X = xf.double()
+    qf = X @ wq.double().t()
+    tok = torch.arange(rows)
+    xq, yq, bq = tok % Wq, (tok // Wq) % Hq, tok // (Wq * Hq)
+    gidx = (bq * ggy + yq // qth) * ggx + xq // qtw
+    Q = F.elu(qf).add(1).reshape(rows, heads, d)
+    num = torch.einsum("rhi,rhij->rhj", Q, kvf.double()[gidx])
+    den = torch.einsum("rhi,rhi->rh", Q, ksf.double()[gidx]) + 1e-6
+    msg = (num / den[..., None] * S).reshape(rows, D)
+    y1 = F.layer_norm(msg @ wm.double().t(), (D,), g1.double(), b1.double(), 1e-5)
+    hmid = F.relu(torch.cat([X, y1], 1) @ w0.double().t())
+    ref = F.layer_norm(hmid @ w2.double().t(), (D,), g2.double(), b2.double(), 1e-5) + X
+    xa = to_act(xf, torch.float32, ld=2 * D)
+    kvd, ksd = kvf.contiguous().to(DEV), ksf.contiguous().to(DEV)
+    P = lambda t: ops.pack_w_x3(t.contiguous().to(DEV))
+    ln1, ln2 = (g1.to(DEV), b1.to(DEV)), (g2.to(DEV), b2.to(DEV))
+    for own_q in (True, False):
+        out = ops.new_act(rows, D, torch.float32, DEV, ld=2 * D, zero=True)
+        out = ops.Act(out.buf, D, D)
+        qa = None if own_q else to_act(qf.float(), torch.float32, ld=3 * D)
+        ops.loftr_tail(qa, kvd, ksd, xa, out, P(wq) if own_q else None, P(wm), P(w0), P(w2), ln1, ln2, NB, Hq, Wq, qth, qtw, S, heads)
+        torch.cuda.synchronize()
+        _x3_close(out.torch().cpu(), ref, f"x3 loftr tail D={D} heads={heads} own_q={own_q}", tol=2e-5)
+        assert float(out.buf[:, :D].abs().max()) == 0
+
+
 @pytest.mark.parametrize("HW", [8 * 8, 30 * 40 + 4, 240 * 320])
 def test_bin_head_fused_x3(HW):
     """The fused bin head in the default numerics (float32 tensors, f16x3 matrix math, float32 prob written by the kernel) against the
