@@ -245,6 +245,204 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
   });
 }
 
+// ---- deep inputs: the halo by 32-CHANNEL CHUNKS, double buffered -------------------------------------------------------------------
+// The whole-depth kernel above loses from 64 input channels up: its halo (95-124 KB) leaves one workgroup per CU whose load phase nothing
+// overlaps.  Here (Cin % 32 == 0) the K loop runs chunk-major -- for every 32-channel chunk the nine taps, i.e. K-step (tap, chunk) of the
+// weight rows in the order chunk 0: taps 0-8, chunk 1: taps 0-8, ... (a K-step of cfp_pack_w_x3's operand is 32 consecutive k = one tap's 32
+// channels when Cin % 32 == 0, so any order is an address) -- and the halo of chunk c + 1 (pixels x 32 channels, split into a hi and a lo
+// plane of 5 sixteen-byte slots per pixel) is fetched into registers at the start of chunk c and stored into the other LDS buffer after
+// chunk c's ninth tap.  LDS: two chunk buffers + two weight stages (16 x 16 pixels, 128 output channels: 104 + 32 KB), so the tile can be
+// 256 pixels at ANY depth and the weights are re-read once per 256 pixels instead of once per 128: head conv 1.9 GB through the L2 -> LDS
+// path instead of the implicit GEMM's 5.7 GB.
+template <int NT, int WN>
+__global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P hp) {
+  constexpr int WM = 4 / WN;
+  constexpr int TH = 4 * WM;
+  constexpr int HC = 18;
+  constexpr int HPIX = (TH + 2) * HC;
+  constexpr int NPAD = NT * WN * 16;
+  constexpr int NBG = NPAD / 8;
+  constexpr int NB = (NBG + 3) / 4;
+  constexpr int WSTAGE = NPAD * 128;
+  constexpr int PPC = 80;                                  // bytes per pixel and plane of a chunk: 32 halves + 16 bytes (5 slots: odd)
+  constexpr int LO = HPIX * PPC;                           // lo plane behind the hi plane
+  constexpr int CBUF = 2 * LO;                             // one chunk buffer
+  constexpr int NLD = (HPIX * 8 + 255) / 256;              // 16-byte float32 pieces per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;
+  unsigned char* sX = smem + 2 * WSTAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n_base = (bid % hp.n_blocks) * NPAD; bid /= hp.n_blocks;
+  const int tx_ = bid % hp.tiles_x; bid /= hp.tiles_x;
+  const int ty_ = bid % hp.tiles_y;
+  const int b = bid / hp.tiles_y;
+  const int x0 = tx_ * 16, y0 = ty_ * TH;
+
+  const float* __restrict__ in = reinterpret_cast<const float*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
+  const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
+  const void* zsrc = reinterpret_cast<const void*>(g_zero16hx);
+  const int NC = p.Cin >> 5;                               // 32-channel chunks
+  const int nit = 9 * NC;
+  const int wrow = nit * 64;
+
+  const f16_t* b_ptr[NB];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n_base + ((j * 4 + wave) % NBG) * 8 + rsub;
+    const bool ok = n < p.Cout;
+    if (ok) b_okmask |= 1u << j;
+    b_ptr[j] = wt + (long long)(ok ? n : 0) * wrow;
+  }
+  auto issue_w = [&](int c, int tap, int buf) {            // K-step (tap, chunk c) of the weight rows
+    unsigned char* s = sW + buf * WSTAGE;
+    const int kk = ((tap * NC + c) * 8 + lc) * 8;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = (b_okmask >> j) & 1u;
+      glds16(ok ? (const void*)(b_ptr[j] + kk) : zsrc, s + ((j * 4 + wave) % NBG) * 1024);
+    }
+  };
+  // this thread's pieces of a chunk's halo: (pixel, quad) -> image offset / LDS offset (the same for every chunk)
+  int src_off[NLD], dst_off[NLD];
+#pragma unroll
+  for (int n = 0; n < NLD; ++n) {
+    const int i = tid + n * 256;
+    const int px = i >> 3, q = i & 7;
+    const int hy = px / HC, hx = px - hy * HC;
+    const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
+    const bool ok = i < HPIX * 8 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    src_off[n] = ok ? (y * p.W + x) * p.in_ld + q * 4 : -1;      // one image < 2^31 elements (host check)
+    dst_off[n] = i < HPIX * 8 ? px * PPC + q * 8 : -1;
+  }
+  f32x4 hv[NLD];
+  auto load_chunk = [&](int c) {
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) hv[n] = src_off[n] >= 0 ? *reinterpret_cast<const f32x4*>(in + src_off[n] + c * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* d = sX + buf * CBUF;
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      if (dst_off[n] < 0) continue;
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi[e] = f2h(hv[n][e]); lo[e] = (f16_t)(hv[n][e] - (float)hi[e]); }
+      *reinterpret_cast<f16x4*>(d + dst_off[n]) = hi;
+      *reinterpret_cast<f16x4*>(d + LO + dst_off[n]) = lo;
+    }
+  };
+
+  issue_w(0, 0, 0);
+  load_chunk(0);
+  store_chunk(0);
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xrow = ((wm * 4) * HC + fr) * PPC + fq * 8;      // tap (0, 0) of output pixel (row wm * 4, column fr), this lane's first quad
+  constexpr int growb = HC * PPC;
+  const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
+
+  int it = 0;
+  for (int c = 0; c < NC; ++c) {
+    const unsigned char* xc = sX + (c & 1) * CBUF + xrow;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap, ++it) {
+      // the weights of this step were issued one step ago; right after a chunk's first step the NLD halo loads of the next chunk are
+      // younger than them and may stay in flight
+      if (tap == 1 && c + 1 < NC) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores / fragment reads of the previous step
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (it + 1 < nit) { const int t1 = tap == 8 ? 0 : tap + 1; issue_w(tap == 8 ? c + 1 : c, t1, (it + 1) & 1); }
+      if (tap == 0 && c + 1 < NC) load_chunk(c + 1);
+      const unsigned char* cW = sW + (it & 1) * WSTAGE + (wn * NT * 16) * 128;
+      f16x8 whi[NT], wlo[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        whi[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc0);
+        wlo[j] = *reinterpret_cast<const f16x8*>(cW + (j * 16 + fr) * 128 + pc1);
+      }
+      const int ty = tap / 3, dx = tap - ty * 3;
+      const unsigned char* xt = xc + (ty * HC + dx) * PPC;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const unsigned char* xb = xt + g * growb;
+        const f16x4 h0 = *reinterpret_cast<const f16x4*>(xb), l0 = *reinterpret_cast<const f16x4*>(xb + LO);
+        const f16x4 h1 = *reinterpret_cast<const f16x4*>(xb + 32), l1 = *reinterpret_cast<const f16x4*>(xb + LO + 32);
+        const f16x8 xhi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        const f16x8 xlo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[j], xhi, acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xlo, acc[g][j], 0, 0, 0);
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xhi, acc[g][j], 0, 0, 0);
+        }
+      }
+      if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1);      // (every wave is past chunk c - 1: the buffer is free)
+    }
+  }
+
+  float* __restrict__ out = reinterpret_cast<float*>(p.out) + (long long)b * p.Ho * p.Wo * p.out_ld;
+  const float* __restrict__ res = p.res ? reinterpret_cast<const float*>(p.res) + (long long)b * p.Ho * p.Wo * p.res_ld : nullptr;
+  const int x = x0 + fr;
+  with_act(p.act, [&](auto A) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n_base + (wn * NT + j) * 16 + fq * 4;
+      if (n >= p.Cout) continue;
+      const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int y = y0 + wm * 4 + g;
+        if (!(y < p.Ho && x < p.Wo)) continue;
+        const long long pix = (long long)y * p.Wo + x;
+        f32x4 yv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = act_c<decltype(A)::value>(acc[g][j][r] * sc[r] + sh[r]);
+        if (res) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(res + pix * p.res_ld + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[r] += rv[r];
+        }
+        *reinterpret_cast<f32x4*>(out + pix * p.out_ld + n) = yv;
+      }
+    }
+  });
+}
+
+template <int NT, int WN>
+int launch_cx(const ConvP& p, hipStream_t s) {
+  constexpr int TH = 4 * (4 / WN);
+  constexpr int NPAD = NT * WN * 16;
+  HaloX3P hp;
+  hp.n_blocks = cdiv(p.Cout, NPAD);
+  hp.QPP = p.Cin / 4; hp.dq = make_fastdiv((unsigned)hp.QPP); hp.PP = 80; hp.LO = (TH + 2) * 18 * 80;
+  if ((long long)p.H * p.W * p.in_ld >= (1ll << 31) || p.Cin % 32 != 0) return -1;
+  hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
+  const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
+  const size_t lds = (size_t)2 * NPAD * 128 + (size_t)2 * 2 * hp.LO;
+  if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
+  auto k = conv3x3_chunk_x3_kernel<NT, WN>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);
+  return 0;
+}
+
 struct HCfg { int nt, wn; };
 constexpr HCfg kHCfg[] = {
     {1, 1},  // 0: Cout <= 16, 16 x 16 pixels
@@ -340,6 +538,13 @@ int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
     case 7: return launch_hx<1, 2>(p, s);
     case 8: return launch_hx<8, 1>(p, s);
     case 9: return launch_hx<5, 1>(p, s);
+    // the chunk-pipelined form (Cin % 32 == 0): 20 + ...
+    case 20: return launch_cx<2, 1>(p, s);      // <= 32 channels, 16 x 16 pixels
+    case 21: return launch_cx<4, 1>(p, s);      // <= 64
+    case 22: return launch_cx<8, 1>(p, s);      // <= 128
+    case 23: return launch_cx<4, 2>(p, s);      // <= 128, 8 x 16 pixels
+    case 24: return launch_cx<2, 2>(p, s);      // <= 64, 8 x 16 pixels
+    case 25: return launch_cx<8, 2>(p, s);      // <= 256, 8 x 16 pixels
     default: return -3;
   }
 }

@@ -316,6 +316,42 @@ X3_HALO_CASES = [
 X3_HALO_CAP = [16, 32, 64, 64, 128, 160, 224, 32, 128, 80]      # output channels per workgroup of each tile (csrc/conv3x3_halo_x3.hip kHCfg)
 
 
+X3_CHUNK_CASES = [
+    (1, 18, 34, 128, 128, 3, 1, (1, 1, 1, 1)),    # the depth head's conv: four chunks
+    (2, 21, 35, 64, 32, 3, 1, (1, 1, 1, 1)),      # two chunks, ragged rows and columns
+    (1, 9, 33, 64, 64, 3, 1, (1, 1, 1, 1)),
+    (1, 25, 20, 32, 128, 3, 1, (0, 2, 2, 0)),     # one chunk (no pipelining), asymmetric padding
+    (1, 16, 16, 256, 256, 3, 1, (1, 1, 1, 1)),    # eight chunks, two channel blocks for the 128-wide tiles
+    (3, 8, 8, 96, 40, 3, 1, (1, 1, 1, 1)),        # three chunks, channel count that fills no tile exactly
+    (1, 5, 70, 160, 96, 3, 1, (1, 1, 1, 1)),      # five chunks, fewer rows than a tile
+]
+
+
+@pytest.mark.parametrize("variant", [20, 21, 22, 23, 24, 25])
+def test_conv3x3_chunk_x3_every_variant(variant):
+    """The chunk-pipelined f16x3 3x3 kernel for deep inputs (Cin % 32 == 0: the halo by 32-channel chunks, double buffered, K loop chunk-major):
+    every tile forced through the debug knob (500 + v) against a float64 reference and the f16x3 implicit GEMM."""
+    lib = hip.load()
+    try:
+        for case in X3_CHUNK_CASES:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            lib.cfp_debug_set(0, 500 + variant)
+            out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
+            out = ops.Act(out.buf, 16, Cout)
+            ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 chunk v{variant} conv {case}")
+            assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
+            lib.cfp_debug_set(0, 413)
+            out2 = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+            ops.conv2d(xa, wx, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+            torch.cuda.synchronize()
+            assert float((out2.torch() - out.torch()).abs().max()) <= 2e-6 * float(ref.abs().max())
+    finally:
+        lib.cfp_debug_set(0, -1)
+
+
 @pytest.mark.parametrize("variant", list(range(10)) + [99])
 def test_conv3x3_halo_x3_every_variant(variant):
     """The f16x3 whole-depth-halo 3x3 kernel (float32 tensors, halo split once into LDS, the implicit GEMM's pre-split weights), every tile
