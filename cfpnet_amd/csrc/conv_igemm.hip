@@ -342,7 +342,8 @@ extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
-    case 16: g_probe = value; return CFP_OK;
+    case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
+    case 28: g_probe = (g_probe & ~16) | (value ? 16 : 0); return CFP_OK;      // f16x3 GEMM: 1 = the plain (not fragment-pipelined) K loop
     case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
     case 19: cfp_attn_debug_set(value); return CFP_OK;

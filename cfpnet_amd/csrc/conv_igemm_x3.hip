@@ -151,6 +151,79 @@ __device__ __forceinline__ void x3_mainloop(const ConvP& p, const f16_t* __restr
 
   const int b_row0 = wn * (BN / WN);
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;      // tile row offsets are multiples of 16 rows
+  if constexpr (KG == 1 && TN <= 2 * TM + 4 && !INTERLEAVE) {
+    // FRAGMENT-PIPELINED loop (round 4): the fragments of K-step it + 1 are read from LDS -- and its A values split -- WHILE the MFMAs of
+    // step it run, from a second register set; the barrier at the top of an iteration then says "everybody has read stage it, stage it + 1
+    // has landed".  Before, a wave read its 2 (TM + TN) fragments, waited for them, split, and only then issued its 3 TM TN MFMAs: with one
+    // or two waves per SIMD the matrix core idled through every read phase (tools/igemm_x3_probe.py: compute without DMA took 2.2x its MFMA
+    // time).  Same products in the same order: results are bit-identical to the plain loop (cfp_debug_set(28, 1) keeps it for A/B runs).
+    if (p.probe == 0) {
+      f16x8 bh[2][TN], bl[2][TN], ah[2][TM], al[2][TM];
+      f32x4 xr[TM][2];
+      auto read_frags = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
+        const unsigned char* cA = gsm + buf * STAGE_BYTES;
+        const unsigned char* cB = gsm + buf * STAGE_BYTES + BM * 128 + b_row0 * 128;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[S][j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc0);
+          bl[S][j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc1);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = (wm * TM + i) * 16 + fr;
+          xr[i][0] = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc0);
+          xr[i][1] = *reinterpret_cast<const f32x4*>(cA + r * 128 + pc1);
+        }
+      };
+      auto split_frags = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) split8(xr[i][0], xr[i][1], ah[S][i], al[S][i]);
+      };
+      // stage 0 -> register set 0
+      {
+        const int ahead = min(nkg - 1, STAGES - 2);             // stages younger than stage 0 that may stay in flight
+        if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * LPS>();
+        else if (ahead == 1) wait_vmcnt<LPS>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (STAGES - 1 < nkg) issue(k0 + (STAGES - 1), (STAGES - 1) % STAGES);
+      read_frags(IntC<0>{}, 0);
+      split_frags(IntC<0>{});
+      auto body = [&](auto CUR, int it) {
+        constexpr int C = decltype(CUR)::value, N = C ^ 1;
+        const bool more = it + 1 < nit;
+        if (more) {
+          const int ahead = min(nkg - 2 - it, STAGES - 2);      // younger stages than it + 1 that may stay in flight
+          if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * LPS>();
+          else if (ahead == 1) wait_vmcnt<LPS>();
+          else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of stage `it` are in its registers
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (it + STAGES < nkg) issue(k0 + it + STAGES, it % STAGES);      // into the stage everybody has just finished reading
+          read_frags(IntC<N>{}, (it + 1) % STAGES);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[C][j], ah[C][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[C][j], al[C][i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[C][j], ah[C][i], acc[i][j], 0, 0, 0);
+          }
+        if (more) split_frags(IntC<N>{});
+      };
+      int it = 0;
+      for (; it + 1 < nit; it += 2) { body(IntC<0>{}, it); body(IntC<1>{}, it + 1); }
+      if (it < nit) body(IntC<0>{}, it);
+      wait_vmcnt<0>();
+      return;
+    }
+  }
   for (int it = 0; it < nit; ++it) {
     const int buf = it % STAGES;
     const int ahead = min(nkg - 1 - it, STAGES - 2);

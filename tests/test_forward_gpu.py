@@ -103,6 +103,17 @@ def test_config5_640x960_with_16x16_zones():
     r16 = rel_l1(p2.cpu().numpy(), p0.numpy())
     print(f"config5 fp16: pred relL1 vs oracle = {r16:.3e}")
     assert r16 < TOL_F16 and torch.equal(p2, p3)
+    del e16
+    ex3 = Engine(sd, layer_names=layers, base_resolution=base)      # the default mode (float32 storage, f16x3 matrix math) at this shape
+    assert ex3.x3
+    _, p4, pr4 = ex3.forward(inp)
+    ex3.capture(inp)
+    _, p5, _ = ex3.replay()
+    torch.cuda.synchronize()
+    per_image = [rel_l1(p4[b].cpu().numpy(), p0[b].numpy()) for b in range(2)]
+    print(f"config5 f32x3: pred relL1 vs oracle per image = {per_image}")
+    assert max(per_image) < TOL_F32 and torch.equal(p4, p5) and pr4.dtype == torch.float32
+    del ex3
     with pytest.raises(Exception):                       # the 480x640 tables cannot hold a 640x960 map: loud, like the reference
         Engine(weights.make_torch_state_dict(spec.model_manifest(layers)), layer_names=layers, dtype=torch.float32).forward(inp)
 

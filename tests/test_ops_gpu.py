@@ -233,6 +233,35 @@ def test_conv2d_x3_every_tile_variant(variant):
         lib.cfp_debug_set(1, -1)
 
 
+@pytest.mark.parametrize("variant", [13, 14, 26, 1, 15, 16, 2, 22])
+def test_conv2d_x3_fragment_pipelined_loop_is_bit_identical_to_the_plain_loop(variant):
+    """The K loop that reads the next step's fragments while the current step's MFMAs run (default) against the plain loop
+    (cfp_debug_set(28, 1)): same products in the same order, so the float32 results must be EQUAL -- on K lengths of 1, 2, 3 and many
+    K-steps, with and without split-K."""
+    lib = hip.load()
+    cases = [(1, 1, 300, 32, 64, 1, 1, (0, 0, 0, 0)), (1, 1, 700, 40, 136, 1, 1, (0, 0, 0, 0)), (1, 9, 11, 8, 40, 3, 1, (1, 1, 1, 1)),
+             (2, 8, 8, 136, 816, 1, 1, (0, 0, 0, 0)), (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)), (2, 15, 20, 1392, 232, 1, 1, (0, 0, 0, 0))]
+    try:
+        lib.cfp_debug_set(0, 400 + variant)
+        for case in cases:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            for splits in (1, 3):
+                lib.cfp_debug_set(1, splits)
+                got = []
+                for plain in (0, 1):
+                    lib.cfp_debug_set(28, plain)
+                    out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+                    ws = torch.empty(splits * B * Ho * Wo * Cout, device=DEV)
+                    ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, ws)
+                    torch.cuda.synchronize()
+                    got.append(out.torch().clone())
+                assert torch.equal(got[0], got[1]), (variant, case, splits)
+                _x3_close(from_nhwc(got[0], B, Ho, Wo), ref, f"x3 pipelined v{variant} {case}")
+    finally:
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1); lib.cfp_debug_set(28, 0)
+
+
 @pytest.mark.parametrize("xscale", [1e-2, 1e-4, 3e3])
 def test_conv2d_x3_small_and_large_magnitudes(xscale):
     """Activations far from 1: at 1e-2 the lo halves are IEEE-half SUBNORMALS (the matrix core must take them as they are), at 1e-4 the

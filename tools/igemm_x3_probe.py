@@ -25,6 +25,10 @@ for B, H, W, Cin, Cout, k, variant in CASES:
         lib.cfp_debug_set(16, probe)
         fn(); torch.cuda.synchronize()
         row.append(min(graph_time_us(fn, calls=12, replays=4) for _ in range(2)))
-    lib.cfp_debug_set(16, 0); lib.cfp_debug_set(0, -1)
+    lib.cfp_debug_set(16, 0)
+    lib.cfp_debug_set(28, 1)      # the plain K loop (probes above force it too; "full" above is the fragment-pipelined loop)
+    fn(); torch.cuda.synchronize()
+    plain = min(graph_time_us(fn, calls=12, replays=4) for _ in range(2))
+    lib.cfp_debug_set(28, 0); lib.cfp_debug_set(0, -1)
     print(f"{M:6d} x {Cout:4d} x {K:5d}  tile v{variant:<2d} {(K + 31) // 32:3d} K-steps: full {row[0]:6.1f} us   no DMA {row[1]:6.1f}   no reads/MFMA {row[2]:6.1f}   "
-          f"neither {row[3]:6.1f}   no split, 1 MFMA {row[4]:6.1f}   split, 1 MFMA {row[5]:6.1f}")
+          f"neither {row[3]:6.1f}   no split, 1 MFMA {row[4]:6.1f}   split, 1 MFMA {row[5]:6.1f}   | plain loop, full {plain:6.1f}")
