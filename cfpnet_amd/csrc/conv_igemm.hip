@@ -472,8 +472,10 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
 extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int dtype, int rows_per_batch, int B, int* variant,
                                int* splits) {
   if (dtype == CFP_F32X3) {
-    if (KH == 3 && stride == 1 && K % 9 == 0 && (K / 9) % 8 == 0 && rows_per_batch <= 0 && g_halo_x3 && g_force_variant < 0 &&
-        halo_x3_wins(M, K / 9, Cout, g_tput != 0)) {
+    const int cin3 = K / 9;
+    const bool chunk3 = cin3 % 32 == 0 && cin3 >= 64 && M >= 30000 && (Cout <= 64 || (Cout == 128 && M >= 300000));
+    if (KH == 3 && stride == 1 && K % 9 == 0 && cin3 % 8 == 0 && rows_per_batch <= 0 && g_halo_x3 && g_force_variant < 0 &&
+        (chunk3 || halo_x3_wins(M, cin3, Cout, g_tput != 0))) {
       if (variant) *variant = 500;          // conv3x3_halo_x3.hip (the tile is chosen from Cout and the LDS the halo takes)
       if (splits) *splits = 1;
       return CFP_OK;
@@ -581,9 +583,12 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     const int rpb = per_image_weights ? Ho * Wo : 0;
     // 3x3 stride-1 layers with the whole-depth halo in LDS (conv3x3_halo_x3.hip): cfp_debug_set(0, 500 + v) forces its tile v, 500 + 99 its
     // automatic tile, 400 + v keeps the implicit GEMM
+    // deep inputs (Cin % 32 == 0, >= 64): the chunk-pipelined form where it measured ahead of the implicit GEMM with four copies side by side
+    // (tools/conv_bench_x3.py --halo --inflight 4: 153600 px 64 -> 64 ch 43.6 vs 49.4 us, 38400 px 128 -> 64 20.4 vs 22.0, head conv 556 vs 565)
+    const int chunk_v = (g_halo_x3 && Cin % 32 == 0 && Cin >= 64 && p.M >= 30000) ? (Cout <= 64 ? 24 : (Cout == 128 && p.M >= 300000) ? 22 : -1) : -1;
     if (!per_image_weights && !ln_gamma && conv3x3_halo_x3_takes(p) &&
-        (g_force_variant >= 500 || (g_force_variant < 0 && g_halo_x3 && halo_x3_wins(p.M, Cin, Cout, tput)))) {
-      const int hv = g_force_variant >= 500 && g_force_variant < 599 ? g_force_variant - 500 : -1;
+        (g_force_variant >= 500 || (g_force_variant < 0 && g_halo_x3 && (chunk_v >= 0 || halo_x3_wins(p.M, Cin, Cout, tput))))) {
+      const int hv = g_force_variant >= 500 && g_force_variant < 599 ? g_force_variant - 500 : chunk_v;
       int rc = conv3x3_halo_x3_launch(hv, p, s);
       if (rc == 0) return cfp_check_launch("cfp_conv2d_nhwc");
       CFP_REQUIRE(g_force_variant < 500, CFP_EHIP, "cfp_conv2d_nhwc: the forced f16x3 halo variant cannot run this problem");

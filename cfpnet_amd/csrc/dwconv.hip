@@ -1055,11 +1055,25 @@ extern "C" int cfp_dwconv_large_toeplitz(const float* w, void* out, int C, int k
   return cfp_check_launch("cfp_dwconv_large_toeplitz");
 }
 
+hipError_t dwlarge_x3_launch(const void* in, int in_ld, const void* toeplitz, long long table_elems, const float* scale, const float* shift, void* out,
+                             int out_ld, int B, int H, int W, int C, int k, int act, hipStream_t s);      // dwlarge_x3.hip
+
 extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void* toeplitz, const float* scale, const float* shift,
                                           void* out, int out_ld, int B, int H, int W, int C, int k, int act, int dtype,
                                           cfp_stream_t stream) {
   CFP_REQUIRE(in && toeplitz && out && scale && shift, CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: null pointer");
-  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: bf16/f16 only (f32 uses cfp_dwconv_large_nhwc)");
+  if (dtype == CFP_F32X3) {      // float32 tensors, f16x3 matrix math, `toeplitz` = [hi table | lo table]: dwlarge_x3.hip
+    CFP_REQUIRE(k == 7 || k == 15 || k == 31, CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: k must be 7, 15 or 31");
+    CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && in_ld >= C && out_ld >= C, CFP_ESHAPE,
+                "cfp_dwconv_large_mfma_nhwc: bad shape");
+    CFP_REQUIRE(aligned16(in) && aligned16(out) && aligned16(toeplitz), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: pointers must be 16-byte aligned");
+    CFP_REQUIRE((long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 4) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: grid too large");
+    hipError_t e3 = dwlarge_x3_launch(in, in_ld, toeplitz, (long long)cfp_dwconv_large_toeplitz_elems(C, k), scale, shift, out, out_ld, B, H, W, C, k, act,
+                                      reinterpret_cast<hipStream_t>(stream));
+    if (e3 != hipSuccess) { cfp_set_error(std::string("cfp_dwconv_large_mfma_nhwc: ") + hipGetErrorString(e3)); return CFP_EHIP; }
+    return cfp_check_launch("cfp_dwconv_large_mfma_nhwc");
+  }
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_dwconv_large_mfma_nhwc: bf16 / f16 or CFP_F32X3 (plain f32 uses cfp_dwconv_large_nhwc)");
   CFP_REQUIRE(k == 7 || k == 15 || k == 31, CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: k must be 7, 15 or 31");
   CFP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0 && in_ld >= C && out_ld >= C,
               CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: bad shape");

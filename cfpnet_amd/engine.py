@@ -324,6 +324,8 @@ class Engine:
                     self.P[k + ".dw.w"] = self._dev(wd[:, 0].transpose(1, 2).reshape(wd.shape[0], kk * kk))   # f32 [C][kx][ky]
                     if self.half and kk in (7, 15, 31):
                         self.P[k + ".dw.tb"] = ops.toeplitz_bands(wd, self.dtype).to(self.device)     # MFMA B-operand bands
+                    elif self.x3 and kk in (7, 15, 31) and os.environ.get("CFP_X3_DWLARGE", "1") != "0":
+                        self.P[k + ".dw.tb"] = ops.toeplitz_bands_x3(wd).to(self.device)              # hi and lo band tables (f16x3)
                     self.P[k + ".dw.s"], self.P[k + ".dw.t"] = self._fold_bn(sd, k + ".bn1", sd[k + ".dwconv2.bias"], wd.shape[0], _BN_EPS)
                     self.P[k + ".norm.g"], self.P[k + ".norm.b"] = self._dev(sd[k + ".norm.weight"]), self._dev(sd[k + ".norm.bias"])
                     self._conv(sd, k + ".pw1", k + ".pwconv1.weight", k + ".pwconv1.bias")

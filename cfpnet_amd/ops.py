@@ -302,6 +302,16 @@ def toeplitz_bands(w: torch.Tensor, dtype) -> torch.Tensor:
     return g.contiguous().to(dtype)
 
 
+def toeplitz_bands_x3(w: torch.Tensor) -> torch.Tensor:
+    """The band tables of the f16x3 large depthwise kernel: [2, ...] float16 = the table of hi = half(w) and the table of lo = half(w - hi)."""
+    w = w.detach().float().cpu()
+    if w.dim() == 4:
+        w = w[:, 0]
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return torch.stack([toeplitz_bands(hi.float(), torch.float16), toeplitz_bands(lo.float(), torch.float16)]).contiguous()
+
+
 def toeplitz_bands_dev(w: torch.Tensor, dtype, flip: bool = False) -> torch.Tensor:
     """`toeplitz_bands` for weights that live (and change every step) on the device: [C,k,k] (ky, kx) float32 -> the band table in
     `dtype` (of the 180-degree-rotated kernel when `flip`), one launch (cfp_dwconv_large_toeplitz), capturable in a HIP graph."""
@@ -313,8 +323,11 @@ def toeplitz_bands_dev(w: torch.Tensor, dtype, flip: bool = False) -> torch.Tens
 
 
 def dwconv_large_mfma(x: Act, tb: torch.Tensor, scale, shift, out: Act, B, H, W, k, act):
+    """16-bit tensors + a 16-bit band table, or float32 tensors + the [hi | lo] float16 tables of toeplitz_bands_x3 (f16x3 matrix math)."""
+    x3 = x.buf.dtype == torch.float32 and tb.dtype == torch.float16
+    assert not x3 or tb.shape[0] == 2
     hip.call("cfp_dwconv_large_mfma_nhwc", x.ptr, x.ld, tb.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.ptr, out.ld,
-             B, H, W, x.C, k, act, x.dt, _s())
+             B, H, W, x.C, k, act, hip.F32X3 if x3 else x.dt, _s())
 
 
 def channel_sum(x: Act, partial: torch.Tensor, B, HW, nsplit):

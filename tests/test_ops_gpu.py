@@ -691,6 +691,24 @@ def test_dwconv_large_mfma_toeplitz(case, dtype):
     assert float(out.buf[:, :8].abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", [(1, 70, 45, 32, 31), (2, 33, 40, 64, 15), (1, 30, 40, 128, 7), (2, 17, 19, 12, 31), (1, 64, 32, 4, 15)])
+def test_dwconv_large_x3_toeplitz(case):
+    """The large-kernel depthwise convolution in the default numerics: float32 tensors, banded-Toeplitz GEMMs with every operand as hi + lo
+    halves (three MFMAs per block) against float64 F.conv2d; ragged patches, channel counts of 4 ... 128."""
+    B, H, W, Cc, k = case
+    x = rnd(B, Cc, H, W, seed=1)
+    w = rnd(Cc, 1, k, k, seed=2, scale=1.0 / k)
+    scale, shift = rnd(Cc, seed=3).abs() + 0.5, rnd(Cc, seed=4)
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, 1, (k - 1) // 2, 1, Cc) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None])
+    tb = ops.toeplitz_bands_x3(w).to(DEV)
+    out = ops.new_act(B * H * W, Cc, torch.float32, DEV, ld=Cc + 8, zero=True)
+    out = ops.Act(out.buf, 4, Cc)
+    ops.dwconv_large_mfma(to_act(nhwc(x), torch.float32, ld=Cc + 16, c0=8), tb, scale.to(DEV), shift.to(DEV), out, B, H, W, k, hip.ACT_RELU)
+    torch.cuda.synchronize()
+    _x3_close(from_nhwc(out.torch(), B, H, W), ref, f"dwlarge x3 {case}")
+    assert float(out.buf[:, :4].abs().max()) == 0 and float(out.buf[:, 4 + Cc:].abs().max()) == 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(2, 30, 40, 224, 2, (0, 0, 1, 1)), (2, 15, 20, 1392, 1, (1, 1, 1, 1)), (3, 30, 40, 816, 1, (1, 1, 1, 1)),
                                   (2, 9, 7, 64, 2, (1, 1, 1, 1)), (1, 5, 3, 8, 1, (1, 1, 1, 1))])
