@@ -396,6 +396,9 @@ int loftr_tail_x3_launch(const void* q, int q_ld, const float* kv, const float* 
                          const float* ln2_g, const float* ln2_b, float ln_eps, int NB, int Hq, int Wq, int qth, int qtw, float v_length,
                          float eps, int heads, int D, hipStream_t s);      // loftr_tail_x3.hip
 
+int lkpm_tail_x3_launch(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1, const void* w2,
+                        const float* b2, const float* ln_g, const float* ln_b, float ln_eps, int rows, int D, hipStream_t s);      // loftr_tail_x3.hip
+
 extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld,
                               void* out, int out_ld, const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2,
                               const float* ln1_g, const float* ln1_b, const float* ln2_g, const float* ln2_b, float ln_eps,
@@ -453,7 +456,17 @@ extern "C" int cfp_loftr_tail(const void* q, int q_ld, const float* kv, const fl
 extern "C" int cfp_lkpm_tail(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1,
                              const void* w2, const float* b2, const float* ln_g, const float* ln_b, float ln_eps, int rows, int D, int dtype,
                              cfp_stream_t stream) {
-  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_lkpm_tail: bf16/f16 only (the f32 parity mode uses the unfused kernels)");
+  if (dtype == CFP_F32X3) {      // float32 tensors, f16x3 matrix math, weights = cfp_pack_w_x3 operands: loftr_tail_x3.hip
+    CFP_REQUIRE(t && xin && out && w1 && b1 && w2 && b2 && ln_g && ln_b, CFP_EINVAL, "cfp_lkpm_tail: null pointer");
+    CFP_REQUIRE(rows > 0 && (D == 32 || D == 64 || D == 128), CFP_ESHAPE, "cfp_lkpm_tail: D must be 32/64/128");
+    CFP_REQUIRE(t_ld >= D && x_ld >= D && out_ld >= D && t_ld % 4 == 0 && x_ld % 4 == 0 && out_ld % 4 == 0, CFP_ESHAPE,
+                "cfp_lkpm_tail: pitches must be >= D and multiples of 4");
+    CFP_REQUIRE(aligned16(t) && aligned16(xin) && aligned16(out) && aligned16(w1) && aligned16(w2), CFP_EINVAL, "cfp_lkpm_tail: pointers must be 16-byte aligned");
+    int rc3 = lkpm_tail_x3_launch(t, t_ld, xin, x_ld, out, out_ld, w1, b1, w2, b2, ln_g, ln_b, ln_eps, rows, D, reinterpret_cast<hipStream_t>(stream));
+    CFP_REQUIRE(rc3 == 0, CFP_EHIP, "cfp_lkpm_tail: f16x3 launch failed");
+    return cfp_check_launch("cfp_lkpm_tail");
+  }
+  CFP_REQUIRE(is16(dtype), CFP_EINVAL, "cfp_lkpm_tail: bf16 / f16 or CFP_F32X3 (the plain f32 parity mode uses the unfused kernels)");
   CFP_REQUIRE(t && xin && out && w1 && b1 && w2 && b2 && ln_g && ln_b, CFP_EINVAL, "cfp_lkpm_tail: null pointer");
   CFP_REQUIRE(rows > 0 && (D == 32 || D == 64 || D == 128), CFP_ESHAPE, "cfp_lkpm_tail: D must be 32/64/128");
   CFP_REQUIRE(t_ld >= D && x_ld >= D && out_ld >= D && t_ld % 8 == 0 && x_ld % 8 == 0 && out_ld % 8 == 0, CFP_ESHAPE,

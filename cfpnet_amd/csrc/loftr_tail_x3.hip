@@ -262,7 +262,135 @@ int launch_tail_x3(const TailX3P& p, hipStream_t s) {
   return 0;
 }
 
+// ---- LKPM tail (Block14.forward after the depthwise conv, convnext.py:48-58): LayerNorm(1e-6) -> pwconv1 (D -> 4 D) -> GELU -> pwconv2
+// (4 D -> D) -> + input, for the 16 token rows of a wave, in the default numerics.  The hidden width runs in FOUR quarters of D channels:
+// a quarter of h is produced (bias + exact erf GELU), then consumed as a K range of pwconv2 into accumulators that stay in registers.
+struct LkpmX3P {
+  const float* t; const float* xin; float* out;
+  const f16_t* w1; const f16_t* w2;             // pre-split operands of cfp_pack_w_x3: [4 D][D], [D][4 D]
+  const float* lg; const float* lb; const float* b1; const float* b2;
+  int t_ld, x_ld, out_ld, rows;
+  float ln_eps;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
+  constexpr int NT = D / 16;
+  constexpr int PA = D + 8;
+  constexpr int TILE = 16 * PA;
+  constexpr int WAVE_LDS = 2 * TILE * 4;                   // normalised input / output tile | hidden quarter
+  constexpr int BSTAGE = D * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  unsigned char* sB = smem;
+  float* tA = reinterpret_cast<float*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  float* tH = tA + TILE;
+  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+  constexpr int XCH = D / 4;
+  constexpr int wrow1 = (D / 32) * 64, wrow2 = (4 * D / 32) * 64;
+
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < p.rows) v = *reinterpret_cast<const f32x4*>(p.t + m * p.t_ld + ch * 4);
+    *reinterpret_cast<f32x4*>(tA + r * PA + ch * 4) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  {      // LayerNorm over the D channels of each row: lane = (row fr, quarter fq of the channels)
+    constexpr int Q = D / 4;
+    float v[Q];
+#pragma unroll
+    for (int c = 0; c < Q; c += 4) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(tA + fr * PA + fq * Q + c);
+      v[c] = t4[0]; v[c + 1] = t4[1]; v[c + 2] = t4[2]; v[c + 3] = t4[3];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) s += v[c];
+    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / (float)D);
+    float qq = 0.f;
+#pragma unroll
+    for (int c = 0; c < Q; ++c) { const float dl = v[c] - mean; qq = fmaf(dl, dl, qq); }
+    qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+    const float rstd = rsqrtf(qq * (1.f / (float)D) + p.ln_eps);
+#pragma unroll
+    for (int c = 0; c < Q; c += 4) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[c + e] - mean) * rstd * p.lg[fq * Q + c + e] + p.lb[fq * Q + c + e];
+      *reinterpret_cast<f32x4*>(tA + fr * PA + fq * Q + c) = o;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  f32x4 acc2[NT];
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    f32x4 acc[NT];
+    tail_gemm_x3<NT, BSTAGE, true>(acc, p.w1 + (long long)part * D * wrow1, wrow1, 0, D / 32, [&](int ks) { return tA + fr * PA + ks * 32; }, sB, wave, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's pwconv2 reads of the previous quarter are complete
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float bj = p.b1[part * D + j * 16 + fr];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PA + j * 16 + fr] = act_c<CFP_ACT_GELU>(acc[j][r] + bj);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (part == 0)
+      tail_gemm_x3<NT, BSTAGE, true>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
+    else
+      tail_gemm_x3<NT, BSTAGE, false>(acc2, p.w2, wrow2, part * (D / 32), D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - part * D); }, sB, wave, lane);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float bj = p.b2[j * 16 + fr];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tA[(fq * 4 + r) * PA + j * 16 + fr] = acc2[j][r] + bj;      // the normalised input is consumed: stage the output tile
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < 16 * XCH; i += 64) {
+    const int r = i / XCH, ch = i - r * XCH;
+    const long long m = row0 + r;
+    if (m < p.rows) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(tA + r * PA + ch * 4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(p.xin + m * p.x_ld + ch * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += b[e];
+      *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + ch * 4) = a;
+    }
+  }
+}
+
+template <int D>
+int launch_lkpm_x3(const LkpmX3P& p, hipStream_t s) {
+  constexpr size_t lds = 2 * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto k = lkpm_tail_x3_kernel<D>;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  return 0;
+}
+
 }  // namespace
+
+// cfp_lkpm_tail for dtype CFP_F32X3 (loftr_tail.hip dispatches here)
+int lkpm_tail_x3_launch(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1, const void* w2,
+                        const float* b2, const float* ln_g, const float* ln_b, float ln_eps, int rows, int D, hipStream_t s) {
+  LkpmX3P p;
+  p.t = (const float*)t; p.xin = (const float*)xin; p.out = (float*)out; p.w1 = (const f16_t*)w1; p.w2 = (const f16_t*)w2;
+  p.lg = ln_g; p.lb = ln_b; p.b1 = b1; p.b2 = b2; p.t_ld = t_ld; p.x_ld = x_ld; p.out_ld = out_ld; p.rows = rows; p.ln_eps = ln_eps;
+  if (D == 32) return launch_lkpm_x3<32>(p, s);
+  if (D == 64) return launch_lkpm_x3<64>(p, s);
+  if (D == 128) return launch_lkpm_x3<128>(p, s);
+  return -2;
+}
 
 // cfp_loftr_tail for dtype CFP_F32X3 (loftr_tail.hip dispatches here): float32 q / x / out, weights = cfp_pack_w_x3 operands.
 int loftr_tail_x3_launch(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld, void* out, int out_ld,

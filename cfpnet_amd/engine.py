@@ -660,7 +660,7 @@ class Engine:
                 else:
                     ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
                 lk_dst = final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D)
-                if self.half and self.lkpm_fused and not self.weights2 and D in (32, 64, 128) and M >= 30000:
+                if ((self.half and not self.weights2) or (self.x3 and os.environ.get("CFP_X3_TAIL", "1") != "0")) and self.lkpm_fused and D in (32, 64, 128) and M >= 30000:
                     # LayerNorm -> pwconv1 -> GELU -> pwconv2 -> + input in one kernel: the 4D-wide hidden tensor stays in LDS.
                     # Measured at batch 8 (tools/small_kernel_bench.py): 24 vs 49 us at the 1/4 scale, 29 vs 34 us at 1/8, 30 vs 25 us at
                     # 1/16 (9 600 rows = 150 workgroups: too few to hide the chain's latency) -> only the many-row scales take it

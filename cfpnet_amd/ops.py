@@ -529,6 +529,8 @@ def mbconv_expand_dw(x: Act, wpw: torch.Tensor, s1, t1, wdw: torch.Tensor, s2, t
 
 def lkpm_tail(t: Act, xin: Act, out: Act, w1, b1, w2, b2, ln_g, ln_b, rows, ln_eps=1e-6):
     D = t.C
-    assert xin.C == D and out.C == D and tuple(w1.shape) == (4 * D, D) and tuple(w2.shape) == (D, 4 * D) and w1.dtype == t.buf.dtype
+    x3 = t.buf.dtype == torch.float32 and w1.dtype == torch.float16      # float32 tensors + pre-split f16x3 operands (pack_w_x3)
+    k1, k2 = (2 * D, 8 * D) if x3 else (D, 4 * D)
+    assert xin.C == D and out.C == D and tuple(w1.shape) == (4 * D, k1) and tuple(w2.shape) == (D, k2) and (x3 or w1.dtype == t.buf.dtype)
     hip.call("cfp_lkpm_tail", t.ptr, t.ld, xin.ptr, xin.ld, out.ptr, out.ld, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-             ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps), rows, D, t.dt, _s())
+             ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps), rows, D, hip.F32X3 if x3 else t.dt, _s())

@@ -1176,6 +1176,27 @@ def test_loftr_tail_x3(D, heads, NB, Hq, Wq, qth, qtw):
         assert float(out.buf[:, :D].abs().max()) == 0
 
 
+@pytest.mark.parametrize("D,rows", [(32, 5000), (64, 777), (128, 300), (32, 64), (128, 4097)])
+def test_lkpm_tail_x3(D, rows):
+    """LKPM's LayerNorm -> pwconv1 -> GELU -> pwconv2 -> + input in one kernel, default numerics (float32 tensors, f16x3 GEMMs, the hidden
+    width in four quarters), against the float64 chain with the exact erf GELU."""
+    t = rnd(rows, D, seed=1) * 1.5 + 0.2
+    xin = rnd(rows, D, seed=2)
+    w1, b1 = rnd(4 * D, D, seed=3, scale=1 / math.sqrt(D)), rnd(4 * D, seed=4, scale=0.2)
+    w2, b2 = rnd(D, 4 * D, seed=5, scale=1 / math.sqrt(4 * D)), rnd(D, seed=6, scale=0.2)
+    g, bt = rnd(D, seed=7).abs() + 0.5, rnd(D, seed=8)
+    y = F.layer_norm(t.double(), (D,), g.double(), bt.double(), 1e-6)
+    h = F.gelu(y @ w1.double().t() + b1.double())
+    ref = h @ w2.double().t() + b2.double() + xin.double()
+    out = ops.new_act(rows, D, torch.float32, DEV, ld=2 * D, zero=True)
+    out = ops.Act(out.buf, D, D)
+    P = lambda w: ops.pack_w_x3(w.contiguous().to(DEV))
+    ops.lkpm_tail(to_act(t, torch.float32, ld=D + 8), to_act(xin, torch.float32), out, P(w1), b1.to(DEV), P(w2), b2.to(DEV), g.to(DEV), bt.to(DEV), rows)
+    torch.cuda.synchronize()
+    _x3_close(out.torch().cpu(), ref, f"x3 lkpm tail D={D} rows={rows}", tol=1e-5)
+    assert float(out.buf[:, :D].abs().max()) == 0
+
+
 @pytest.mark.parametrize("HW", [8 * 8, 30 * 40 + 4, 240 * 320])
 def test_bin_head_fused_x3(HW):
     """The fused bin head in the default numerics (float32 tensors, f16x3 matrix math, float32 prob written by the kernel) against the
