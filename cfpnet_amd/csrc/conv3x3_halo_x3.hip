@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   };
   // this thread's pieces of a chunk's halo: (pixel, quad) -> image offset / LDS offset (the same for every chunk)
   int src_off[NLD], dst_off[NLD];
+  unsigned src_okmask = 0;
 #pragma unroll
   for (int n = 0; n < NLD; ++n) {
     const int i = tid + n * 256;
@@ -321,22 +322,31 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
     const int hy = px / HC, hx = px - hy * HC;
     const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
     const bool ok = i < HPIX * 8 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    src_off[n] = ok ? (y * p.W + x) * p.in_ld + q * 4 : -1;      // one image < 2^31 elements (host check)
+    src_off[n] = ok ? (y * p.W + x) * p.in_ld + q * 4 : 0;       // one image < 2^31 elements (host check); invalid pieces read the image's first quad
+    if (ok) src_okmask |= 1u << n;
     dst_off[n] = i < HPIX * 8 ? px * PPC + q * 8 : -1;
   }
   f32x4 hv[NLD];
+  // EVERY wave issues exactly NLD loads per chunk (clamped address, value selected afterwards): the counted `s_waitcnt vmcnt(NLD)` below, which
+  // lets them stay in flight behind the weight DMA, is only right if the count is exact -- a wave whose last pieces lie outside the halo must
+  // not skip the instruction
   auto load_chunk = [&](int c) {
 #pragma unroll
-    for (int n = 0; n < NLD; ++n) hv[n] = src_off[n] >= 0 ? *reinterpret_cast<const f32x4*>(in + src_off[n] + c * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NLD; ++n) {
+      const float* src = in + src_off[n] + c * 32;
+      asm volatile("" : "+v"(src));                          // keep the load unconditional (no exec-masked skip)
+      hv[n] = *reinterpret_cast<const f32x4*>(src);
+    }
   };
   auto store_chunk = [&](int buf) {
     unsigned char* d = sX + buf * CBUF;
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
       if (dst_off[n] < 0) continue;
+      const bool okn = (src_okmask >> n) & 1u;
       f16x4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { hi[e] = f2h(hv[n][e]); lo[e] = (f16_t)(hv[n][e] - (float)hi[e]); }
+      for (int e = 0; e < 4; ++e) { const float v = okn ? hv[n][e] : 0.f; hi[e] = f2h(v); lo[e] = (f16_t)(v - (float)hi[e]); }
       *reinterpret_cast<f16x4*>(d + dst_off[n]) = hi;
       *reinterpret_cast<f16x4*>(d + LO + dst_off[n]) = lo;
     }
@@ -360,14 +370,14 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
     const unsigned char* xc = sX + (c & 1) * CBUF + xrow;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++it) {
-      // the weights of this step were issued one step ago; right after a chunk's first step the NLD halo loads of the next chunk are
-      // younger than them and may stay in flight
-      if (tap == 1 && c + 1 < NC) wait_vmcnt<NLD>(); else wait_vmcnt<0>();
+      // the weights of this step were issued one step ago.  (No counted wait here: the halo loads of the next chunk, issued at tap 7, are
+      // plain register loads the compiler may order either side of the DMA builtin, so "leave NLD in flight" would not be exact.)
+      wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores / fragment reads of the previous step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (it + 1 < nit) { const int t1 = tap == 8 ? 0 : tap + 1; issue_w(tap == 8 ? c + 1 : c, t1, (it + 1) & 1); }
-      if (tap == 0 && c + 1 < NC) load_chunk(c + 1);
+      if (tap == 7 && c + 1 < NC) load_chunk(c + 1);       // lands during this step's MFMAs; stored after the next (last) tap
       const unsigned char* cW = sW + (it & 1) * WSTAGE + (wn * NT * 16) * 128;
       f16x8 whi[NT], wlo[NT];
 #pragma unroll

@@ -230,6 +230,7 @@ __device__ __forceinline__ void x3_mainloop(const ConvP& p, const f16_t* __restr
     if (ahead >= 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * LPS>();
     else if (ahead == 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads of the previous step are complete (see loftr_tail_x3.hip)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (KG == 2 && it >= nkg) continue;

@@ -63,11 +63,15 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict_
   };
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the wait + clobber in front of the barrier: `s_barrier` has no memory semantics for the compiler and LDS reads are asynchronous, so the
+  // previous GEMM's last fragment reads must be forced complete before a faster wave may stream the next weights into the slab they read
+  // (round 4: the float32 twin of this kernel, loftr_tail_x3.hip, showed the race at D = 32; this one never did, same protocol now)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();               // every wave is done with the previous GEMM's slabs
   asm volatile("" ::: "memory");
   issue(0, 0);
   for (int ks = 0; ks < nk; ++ks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);

@@ -66,12 +66,18 @@ __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __re
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // Hand-over of the shared weight stages.  `s_barrier` has no memory semantics for the compiler and LDS reads are asynchronous: without the
+  // wait + clobber IN FRONT of the barrier the previous GEMM's last fragment reads (one K-step GEMMs at D = 32 are straight-line code once
+  // inlined) may be scheduled -- or still be in flight -- behind it, while a faster wave already streams the next weights into the stage they
+  // read.  Found as a timing-dependent mismatch of a few 16-row tiles at D = 32 (tools/probes/x3_tail_stability.py: 109 of 76 800 rows in one
+  // of 20 runs); D = 64 / 128 never showed it.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();               // every wave is done with the previous GEMM's stages
   asm volatile("" ::: "memory");
   issue(ks0, 0);
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
   for (int i = 0; i < nks; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (i + 1 < nks) issue(ks0 + i + 1, (i + 1) & 1);

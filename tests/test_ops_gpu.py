@@ -1176,6 +1176,44 @@ def test_loftr_tail_x3(D, heads, NB, Hq, Wq, qth, qtw):
         assert float(out.buf[:, :D].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fused_tails_are_bit_stable_at_d32(dtype):
+    """D = 32 makes every GEMM of the fused tails one or two K-steps long: straight-line code in which the hand-over of the shared weight
+    stages between consecutive GEMMs is the whole synchronisation.  Round 4 found the float32 (f16x3) kernel handing a stage over while
+    another wave's fragment reads were still in flight (109 of 76 800 rows wrong in 1 run of 20, only at this width).  12 runs on 76 800
+    rows (config5's 1/4-scale fusion block) must be bit-identical, LoFTR tail (both q paths) and LKPM tail, both kernels."""
+    D, heads, NB, Hq, Wq, qth, qtw = 32, 8, 2, 160, 240, 14, 14
+    d, rows = D // heads, NB * Hq * Wq
+    G = NB * (-(-Hq // qth)) * (-(-Wq // qtw))
+    x3 = dtype == torch.float32
+    x = to_act(rnd(rows, D, seed=1), dtype, ld=2 * D)
+    kv, ks = (rnd(G, heads, d, d, seed=2) * 0.3).to(DEV), (rnd(G, heads, d, seed=3).abs() + 0.5).to(DEV)
+    P = (lambda w: ops.pack_w_x3(w.contiguous().to(DEV))) if x3 else (lambda w: w.to(dtype).to(DEV))
+    wq, wm = P(rnd(D, D, seed=4, scale=1 / math.sqrt(D))), P(rnd(D, D, seed=5, scale=1 / math.sqrt(D)))
+    w0, w2 = P(rnd(2 * D, 2 * D, seed=6, scale=1 / math.sqrt(2 * D))), P(rnd(D, 2 * D, seed=7, scale=1 / math.sqrt(2 * D)))
+    ln1, ln2 = (torch.ones(D, device=DEV), torch.zeros(D, device=DEV)), (torch.ones(D, device=DEV), torch.zeros(D, device=DEV))
+    qa = to_act(rnd(rows, D, seed=8), dtype, ld=3 * D)
+    w1l, w2l = P(rnd(4 * D, D, seed=9, scale=1 / math.sqrt(D))), P(rnd(D, 4 * D, seed=10, scale=1 / math.sqrt(4 * D)))
+    b1l, b2l = rnd(4 * D, seed=11).to(DEV), rnd(D, seed=12).to(DEV)
+    refs = [None, None, None]
+    for it in range(12):
+        outs = []
+        for own_q in (True, False):
+            out = ops.new_act(rows, D, dtype, DEV)
+            ops.loftr_tail(None if own_q else qa, kv, ks, x, out, wq if own_q else None, wm, w0, w2, ln1, ln2, NB, Hq, Wq, qth, qtw, float(qth * qtw), heads)
+            outs.append(out.buf)
+        out = ops.new_act(rows, D, dtype, DEV)
+        ops.lkpm_tail(x, qa, out, w1l, b1l, w2l, b2l, ln1[0], ln1[1], rows)
+        outs.append(out.buf)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            if refs[i] is None:
+                refs[i] = o.clone()
+                assert bool(torch.isfinite(o.float()).all())
+            else:
+                assert torch.equal(refs[i], o), (it, i, int((refs[i] != o).any(1).sum()))
+
+
 @pytest.mark.parametrize("D,rows", [(32, 5000), (64, 777), (128, 300), (32, 64), (128, 4097)])
 def test_lkpm_tail_x3(D, rows):
     """LKPM's LayerNorm -> pwconv1 -> GELU -> pwconv2 -> + input in one kernel, default numerics (float32 tensors, f16x3 GEMMs, the hidden
