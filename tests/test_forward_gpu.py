@@ -494,13 +494,16 @@ def test_batches_in_flight_match_forward(dtype, tol):
     assert rel_l1(p.cpu().numpy(), want[3][1].cpu().numpy()) <= tol
 
 
-def test_in_flight_stress_is_bit_exact():
-    """Regression guard for the stage hand-over race round 2 found in the fused head (one wave's 32 pixels wrong about once per 640
+@pytest.mark.parametrize("mode", ["f16", "f32x3"])
+def test_in_flight_stress_is_bit_exact(mode):
+    """(f32x3: the default mode's kernels -- f16x3 GEMMs with the fragment-pipelined loop, halo / chunk 3x3, fused tails, Toeplitz
+    depthwise, fused bin head; round 4 found a hand-over race in its fused tails with exactly this kind of test.)
+    Regression guard for the stage hand-over race round 2 found in the fused head (one wave's 32 pixels wrong about once per 640
     forwards, ONLY with several captured forwards in flight and DIFFERENT inputs per slot; profiles/r2_inflight_race.txt): 300 rounds
     of 8 different inputs through 4 in-flight slots = 2 400 forwards, every result bit-compared with the eager forward of the
     same input.  The kernels that stage through LDS-DMA (gen-2 GEMM, LoFTR / LKPM tails, fused head) all run in it."""
     layers, sd, _ = _full_case(2, 256, 320, 3, 64, 21, 0.0)
-    eng = Engine(sd, layer_names=layers, dtype=torch.float16)
+    eng = Engine(sd, layer_names=layers, dtype=torch.float16) if mode == "f16" else Engine(sd, layer_names=layers)
     inps = [synthetic.to_device(synthetic.make_inputs(2, 256, 320, 3, 64, seed=40 + i, drop_hist=0.2 * (i % 2)), "cuda:0") for i in range(8)]
     eng.plan_mode(True)                             # the kernel plan the in-flight slots are captured with (tile choices differ: summation order)
     try:
