@@ -99,7 +99,7 @@ def kernel_times(engine, inputs, return_prob, reps=5, dw=True):
             piw = flags & 1
             cdt = hip.F32X3 if (flags & hip.CONV_X3) else a[22]
             esz = 4.0 if a[22] == hip.F32 else 2.0
-            byts = esz * (M * Cout + B * H * W * Cin + Cout * KH * KW * Cin)
+            byts = esz * (M * Cout + B * H * W * Cin + (B if piw else 1) * Cout * KH * KW * Cin)      # per-image weights (SE-folded project GEMMs): B matrices are read
             v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, cdt, Ho * Wo if piw else 0, B, KH, stride)
             fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
         elif name in ("cfp_dwconv3x3_nhwc", "cfp_dwconv3x3_sum_nhwc", "cfp_dwconv3x3_se_nhwc"):
