@@ -65,6 +65,11 @@ class Tape:
         # weight-gradient slab reductions batched into a few launches at the end of backward() (train_ops.WgradQueue; CFP_WGRAD_DEFER=0: per layer)
         self.wq = train_ops.WgradQueue() if os.environ.get("CFP_WGRAD_DEFER", "1") != "0" else None
         self.conv_stats = os.environ.get("CFP_CONV_STATS", "1") != "0"      # BatchNorm statistics from the producing conv's epilogue (16-bit modes)
+        # `defer`: the parameter-gradient closures are queued instead of run (`run_deferred()` runs them, in recording order, wherever
+        # the caller wants: the trainer captures them as graphs of their own and replays those on a second stream beside the next
+        # segment of the backward -- two cross-stream edges per segment instead of one fork and join per layer)
+        self.defer = False
+        self.deferred: List[Callable[[], None]] = []
 
     # ------------------------------------------------------------------ helpers
     def new(self, rows: int, C: int, dtype=None) -> torch.Tensor:
@@ -126,6 +131,9 @@ class Tape:
     def off_path(self, fn: Callable[[], None]) -> None:
         """Run `fn` (parameter-gradient kernels of the op whose backward is executing) on the side stream, after everything
         issued so far on the current stream."""
+        if self.defer:
+            self.deferred.append(fn)
+            return
         if self.side is None:
             fn()
             return
@@ -133,6 +141,16 @@ class Tape:
         with torch.cuda.stream(self.side):
             fn()
         self._forked = True
+
+    def run_deferred(self) -> List[Callable[[], None]]:
+        """Run the queued parameter-gradient closures and the slab reductions they leave behind.  Returns the closures: they hold the
+        activations / output gradients the kernels read, and a caller that captures this call into a graph replayed BESIDE later work
+        must keep them referenced until everything that could reuse those blocks has been captured."""
+        fns, self.deferred = self.deferred, []
+        for fn in fns:
+            fn()
+        self.flush_wgrad()
+        return fns
 
     def mark(self, name: str) -> None:
         """Remember the current tape position (the trainer splits the backward there: everything recorded AFTER the mark is
@@ -296,7 +314,8 @@ class Tape:
         def bw():
             if y.g is None:
                 return
-            self.off_path(lambda: self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, y.g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta,
+            g = y.g          # bound now: a deferred closure runs after the tape has moved on
+            self.off_path(lambda: self.pgrad(w, lambda out, beta: train_ops.dwconv3x3_wgrad(x.t, g, B, H, W, stride, pt, pl, Ho, Wo, dw=out, beta=beta,
                                                                                             queue=self._queue(out, beta))))
             self.acc(x, train_ops.dwconv3x3_dgrad(y.g, w.t, B, H, W, stride, pt, pl, Ho, Wo))
         self.bw.append(bw)
@@ -318,9 +337,10 @@ class Tape:
         def bw():
             if y.g is None:
                 return
+            g = y.g
             def param_grads():
-                self.pgrad(bias, lambda out, beta: train_ops.colsum(y.g, out=out, beta=beta))
-                self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, y.g, B, H, W, k, dw=out, beta=beta))
+                self.pgrad(bias, lambda out, beta: train_ops.colsum(g, out=out, beta=beta))
+                self.pgrad(w, lambda out, beta: train_ops.dwconv_large_wgrad(x.t, g, B, H, W, k, dw=out, beta=beta))
             self.off_path(param_grads)
             dx = torch.empty_like(x.t)                                                   # data gradient = correlation with the flipped kernel
             if mfma:

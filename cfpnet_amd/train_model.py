@@ -38,6 +38,10 @@ def _pad_cols(t2d: torch.Tensor, cin: int, cin_pad: int, k2: int) -> torch.Tenso
 
 
 class TrainNet:
+    # tape marks in the order the backward reaches them (`forward_backward(stop=...)`, `finish_backward(stop=...)`): the trainer cuts
+    # the captured step there
+    BACKWARD_MARKS = ("encoder",)
+
     """Parameters of the reference's state_dict as tape parameters + the training-mode forward/backward."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], layer_names: Sequence[str], device="cuda:0", n_bins=256, min_val=1e-3,
@@ -67,6 +71,7 @@ class TrainNet:
         self.res_fused = os.environ.get("CFP_RES_FUSED_TRAIN", "1") != "0"    # skip connections added inside the BatchNorm-apply / LayerNorm pass
         self.se_fused = os.environ.get("CFP_SE_FUSED_TRAIN", "1") != "0"      # squeeze-excite gate + its backward as three kernels (csrc/se_train.hip)
         self.side_stream: Optional[torch.cuda.Stream] = None      # set by the trainer: parameter gradients beside the dY -> dX chain
+        self._open_tape = None
         self.flipped: Dict[str, torch.Tensor] = {}        # bound mode: name -> flipped conv weight, refreshed by the trainer every step
         self._bound = None                                # (FlatParams in kernel layouts, 16-bit shadow) once `bind` was called
         self.discovered: Optional[Dict[str, tuple]] = None    # set to {} to collect name -> (float32 kernel layout, to_torch, is16)
@@ -442,13 +447,16 @@ class TrainNet:
         return pred, edges, (B, h0, w0)
 
     def forward_backward(self, input_data: dict, target: torch.Tensor, loss_mask: Optional[torch.Tensor] = None, pos_offsets: Optional[dict] = None,
-                         stop_before_encoder: bool = False, loss_sync=None):
+                         stop_before_encoder: bool = False, loss_sync=None, stop: Optional[str] = None, defer_param_grads: bool = False):
         """One forward in training mode + SILog + backward.  Returns (loss as a device scalar, pred [B,1,H/2,W/2], edges);
         gradients are in `self.grads()`, running statistics in `self.buf`.  `stop_before_encoder`: the backward stops where the
         RGB encoder's begins (every non-encoder parameter gradient is final) and `finish_backward()` runs the rest.
-        `loss_sync` = (torch.distributed module, world size): the loss is the global-batch SILog over the ranks (SILogLoss.sync_moments)."""
+        `loss_sync` = (torch.distributed module, world size): the loss is the global-batch SILog over the ranks (SILogLoss.sync_moments).
+        `stop`: any tape mark (BACKWARD_MARKS) instead of "encoder"; `finish_backward(stop=...)` continues to the next one.
+        `defer_param_grads`: weight / bias gradient kernels are queued on the tape; `run_deferred_param_grads()` issues them."""
         dev = self.dev
         t = Tape(dev, self.dtype, side=self.side_stream)
+        t.defer = defer_param_grads
         pred, edges, (B, h0, w0) = self.forward(t, input_data, pos_offsets)
         # SILog (loss.py:9-19) on the half-resolution prediction against the full-resolution target
         crit = train_ops.SILogLoss()
@@ -459,14 +467,22 @@ class TrainNet:
             loss = crit.sync_moments(loss_sync[0])
             gl = float(loss_sync[1])                                            # the gradient average over the ranks divides by it again
         pred.g = crit.backward(gl).reshape(-1, 1).contiguous()
-        if stop_before_encoder:
-            t.backward(stop="encoder")
-            self._open_tape = t
-        else:
-            t.backward()
+        stop = stop or ("encoder" if stop_before_encoder else None)
+        t.backward(stop=stop)
+        self._open_tape = t if (stop is not None or defer_param_grads) else None
         return loss, pred4, edges
 
-    def finish_backward(self) -> None:
-        """Second half of `forward_backward(stop_before_encoder=True)`: the RGB encoder's backward."""
-        t, self._open_tape = self._open_tape, None
-        t.backward()
+    def finish_backward(self, stop: Optional[str] = None) -> None:
+        """The next part of a backward that `forward_backward(stop=...)` left open: down to mark `stop`, or to the end."""
+        t = self._open_tape
+        t.backward(stop=stop)
+        if stop is None and not t.defer:
+            self._open_tape = None
+
+    def run_deferred_param_grads(self, last: bool = False) -> list:
+        """Issue the parameter-gradient kernels queued so far (`defer_param_grads`); `last`: the tape is closed afterwards."""
+        t = self._open_tape
+        fns = t.run_deferred()
+        if last:
+            self._open_tape = None
+        return fns

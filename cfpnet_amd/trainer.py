@@ -12,6 +12,7 @@ elementwise, so the update is the same numbers; padding elements are and stay ze
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -47,6 +48,7 @@ class Trainer:
         self.comm = comm
         self._comm_stream = None
         self._graph2 = None
+        self._segments = None
         names = [(k, tuple(v.shape)) for k, v in state_dict.items()
                  if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))]
         self.flat = train_ops.FlatParams(names, train_ops.lr_group_of(hist_encoder_10x), device=self.dev)
@@ -147,7 +149,7 @@ class Trainer:
     def _loss_sync(self):
         return (self.dist, self.world) if self.sync_loss else None
 
-    def _grads_to_flat(self, input_data, target, offs, stop_before_encoder: bool = False):
+    def _grads_to_flat(self, input_data, target, offs, stop_before_encoder: bool = False, stop: Optional[str] = None, defer: bool = False):
         if self.kernel_layout and self._to_torch is None:
             self._bind_kernel_layout(input_data, offs)
         self.net.zero_grad()
@@ -157,7 +159,8 @@ class Trainer:
             if self._flip_jobs is not None:
                 self._refresh_weight_flips()
             loss, _, _ = self.net.forward_backward(input_data, target, target > self.min_val, pos_offsets=offs,
-                                                   stop_before_encoder=stop_before_encoder, loss_sync=self._loss_sync())
+                                                   stop_before_encoder=stop_before_encoder, loss_sync=self._loss_sync(), stop=stop,
+                                                   defer_param_grads=defer)
             if self._flip_jobs is None:
                 self._plan_weight_flips()
             return loss                                             # every gradient is already at its flat address
@@ -167,7 +170,7 @@ class Trainer:
             self.flat.view(name, "grad").copy_(g)
         return loss
 
-    def capture(self, input_data: dict, target: torch.Tensor, split: Optional[bool] = None):
+    def capture(self, input_data: dict, target: torch.Tensor, split: Optional[bool] = None, wgrad_beside: Optional[bool] = None):
         """Record forward + loss + backward + gradient gathering for this batch shape into ONE HIP graph (the eager step is
         ~5 600 launches and host-bound in 16-bit mode).  Inputs are copied into static buffers at every `step`; the random
         positional-encoding windows are read by the kernels from a device buffer, so they still change per step.
@@ -175,7 +178,20 @@ class Trainer:
         `split` (default: when there is a process group and comm == "overlap"): TWO graphs instead, cut where the backward of the
         RGB encoder begins.  After the first one every non-encoder gradient (the "10x" group of the flat buffer, 2/3 of the bytes)
         is final and its all-reduce runs on a communication stream beside the second graph; same kernels in the same order as
-        the single graph, so the results are bit-identical."""
+        the single graph, so the results are bit-identical.
+
+        `wgrad_beside` (default OFF; CFP_TRAIN_WGRAD_BESIDE=1 turns it on -- measured 30.00 vs 30.00 ms on the benched shard: the step is
+        the SUM of its kernels' durations, rocprofv3 span 31.9 ms vs 31.3 ms of kernel time, i.e. every kernel already fills the chip and
+        a second queue only interleaves them; kept because it is the tested way to move work off the critical path): the weight / bias gradient kernels
+        of the dense and depthwise convolutions leave the critical path  dY -> dX -> dY ...: the backward is cut at the tape marks
+        (TrainNet.BACKWARD_MARKS) into segments, each segment's parameter-gradient kernels are captured as a graph of their own and
+        replayed on a second hardware queue while the NEXT segment's data gradients run on the first.  Nothing on the critical path
+        reads a weight gradient before the optimizer, so only the last segment's stay exposed.  Same kernels, same order within
+        each stream, same operands: bit-identical to the single graph (tests/test_train_gpu.py)."""
+        if wgrad_beside is None:
+            wgrad_beside = self.kernel_layout and os.environ.get("CFP_TRAIN_WGRAD_BESIDE", "0") == "1"
+        if wgrad_beside and not self.kernel_layout:
+            raise ValueError("wgrad_beside needs kernel_layout=True (gradients written at their final flat addresses)")
         if split is None:
             split = self.dist is not None and self.comm == "overlap"
         if split and not self.kernel_layout:
@@ -201,6 +217,12 @@ class Trainer:
                 self._grads_to_flat(self._sin, self._starget, self._offs_dev)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        self._segments = None
+        if wgrad_beside:
+            self._capture_segments()
+            for k, v in saved.items():
+                self.net.buf[k].copy_(v)
+            return
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._sloss = self._grads_to_flat(self._sin, self._starget, self._offs_dev, stop_before_encoder=split)
@@ -214,6 +236,59 @@ class Trainer:
             self.net.buf[k].copy_(v)
         self._graph = g
 
+    def _capture_segments(self) -> None:
+        """The captured step as 2 n graphs: data-path segment i (main pool, main stream) and its parameter gradients (own pool, the
+        second stream).  A parameter-gradient graph runs beside the NEXT data-path segment, so nothing it reads may be handed out
+        again by the allocator while that segment is captured: the queued closures (which hold those tensors) stay referenced until
+        every graph exists; after that the pools' block assignments are fixed."""
+        from .engine import concurrent_streams
+        dev = self.dev
+        marks = list(self.net.BACKWARD_MARKS)
+        # both from the probed set: a stream picked blindly may share its hardware queue with the caller's stream, and then nothing overlaps
+        self._mstream, self._wstream = concurrent_streams(dev, want=2)
+        keep, segs = [], []
+        wpool = None
+        main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(main):
+            self._sloss = self._grads_to_flat(self._sin, self._starget, self._offs_dev, stop=marks[0], defer=True)
+        pool = main.pool()
+        for i in range(len(marks) + 1):
+            if i > 0:
+                main = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(main, pool=pool):
+                    self.net.finish_backward(stop=marks[i] if i < len(marks) else None)
+            wg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(wg, **({"pool": wpool} if wpool is not None else {})):
+                keep.append(self.net.run_deferred_param_grads(last=i == len(marks)))
+            wpool = wg.pool()
+            segs.append((main, wg, marks[i] if i < len(marks) else None))
+        del keep
+        self._segments = segs
+        self._graph = segs[0][0]
+
+    def _replay_segments(self) -> None:
+        """main: D0 D1 ... Dn | second stream: W0 after D0, W1 after D1 and W0, ...; with a process group and comm == "overlap" the
+        non-encoder bucket is reduced on the communication stream once the last segment above the encoder mark has its gradients."""
+        cur, ms, ws = torch.cuda.current_stream(self.dev), self._mstream, self._wstream
+        overlap = self.dist is not None and self.comm == "overlap"
+        ms.wait_stream(cur)
+        ws.wait_stream(cur)
+        for main, wg, mark in self._segments:
+            with torch.cuda.stream(ms):
+                main.replay()
+            ws.wait_stream(ms)
+            with torch.cuda.stream(ws):
+                wg.replay()
+                if overlap and mark == "encoder":
+                    self._reduce_group(1, beside=True)       # ordered after this segment's parameter gradients (current stream = ws)
+        cur.wait_stream(ms)
+        cur.wait_stream(ws)
+        if overlap:
+            self._reduce_group(0, beside=True)
+            cur.wait_stream(self._comm_stream)
+        else:
+            self._reduce_group(None)
+
     def step(self, input_data: dict, target: torch.Tensor, pos_offsets: Optional[dict] = None):
         """-> (loss as a device scalar, lr, beta1).  `target` [B,1,H,W]; the loss mask is target > min_depth (train.py:121)."""
         H, W = input_data["rgb"].shape[-2:]
@@ -225,8 +300,12 @@ class Trainer:
             self._sin["additional"]["mask"].copy_(add["mask"], non_blocking=True)
             self._starget.copy_(target, non_blocking=True)
             self._soffs.copy_(torch.tensor([offs[n] for n in ("cross_atten3", "cross_atten2", "cross_atten1")], dtype=torch.int32), non_blocking=True)
-            self._graph.replay()
             loss = self._sloss
+            if self._segments is not None:
+                self._replay_segments()
+                lr, beta1 = self.opt.step()
+                return loss, lr, beta1
+            self._graph.replay()
             if self._graph2 is not None and self.comm != "overlap":
                 self._graph2.replay()
                 self._reduce_group(None)

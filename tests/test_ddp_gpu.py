@@ -109,14 +109,42 @@ def test_split_step_graphs_equal_the_single_graph():
     dinp, dtgt = synthetic.to_device(inp, "cuda:0"), target.cuda()
     a = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=torch.bfloat16)
     b = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=torch.bfloat16, comm="off")
-    a.capture(dinp, dtgt)
-    b.capture(dinp, dtgt, split=True)
+    a.capture(dinp, dtgt, wgrad_beside=False)
+    b.capture(dinp, dtgt, split=True, wgrad_beside=False)
     assert a._graph2 is None and b._graph2 is not None
     for _ in range(3):
         la, _, _ = a.step(dinp, dtgt, pos_offsets=OFFS)
         lb, _, _ = b.step(dinp, dtgt, pos_offsets=OFFS)
     torch.cuda.synchronize()
     assert float(la) == float(lb) and torch.equal(a.flat.param, b.flat.param)
+    for k in a.net.buf:
+        assert torch.equal(a.net.buf[k], b.net.buf[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_parameter_gradients_beside_the_backward_equal_the_single_graph(dtype):
+    """Trainer.capture(wgrad_beside=True): the backward cut at the tape marks, each segment's weight / bias gradient kernels replayed as their
+    own graph on a second stream beside the next segment.  Same kernels on the same operands: parameters, running statistics and
+    the loss are bit-identical to the one-graph step, step after step (a block handed out twice between the two pools, or a
+    gradient read after a later segment overwrote it, would show here)."""
+    from cfpnet_amd import spec, synthetic, weights
+    from cfpnet_amd.trainer import Trainer
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    inp, target = _shard(0)
+    dinp, dtgt = synthetic.to_device(inp, "cuda:0"), target.cuda()
+    a = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=dtype)
+    b = Trainer(sd, layers, lr=3e-4, total_steps=20, dtype=dtype)
+    a.capture(dinp, dtgt, wgrad_beside=False)
+    b.capture(dinp, dtgt, wgrad_beside=True)
+    assert a._segments is None and len(b._segments) == len(b.net.BACKWARD_MARKS) + 1
+    for s in range(4):
+        la, _, _ = a.step(dinp, dtgt, pos_offsets=OFFS)
+        lb, _, _ = b.step(dinp, dtgt, pos_offsets=OFFS)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb), (s, float(la), float(lb))
+        assert torch.equal(a.flat.grad, b.flat.grad), s
+    assert torch.equal(a.flat.param, b.flat.param)
     for k in a.net.buf:
         assert torch.equal(a.net.buf[k], b.net.buf[k]), k
 

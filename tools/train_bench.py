@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cfpnet_amd import spec, synthetic, weights
 from cfpnet_amd.trainer import Trainer
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16")); ap.add_argument("--graph", action="store_true"); ap.add_argument("--debug", default="", help="cfp_debug_set switches, e.g. 20=2048,21=4096")
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "f16")); ap.add_argument("--graph", action="store_true"); ap.add_argument("--beside", action="store_true", help="parameter-gradient kernels as graphs of their own on a second stream (Trainer.capture(wgrad_beside=True))"); ap.add_argument("--debug", default="", help="cfp_debug_set switches, e.g. 20=2048,21=4096")
 a = ap.parse_args()
 if a.debug:
     from cfpnet_amd import hip
@@ -21,7 +21,7 @@ target = torch.from_numpy(np.stack([synthetic.make_depth(H, W, seed=50 + i, hole
 DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[a.dtype]
 tr = Trainer(sd, layers, lr=3e-4, total_steps=100, dtype=DT)
 if a.graph:
-    tr.capture(inp, target)
+    tr.capture(inp, target, wgrad_beside=a.beside)
 for _ in range(2):
     tr.step(inp, target)
 torch.cuda.synchronize(); t0 = time.perf_counter()
