@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     T* __restrict__ out, int out_ld, float* __restrict__ partial, int B, int H,
                                                     int W, int C, int pad_t, int pad_l, int Ho, int Wo, int act, int R,
-                                                    int nstrips) {
+                                                    int nstrips, const float* __restrict__ w_red, int RD, float* __restrict__ hpart) {
   constexpr int VE = Vec<T>::N;
   constexpr int NSLOT = 256 / CVB;
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
       }
     }
   });
-  if (partial == nullptr) return;   // uniform
+  if (partial == nullptr && hpart == nullptr) return;   // uniform
 
   // ---- 3. channel sums over the pixel slots ---------------------------------------------------
   __syncthreads();                  // everyone is done reading the tile: reuse it
@@ -155,13 +155,27 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in, in
 #pragma unroll
   for (int e = 0; e < VE; ++e) red[slot * (CVB * VE) + cvl * VE + e] = csum[e];
   __syncthreads();
+  float s = 0.f;
   if (tid < CVB * VE) {
     const int c = cv0 * VE + tid;
     if (c < C) {
-      float s = 0.f;
       for (int j = 0; j < NSLOT; ++j) s += red[j * (CVB * VE) + tid];
-      partial[((long long)b * nstrips + strip) * C + c] = s;
+      if (partial) partial[((long long)b * nstrips + strip) * C + c] = s;
     }
+  }
+  if (hpart == nullptr) return;     // uniform
+  // squeeze-excite reduce FC applied to this workgroup's channel sums (it is linear in them): hpart[b][strip * ncb + block][r], the
+  // part of  w_red[r][:] . sum[:]  this block's channels contribute; cfp_se_gate_fold2 adds the parts in index order
+  __syncthreads();
+  if (tid < CVB * VE) red[tid] = s;                 // channels past C hold 0
+  __syncthreads();
+  if (tid < RD) {
+    float dot = 0.f;
+    for (int j = 0; j < CVB * VE; ++j) {
+      const int c = cv0 * VE + j;
+      if (c < C) dot = fmaf(w_red[(long long)tid * C + c], red[j], dot);
+    }
+    hpart[(((long long)b * nstrips + strip) * gridDim.x + blockIdx.x) * RD + tid] = dot;
   }
 }
 
@@ -887,8 +901,8 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   CFP_REQUIRE(aligned16(in) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
               std::string(who) + ": pointers must be 16-byte aligned");
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
-  CFP_REQUIRE(hpart == nullptr || (mfma && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
-              std::string(who) + ": the squeeze-excite partials need 16-bit storage, C % 16 == 0 and R <= 64");
+  CFP_REQUIRE(hpart == nullptr || ((mfma || dtype == CFP_F32) && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
+              std::string(who) + ": the squeeze-excite partials need R <= 64 and, in 16-bit storage, C % 16 == 0");
   if (mfma && g_dw_no_stream == 2 && act != 99) {
     // the sliding-window kernel (dw3x3_slide.hip): register window over input columns, one barrier per workgroup
     const int rc = cfp_dwl_launch(in, in_ld, w, scale, shift, out, out_ld, partial, w_red, RD, hpart, B, H, W, C, stride, pad_t, pad_l, Ho, Wo,
@@ -914,7 +928,7 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
       attr = true;                                                                                                        \
     }                                                                                                                     \
     hipLaunchKernelGGL((dw3x3_kernel<T, S, V>), grid, dim3(256), d.lds, s, (const T*)in, in_ld, (const T*)w, scale, shift,  \
-                       (T*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips);                  \
+                       (T*)out, out_ld, partial, B, H, W, C, pad_t, pad_l, Ho, Wo, act, d.R, d.nstrips, w_red, RD, hpart);  \
   } while (0)
 #define DW_CVB(T, S) do { if (d.cvb == 16) DW_LAUNCH(T, S, 16); else DW_LAUNCH(T, S, 8); } while (0)
 #define DWM_LAUNCH(HH, S, V)                                                                                                  \
@@ -977,7 +991,12 @@ extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, 
 }
 
 extern "C" int cfp_dwconv3x3_se_parts(int B, int Ho, int Wo, int C, int stride, int dtype) {
-  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2) || !is16(dtype) || C % 16 != 0 || g_dw_valu) return 0;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (dtype == CFP_F32 && C % 8 == 0) {     // float32 storage (the default f16x3 mode): the VALU kernel, 4 channels per vector
+    const DwPlan d = dw_plan(B, Ho, Wo, C, stride, 4, false);
+    return d.nstrips * cdiv(C / 4, d.cvb);
+  }
+  if (!is16(dtype) || C % 16 != 0 || g_dw_valu) return 0;
   if (g_dw_no_stream == 2) {
     const int n = cfp_dwl_slots(B, Ho, Wo, C, stride);
     if (n > 0) return n * cdiv(C, 64);

@@ -141,7 +141,10 @@ class Engine:
         # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
         self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
         # squeeze-excite through cfp_dwconv3x3_se_nhwc + cfp_se_gate_fold2 (16-bit modes; CFP_SE2=0: the round-2 pair)
-        self.se2 = dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1"
+        # The float32 depthwise kernel leaves the same partial dot products, so the default f16x3 mode can take this path too
+        # (CFP_SE2_X3=1): measured neutral -- 4.63 vs 4.59 ms per batch with four in flight, 7.08 vs 7.17 ms for one graph -- so it stays off.
+        self.se2 = ((dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1")
+                    or (self.x3 and os.environ.get("CFP_SE2_X3", "0") == "1"))
         # DIAGNOSTIC ONLY (tools/precision_family.py --acts): "name:dtype,..." rounds the named encoder tensors of a float32 engine to a
         # 16-bit format in place right after they are produced, to attribute the 16-bit error to single tensors.  Never set in product use.
         self._dbg_round = {}
@@ -451,9 +454,12 @@ class Engine:
                     hpart = self._f32(plan, f"enc{bi}.hpart", B * K * b.se_rd)
                     ops.dwconv3x3_se(mid, self.P[q + ".dw.w"], self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, self.P[q + ".se.wr"], hpart,
                                      B, h, w, b.stride, pads[0][0], pads[1][0], ho, wo, hip.ACT_SILU)
-                    wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
+                    if self.x3:      # per-image pre-split operands; the K padding of the rows is zeroed once and never written
+                        wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, (b.mid + 31) // 32 * 64), torch.float16, zero=True)
+                    else:
+                        wb = self._buf(plan, f"enc{bi}.wb", (B, b.cout, b.mid), self.dtype)
                     ops.se_gate_fold2(hpart, K, 1.0 / (ho * wo), self.P[q + ".se.br"], self.P[q + ".se.we_t"], self.P[q + ".se.be"],
-                                      self.P[q + ".pwl.w32"], wb, B, b.cout, b.mid, b.se_rd)
+                                      self.P[q + ".pwl.w32"], wb, B, b.cout, b.mid, b.se_rd, x3=self.x3)
                     ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
                                res, None, per_image_weights=True)
                     x, h, w = out, ho, wo

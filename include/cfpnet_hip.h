@@ -203,7 +203,8 @@ int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, const float
                      const float* w_expand_t, const float* b_expand, const void* w_proj, void* w_out,
                      int B, int Cout, int C, int R, int dtype, cfp_stream_t stream);
 
-/* cfp_dwconv3x3_nhwc + the squeeze-excite reduce FC applied to the workgroup's channel sums (16-bit storage, C % 16 == 0, R <= 64):
+/* cfp_dwconv3x3_nhwc + the squeeze-excite reduce FC applied to the workgroup's channel sums (16-bit storage with C % 16 == 0, or
+ * float32 storage -- the default f16x3 mode -- with C % 8 == 0; R <= 64):
  * timm InvertedResidual conv_dw -> bn2 -> act, and of SqueezeExcite (x.mean((2, 3)) -> conv_reduce) the part that is LINEAR in the
  * sums: every workgroup (image b, row strip, channel block) writes
  *   hpart[b][k][r] = sum_{c in block} w_reduce[r][c] * (sum of its stored output pixels of channel c),   k = strip * blocks + block,

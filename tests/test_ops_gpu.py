@@ -784,6 +784,57 @@ def test_squeeze_excite_through_the_depthwise_kernel(case, dtype):
     assert float((wb.float() - wb_old.float()).abs().max()) <= 3.0 * ulp * float(want.abs().max())
 
 
+@pytest.mark.parametrize("case", [(8, 15, 20, 1392, 1, 58, 232), (2, 30, 40, 448, 1, 28, 112), (8, 60, 80, 224, 2, 14, 112), (3, 13, 17, 672, 1, 28, 136),
+                                  (1, 7, 5, 48, 1, 6, 24)])
+def test_squeeze_excite_through_the_float32_depthwise_kernel(case):
+    """The same path in float32 storage (the default f16x3 mode): the VALU depthwise kernel leaves the reduce FC's partial dot products,
+    cfp_se_gate_fold2 finishes the gate and writes the per-image project weights as pre-split f16x3 operands.  Against the round-2 pair
+    (channel sums -> cfp_se_gate_fold): depthwise output bit for bit, the folded operands (hi + lo) to float32 round-off."""
+    B, H, W, C, s, R, Cout = case
+    dtype = torch.float32
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = max((Ho - 1) * s + 3 - H, 0) // 2, max((Wo - 1) * s + 3 - W, 0) // 2
+    x = rnd(B, C, H, W, seed=21)
+    wdw = rnd(C, 1, 3, 3, seed=22, scale=0.4)
+    scale, shift = (rnd(C, seed=23).abs() + 0.5).to(DEV), rnd(C, seed=24).to(DEV)
+    wr, br = rnd(R, C, seed=25, scale=1.0 / math.sqrt(C)).to(DEV), rnd(R, seed=26, scale=0.1).to(DEV)
+    we_t, be = rnd(R, C, seed=27, scale=0.3).to(DEV), rnd(C, seed=28, scale=0.1).to(DEV)
+    wp = rnd(Cout, C, seed=29, scale=1.0 / math.sqrt(C)).to(DEV)
+    wa = wdw.reshape(C, 9).t().contiguous().to(DEV)
+    xin = to_act(nhwc(x), dtype)
+    out1, out2 = ops.new_act(B * Ho * Wo, C, dtype, DEV), ops.new_act(B * Ho * Wo, C, dtype, DEV)
+    K = ops.dwconv3x3_se_parts(B, Ho, Wo, C, s, ops.DT[dtype])
+    assert K > 0
+    hpart = torch.full((B, K, R), float("nan"), device=DEV)
+    ops.dwconv3x3_se(xin, wa, scale, shift, out1, wr, hpart, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    wrow = (C + 31) // 32 * 64
+    wb = torch.zeros(B, Cout, wrow, dtype=torch.float16, device=DEV)
+    ops.se_gate_fold2(hpart, K, 1.0 / (Ho * Wo), br, we_t, be, wp, wb, B, Cout, C, R, x3=True)
+    ns = ops.dwconv3x3_strips(B, Ho, Wo, C, s, ops.DT[dtype])
+    part = torch.empty(B, ns, C, device=DEV)
+    ops.dwconv3x3_sum(xin, wa, scale, shift, out2, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+    wb_old = torch.zeros_like(wb)
+    ops.se_gate_fold(part, ns, 1.0 / (Ho * Wo), wr, br, we_t, be, wp, wb_old, B, Cout, C, R)
+    torch.cuda.synchronize()
+    assert torch.equal(out1.buf, out2.buf)
+    assert torch.isfinite(hpart).all()
+    mean = part.sum(1) / (Ho * Wo)
+    # the partial dot products add up to the reduce FC of the channel sums
+    got_h = hpart.sum(1)
+    want_h = part.sum(1) @ wr.t()
+    assert float((got_h - want_h).abs().max()) <= 2e-5 * float(want_h.abs().max()) + 1e-5
+    hid = F.silu(mean @ wr.t() + br)
+    gate = torch.sigmoid(hid @ we_t + be)
+    want = ops.pack_w_x3((wp[None] * gate[:, None, :]).reshape(B * Cout, C).contiguous()).reshape(B, Cout, wrow).float()
+    # hi planes agree except where round-off moves a value across a half boundary; compare the VALUES hi + lo instead
+    def value(t):
+        t = t.reshape(B, Cout, wrow // 64, 2, 32)
+        return t[:, :, :, 0] + t[:, :, :, 1]
+    err = (value(wb.float()) - value(want)).abs()
+    assert float(err.max()) <= 4e-6 * float(value(want).abs().max()), float(err.max())
+    assert float((value(wb.float()) - value(wb_old.float())).abs().max()) <= 4e-6 * float(value(want).abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_se_fold_equals_gated_activation(dtype):
     """(x * gate) @ W^T == x @ (W * gate)^T with the gate computed from the squeezed means."""
