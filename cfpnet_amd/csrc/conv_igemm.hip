@@ -307,6 +307,8 @@ int g_tput = 0;                 // cfp_debug_set key 17 (tools): 1 = every call 
                                 // copies running together (tools/conv_bench.py --sweep --inflight 4, three runs, profiles/r3_conv_sweep_inflight4.json)
                                 // prefers larger tiles than the isolated sweep the default plan is fitted on
 int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
+int g_x3_ad = 0;                // cfp_debug_set key 29: f16x3 implicit GEMMs with four row waves take their A-direct form (A values global -> registers)
+static int x3_ad_of(int v) { return v == 26 ? 28 : v == 14 ? 29 : v == 13 ? 30 : v == 23 ? 31 : v == 16 ? 32 : v; }
 int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
 int g_halo_s2 = 1;              // cfp_debug_set key 18: 0 = stride-2 convs never take the halo kernel
@@ -343,6 +345,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
+    case 29: g_x3_ad = value; return CFP_OK;
     case 28: g_probe = (g_probe & ~16) | (value ? 16 : 0); return CFP_OK;      // f16x3 GEMM: 1 = the plain (not fragment-pipelined) K loop
     case 15: g_small_s2 = value; return CFP_OK;
     case 14: g_up_halo = value; return CFP_OK;
@@ -466,6 +469,7 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
   if (pl.variant == 0 || pl.variant == 1) pl.variant = 26;
   if (tput && pl.variant == 15 && M >= 9000 && N >= 128 && N <= 256 && K >= 500) pl.variant = 26;
   if (pl.variant < 0 || pl.variant >= igemm_x3_num_variants()) pl.variant = 13;
+  if (g_x3_ad && pl.splits <= 1) pl.variant = x3_ad_of(pl.variant);
   return pl;
 }
 
@@ -604,7 +608,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (ln_gamma && rpb == 0 && g_x3_ln_fused) ln_v = Cout == 128 ? (p.M >= 30000 ? 26 : 27) : Cout == 64 ? (p.M >= 100000 ? 14 : 13) : Cout == 32 ? 16 : Cout == 16 ? 11 : -1;
     if (ln_v >= 0) {
       CFP_REQUIRE(aligned16(ln_gamma) && aligned16(ln_beta), CFP_EINVAL, "cfp_conv2d_nhwc: LayerNorm parameters must be 16-byte aligned");
-      pl.variant = ln_v; pl.splits = 1; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;
+      pl.variant = g_x3_ad ? x3_ad_of(ln_v) : ln_v; pl.splits = 1; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;
     } else if (ln_gamma) {
       p.res = nullptr;      // the residual is added after the LayerNorm kernel
     }

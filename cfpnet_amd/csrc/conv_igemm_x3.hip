@@ -301,9 +301,188 @@ __device__ __forceinline__ void x3_mainloop(const ConvP& p, const f16_t* __restr
   wait_vmcnt<0>();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1>
+
+// ---- A-direct K loop (round 4, late): the 4 x 1 wave layouts keep a wave's A rows private, so staging them in LDS buys nothing -- and the LDS
+// port is what bounds these kernels (fragment reads + DMA writes need 1.2-2.3x the MFMA clocks of a K-step).  Here the A values go
+// straight from global memory into the registers of the lane that feeds them to the matrix core (lane (fr, fq) of row block i: row 16 i + fr,
+// 16-byte chunks fq and fq + 4 of the K-step -- one wave instruction covers sixteen 64-byte row segments), two K-steps ahead; only the W tile
+// travels through LDS.  LDS traffic per K-step drops by the whole A part (read + DMA write): 128 x 128: 112 -> 80 KB, 128 x 64: 72 -> 40 KB.
+// Same products in the same order as the staged loops: bit-identical results.  Two W stages, no K groups, no split-K.
+//
+// Order of the vector-memory operations (the counted wait relies on it; the empty asm statements keep the compiler from moving the plain
+// loads across the DMA builtins):  W(0) A(0) W(1) A(1) | top of iteration it, after the barrier: W(it + 2) A(it + 2).  At the top of
+// iteration it the youngest operations are W(it + 1) A(it + 1): the W stage has landed once at most the 2 TM loads of A(it + 1) are
+// outstanding; those are waited for (by the compiler) where they are split, after the MFMAs of step it.
+template <int BM, int BN>
+__device__ __forceinline__ void x3_mainloop_ad(const ConvP& p, const f16_t* __restrict__ wt, int m0, int m_end, int n0, int nk,
+                                               unsigned char* smem, f32x4 (&acc)[BM / 64][BN / 16]) {
+  constexpr int TM = BM / 64, TN = BN / 16;
+  constexpr int NBG = BN / 8;
+  constexpr int NB = (NBG + 3) / 4;
+  constexpr int STAGE_BYTES = BN * 128;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rsub = lane >> 3;
+  const int lc = (lane & 7) ^ rsub;
+  const int wrow = ((p.K + 31) >> 5) * 64;
+  const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
+  const void* zsrc = reinterpret_cast<const void*>(g_zero16_x3);
+
+  const float* a_ptr[TM];
+  int a_hi0[TM], a_wi0[TM];
+  unsigned a_okmask = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wave * TM + i) * 16 + fr;
+    const bool ok = m < m_end;
+    if (ok) a_okmask |= 1u << i;
+    const int mm = ok ? m : m0;
+    {      // one path for 1x1 and k x k (a pointwise layer is a 1 x 1 window: no uniform branch around the loads below)
+      const int wo = mm % p.Wo;
+      const int t = mm / p.Wo;
+      const int ho = t % p.Ho;
+      const int b = t / p.Ho;
+      a_hi0[i] = ho * p.stride - p.pad_t;
+      a_wi0[i] = wo * p.stride - p.pad_l;
+      a_ptr[i] = in + (((long long)b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.in_ld;   // virtual when in the halo
+    }
+  }
+  // im2col position of this lane's two chunks in the next K-step to be loaded
+  int c_cc[2] = {0, 0}, c_kh[2] = {0, 0}, c_kw[2] = {0, 0};
+  {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = (fq + 4 * h) * 4;
+      const int tap = kk / p.Cin;
+      c_cc[h] = kk - tap * p.Cin;
+      c_kh[h] = tap / p.KW;
+      c_kw[h] = tap - c_kh[h] * p.KW;
+    }
+  }
+  const f16_t* b_ptr[NB];
+  unsigned b_okmask = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + ((j * 4 + wave) % NBG) * 8 + rsub;
+    const bool ok = n < p.Cout;
+    if (ok) b_okmask |= 1u << j;
+    b_ptr[j] = wt + (long long)(ok ? n : 0) * wrow;
+  }
+  auto issue_w = [&](int ks, int buf) {
+    unsigned char* sB = smem + buf * STAGE_BYTES;
+    const int kw16 = (ks * 8 + lc) * 8;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool ok = (b_okmask >> j) & 1u;
+      glds16(ok ? (const void*)(b_ptr[j] + kw16) : zsrc, sB + ((j * 4 + wave) % NBG) * 1024);
+    }
+    asm volatile("" ::: "memory");
+  };
+  f32x4 xr[2][TM][2];
+  auto load_a = [&](auto SET, int ks) {      // K-steps must be asked for in order (the im2col position advances by one step per call)
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = (ks * 8 + fq + 4 * h) * 4;
+      const bool kok = kk < p.K;
+      {
+        const int off = (c_kh[h] * p.W + c_kw[h]) * p.in_ld + c_cc[h];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const bool ok = kok && ((a_okmask >> i) & 1u) && (unsigned)(a_hi0[i] + c_kh[h]) < (unsigned)p.H &&
+                          (unsigned)(a_wi0[i] + c_kw[h]) < (unsigned)p.W;
+          xr[S][i][h] = *reinterpret_cast<const f32x4*>(ok ? (const void*)(a_ptr[i] + off) : zsrc);
+        }
+        c_cc[h] += 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {      // Cin >= 8 (host): at most four taps per 32 channels; selects, no divergent loop
+          const bool wrap = c_cc[h] >= p.Cin;
+          c_cc[h] -= wrap ? p.Cin : 0;
+          const int kw1 = c_kw[h] + (wrap ? 1 : 0);
+          const bool roww = kw1 == p.KW;
+          c_kw[h] = roww ? 0 : kw1;
+          c_kh[h] += roww ? 1 : 0;
+        }
+      }
+    }
+    asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nk <= 0) return;
+
+  const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
+  f16x8 bh[2][TN], bl[2][TN], ah[2][TM], al[2][TM];
+  auto read_w = [&](auto SET, int buf) {
+    constexpr int S = decltype(SET)::value;
+    const unsigned char* cB = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[S][j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc0);
+      bl[S][j] = *reinterpret_cast<const f16x8*>(cB + (j * 16 + fr) * 128 + pc1);
+    }
+  };
+  auto split_a = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) split8(xr[S][i][0], xr[S][i][1], ah[S][i], al[S][i]);
+  };
+  issue_w(0, 0);
+  load_a(IntC<0>{}, 0);
+  if (nk > 1) {
+    issue_w(1, 1);
+    load_a(IntC<1>{}, 1);
+    wait_vmcnt<NB + 2 * TM>();          // W(0) and A(0) have landed; W(1) / A(1) may still be in flight
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_w(IntC<0>{}, 0);
+  split_a(IntC<0>{});
+  // CUR: register set of step it; MORE: step it + 1 exists; LOAD: step it + 2 exists
+  auto body = [&](auto CUR, auto MORE, auto LOAD, int it) {
+    constexpr int C = decltype(CUR)::value, N = C ^ 1;
+    if constexpr (decltype(MORE)::value) {
+      wait_vmcnt<2 * TM>();                                    // W(it + 1) has landed (see the order above)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's reads of W stage `it` are in its registers
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (decltype(LOAD)::value) {
+        issue_w(it + 2, it & 1);                               // into the stage everybody has just finished reading
+        load_a(IntC<C>{}, it + 2);                             // set C held A(it), split during the previous iteration
+      }
+      read_w(IntC<N>{}, (it + 1) & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[C][j], ah[C][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[C][j], al[C][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[C][j], ah[C][i], acc[i][j], 0, 0, 0);
+      }
+    if constexpr (decltype(MORE)::value) split_a(IntC<N>{});
+  };
+  constexpr IntC<0> F{};
+  constexpr IntC<1> T{};
+  int it = 0;
+  for (; it + 3 < nk; it += 2) { body(F, T, T, it); body(T, T, T, it + 1); }
+  const int left = nk - it;            // 1, 2 or 3 (it is even)
+  if (left == 3) { body(F, T, T, it); body(T, T, F, it + 1); body(F, F, F, it + 2); }
+  else if (left == 2) { body(F, T, F, it); body(T, F, F, it + 1); }
+  else body(F, F, F, it);
+  wait_vmcnt<0>();
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1, bool AD = false>
 __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __restrict__ slabs, int splits) {
   static_assert(WM * WN == 4, "four waves per group");
+  static_assert(!AD || (WM == 4 && WN == 1 && KG == 1 && !SPLITK && STAGES == 2), "A-direct: 4 x 1 waves, two stages, whole K");
   static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
@@ -345,7 +524,8 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
     k1 = min(nk_all, k0 + per);
   }
   f32x4 acc[TM][TN];
-  x3_mainloop<BM, BN, WM, WN, STAGES, KG>(p, wt, m0, m_end, n0, k0, k1, smem, acc);
+  if constexpr (AD) x3_mainloop_ad<BM, BN>(p, wt, m0, m_end, n0, nk_all, smem, acc);
+  else x3_mainloop<BM, BN, WM, WN, STAGES, KG>(p, wt, m0, m_end, n0, k0, k1, smem, acc);
   const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
   if constexpr (KG == 2) {
     __syncthreads();   // every wave is done with the operand stages: LDS carries the second group's accumulators to the first
@@ -457,7 +637,7 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   }
 }
 
-struct Cfg { int bm, bn, stages, kg = 1; };
+struct Cfg { int bm, bn, stages, kg = 1; bool ad = false; };
 // same variant ids as conv_igemm2.hip (the plan function is shared); a K-step here is 32 channels
 constexpr Cfg kCfg[] = {
     {128, 128, 3}, {128, 128, 2}, {128, 64, 3}, {128, 64, 4}, {64, 64, 3}, {64, 64, 4}, {256, 32, 3}, {256, 32, 2}, {128, 32, 3}, {128, 32, 4},
@@ -465,22 +645,25 @@ constexpr Cfg kCfg[] = {
     {64, 64, 2, 2}, {64, 64, 3, 2}, {64, 128, 2, 2},
     // f16x3 only (ids >= 22): larger row tiles (fewer L2 -> LDS bytes per MFMA) and the other wave layouts of the common shapes
     {256, 128, 2}, {256, 64, 2}, {64, 64, 2}, {128, 64, 2}, {128, 128, 2}, {64, 128, 2},
+    // A-direct (ids >= 28): 4 x 1 waves, the A values go global -> registers, only the W tile through LDS
+    {128, 128, 2, 1, true}, {128, 64, 2, 1, true}, {64, 64, 2, 1, true}, {256, 64, 2, 1, true}, {128, 32, 2, 1, true}, {256, 128, 2, 1, true},
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1>
+template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1, bool AD = false>
 int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
-  const size_t lds = (size_t)KG * STAGES * (BM + BN) * 128;
+  const size_t lds = AD ? (size_t)STAGES * BN * 128 : (size_t)KG * STAGES * (BM + BN) * 128;
   if (lds > 160 * 1024) return -1;
-  if (KG == 2 && splits > 1) return -4;
+  if ((KG == 2 || AD) && splits > 1) return -4;
+  if (AD && p.Cin < 8) return -5;
   long long tiles_m = p.rows_per_batch > 0 ? (long long)p.B * cdiv(p.rows_per_batch, BM) : cdiv(p.M, BM);
   long long tiles = tiles_m * cdiv(p.Cout, BN);
   if (splits <= 1) {
-    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG>;
+    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG, AD>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1);
-  } else if constexpr (KG == 1) {
+  } else if constexpr (KG == 1 && !AD) {
     auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
@@ -615,6 +798,12 @@ int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t
     case 25: return launch_x3<128, 64, 2, 2, 2>(p, slabs, splits, s);
     case 26: return launch_x3<128, 128, 4, 1, 2>(p, slabs, splits, s);
     case 27: return launch_x3<64, 128, 4, 1, 2>(p, slabs, splits, s);
+    case 28: return launch_x3<128, 128, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 29: return launch_x3<128, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 30: return launch_x3<64, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 31: return launch_x3<256, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 32: return launch_x3<128, 32, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 33: return launch_x3<256, 128, 4, 1, 2, 1, true>(p, slabs, splits, s);
     default: return -3;
   }
 }

@@ -210,7 +210,7 @@ def test_conv2d_x3(case):
         assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("variant", list(range(28)))      # 0-21: conv_igemm2.hip's ids, 22-27: f16x3 only
+@pytest.mark.parametrize("variant", list(range(34)))      # 0-21: conv_igemm2.hip's ids, 22-27: f16x3 only, 28-33: f16x3 A-direct
 def test_conv2d_x3_every_tile_variant(variant):
     """Every f16x3 tile configuration on every conv case, forced through the debug knob (400 + v), un-split and with 4 K-splits."""
     lib = hip.load()
@@ -219,7 +219,7 @@ def test_conv2d_x3_every_tile_variant(variant):
         for case in CONV_CASES:
             B, H, W, Cin, Cout, k, s, pads = case
             ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
-            for splits in ((1,) if variant in GEN2_KGROUPS else (1, 4)):
+            for splits in ((1,) if (variant in GEN2_KGROUPS or variant in ops.X3_ADIRECT) else (1, 4)):
                 lib.cfp_debug_set(1, splits)
                 out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
                 out = ops.Act(out.buf, 16, Cout)
@@ -231,6 +231,35 @@ def test_conv2d_x3_every_tile_variant(variant):
     finally:
         lib.cfp_debug_set(0, -1)
         lib.cfp_debug_set(1, -1)
+
+
+@pytest.mark.parametrize("pair", [(28, 26), (29, 14), (30, 13), (31, 23), (32, 16)])
+def test_conv2d_x3_a_direct_loop_is_bit_identical_to_the_staged_loop(pair):
+    """The A-direct K loop (A values global -> registers, only the W tile through LDS) against the staged loop of the same tile: same
+    products in the same order, so the float32 results must be EQUAL -- K lengths of 1, 2, 3, 4 and many K-steps, 1x1 and 3x3 (taps that
+    straddle K-steps: Cin = 8, 40, 392), stride 2, ragged row and channel tails."""
+    ad, staged = pair
+    lib = hip.load()
+    cases = [(1, 1, 300, 32, 64, 1, 1, (0, 0, 0, 0)), (1, 1, 700, 40, 136, 1, 1, (0, 0, 0, 0)), (1, 9, 11, 8, 40, 3, 1, (1, 1, 1, 1)),
+             (2, 8, 8, 136, 816, 1, 1, (0, 0, 0, 0)), (1, 15, 20, 392, 256, 3, 1, (1, 1, 1, 1)), (2, 15, 20, 1392, 232, 1, 1, (0, 0, 0, 0)),
+             (1, 1, 77, 64, 16, 1, 1, (0, 0, 0, 0)), (2, 17, 23, 40, 72, 3, 2, (0, 1, 0, 1)), (1, 1, 515, 128, 128, 1, 1, (0, 0, 0, 0)),
+             (3, 7, 9, 96, 64, 3, 1, (1, 1, 1, 1))]
+    try:
+        for case in cases:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            got = []
+            for v in (ad, staged):
+                lib.cfp_debug_set(0, 400 + v)
+                lib.cfp_debug_set(1, 1)
+                out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+                ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+                torch.cuda.synchronize()
+                got.append(out.torch().clone())
+            assert torch.equal(got[0], got[1]), (pair, case)
+            _x3_close(from_nhwc(got[0], B, Ho, Wo), ref, f"x3 a-direct v{ad} {case}")
+    finally:
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
 
 
 @pytest.mark.parametrize("variant", [13, 14, 26, 1, 15, 16, 2, 22])

@@ -18,6 +18,7 @@ ap.add_argument("--inflight", type=int, default=1)
 ap.add_argument("--quick", action="store_true", help="plan only, no sweep")
 ap.add_argument("--halo", action="store_true", help="3x3 stride-1 problems only: the halo kernel's tiles against the implicit GEMM")
 ap.add_argument("--out", default="gpurun_out/conv_bench_x3.json")
+ap.add_argument("--only", default="", help="comma-separated implicit-GEMM variant ids to sweep instead of all (their times are printed per problem), e.g. 13,14,26,28,29,30")
 a = ap.parse_args()
 
 layers = spec.COMBINE1_LAYERS
@@ -56,7 +57,8 @@ def timeit(args, reps):
     return graph_time_us(fn, calls=max(4, reps // 2), replays=4)
 
 
-NV = 28
+NV = 34
+VLIST = [int(x) for x in a.only.split(",")] if a.only else list(range(NV))
 rows, tot_auto, tot_best = [], 0.0, 0.0
 for key, (args, cnt) in uniq.items():
     B, H, W, Cin, Cout, KH, st, Ho, Wo, ln, piw, has_res = key
@@ -66,7 +68,7 @@ for key, (args, cnt) in uniq.items():
     t_auto = timeit(args, a.reps)
     best, sweep = (t_auto, "auto"), {}
     if not a.quick and not a.halo:
-        for v in range(NV):
+        for v in VLIST:
             for sp in ((1, 2, 4, 8) if (M * Cout < 2_000_000 and K >= 512 and not piw and v < 19) else (1,)):
                 lib.cfp_debug_set(0, 400 + v); lib.cfp_debug_set(1, sp)
                 try:
@@ -77,7 +79,7 @@ for key, (args, cnt) in uniq.items():
                 if t < best[0]:
                     best = (t, f"v{v}/s{sp}")
         lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
-    if KH == 3 and st == 1 and Cin % 8 == 0 and not piw and not ln:      # conv3x3_halo_x3.hip: every tile + the implicit GEMM's plan without it
+    if KH == 3 and st == 1 and Cin % 8 == 0 and not piw and not ln and not a.only:      # conv3x3_halo_x3.hip: every tile + the implicit GEMM's plan without it
         lib.cfp_debug_set(1, 1)
         for v in list(range(10)) + [99] + ([20, 21, 22, 23, 24, 25] if Cin % 32 == 0 else []):
             lib.cfp_debug_set(0, 500 + v)
@@ -102,7 +104,8 @@ print(f"{'M':>7} {'N':>5} {'K':>5} k s  x  {'auto':>8} {'best':>8}  plan      be
 for r in rows:
     print(f"{r['M']:7d} {r['N']:5d} {r['K']:5d} {r['k']} {r['stride']} {r['count']:2d} {r['auto_us']:8.1f} {r['best_us']:8.1f}  {r['plan']:9s} {r['best']:10s} "
           f"{r['gflop'] / r['auto_us'] * 1e-3:7.1f}" + (" LN" if r["ln"] else "") + (" PIW" if r["piw"] else "")
-          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] in "hn") if a.halo else ""))
+          + ("   " + "  ".join(f"{k}={v:.1f}" for k, v in r["sweep"].items() if k[0] in "hn") if a.halo else "")
+          + ("   " + "  ".join(f"v{k}={v:.1f}" for k, v in r["sweep"].items() if k.endswith("/1")) if a.only else ""))
 print(f"total per forward: auto {tot_auto / 1e3:.3f} ms, best-of-sweep {tot_best / 1e3:.3f} ms, launches {len(calls)}")
 os.makedirs(os.path.dirname(a.out), exist_ok=True)
 json.dump(rows, open(a.out, "w"))
