@@ -325,6 +325,47 @@ def pmc_traffic(kernel_family: str):
     return None if e is None else e.get("hbm_bytes_per_launch")
 
 
+def _train_pmc_table():
+    """Newest profiles/*train_pmc.json (tools/profile_train.sh: FETCH_SIZE / WRITE_SIZE passes over the captured TRAINING step; kept apart
+    from the inference summaries because the same kernel names run other shapes there)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*train_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
+def train_pmc_traffic(kernels):
+    """HBM bytes per launch, averaged over the launches of the named kernel families in the training step's PMC passes; None without them."""
+    tab, _ = _train_pmc_table()
+    if not tab:
+        return None
+    byts = n = 0
+    for k, v in tab.items():
+        if isinstance(v, dict) and any(k.startswith(q) or (q in k) for q in kernels):
+            byts += v["hbm_bytes_per_launch"] * v["launches_fetch_pass"]
+            n += v["launches_fetch_pass"]
+    return byts / n if n else None
+
+
+def train_pmc_source():
+    return _train_pmc_table()[1]
+
+
+def train_pmc_step_bytes():
+    """HBM bytes of ONE training step from the same passes: all kernels' bytes over the number of steps in the trace (= launches of the
+    once-per-step SILog forward kernel; the pass also holds the scratch forward that fixes the kernel layouts, so this reads ~2 % high)."""
+    tab, _ = _train_pmc_table()
+    if not tab:
+        return None
+    steps = sum(v["launches_fetch_pass"] for k, v in tab.items() if isinstance(v, dict) and "silog_fwd_kernel" in k)
+    tot = sum(v["hbm_bytes_per_launch"] * v["launches_fetch_pass"] for v in tab.values() if isinstance(v, dict))
+    return tot / steps if steps else None
+
+
 def pmc_traffic_source():
     pmc_traffic("")
     files = sorted({v["_file"] for v in _PMC_TABLE.values()})
@@ -609,10 +650,15 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
             extra["roofline"] = {"kernel": dom, "bound": "hbm" if hbm else "mfma", "achieved": gbs if hbm else tf, "peak": PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS,
                                  "unit": "GB/s" if hbm else "TFLOP/s", "frac": gbs / PEAK_HBM_GBS if hbm else tf / PEAK_BF16_TFLOPS, "achieved_TFLOPs": tf,
                                  "flop_per_byte": ai, "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                                 "traffic": pmc_traffic("conv_wgrad16_kernel") if "weight" in dom else pmc_traffic("igemm2_kernel"),
+                                 "traffic": train_pmc_traffic(("conv_wgrad16_kernel", "wgrad_reduce_jobs_kernel") if "weight" in dom else
+                                                              ("igemm2_kernel", "conv_igemm_kernel", "conv3x3_halo_kernel", "conv3x3_direct_kernel", "igemm2<", "conv_igemm<", "conv3x3_halo<", "conv3x3_direct<")),
+                                 "traffic_source": train_pmc_source(),
                                  "families": {k: {"launches": v["launches"], "ms_eager_event_pairs": round(v["ms"], 3), "GFLOP": round(v["flops"] / 1e9, 1),
                                                   "TFLOPs": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None} for k, v in kt.items()},
-                                 "whole_step": {"GFLOP": all_fl / 1e9, "TFLOPs_at_the_timed_step": all_fl / dt / 1e12, "frac_of_mfma_peak": all_fl / dt / 1e12 / PEAK_BF16_TFLOPS},
+                                 "whole_step": {"GFLOP": all_fl / 1e9, "TFLOPs_at_the_timed_step": all_fl / dt / 1e12, "frac_of_mfma_peak": all_fl / dt / 1e12 / PEAK_BF16_TFLOPS,
+                                                "hbm_bytes_pmc": train_pmc_step_bytes(),
+                                                "hbm_GBps_at_the_timed_step": (train_pmc_step_bytes() / dt / 1e9) if train_pmc_step_bytes() else None,
+                                                "frac_of_hbm_peak": (train_pmc_step_bytes() / dt / 1e9 / PEAK_HBM_GBS) if train_pmc_step_bytes() else None},
                                  "protocol": "one instrumented EAGER step after the timed region: HIP events around every C-ABI call on the launch stream; "
                                              "algorithmic FLOPs 2 M N K of the forward / data-gradient / weight-gradient GEMMs, 16-bit operand bytes"}
     if dtype == torch.float16:
