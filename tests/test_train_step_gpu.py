@@ -309,6 +309,28 @@ def test_train_cli_on_dataset_files(tmp_path):
     assert bool(torch.isfinite(pred).all())
 
 
+def test_train_cli_stop_and_resume_repeats_the_uninterrupted_run(tmp_path):
+    """Checkpoint / resume of train.py (model_io.py:25-31 + this loop's extras): a run that is stopped after 3 of its 8 steps
+    (`--stop_after`, the schedule untouched) and resumed from the `.ckpt.pt` it left -- weights, running statistics, flat AdamW moments,
+    OneCycle position, and the state of every generator the loop draws from (dropped zones, crop / flip / jitter / rotation, positional
+    windows) -- ends with exactly the weights of the uninterrupted run."""
+    import train as train_cli
+    common = ["@" + os.path.join(ROOT, "configs", "cfpnet_combine1.txt"), "--synthetic", "8", "--bs", "2", "--epochs", "2", "--do_random_rotate",
+              "--log_every", "100", "--seed", "7"]
+    a, b1, b2 = tmp_path / "a" / "w.pt", tmp_path / "b" / "w.pt", tmp_path / "b2" / "w.pt"
+    train_cli.main(common + ["--save", str(a)])
+    train_cli.main(common + ["--save", str(b1), "--stop_after", "3"])
+    ck = torch.load(str(b1)[:-3] + ".ckpt.pt", map_location="cpu", weights_only=False)
+    assert ck["global_step"] == 3 and ck["epoch"] == -1 and set(ck["data_rng"]) == {"drop", "python", "numpy", "torch"}
+    train_cli.main(common + ["--save", str(b2), "--resume", str(b1)[:-3] + ".ckpt.pt"])
+    wa, wb = torch.load(a, map_location="cpu"), torch.load(b2, map_location="cpu")
+    assert set(wa) == set(wb)
+    diff = [k for k in wa if torch.is_tensor(wa[k]) and not torch.equal(wa[k], wb[k])]
+    assert not diff, diff[:5]
+    moved = float((wa["decoder.conv0.weight"] - torch.load(b1, map_location="cpu")["decoder.conv0.weight"]).abs().max())
+    assert moved > 0          # the resumed part really trained
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2..3]: the per-GPU shard the training bench times (16 crops of 416x544, 6x6 zones of 64 px, 34 % of
 # the valid zones dropped), one training step against PyTorch autograd of the CPU oracle run in model.train() semantics.

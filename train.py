@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training with the reference's CLI and loop (`/root/reference/train.py:41-209`):
 
-    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager] [--validate N]
+    python train.py @configs/cfpnet_combine1.txt [--synthetic N] [--max_steps K] [--stop_after K] [--seed S] [--save weights/x.pt] [--dtype bf16|f16|f32] [--eager] [--validate N]
                     [--resume checkpoints/x.pt] [--weight_path weights/x.pt] [--backend nccl|gloo] [--local_gpu I]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py @configs/cfpnet_combine1.txt --synthetic 4096
 
@@ -118,13 +118,22 @@ def load_model_file(path, manifest_sd):
     return sd, opt, epoch
 
 
-def save_training_checkpoint(path, weights_now, trainer, epoch, global_step):
+def save_training_checkpoint(path, weights_now, trainer, epoch, global_step, data_rng=None):
     """`save_checkpoint` of model_io.py:25-31: {"model", "optimizer", "epoch"}; the optimizer entry is the flat AdamW state.
     `epoch` is the last FULLY completed epoch (-1: none yet) -- the reference's meaning, `--resume` continues at epoch + 1 -- and
     `global_step` the number of optimizer steps taken so far, so a run that stopped inside an epoch (--max_steps) resumes where it
-    stopped instead of being taken for finished."""
+    stopped instead of being taken for finished.  `data_rng`: the numpy Generator that draws the dropped zones (rank 0's): its state and
+    that of the other generators of the loop go in, so a resumed single-process run repeats the uninterrupted one bit for bit
+    (tests/test_train_step_gpu.py); the other ranks of a multi-process run restart their generators."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    torch.save({"model": weights_now, "optimizer": trainer.optimizer_state_dict(), "epoch": int(epoch), "global_step": int(global_step)}, path)
+    ck = {"model": weights_now, "optimizer": trainer.optimizer_state_dict(), "epoch": int(epoch), "global_step": int(global_step)}
+    if data_rng is not None:
+        # every generator the loop draws from: dropped zones (own Generator), crop / flip / jitter / rotation (`random`, `np.random`, as the
+        # reference's loader), positional-encoding windows (torch's CPU generator)
+        import random
+        ck["data_rng"] = {"drop": data_rng.bit_generator.state, "python": random.getstate(), "numpy": np.random.get_state(),
+                          "torch": torch.get_rng_state()}
+    torch.save(ck, path)
 
 
 def drop_zones(sim, s, drop, rng):
@@ -148,6 +157,11 @@ def main(argv=None):
     argv = list(argv if argv is not None else sys.argv[1:])
     n_syn = _pop(argv, "--synthetic", 0, int)
     max_steps = _pop(argv, "--max_steps", 0, int)
+    seed = _pop(argv, "--seed", None, int)               # seeds `random`, `np.random` and torch's CPU generator (the reference's loop is unseeded)
+    if seed is not None:
+        import random
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+    stop_after = _pop(argv, "--stop_after", 0, int)      # leave after this many steps of THIS process without touching the schedule (preemption)
     save_path = _pop(argv, "--save", "", str)
     log_every = _pop(argv, "--log_every", 10, int)
     n_val = _pop(argv, "--validate", 0, int)
@@ -237,6 +251,12 @@ def main(argv=None):
     patch_info["zone_num"] = torch.from_numpy(pi["zone_num"])
     ds = SyntheticTrainSet(n_syn, H, W, seed=1000 + rank)
     rng = np.random.default_rng(4242 + rank)
+    resumed_rng = None
+    if rank == 0 and getattr(args, "resume", ""):      # a checkpoint of this loop carries rank 0's generator states (other ranks restart theirs)
+        st = torch.load(args.resume, map_location="cpu", weights_only=False)
+        if isinstance(st, dict) and isinstance(st.get("data_rng"), dict) and "drop" in st["data_rng"]:
+            resumed_rng = st["data_rng"]
+        del st
     drop = float(args.drop_hist)
     best_rmse, last_validated = float("inf"), -1
 
@@ -248,8 +268,9 @@ def main(argv=None):
         from cfpnet_amd.engine import Engine
         torch.cuda.synchronize()
         weights_now = tr.state_dict()
+        # the drop-in boundary's default numerics (float32 storage, f16x3 matrix math: inside the 1e-3 gate on every weight family)
         eng = Engine(weights_now, layer_names=layers, n_bins=int(args.n_bins), min_val=float(args.min_depth), max_val=float(args.max_depth),
-                     dtype=torch.float16 if dtype == torch.float32 else dtype, device=dev)
+                     device=dev)
         build = data.EvalInputBuilder(args, dev)
         avg = metrics.RunningAverageDict()
         for img, dep, _ in data.batches(data.SyntheticEvalSamples(n_val, 480, 640, seed=99), 8):
@@ -266,7 +287,7 @@ def main(argv=None):
                 if steps_here > 0:                                   # the optimizer state exists once a step ran in this process
                     # the `epoch` FIELD is the last fully completed epoch (a mid-epoch validation has not finished `epoch` yet): a
                     # reference-style consumer that resumes at epoch + 1 must not skip the rest of this one
-                    save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, at_step // steps_per_epoch - 1, at_step)
+                    save_training_checkpoint(os.path.join(d, f"checkpoint_{epoch}.pt"), weights_now, tr, at_step // steps_per_epoch - 1, at_step, rng)
             if m["rmse"] < best_rmse:
                 torch.save(weights_now, os.path.join(d, "best.pt"))
         best_rmse = min(best_rmse, m["rmse"])
@@ -276,6 +297,10 @@ def main(argv=None):
 
     t0, seen, step, steps_here = time.perf_counter(), 0, start_step, 0
     loss = torch.zeros(())
+    if resumed_rng is not None:          # set here: everything above (model init, simulator tables) has drawn what it draws in any run
+        import random
+        rng.bit_generator.state = resumed_rng["drop"]
+        random.setstate(resumed_rng["python"]); np.random.set_state(resumed_rng["numpy"]); torch.set_rng_state(resumed_rng["torch"])
     if start_step >= total_steps and rank == 0:
         print(f"nothing left to train: the checkpoint is at step {start_step} of {total_steps}", flush=True)
     for epoch in range(start_epoch, int(args.epochs)):
@@ -284,7 +309,7 @@ def main(argv=None):
         if files is None and not no_augment:
             file_batches = _prefetch(lambda i, e=epoch: ds.raw_batch(e * steps_per_epoch + i, per_rank) + (None,), steps_per_epoch)
         for i in range(steps_per_epoch):
-            if step >= total_steps:
+            if step >= total_steps or (stop_after and steps_here >= stop_after):
                 break
             if epoch * steps_per_epoch + i < start_step:          # resumed inside this epoch: these batches were consumed before
                 if file_batches is not None:
@@ -321,6 +346,8 @@ def main(argv=None):
                 print(f"epoch {epoch + 1} step {step}/{total_steps} loss {float(loss):.4f} lr {lr:.2e} beta1 {beta1:.3f} {seen / dt:.1f} samples/s", flush=True)
         if rank == 0 and n_val > 0 and step % max(1, int(args.validate_every)) == 0 and step != last_validated:      # train.py:137: end of epoch
             validate(step, epoch)
+        if stop_after and steps_here >= stop_after:
+            break
     torch.cuda.synchronize()
     if rank == 0 and n_val > 0 and last_validated != step:
         validate(step)
@@ -328,7 +355,7 @@ def main(argv=None):
         os.makedirs(os.path.dirname(os.path.abspath(save_path)), exist_ok=True)
         torch.save(tr.state_dict(), save_path)        # the reference's `model.state_dict()` file (model_io.py:14-17)
         if steps_here > 0:            # the last FULLY completed epoch (-1: none) + the global step: a cut-short run resumes, not "finished"
-            save_training_checkpoint(os.path.splitext(save_path)[0] + ".ckpt.pt", tr.state_dict(), tr, step // steps_per_epoch - 1, step)
+            save_training_checkpoint(os.path.splitext(save_path)[0] + ".ckpt.pt", tr.state_dict(), tr, step // steps_per_epoch - 1, step, rng)
     if dist:
         dist.barrier(); dist.destroy_process_group()
     return float(loss)
