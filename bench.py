@@ -82,6 +82,7 @@ def kernel_times(engine, inputs, return_prob, reps=5, dw=True):
     dw_calls = []
     real_call = hip.call
     stem_w = engine.P["stem.w"].data_ptr()
+    model_bytes = {}      # family -> bytes one pass fetches / writes beyond L2 under the eight-private-L2 model (see `traffic_model` in main)
 
     def timed_call(name, *a):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -102,6 +103,15 @@ def kernel_times(engine, inputs, return_prob, reps=5, dw=True):
             byts = esz * (M * Cout + B * H * W * Cin + (B if piw else 1) * Cout * KH * KW * Cin)      # per-image weights (SE-folded project GEMMs): B matrices are read
             v, sp = ops.conv2d_plan(M, Cout, KH * KW * Cin, cdt, Ho * Wo if piw else 0, B, KH, stride)
             fam = ops.conv2d_kernel_name(v, 1, a[22])       # split-K launches are folded into their tile family
+            # what the launch must move past the L2s if each of the 8 XCDs (each with its own L2, each given a contiguous range of the tile
+            # ids by xcd_remap, i.e. a range of ROWS) fetches the weight matrix itself: inputs and outputs once, weights once per XCD that
+            # has work; per-image weights: an XCD fetches the matrices of the images its row range touches
+            bm = ((ops.GEN2_TILES + ops.X3_ONLY_TILES)[v % 100][0] if v >= 400 else ops.GEN2_TILES[v - 100][0]) if (100 <= v < 200 or 400 <= v < 500) else 128
+            tiles = -(-M // bm) * max(1, -(-Cout // 64))
+            xcds = min(8, tiles)
+            wbytes = (4.0 if cdt == hip.F32X3 else esz) * Cout * KH * KW * Cin
+            wfetch = wbytes * ((B + xcds - 1) if piw else xcds)
+            model_bytes[fam] = model_bytes.get(fam, 0.0) + esz * (M * Cout + B * H * W * Cin) + wfetch
         elif name in ("cfp_dwconv3x3_nhwc", "cfp_dwconv3x3_sum_nhwc", "cfp_dwconv3x3_se_nhwc"):
             B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16] if name == "cfp_dwconv3x3_nhwc" else (a[8:17] if name == "cfp_dwconv3x3_sum_nhwc" else a[10:19])
             fam = "cfp_dwconv3x3_nhwc"
@@ -139,7 +149,7 @@ def kernel_times(engine, inputs, return_prob, reps=5, dw=True):
         ts = sorted(r[i][1] for r in per_rep)
         d = agg.setdefault(fam, [0, 0.0, 0.0, 0.0])
         d[0] += reps; d[1] += ts[len(ts) // 2] * reps; d[2] += flops * reps; d[3] += byts * reps
-    out = {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps) for k, v in agg.items()}
+    out = {k: dict(launches=v[0] // reps, ms=v[1] / reps, flops=v[2] / reps, bytes=v[3] / reps, model_bytes=model_bytes.get(k, 0.0) / reps) for k, v in agg.items()}
     if dw_shapes and dw:
         out["_dw3x3_copy"] = same_size_copy_ms(dw_shapes[:len(dw_shapes) // reps], engine.dtype, engine.device)
         out["_dw3x3_in_graph"] = dw3x3_in_graph(dw_calls[:len(dw_calls) // reps], engine.dtype, engine.device)
@@ -314,7 +324,7 @@ def pmc_traffic(kernel_family: str):
     if _PMC_TABLE is None:
         import glob
         _PMC_TABLE = {}
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=lambda q: (os.path.basename(q)[0] != "r", os.path.basename(q))):
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=lambda q: (os.path.basename(q)[0] == "r", os.path.basename(q))):      # un-numbered (round 1) files first, then r2f < ... < r4z
             try:
                 for k, v in json.load(open(path)).items():
                     if isinstance(v, dict):
@@ -366,9 +376,12 @@ def train_pmc_step_bytes():
     return tot / steps if steps else None
 
 
-def pmc_traffic_source():
+def pmc_traffic_source(kernel_family: str = ""):
+    """The committed summary the figure of `kernel_family` (or of any of its tile instantiations) was read from."""
     pmc_traffic("")
-    files = sorted({v["_file"] for v in _PMC_TABLE.values()})
+    hits = sorted({v["_file"] for k, v in _PMC_TABLE.items() if kernel_family and k.startswith(kernel_family.split(" ")[0].replace("_kernel", ""))},
+                  key=lambda q: (q[0] == "r", q))
+    files = hits or sorted({v["_file"] for v in _PMC_TABLE.values()}, key=lambda q: (q[0] == "r", q))
     return files[-1] if files else None
 
 
@@ -847,8 +860,8 @@ def main():
             # one hand-written kernel = one row: the tile shapes of igemm2_kernel are template instantiations of the same code
             groups = {}
             for k, v in convs.items():
-                g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "traffic": 0.0, "traffic_known": True, "tiles": {}})
-                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
+                g = groups.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "traffic": 0.0, "traffic_known": True, "tiles": {}, "model": 0.0})
+                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]; g["model"] += v.get("model_bytes", 0.0)
                 t = pmc_traffic(k)
                 if t is None:
                     g["traffic_known"] = False
@@ -877,8 +890,12 @@ def main():
                                 "achieved": dom_gbs if dom_hbm else ach, "peak": PEAK_HBM_GBS if dom_hbm else PEAK_BF16_TFLOPS,
                                 "unit": "GB/s" if dom_hbm else "TFLOP/s", "frac": dom_gbs / PEAK_HBM_GBS if dom_hbm else ach / PEAK_BF16_TFLOPS,
                                 "achieved_TFLOPs": ach, "mfma_frac": ach / PEAK_BF16_TFLOPS,
-                                "traffic": (d["traffic"] / d["launches"]) if d["traffic_known"] else None, "traffic_source": pmc_traffic_source(),
+                                "traffic": (d["traffic"] / d["launches"]) if d["traffic_known"] else None, "traffic_source": pmc_traffic_source(dom),
                                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                                "traffic_model": {"bytes_per_launch": d["model"] / d["launches"] if d["model"] else None,
+                                                  "what": "inputs and outputs once + the weight matrix once per XCD with work (8 private L2s; xcd_remap gives each a "
+                                                          "contiguous range of rows, so activations are fetched by one L2 and weights by all eight); per-image weights: "
+                                                          "the matrices of the images an XCD's rows touch.  Compare with `traffic` (PMC) and `algorithmic_bytes_per_launch`"},
                                 "launches_per_step": d["launches"], "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                 "share_of_gpu_time": d["ms"] / total_ms, "flop_per_launch": d["flops"] / d["launches"],
                                 "flop_per_byte": d["flops"] / max(d["bytes"], 1.0), "achieved_GBps": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
