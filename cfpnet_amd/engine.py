@@ -141,10 +141,12 @@ class Engine:
         # four copies side by side; whole step 2.96 vs 2.57 ms with its first version): OFF by default, CFP_MBCONV_FUSED=1 enables it.
         self.mbconv_fused = os.environ.get("CFP_MBCONV_FUSED", "0") == "1"
         # squeeze-excite through cfp_dwconv3x3_se_nhwc + cfp_se_gate_fold2 (16-bit modes; CFP_SE2=0: the round-2 pair)
-        # The float32 depthwise kernel leaves the same partial dot products, so the default f16x3 mode can take this path too
-        # (CFP_SE2_X3=1): measured neutral -- 4.63 vs 4.59 ms per batch with four in flight, 7.08 vs 7.17 ms for one graph -- so it stays off.
-        self.se2 = ((dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1")
-                    or (self.x3 and os.environ.get("CFP_SE2_X3", "0") == "1"))
+        # The float32 depthwise kernel leaves the same partial dot products, so the default f16x3 mode can take this path too.  Measured:
+        # one graph at a time it is faster at every batch (3.69 vs 3.87 ms at batch 1, 4.03 vs 4.26 at 2, 4.91 vs 5.05 at 4, 7.08 vs 7.17 at 8:
+        # one launch fewer per block on the critical path), with four batches in flight it is neutral to slightly slower (4.63 vs 4.59 ms at
+        # batch 8).  So the f16x3 engine takes it outside the in-flight plan (`se2_x3`; CFP_SE2_X3=0 never, =1 always).
+        self.se2 = dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1"
+        self.se2_x3 = os.environ.get("CFP_SE2_X3", "auto") if self.x3 else "0"
         # DIAGNOSTIC ONLY (tools/precision_family.py --acts): "name:dtype,..." rounds the named encoder tensors of a float32 engine to a
         # 16-bit format in place right after they are produced, to attribute the 16-bit error to single tensors.  Never set in product use.
         self._dbg_round = {}
@@ -445,7 +447,8 @@ class Engine:
                     part = self._f32(plan, f"enc{bi}.sum", B * ns * b.mid)
                     ops.mbconv_expand_dw(x, self.P[q + ".pw.wimg"], self.P[q + ".pw.s"], self.P[q + ".pw.t"], self.P[q + ".dw.w"],
                                          self.P[q + ".dw.s"], self.P[q + ".dw.t"], mid2, part, B, h, w)
-                elif self.se2 and b.se_rd <= 64 and ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype]) > 0:
+                elif ((self.se2 or self.se2_x3 == "1" or (self.se2_x3 == "auto" and not ops.PLAN_IN_FLIGHT)) and b.se_rd <= 64
+                      and ops.dwconv3x3_se_parts(B, ho, wo, b.mid, b.stride, ops.DT[self.dtype]) > 0):
                     # round 3: the depthwise kernel applies the reduce FC to its own channel sums (it is linear in them), the tail kernel
                     # adds the K partial vectors, finishes the gate and folds it into float32 project weights in one full-chip launch
                     mid = self._act(plan, f"enc{bi}.mid", B * h * w, b.mid)
