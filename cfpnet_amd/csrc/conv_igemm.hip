@@ -327,7 +327,8 @@ int g_halo_x3 = 1;              // cfp_debug_set key 24: 0 = the f16x3 3x3 convo
 // 16 -> 16 23 / 41; 153600 px 40 -> 160 62 / 97; 38400 px 56 -> 224 33 / 41 -- and loses from 64 input channels up (the head's 128 -> 128:
 // 692 / 573, 153600 px 168 -> 64: 182 / 136, 38400 px 128 -> 64: 39 / 23): a deep halo leaves one workgroup per CU, whose load phase
 // (95-124 KB through registers) nothing overlaps, where the implicit GEMM pipelines its operand stream over K.
-static bool halo_x3_wins(long long M, int Cin, int Cout, bool tput) { return M >= 30000 && Cin <= 56; }
+// alone (one graph at a time) the halo kernel already wins at half the pixels (batch 1: 19200 px x 160 x 360 19.3 vs 24.2 us, profiles/r4_conv_bench_x3_b1_alone.txt)
+static bool halo_x3_wins(long long M, int Cin, int Cout, bool tput) { return M >= (tput ? 30000 : 15000) && Cin <= 56; }
 static bool halo_wins_s2(long long M, int Cout) { return g_halo == 2 || (g_halo == 1 && g_halo_s2 && M >= 30000 && Cout <= 160); }
 static bool halo_wins(long long M, int Cout, bool tput) {
   if (g_halo == 2) return true;
@@ -469,6 +470,11 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
   if (pl.variant == 0 || pl.variant == 1) pl.variant = 26;
   if (tput && pl.variant == 15 && M >= 9000 && N >= 128 && N <= 256 && K >= 500) pl.variant = 26;
   if (pl.variant < 0 || pl.variant >= igemm_x3_num_variants()) pl.variant = 13;
+  // single images (tools/conv_bench_x3.py --batch 1, profiles/r4_conv_bench_x3_b1_alone.txt): few row tiles and a long K -> the two-K-group
+  // tile halves the serial chain (1200 x 256 x 3528: 43.7 vs 77.5 us, x 2304: 30.4 vs 49.7); a few hundred rows x many channels -> 32-row tiles
+  // (300 x 1392 x 232: 7.7 vs 10.5 us)
+  if (!tput && rpb == 0 && pl.splits <= 1 && M <= 2400 && K >= 2000 && N >= 128 && (pl.variant == 15 || pl.variant == 13)) pl.variant = 19;
+  if (!tput && rpb == 0 && pl.splits <= 1 && M <= 512 && N >= 512 && K <= 512) pl.variant = 17;
   if (g_x3_ad && pl.splits <= 1) pl.variant = x3_ad_of(pl.variant);
   return pl;
 }
@@ -477,7 +483,7 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int d
                                int* splits) {
   if (dtype == CFP_F32X3) {
     const int cin3 = K / 9;
-    const bool chunk3 = cin3 % 32 == 0 && cin3 >= 64 && M >= 30000 && (Cout <= 64 || (Cout == 128 && M >= 300000));
+    const bool chunk3 = cin3 % 32 == 0 && cin3 >= 64 && M >= 30000 && (Cout <= 64 || (Cout == 128 && M >= 60000));
     if (KH == 3 && stride == 1 && K % 9 == 0 && cin3 % 8 == 0 && rows_per_batch <= 0 && g_halo_x3 && g_force_variant < 0 &&
         (chunk3 || halo_x3_wins(M, cin3, Cout, g_tput != 0))) {
       if (variant) *variant = 500;          // conv3x3_halo_x3.hip (the tile is chosen from Cout and the LDS the halo takes)
@@ -589,7 +595,8 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     // automatic tile, 400 + v keeps the implicit GEMM
     // deep inputs (Cin % 32 == 0, >= 64): the chunk-pipelined form where it measured ahead of the implicit GEMM with four copies side by side
     // (tools/conv_bench_x3.py --halo --inflight 4: 153600 px 64 -> 64 ch 43.6 vs 49.4 us, 38400 px 128 -> 64 20.4 vs 22.0, head conv 556 vs 565)
-    const int chunk_v = (g_halo_x3 && Cin % 32 == 0 && Cin >= 64 && p.M >= 30000) ? (Cout <= 64 ? 24 : (Cout == 128 && p.M >= 300000) ? 22 : -1) : -1;
+    // (batch 1: the head conv, 76800 px, 84 us through chunk tile 24 against 118 us through the 128 x 128 implicit GEMM)
+    const int chunk_v = (g_halo_x3 && Cin % 32 == 0 && Cin >= 64 && p.M >= 30000) ? (Cout <= 64 ? 24 : (Cout == 128 && p.M >= 300000) ? 22 : (Cout == 128 && p.M >= 60000) ? 24 : -1) : -1;
     if (!per_image_weights && !ln_gamma && conv3x3_halo_x3_takes(p) &&
         (g_force_variant >= 500 || (g_force_variant < 0 && g_halo_x3 && (chunk_v >= 0 || halo_x3_wins(p.M, Cin, Cout, tput))))) {
       const int hv = g_force_variant >= 500 && g_force_variant < 599 ? g_force_variant - 500 : chunk_v;
