@@ -432,6 +432,9 @@ Plan2 plan2(long long M, int N, int K, int rpb, int B, bool allow_split, bool co
   // pointwise layers at the 1/16 scale on 128x64 tiles (9600 x 816 x 136: equal alone, 8.4 vs 9.6 in flight)
   if (pl.variant == 12 && pl.splits == 1 && !pl.gen1 && pl.direct < 0 && g_small_s2) pl.variant = 15;
   if (pl.variant == 13 && !pl.gen1 && pl.direct < 0 && rpb == 0 && M >= 9000 && M < 30000 && N >= 512 && K <= 256 && g_small_s2) pl.variant = 14;
+  // single images: the deep decoder convs on a few row tiles (1200 x 256 x 3528 / x 2304) run 21.4 / 14.6 us through the direct kernel's 8 x 16 pixel tiles
+  // against 37.8 / 25.8 us on 64 x 128 GEMM tiles (tools/conv_bench.py --sweep --batch 1, profiles/r4_conv_bench_bf16_b1_alone.txt)
+  if (!tput && !g_tput && conv3x3s1 && rpb == 0 && !pl.gen1 && pl.splits == 1 && pl.direct < 0 && M <= 2400 && N >= 256 && K >= 2048) pl.direct = 4;
   if ((tput || g_tput) && !pl.gen1 && pl.splits == 1) {
     if (pl.direct < 0 && M <= 20000 && N >= 256 && K >= 2048) pl.variant = 1;                    // 9600 x 256 x 3528: 20.6 vs 31.0 us per call in flight (alone: 51 vs 42)
     if (pl.direct < 0 && pl.variant == 13 && rpb == 0 && M >= 30000 && M < 100000 && N <= 64 && K >= 512) pl.variant = 14;      // 38400 x 64 x 1152: 7.8 vs 10.1
