@@ -46,6 +46,11 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict_
   constexpr int N = NT * 16;
   constexpr int NBG = N / 8;                  // 8-row DMA groups of a weight slab
   constexpr int NBW = (NBG + 3) / 4;
+  // weight slabs of THIS GEMM are N * 128 bytes; the region holds 2 * BSTAGE bytes (two slabs of the widest GEMM, N = 2 D): the N = D GEMMs
+  // fit three of theirs in it and keep two K-steps of DMA in flight (round 4: a K-step is a few MFMAs against a ~0.7-1 us round trip of
+  // its weight tile from L2; counted wait as in loftr_tail_x3.hip)
+  constexpr int SST = N * 128;
+  constexpr int STG = (3 * SST <= 2 * BSTAGE) ? 3 : 2;
   const int fr = lane & 15, fq = lane >> 4;
   const int rsub = lane >> 3;
   const int lc = (lane & 7) ^ rsub;
@@ -58,7 +63,7 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict_
     for (int j = 0; j < NBW; ++j) {
       const int g = (j * 4 + wave) % NBG;
       const int n = g * 8 + rsub;
-      glds16(kok ? W + (long long)n * K + kk : zsrc, sB + st * BSTAGE + g * 1024);
+      glds16(kok ? W + (long long)n * K + kk : zsrc, sB + st * SST + g * 1024);
     }
   };
 #pragma unroll
@@ -70,12 +75,16 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict_
   __builtin_amdgcn_s_barrier();               // every wave is done with the previous GEMM's slabs
   asm volatile("" ::: "memory");
   issue(0, 0);
+  if (STG == 3 && nk > 1) issue(1, 1);
   for (int ks = 0; ks < nk; ++ks) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (STG == 3 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");      // slab ks landed, slab ks + 1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
-    const unsigned char* cB = sB + (ks & 1) * BSTAGE;
+    if (STG == 3) { if (ks + 2 < nk) issue(ks + 2, (ks + 2) % 3); }      // slab (ks - 1) % 3: everybody has read it (barrier above)
+    else if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+    const unsigned char* cB = sB + (ks % STG) * SST;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       const int k = ks * 64 + sub * 32;

@@ -17,7 +17,7 @@
 //     and wave (16 rows), ~20 VALU instructions beside 3 x NT MFMAs;
 //   * mlp.0 / mlp.2 run in two halves of the hidden width: half of h (D channels) is produced, then consumed as a K range of mlp.2 into
 //     accumulators that stay in registers -- the hidden tile is D wide instead of 2 D, so that four waves' tiles and the weight stages
-//     fit the LDS at D = 128 (136 KB);
+//     fit the LDS at D = 128 (152 KB with the three weight stages);
 //   * nothing is rounded on the way: msg, y1, h stay float32 (the unfused float32 path stores them in float32 as well).
 #include "common.h"
 
@@ -44,6 +44,7 @@ struct TailX3P {
 // One GEMM of the chain for this wave's 16 rows: acc[j] += A[16 x 32 nks] * W[N x ..]^T over the K-steps [ks0, ks0 + nks) of the weight rows
 // (N = NT * 16 rows starting at W, `wrow` halves per row).  `arow(ks)` returns the wave-private float32 row pointer (lane's row fr) of the
 // A operand's 32 channels of K-step ks.  All four waves of the workgroup must call it together (they share the weight stages).
+constexpr int TAIL_STAGES = 3;
 template <int NT, int BSTAGE, bool ZERO, typename AF>
 __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __restrict__ W, int wrow, int ks0, int nks, AF arow, unsigned char* sB,
                                              int wave, int lane) {
@@ -74,14 +75,23 @@ __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __re
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();               // every wave is done with the previous GEMM's stages
   asm volatile("" ::: "memory");
+  // THREE weight stages, two K-steps of DMA in flight (round 4, late): a K-step here is 3 NT MFMAs (~0.1-0.2 us) against a ~0.7-1 us round
+  // trip of its weight tile from L2 -- with two stages every step of the chain (32 of them at D = 128) waited out that round trip
+  // (batch-1 forward 3.50 -> 3.41 ms).  Counted wait: the loads of a stage are this wave's NBW youngest vector-memory operations when the
+  // next stage has been issued behind it, and they complete in order; the last step waits for everything.  Issuing the first stages of the
+  // NEXT GEMM of the chain right after a K loop (under the LayerNorm / attention / GELU work between the GEMMs) was built too and measured
+  // no gain (3.42 ms; it costs a barrier per GEMM) -- not kept.
   issue(ks0, 0);
+  if (nks > 1) issue(ks0 + 1, 1);
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
   for (int i = 0; i < nks; ++i) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + 1 < nks) issue(ks0 + i + 1, (i + 1) & 1);
-    const unsigned char* cB = sB + (i & 1) * BSTAGE;
+    if (i + 2 < nks) issue(ks0 + i + 2, (i + 2) % TAIL_STAGES);      // stage (i - 1) % 3: everybody has read it (barrier above)
+    const unsigned char* cB = sB + (i % TAIL_STAGES) * BSTAGE;
     const float* ar = arow(ks0 + i);
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(ar + 4 * fq);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(ar + 16 + 4 * fq);
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   unsigned char* sB = smem;
-  float* tMsg = reinterpret_cast<float*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  float* tMsg = reinterpret_cast<float*>(smem + TAIL_STAGES * BSTAGE + wave * WAVE_LDS);
   float* tX = tMsg + TILE;
   float* tH = tX + TILE;
   const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
 
 template <int D, int HEADS>
 int launch_tail_x3(const TailX3P& p, hipStream_t s) {
-  constexpr size_t lds = 2 * (D * 128) + 4 * (3 * 16 * (D + 8) * 4);
+  constexpr size_t lds = TAIL_STAGES * (D * 128) + 4 * (3 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = loftr_tail_x3_kernel<D, HEADS>;
   static bool attr = false;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   unsigned char* sB = smem;
-  float* tA = reinterpret_cast<float*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
+  float* tA = reinterpret_cast<float*>(smem + TAIL_STAGES * BSTAGE + wave * WAVE_LDS);
   float* tH = tA + TILE;
   const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
   constexpr int XCH = D / 4;
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
 
 template <int D>
 int launch_lkpm_x3(const LkpmX3P& p, hipStream_t s) {
-  constexpr size_t lds = 2 * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
+  constexpr size_t lds = TAIL_STAGES * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = lkpm_tail_x3_kernel<D>;
   static bool attr = false;
