@@ -184,8 +184,10 @@ def trained_like_state_dict(layer_names, steps: int = 300, batch: int = 4, devic
         data.append((synthetic.to_device(inp, device), tgt.to(device)))
     tr = Trainer(sd, list(layer_names), lr=lr, total_steps=steps, dtype=dtype or torch.float32, device=device)
     tr.capture(*data[0])
-    for i in range(steps):
-        loss, _, _ = tr.step(*data[i % len(data)])
+    with torch.random.fork_rng(devices=[]):          # the positional-encoding windows are drawn from torch's CPU generator: same family every run
+        torch.manual_seed(seed)
+        for i in range(steps):
+            loss, _, _ = tr.step(*data[i % len(data)])
     torch.cuda.synchronize()
     out = tr.state_dict()
     out["__loss__"] = float(loss)
