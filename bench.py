@@ -813,7 +813,7 @@ def main():
         return e2, el2, timed_path_pred(e2)
 
     f16 = f32 = x3 = None
-    if rank == 0 and world == 1 and a.dtype == "bf16" and not a.no_x3:
+    if rank == 0 and world == 1 and (a.dtype == "bf16" or a.config5) and not a.no_x3:
         # THE DEFAULT MODE of the drop-in boundary: float32 storage, split-precision (f16 x 3) matrix math -- the mode inside the 1e-3 gate
         # on every weight family; same workload, launch mode and protocol as the headline line
         x3 = timed_mode("x3")
@@ -1014,6 +1014,9 @@ def main():
     if rank == 0:
         if train_multi is not None:
             line["training"] = train_multi
+        if x3 is not None and "f32x3" not in line:      # --config5: the default mode timed under the same protocol (parity: tests/test_forward_gpu.py's config5 case)
+            line["f32x3"] = {"value": a.batch * a.steps / x3[1], "unit": "maps/s", "ms_per_step": x3[1] / a.steps * 1e3, "dtype": "f32x3",
+                             "launch": "same as the headline line", "note": "the drop-in boundary's default numerics (float32 storage, f16x3 matrix math, float32 prob)"}
         print(json.dumps(line))
     if dist:
         dist.barrier()
