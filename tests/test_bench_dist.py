@@ -51,3 +51,21 @@ def test_single_rank_needs_no_process_group(monkeypatch):
     assert bench.init_dist("gloo") == (0, 1, 0, None)
     assert bench.max_over_ranks(3.5, None) == 3.5
     assert bench.job_value(1, 8, 10, 2.0) == (40.0, 40.0)
+
+
+def test_pmc_summaries_are_read_oldest_first():
+    """bench.pmc_traffic(): every committed profiles/*pmc_traffic.json is read oldest first (the un-numbered round-1 file, then r2f < ...
+    < r4z), so the figure of a kernel family is the NEWEST summary that measured it.  (Round 4 found the round-1 file sorted last and
+    overriding everything: the bench line reported a two-rounds-old 20.8 MB per igemm2 launch where the current kernels move 11.8 MB.)"""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=lambda q: (os.path.basename(q)[0] == "r", os.path.basename(q)))
+    assert files and os.path.basename(files[0])[0] != "r" and os.path.basename(files[-1]).startswith("r")
+    fam = "igemm2<bf16,64x64,s2>"
+    newest = [f for f in files if fam in json.load(open(f))][-1]
+    bench._PMC_TABLE = None
+    assert bench.pmc_traffic(fam) == json.load(open(newest))[fam]["hbm_bytes_per_launch"]
+    assert bench.pmc_traffic_source("igemm2") == os.path.basename(newest)
+    assert os.path.basename(newest) != "pmc_traffic.json"
