@@ -966,9 +966,16 @@ def main():
                         ms3 = sum(v["ms"] for v in g3.values()); fl3 = sum(v["flops"] for v in g3.values()); by3 = sum(v["bytes"] for v in g3.values())
                         n3 = sum(v["launches"] for v in g3.values())
                         big3 = max(g3, key=lambda k: g3[k]["flops"] / max(g3[k]["launches"], 1))
+                        # which roof: the family's algorithmic intensity (2 M N K over float32 inputs + outputs + weights) against the ridge,
+                        # the rule of the headline's roofline object above
+                        x3_hbm = fl3 / max(by3, 1.0) < RIDGE_FLOP_PER_BYTE
+                        x3_tfs, x3_gbs = fl3 / (ms3 * 1e-3) / 1e12, by3 / (ms3 * 1e-3) / 1e9
                         line["f32x3"]["roofline"] = {
-                            "kernel": "igemm_x3_kernel (float32 storage, 3 half MFMAs per product block; all tile instantiations)", "bound": "mfma",
-                            "achieved": fl3 / (ms3 * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl3 / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                            "kernel": "igemm_x3_kernel (float32 storage, 3 half MFMAs per product block; all tile instantiations)",
+                            "bound": "hbm" if x3_hbm else "mfma", "achieved": x3_gbs if x3_hbm else x3_tfs, "peak": PEAK_HBM_GBS if x3_hbm else PEAK_BF16_TFLOPS,
+                            "unit": "GB/s" if x3_hbm else "TFLOP/s", "frac": x3_gbs / PEAK_HBM_GBS if x3_hbm else x3_tfs / PEAK_BF16_TFLOPS,
+                            "achieved_TFLOPs": x3_tfs, "mfma_frac": x3_tfs / PEAK_BF16_TFLOPS, "algorithmic_bytes_per_launch": by3 / n3,
+                            "traffic_source": pmc_traffic_source("igemm_x3_kernel"),
                             "mfma_issue_TFLOPs": 3 * fl3 / (ms3 * 1e-3) / 1e12, "mfma_issue_frac": 3 * fl3 / (ms3 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                             "what": "achieved = ALGORITHMIC FLOPs (2 M N K) per second; the kernel issues three matrix instructions per product block, "
                                     "so its own ceiling is a third of the 16-bit peak (mfma_issue_* counts all three)",
@@ -977,6 +984,18 @@ def main():
                             "largest_gemm": {"kernel": big3, "achieved": g3[big3]["flops"] / (g3[big3]["ms"] * 1e-3) / 1e12,
                                              "avg_launch_us": g3[big3]["ms"] * 1e3 / g3[big3]["launches"], "launches_per_step": g3[big3]["launches"]}}
                     line["f32x3"]["kernel_ms_per_step"] = {k: round(v["ms"], 4) for k, v in sorted(kt3.items(), key=lambda kv: -kv[1]["ms"])}
+            # what the driver's parsed line keeps is `config`: say there which number is inside the tolerance
+            line["config"]["parity"] = {k: line[k] for k in ("rel_l1", "abs_rel", "rel_l1_worst_image", "gate", "gate_met") if k in line}
+            line["config"]["parity"]["what"] = f"{a.dtype} storage (the headline `value`) vs the float32 CPU oracle on the benched batch; gate = north-star 1e-3 relative L1"
+            if x3 is not None:
+                line["config"]["compliant_default"] = {
+                    "dtype": "f32x3", "value": line["f32x3"]["value"], "unit": "maps/s", "ms_per_step": line["f32x3"]["ms_per_step"],
+                    "rel_l1": line["f32x3"]["rel_l1"], "abs_rel": line["f32x3"]["abs_rel"], "gate_met": line["f32x3"]["gate_met"],
+                    "gate_met_on_every_family": line["f32x3"]["gate_met_on_every_family"],
+                    "what": "the drop-in boundary's DEFAULT mode (Deltar / make_model): float32 storage, f16 x 3 split-precision matrix math, float32 prob"}
+                if not line.get("gate_met", False):
+                    line["config"]["workload"] += (f"; {a.dtype} storage = OPT-IN SPEED MODE OUTSIDE the 1e-3 gate (rel_l1 {line['rel_l1']:.2e}); "
+                                                   f"gate-compliant default = f32x3 {line['f32x3']['value']:.0f} maps/s (config.compliant_default)")
             if f32 is not None:
                 line["f32"]["note"] = ("float32 parity mode: f32 storage, v_mfma_f32_16x16x4_f32 -- the mode that meets the north-star 1e-3 relative-L1 gate "
                                        "by three orders of magnitude, timed under the same protocol")
@@ -990,13 +1009,18 @@ def main():
                 model = boundary_model(sd, layers, mdt, dev, base)
                 for bsz in (1, a.batch):
                     li = synthetic.to_device(synthetic.make_inputs(bsz, a.height, a.width, zones, zone_px, seed=synthetic.SEED, image_hw=base), dev)
+                    model.eval_static_outputs = True       # the latency loop's opt-in (evaluate_time.py of this repo sets it too): results are the ring's buffers
                     mean_ms, med_ms = reference_latency_ms(model, li)
                     tgt = lat if mode == a.dtype else lat.setdefault("f32x3", {})
                     tgt[f"latency_b{bsz}"] = {"ms": mean_ms, "median_ms": med_ms, "maps_per_s": bsz / mean_ms * 1e3}
+                    model.eval_static_outputs = False      # the module's DEFAULT: fresh (edges, pred, prob) tensors per call like the reference (three clone kernels)
+                    mean_ms, med_ms = reference_latency_ms(model, li, warmup=20, iters=100)
+                    tgt[f"latency_b{bsz}"]["fresh_outputs_ms"] = mean_ms
                 del model
                 torch.cuda.empty_cache()
             lat["protocol"] = ("evaluate_time.py:56-82 on the reference's own call: 100 warm-up + 500 timed `model(input_data)` of the drop-in module "
-                               "(cfpnet_amd.Deltar, eval mode: one HIP-graph replay per forward reading the caller's tensors), each synchronised, min 1 / max 2 "
+                               "(cfpnet_amd.Deltar, eval mode, eval_static_outputs=True: one HIP-graph replay per forward reading the caller's tensors, results in the module's "
+                               "output ring; fresh_outputs_ms = the module's default, which clones the three results per call), each synchronised, min 1 / max 2 "
                                f"dropped, mean; top level = {a.dtype} storage with prob as stored, f32x3 = the module's default mode (float32 prob)")
             line["latency"] = lat
         if world == 1 and not a.no_train and not a.no_cpu_baseline:

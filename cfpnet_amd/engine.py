@@ -589,8 +589,15 @@ class Engine:
         N = self.zone_sample_num
         tok = [self._act(plan, f"{name}.tokA", M, 2 * D), self._act(plan, f"{name}.tokB", M, 2 * D)]
         cur = 0
-        oy, ox = pos_offset
-        ops.add_rowtable(x, self.P[p + ".pe"], tok[0].slice(0, D), M, H, W, Wm, oy, ox)
+        if torch.is_tensor(pos_offset):
+            # window origin read from DEVICE memory (int32[2]): a captured graph then serves every random window (fusion.py:87-91)
+            assert pos_offset.dtype == torch.int32 and pos_offset.numel() == 2 and pos_offset.is_cuda
+            d0 = tok[0].slice(0, D)
+            hip.call("cfp_add_rowtable_dev", x.ptr, x.ld, self.P[p + ".pe"].data_ptr(), d0.ptr, d0.ld, M, x.C, H, W, Hm, Wm,
+                     pos_offset.data_ptr(), x.dt, hip.current_stream())
+        else:
+            oy, ox = pos_offset
+            ops.add_rowtable(x, self.P[p + ".pe"], tok[0].slice(0, D), M, H, W, Wm, oy, ox)
         emb0 = None
         if not self.change_embedding:
             emb0 = self._act(plan, f"{name}.emb0", M, D)

@@ -42,6 +42,7 @@ def main(argv=None):
     # what is timed is `model(input_data)`, the call the reference times (evaluate_time.py:73-82): Deltar.forward replays the forward as a
     # HIP graph that reads these very tensors (same tensors every iteration: no copy, no torch kernel); --eager launches kernel by kernel
     model.eval_graphs = use_graph
+    model.eval_static_outputs = True          # a latency loop never holds a result past the next forward (evaluate_time.py:73-82)
     run = lambda: model(inp)
     with torch.no_grad():
         for _ in range(100):
