@@ -60,6 +60,10 @@ class Deltar(_Store):
                              tolerance (1e-3 relative L1 against the reference's float32 forward, deltar.py:34-67) on every weight family
                              -- measured ~2e-6 (tests/test_forward_gpu.py::test_f32x3_meets_the_gate_on_every_image_of_every_weight_family);
                              `prob` comes out of the kernels in float32 like the reference's.  Training-mode forwards run in float32.
+                             DYNAMIC RANGE: a value is held as two IEEE halves -- full precision up to |x| = 6.5e4, 11 bits up to 1.31e5,
+                             non-finite beyond (the float32 reference has no such limit; BatchNorm networks sit at O(1) ... O(100)).
+                             `model.check_finite = True` makes every eval forward verify its depth map and raise FloatingPointError
+                             (one host sync per forward); dtype=torch.float32 is the mode without the limit.
           torch.float32      float32 storage and float32 matrix cores: the bit-level parity mode (1/16 of the 16-bit matrix rate)
           torch.float16 / torch.bfloat16   16-bit storage, opt-in SPEED modes: 2.4 x the default's throughput, but outside the tolerance
                              on ill-conditioned (confident-head) networks -- fp16 0.8e-3 ... 1.2e-2, bf16 ~6e-3."""
@@ -109,6 +113,7 @@ class Deltar(_Store):
         # `preds.append(model(x)[1])` over a dataset is safe.  eval_static_outputs = True is the opt-in fast path of a latency loop
         # (evaluate_time.py, bench.py): the returned tensors ARE the ring's buffers and are overwritten `eval_out_ring` forwards later.
         self.eval_static_outputs = False
+        self.check_finite = False         # True: eval forwards raise FloatingPointError on a non-finite depth map (f32x3 range limit, see __init__)
         self._eval_caps: Dict = {}
         self._eval_offs = None            # int32[3, 2] on the device: the positional-table windows the captured graphs read
         self._eval_offs_host = None
@@ -188,6 +193,9 @@ class Deltar(_Store):
         # type themselves; only the opt-in 16-bit speed modes store 2 bytes per element and pay this cast (prob_dtype=None: as stored)
         if prob is not None and self.prob_dtype is not None and prob.dtype != self.prob_dtype:
             prob = prob.to(self.prob_dtype)
+        if self.check_finite and not bool(torch.isfinite(pred).all()):
+            raise FloatingPointError("cfpnet_amd: non-finite depth map" + (" -- the f32x3 mode holds values as two IEEE halves (|activation| < 1.31e5); "
+                                     "build the model with dtype=torch.float32 for inputs / weights of this magnitude" if self.x3 else ""))
         return edges, pred, prob, None
 
     def _forward_eval_graph(self, eng, input_data: Dict, pos_offsets, return_prob: bool):

@@ -183,17 +183,16 @@ def test_config1_batch8_as_benched_vs_oracle(dtype, bound):
 # 0.5e-4), and an inference engine with 16-bit storage makes ~150 of them; the bound below is the gate plus that measured spread,
 # and the bench line says `gate_met` per family.  kaiming_peaked (a confident head on the same network) is not a gate at all: rounding
 # only the INPUT IMAGE to fp16, everything else float32, already moves its prediction by 2.4e-3 (test below).
-FAMILY_BOUND = {"uniform": TOL_F16, "kaiming": 1.2e-3}
 
 
-@pytest.mark.parametrize("family", ["uniform", "kaiming"])
-def test_fp16_meets_the_gate_on_three_seeds_of_every_weight_family(family):
-    """The one 16-bit mode that is inside the north-star tolerance must be inside it ROBUSTLY, not on one batch and one weight
-    distribution: configs[1] (batch 8, 480x640) through the captured graph, three input seeds x three weight families -- the
-    key-addressed uniform one the other tests use; the reference's own initialisation (kaiming-normal fan_out for every Conv / Linear
-    outside the encoder, trunc_normal(0.2) positional tables, deltar.py:23-32, fusion.py:22-23) with BatchNorm running statistics
-    calibrated to the network's batch statistics (variances 25-30, means far from 0: what training leaves there); and the same
-    with a confident head (peaked softmax).  fp16 relative L1 <= 1e-3 on EVERY image."""
+@pytest.mark.parametrize("family,bound", [("uniform", TOL_F16), ("kaiming", 1.2e-3)], ids=["uniform_at_the_1e-3_gate", "kaiming_bounded_at_1.2e-3_OUTSIDE_the_gate"])
+def test_fp16_speed_mode_error_bound_on_three_seeds_of_two_weight_families(family, bound):
+    """fp16 storage is an OPT-IN SPEED MODE, not the compliant one (that is f32x3: next test, all four families at 1e-3).  What this test
+    asserts is exactly its parametrisation: configs[1] (batch 8, 480x640) through the captured graph, three input seeds, every image --
+    uniform family inside the north-star gate (<= 1e-3); the reference's own initialisation (kaiming-normal fan_out, trunc_normal(0.2)
+    positional tables, deltar.py:23-32, fusion.py:22-23, BatchNorm statistics calibrated) bounded at 1.2e-3, i.e. OUTSIDE the gate by up
+    to 20 % (measured 0.72-1.08e-3).  The confident-head and trained-like families are not asserted for fp16 at all (1.1e-2 / 8e-5
+    measured; `test_ill_conditioned_network_is_reported_not_gated`, bench line `f32x3.families.*.f16`)."""
     layers = spec.COMBINE1_LAYERS
     sd = weights.make_torch_state_dict(spec.model_manifest(layers), family=family)
     if family != "uniform":
@@ -213,7 +212,7 @@ def test_fp16_meets_the_gate_on_three_seeds_of_every_weight_family(family):
         print(f"fp16 {family} seed {seed}: rel-L1 {rel_l1(p1.cpu().numpy(), p0.numpy()):.3e}, worst image {max(per_image):.3e}, "
               f"pred std {float(p0.std()):.3f}")
         worst = max(worst, max(per_image))
-        assert max(per_image) <= FAMILY_BOUND[family], (family, seed, per_image)
+        assert max(per_image) <= bound, (family, seed, per_image)
     print(f"fp16 {family}: worst image of 24 = {worst:.3e}")
 
 
@@ -414,6 +413,18 @@ def test_eval_forward_returns_fresh_tensors_by_default_like_the_reference():
     for x, (e, p, pr, _) in zip(xs, held):
         we, wp, wpr, _ = ref(x)
         assert torch.equal(p, wp) and torch.equal(e, we) and torch.equal(pr, wpr)
+
+
+def test_check_finite_turns_the_f32x3_range_limit_into_a_clean_error():
+    """inputs far outside the two-half range of the f16x3 split give a non-finite map; with `model.check_finite` the boundary
+    raises instead of returning it, and the float32 mode of the same module still serves the input."""
+    model = _boundary_model()
+    model.check_finite = True
+    inp = synthetic.to_device(synthetic.make_inputs(1, seed=3), "cuda:0")
+    model(inp)                                                           # ordinary input: fine
+    big = {"rgb": inp["rgb"] * 1e7, "additional": inp["additional"]}
+    with pytest.raises(FloatingPointError, match="two IEEE halves"):
+        model(big)
 
 
 def test_eval_graph_serves_every_random_positional_window_from_one_capture():

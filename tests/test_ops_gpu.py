@@ -305,6 +305,27 @@ def test_conv2d_x3_small_and_large_magnitudes(xscale):
     _x3_close(from_nhwc(out.torch(), B, Ho, Wo), ref, f"x3 magnitudes {xscale}", tol=4e-6 if xscale >= 1e-2 else 2e-4)
 
 
+def test_conv2d_x3_dynamic_range_limit_is_what_the_docs_say():
+    """the f16x3 split holds a float32 value as TWO IEEE halves, so its range is 2 x 65504: up to 6.5e4 with ~22 bits, from
+    there to 1.31e5 with the 11 bits of the lo half alone (hi saturates at 65504), beyond that lo overflows (non-finite result).  The
+    float32 reference has no such limit; `Deltar(check_finite=True)` / `dtype=torch.float32` are the documented ways out.  Activations
+    of a BatchNorm network are O(1) ... O(100)."""
+    case = (2, 15, 20, 136, 232, 1, 1, (0, 0, 0, 0))
+    B, H, W, Cin, Cout, k, s, pads = case
+    for xscale, tol, finite in ((1.4e4, 4e-6, True), (2.7e4, 2e-3, True), (1e5, None, False)):      # max |x| ~ 4.5 sigma: 6.3e4 / 1.2e5 / 4.5e5
+        ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case, xscale=xscale)
+        out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV)
+        ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, 0, 0, Ho, Wo, hip.ACT_NONE, None, None)
+        torch.cuda.synchronize()
+        got = from_nhwc(out.torch(), B, Ho, Wo)
+        assert bool(torch.isfinite(got).all()) == finite, xscale
+        if finite:
+            x = rnd(B, Cin, H, W, seed=1) * xscale                        # _x3_problem's own draws (seed 1: x, seed 2: w)
+            w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
+            y = F.conv2d(x.double(), w.double()) * scale.cpu().double()[None, :, None, None] + shift.cpu().double()[None, :, None, None]
+            _x3_close(got.cpu(), y, f"x3 range {xscale}", tol=tol)
+
+
 def test_conv2d_x3_per_image_weights_and_layernorm():
     """Per-image pre-split weights (the squeeze-excite fold) and the LayerNorm that follows as a second kernel."""
     B, HW, Cin, Cout = 3, 300, 232, 128
