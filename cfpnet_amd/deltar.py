@@ -213,11 +213,12 @@ class Deltar(_Store):
         if self._eval_offs is None or self._eval_offs.device != eng.device:
             self._eval_offs = torch.zeros(3, 2, dtype=torch.int32, device=eng.device)
             self._eval_offs_host = (0,) * 6
+            self._eval_offs_views = {n: self._eval_offs[i] for i, n in enumerate(_OFFSET_NAMES)}     # made once: no aten::select per forward
         host = tuple(int(v) for n in _OFFSET_NAMES for v in pos_offsets.get(n, (0, 0)))
         if host != self._eval_offs_host:
             self._eval_offs.copy_(torch.tensor(host, dtype=torch.int32).view(3, 2))
             self._eval_offs_host = host
-        pos_offsets = {n: self._eval_offs[i] for i, n in enumerate(_OFFSET_NAMES)}
+        pos_offsets = self._eval_offs_views
         st = self._eval_caps.get(key)
         if st is None:
             if len(self._eval_caps) >= 4:                      # a handful of geometries at most: each pins its output ring
