@@ -343,7 +343,7 @@ void cfp_attn_debug_set(int value);          // attention.hip: key 19 = waves th
 void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vectors per workgroup, 4 = rows per strip (0 = automatic), 5 = 1 forces the VALU kernel
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
-    case 3: case 4: case 5: case 6: case 7: case 8: case 9: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: cfp_dw_debug_set(key, value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
     case 29: g_x3_ad = value; return CFP_OK;

@@ -837,6 +837,11 @@ int cfp_dwl_launch(const void* in, int in_ld, const void* w, const float* scale,
                    int act, int dtype, cfp_stream_t stream, const char* who);
 int cfp_dwl_slots(int B, int Ho, int Wo, int C, int stride);
 void cfp_dwl_debug_set(int value);
+// dw3x3_rows.hip: float32 storage, register-sliding rows (round 5)
+int cfp_dwr_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld, float* partial,
+                   int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who);
+int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride);
+void cfp_dwr_debug_set(int key, int value);
 
 namespace {
 // Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
@@ -903,6 +908,11 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
   CFP_REQUIRE(hpart == nullptr || ((mfma || dtype == CFP_F32) && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
               std::string(who) + ": the squeeze-excite partials need R <= 64 and, in 16-bit storage, C % 16 == 0");
+  if (dtype == CFP_F32 && hpart == nullptr && act != 99) {
+    // float32 storage (the default f16x3 mode): the register-sliding kernel (dw3x3_rows.hip), no LDS, no barrier
+    const int rc = cfp_dwr_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, stream, who);
+    if (rc != 1) return rc;
+  }
   if (mfma && g_dw_no_stream == 2 && act != 99) {
     // the sliding-window kernel (dw3x3_slide.hip): register window over input columns, one barrier per workgroup
     const int rc = cfp_dwl_launch(in, in_ld, w, scale, shift, out, out_ld, partial, w_red, RD, hpart, B, H, W, C, stride, pad_t, pad_l, Ho, Wo,
@@ -959,7 +969,8 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
 
 void cfp_dw_debug_set(int key, int value) {
   if (key == 3) g_dw_force_cvb = value; else if (key == 4) g_dw_force_R = value; else if (key == 5) g_dw_valu = value;
-  else if (key == 6) g_dw_no_stream = value; else if (key == 9) cfp_dwl_debug_set(value); else cfp_dws_debug_set(key, value);
+  else if (key == 6) g_dw_no_stream = value; else if (key == 9) cfp_dwl_debug_set(value); else if (key == 10 || key == 11) cfp_dwr_debug_set(key, value);
+  else cfp_dws_debug_set(key, value);
 }
 
 extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
@@ -971,6 +982,10 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
+  if (dtype == CFP_F32) {
+    const int n = cfp_dwr_slots(B, (Ho - 1) * stride + 3, (Wo - 1) * stride + 3, Ho, Wo, C, stride);
+    if (n > 0) return n;
+  }
   if (is16(dtype) && C % 16 == 0 && !g_dw_valu && g_dw_no_stream == 2) {
     const int n = cfp_dwl_slots(B, Ho, Wo, C, stride);
     if (n > 0) return n;

@@ -1785,6 +1785,55 @@ def test_dwconv3x3_sliding_window_kernel(case, dtype):
     assert torch.isfinite(h_new).all() and torch.allclose(h_new, h_old, rtol=1e-4, atol=1e-4 * float(h_old.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(8, 30, 40, 816, 1), (8, 15, 20, 1392, 1), (8, 60, 80, 224, 2), (8, 30, 40, 816, 2), (8, 30, 40, 448, 1),
+                                  (2, 26, 34, 672, 1), (2, 13, 17, 1392, 1), (2, 40, 60, 208, 1), (2, 52, 68, 224, 2),
+                                  (1, 7, 5, 16, 1), (3, 16, 16, 80, 1), (1, 33, 130, 48, 2), (2, 17, 3, 40, 1), (1, 1, 1, 8, 1), (2, 2, 9, 8, 2)])
+def test_dw3x3_rows_kernel_float32(case):
+    """dw3x3_rows_kernel (round 5; float32 storage = the default f16x3 mode's depthwise 3x3: a wave slides down the columns of 8 pixel
+    slots with the 3x3 window in registers, borders through the buffer descriptor's out-of-range zeros, no LDS) against the round-1
+    LDS-strip kernel it replaces and torch: the stored tensor is BIT-IDENTICAL to the old kernel's (same tap order, same epilogue),
+    at the plan's run length and at forced ones (1 row, 3 rows, the whole height); channel sums equal to float32 round-off; nothing
+    is written outside the output's column slice; input and output live in wider buffers."""
+    B, H, W, Cc, s = case
+    lib = hip.load()
+    dtype = torch.float32
+    Ho, Wo = -(-H // s), -(-W // s)
+    pt, pl = max((Ho - 1) * s + 3 - H, 0) // 2, max((Wo - 1) * s + 3 - W, 0) // 2
+    x = rnd(B, Cc, H, W, seed=11)
+    w = rnd(Cc, 1, 3, 3, seed=12, scale=0.4)
+    scale, shift = (rnd(Cc, seed=13).abs() + 0.5).to(DEV), rnd(Cc, seed=14).to(DEV)
+    wa = w.reshape(Cc, 9).t().contiguous().to(DEV)
+    xin = to_act(nhwc(x), dtype, ld=Cc + 12, c0=4)
+    res = []
+    try:
+        for mode, force_r in ((0, 0), (1, 0), (1, 1), (1, 3), (1, 10 ** 6)):
+            lib.cfp_debug_set(10, mode)
+            lib.cfp_debug_set(11, force_r)
+            buf = ops.new_act(B * Ho * Wo, Cc, dtype, DEV, ld=Cc + 8, zero=True)
+            out = ops.Act(buf.buf, 4, Cc)
+            ns = ops.dwconv3x3_strips(B, Ho, Wo, Cc, s, ops.DT[dtype])
+            part = torch.full((B, ns, Cc), float("nan"), device=DEV)
+            ops.dwconv3x3_sum(xin, wa, scale, shift, out, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
+            buf2 = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+            ops.dwconv3x3(xin, wa, scale, shift, buf2, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)          # without sums: same tensor
+            torch.cuda.synchronize()
+            assert torch.equal(buf2.buf, out.torch().contiguous())
+            res.append((buf.buf.clone(), part.sum(1).cpu(), ns))
+    finally:
+        lib.cfp_debug_set(10, 1)
+        lib.cfp_debug_set(11, 0)
+    ref = F.silu(F.conv2d(F.pad(x, (pl, (Wo - 1) * s + 3 - W - pl, pt, (Ho - 1) * s + 3 - H - pt)), w, None, s, 0, 1, Cc)
+                 * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None])
+    o_old, s_old, _ = res[0]
+    close(from_nhwc(ops.Act(o_old, 4, Cc).torch(), B, Ho, Wo), ref, dtype, f"dw3x3 old {case}")
+    for o_new, s_new, ns in res[1:]:
+        assert torch.equal(o_new, o_old), f"{int((o_new != o_old).sum())} elements differ from the LDS-strip kernel (slots {ns})"
+        assert float(o_new[:, :4].abs().max()) == 0 and float(o_new[:, 4 + Cc:].abs().max()) == 0
+        assert torch.isfinite(s_new).all() and torch.allclose(s_new, s_old, rtol=1e-5, atol=1e-5 * float(s_old.abs().max()))
+    want = ref.sum((2, 3))
+    assert torch.allclose(res[1][1], want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("case", [(1, 40, 50, 32, 31), (2, 33, 47, 16, 15), (1, 30, 40, 128, 7), (1, 64, 32, 8, 31)])
 def test_dwconv_large_toeplitz_bit_exact_on_integers(case, dtype):
