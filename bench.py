@@ -116,7 +116,7 @@ def kernel_times(engine, inputs, return_prob, reps=5, dw=True):
             B, H, W, C, stride, pt, pl, Ho, Wo = a[7:16] if name == "cfp_dwconv3x3_nhwc" else (a[8:17] if name == "cfp_dwconv3x3_sum_nhwc" else a[10:19])
             fam = "cfp_dwconv3x3_nhwc"
             flops = 2.0 * 9 * B * Ho * Wo * C
-            byts = 2.0 * (B * H * W * C + B * Ho * Wo * C + 9 * C)
+            byts = (4.0 if engine.dtype == torch.float32 else 2.0) * (B * H * W * C + B * Ho * Wo * C + 9 * C)
             dw_shapes.append((B * H * W, B * Ho * Wo, C))
             dw_calls.append((B, H, W, C, stride, pt, pl, Ho, Wo))
         elif name == "cfp_depth_head_fused":
@@ -194,8 +194,9 @@ def dw3x3_at_hbm_scale(calls, dtype, dev, scale_b=16):
     rows, t_k, t_c, byts = [], 0.0, 0.0, 0.0
     for (B, H, W, C, stride, pt, pl, Ho, Wo), n in shapes.items():
         Bs = B * scale_b
-        if Bs * H * W * C * 2 >= 2 ** 31 - 65536:
-            Bs = int((2 ** 31 - 65536) // (H * W * C * 2))
+        esz = 4 if dtype == torch.float32 else 2
+        if Bs * H * W * C * esz >= 2 ** 31 - 65536:
+            Bs = int((2 ** 31 - 65536) // (H * W * C * esz))
         NB = 3
         xs = [ops.new_act(Bs * H * W, C, dtype, dev) for _ in range(NB)]
         for x in xs:
@@ -205,15 +206,19 @@ def dw3x3_at_hbm_scale(calls, dtype, dev, scale_b=16):
         sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         R = max(8, C // 24)
         wr = torch.randn(R, C, device=dev) / math.sqrt(C)
-        K = ops.dwconv3x3_se_parts(Bs, Ho, Wo, C, stride, ops.DT[dtype])
+        f32 = dtype == torch.float32
+        K = ops.dwconv3x3_strips(Bs, Ho, Wo, C, stride, ops.DT[dtype]) if f32 else ops.dwconv3x3_se_parts(Bs, Ho, Wo, C, stride, ops.DT[dtype])
         if K <= 0:
             continue
-        hpart = torch.zeros(Bs * K * R, device=dev)
+        hpart = torch.zeros(Bs * K * (C if f32 else R), device=dev)
         k = [0]
 
         def run():
             i = k[0] % NB; k[0] += 1
-            ops.dwconv3x3_se(xs[i], w, sc, sh, outs[i], wr, hpart, Bs, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
+            if f32:      # float32 storage (the default f16x3 mode): depthwise + per-slot channel sums, as the in-flight plan launches it
+                ops.dwconv3x3_sum(xs[i], w, sc, sh, outs[i], hpart, Bs, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
+            else:
+                ops.dwconv3x3_se(xs[i], w, sc, sh, outs[i], wr, hpart, Bs, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
 
         crow = (Bs * H * W + Bs * Ho * Wo) // 2
         cdst = [ops.new_act(crow, C, dtype, dev) for _ in range(NB)] if crow > Bs * Ho * Wo else outs
@@ -223,8 +228,8 @@ def dw3x3_at_hbm_scale(calls, dtype, dev, scale_b=16):
             i = k[0] % NB; k[0] += 1
             ops.copy_rows(csrc[i], cdst[i], crow)
         tk, tc = _graph_us(run, calls=6, replays=5), _graph_us(cp, calls=6, replays=5)
-        nbytes = 2.0 * (Bs * H * W * C + Bs * Ho * Wo * C)
-        cbytes = 2.0 * 2 * crow * C
+        nbytes = float(esz) * (Bs * H * W * C + Bs * Ho * Wo * C)
+        cbytes = float(esz) * 2 * crow * C
         rows.append({"shape": f"{Bs}x{H}x{W}x{C} s{stride}", "launches": n, "MB": nbytes / 1e6, "us": tk, "GBps": nbytes / tk / 1e3, "copy_us": tc,
                      "copy_GBps": cbytes / tc / 1e3, "frac_of_measured_copy_rate": (nbytes / tk) / (cbytes / tc), "frac_of_hbm_peak": nbytes / tk / 1e3 / PEAK_HBM_GBS})
         t_k += n * tk; t_c += n * tc * nbytes / cbytes; byts += n * nbytes
@@ -259,13 +264,18 @@ def dw3x3_in_graph(calls, dtype, dev):
         sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         R = max(8, C // 24)
         wr = torch.randn(R, C, device=dev) / math.sqrt(C)
-        K = ops.dwconv3x3_se_parts(B, Ho, Wo, C, stride, ops.DT[dtype])
-        hpart = torch.zeros(B * max(K, 1) * R, device=dev)
+        f32 = dtype == torch.float32
+        esz = 4 if f32 else 2
+        K = ops.dwconv3x3_strips(B, Ho, Wo, C, stride, ops.DT[dtype]) if f32 else ops.dwconv3x3_se_parts(B, Ho, Wo, C, stride, ops.DT[dtype])
+        hpart = torch.zeros(B * max(K, 1) * (C if f32 else R), device=dev)
         k = [0]
 
         def run():
             i = k[0] % NB; k[0] += 1
-            ops.dwconv3x3_se(xs[i], w, sc, sh, outs[i], wr, hpart, B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
+            if f32:
+                ops.dwconv3x3_sum(xs[i], w, sc, sh, outs[i], hpart, B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
+            else:
+                ops.dwconv3x3_se(xs[i], w, sc, sh, outs[i], wr, hpart, B, H, W, stride, pt, pl, Ho, Wo, hip.ACT_SILU)
 
         crow = (B * H * W + B * Ho * Wo) // 2                  # a copy that reads and writes the kernel's bytes: (rows_in + rows_out) / 2 rows each way
         cdst = [ops.new_act(crow, C, dtype, dev) for _ in range(NB)] if crow > B * Ho * Wo else outs
@@ -275,8 +285,8 @@ def dw3x3_in_graph(calls, dtype, dev):
             i = k[0] % NB; k[0] += 1
             ops.copy_rows(csrc[i], cdst[i], crow)
         tk, tc = _graph_us(run), _graph_us(cp)
-        nbytes = 2.0 * (B * H * W * C + B * Ho * Wo * C)
-        cbytes = 2.0 * 2 * crow * C
+        nbytes = float(esz) * (B * H * W * C + B * Ho * Wo * C)
+        cbytes = float(esz) * 2 * crow * C
         rows.append({"shape": f"{B}x{H}x{W}x{C} s{stride}", "launches": n, "us": tk, "GBps": nbytes / tk / 1e3, "copy_us": tc, "copy_GBps": cbytes / tc / 1e3,
                      "frac_of_measured_copy_rate": (nbytes / tk) / (cbytes / tc)})
         t_k += n * tk; t_c += n * tc * nbytes / cbytes; byts += n * nbytes
@@ -819,7 +829,7 @@ def main():
         x3 = timed_mode("x3")
         x3_kt = None
         if not a.no_kernel_times:
-            x3_kt = kernel_times(x3[0], inputs, return_prob, reps=3, dw=False)
+            x3_kt = kernel_times(x3[0], inputs, return_prob, reps=3, dw=True)
         x3[0]._graph = None; x3[0]._slots = None
         x3 = (None,) + x3[1:] + (x3_kt,)
         torch.cuda.empty_cache()

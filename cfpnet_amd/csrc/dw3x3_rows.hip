@@ -30,6 +30,7 @@ namespace {
 
 struct DwrP {
   const float* in; const float* w; const float* scale; const float* shift; float* out; float* partial;
+  const float* w_red; float* hpart; int RD;      // squeeze-excite reduce FC [RD][C] and its partial dot products [B][nps * ncb][RD], or null
   int in_ld, out_ld, B, H, W, C, pad_t, pad_l, Ho, Wo, act;
   int R, nruns, CV, ncb, npx, nps;      // output rows per run, runs, C / 4, ceil(CV / 8), Wo * nruns, ceil(npx / 8)
   unsigned img_bytes, oimg_bytes;       // extent of one image of `in` / `out` in bytes (< 2^30)
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
     }
   }
 
-  if (p.partial == nullptr) return;
+  if (p.partial == nullptr && p.hpart == nullptr) return;
   // sum over the wave's 8 pixel slots (lane bits 3-5) in a fixed order; lanes 0-7 hold the result
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -134,7 +135,21 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
     v += __shfl_xor(v, 32, 64);
     csum[e] = v;
   }
-  if (pxl == 0 && cv < p.CV) *reinterpret_cast<f32x4*>(p.partial + ((long long)b * p.nps + psg) * p.C + c) = csum;
+  if (p.partial != nullptr && pxl == 0 && cv < p.CV) *reinterpret_cast<f32x4*>(p.partial + ((long long)b * p.nps + psg) * p.C + c) = csum;
+  if (p.hpart == nullptr) return;
+  // squeeze-excite: the reduce FC is linear in the channel sums, so the wave applies it to its own 32 channels (lane = hidden unit r <= 64):
+  // hpart[b][psg * ncb + cb][r] = sum_c w_red[r][c] * sum[c]; cfp_se_gate_fold2 adds the parts in index order.  Dead channels hold 0.
+  float dot = 0.f;
+  const bool r_ok = lane < p.RD;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const int cvv = (int)cb * 8 + l;                                             // wave-uniform
+    f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+    if (cvv < p.CV && r_ok) wq = *reinterpret_cast<const f32x4*>(p.w_red + (long long)lane * p.C + cvv * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot = fmaf(wq[e], lane_value(csum[e], l), dot);
+  }
+  if (r_ok) p.hpart[(((long long)b * p.nps + psg) * p.ncb + cb) * p.RD + lane] = dot;
 }
 
 }  // namespace
@@ -171,24 +186,27 @@ static bool dwr_plan(int B, int H, int W, int Ho, int Wo, int C, int stride, int
 
 void cfp_dwr_debug_set(int key, int value) { if (key == 10) g_dwr_mode = value; else if (key == 11) g_dwr_force_R = value; }
 
-int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride) {
+int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int* ncb) {
   DwrPlan d;
   if (!g_dwr_mode) return 0;
-  return dwr_plan(B, H, W, Ho, Wo, C, stride, C, C, d) ? d.nps : 0;
+  if (!dwr_plan(B, H, W, Ho, Wo, C, stride, C, C, d)) return 0;
+  if (ncb) *ncb = d.ncb;
+  return d.nps;
 }
 
 // -> CFP_OK, an error code, or 1 when the shape is not taken (the caller falls back to dw3x3_kernel<float>)
 int cfp_dwr_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld, float* partial,
-                   int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who) {
+                   const float* w_red, int RD, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who) {
   DwrPlan d, d0;
   if (!g_dwr_mode || (act != CFP_ACT_SILU && act != CFP_ACT_RELU && act != CFP_ACT_NONE)) return 1;
   const bool dense_ok = dwr_plan(B, H, W, Ho, Wo, C, stride, C, C, d0);          // what cfp_dwr_slots told the caller (it sized `partial` by it)
   if (!dwr_plan(B, H, W, Ho, Wo, C, stride, in_ld, out_ld, d) || !dense_ok || d0.nps != d.nps) {
-    if (partial && dense_ok) { cfp_set_error(std::string(who) + ": row pitch too large for the float32 depthwise kernel"); return CFP_ESHAPE; }
+    if ((partial || hpart) && dense_ok) { cfp_set_error(std::string(who) + ": row pitch too large for the float32 depthwise kernel"); return CFP_ESHAPE; }
     return 1;
   }
   DwrP p;
   p.in = (const float*)in; p.w = (const float*)w; p.scale = scale; p.shift = shift; p.out = (float*)out; p.partial = partial;
+  p.w_red = w_red; p.hpart = hpart; p.RD = RD;
   p.in_ld = in_ld; p.out_ld = out_ld; p.B = B; p.H = H; p.W = W; p.C = C; p.pad_t = pad_t; p.pad_l = pad_l; p.Ho = Ho; p.Wo = Wo; p.act = act;
   p.R = d.R; p.nruns = d.nruns; p.CV = C / 4; p.ncb = d.ncb; p.npx = d.npx; p.nps = d.nps;
   p.img_bytes = (unsigned)(((long long)(H * W - 1) * in_ld + C) * 4);

@@ -839,8 +839,8 @@ int cfp_dwl_slots(int B, int Ho, int Wo, int C, int stride);
 void cfp_dwl_debug_set(int value);
 // dw3x3_rows.hip: float32 storage, register-sliding rows (round 5)
 int cfp_dwr_launch(const void* in, int in_ld, const void* w, const float* scale, const float* shift, void* out, int out_ld, float* partial,
-                   int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who);
-int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride);
+                   const float* w_red, int RD, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who);
+int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int* ncb);
 void cfp_dwr_debug_set(int key, int value);
 
 namespace {
@@ -908,9 +908,9 @@ int dw3x3_launch(const void* in, int in_ld, const void* w, const float* scale, c
   const bool mfma = is16(dtype) && C % 16 == 0 && !g_dw_valu;
   CFP_REQUIRE(hpart == nullptr || ((mfma || dtype == CFP_F32) && w_red && RD > 0 && RD <= 64 && aligned16(w_red)), CFP_ESHAPE,
               std::string(who) + ": the squeeze-excite partials need R <= 64 and, in 16-bit storage, C % 16 == 0");
-  if (dtype == CFP_F32 && hpart == nullptr && act != 99) {
+  if (dtype == CFP_F32 && act != 99) {
     // float32 storage (the default f16x3 mode): the register-sliding kernel (dw3x3_rows.hip), no LDS, no barrier
-    const int rc = cfp_dwr_launch(in, in_ld, w, scale, shift, out, out_ld, partial, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, stream, who);
+    const int rc = cfp_dwr_launch(in, in_ld, w, scale, shift, out, out_ld, partial, w_red, RD, hpart, B, H, W, C, stride, pad_t, pad_l, Ho, Wo, act, stream, who);
     if (rc != 1) return rc;
   }
   if (mfma && g_dw_no_stream == 2 && act != 99) {
@@ -983,7 +983,7 @@ extern "C" int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, cons
 extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
   if (dtype == CFP_F32) {
-    const int n = cfp_dwr_slots(B, (Ho - 1) * stride + 3, (Wo - 1) * stride + 3, Ho, Wo, C, stride);
+    const int n = cfp_dwr_slots(B, (Ho - 1) * stride + 3, (Wo - 1) * stride + 3, Ho, Wo, C, stride, nullptr);
     if (n > 0) return n;
   }
   if (is16(dtype) && C % 16 == 0 && !g_dw_valu && g_dw_no_stream == 2) {
@@ -1007,7 +1007,10 @@ extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, 
 
 extern "C" int cfp_dwconv3x3_se_parts(int B, int Ho, int Wo, int C, int stride, int dtype) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2)) return 0;
-  if (dtype == CFP_F32 && C % 8 == 0) {     // float32 storage (the default f16x3 mode): the VALU kernel, 4 channels per vector
+  if (dtype == CFP_F32 && C % 8 == 0) {     // float32 storage (the default f16x3 mode): the register-sliding kernel, else the LDS-strip one
+    int ncb = 0;
+    const int n = cfp_dwr_slots(B, (Ho - 1) * stride + 3, (Wo - 1) * stride + 3, Ho, Wo, C, stride, &ncb);
+    if (n > 0) return n * ncb;
     const DwPlan d = dw_plan(B, Ho, Wo, C, stride, 4, false);
     return d.nstrips * cdiv(C / 4, d.cvb);
   }

@@ -1804,6 +1804,8 @@ def test_dw3x3_rows_kernel_float32(case):
     scale, shift = (rnd(Cc, seed=13).abs() + 0.5).to(DEV), rnd(Cc, seed=14).to(DEV)
     wa = w.reshape(Cc, 9).t().contiguous().to(DEV)
     xin = to_act(nhwc(x), dtype, ld=Cc + 12, c0=4)
+    RD = 24
+    wr = rnd(RD, Cc, seed=15, scale=0.1).to(DEV)
     res = []
     try:
         for mode, force_r in ((0, 0), (1, 0), (1, 1), (1, 3), (1, 10 ** 6)):
@@ -1816,17 +1818,23 @@ def test_dw3x3_rows_kernel_float32(case):
             ops.dwconv3x3_sum(xin, wa, scale, shift, out, part, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)
             buf2 = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
             ops.dwconv3x3(xin, wa, scale, shift, buf2, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)          # without sums: same tensor
+            K = ops.dwconv3x3_se_parts(B, Ho, Wo, Cc, s, ops.DT[dtype])
+            hpart = torch.full((B, K, RD), float("nan"), device=DEV)
+            buf3 = ops.new_act(B * Ho * Wo, Cc, dtype, DEV)
+            ops.dwconv3x3_se(xin, wa, scale, shift, buf3, wr, hpart, B, H, W, s, pt, pl, Ho, Wo, hip.ACT_SILU)   # with the reduce FC's partial dot products
             torch.cuda.synchronize()
-            assert torch.equal(buf2.buf, out.torch().contiguous())
-            res.append((buf.buf.clone(), part.sum(1).cpu(), ns))
+            assert torch.equal(buf2.buf, out.torch().contiguous()) and torch.equal(buf3.buf, buf2.buf)
+            res.append((buf.buf.clone(), part.sum(1).cpu(), ns, hpart.sum(1).cpu()))
     finally:
         lib.cfp_debug_set(10, 1)
         lib.cfp_debug_set(11, 0)
     ref = F.silu(F.conv2d(F.pad(x, (pl, (Wo - 1) * s + 3 - W - pl, pt, (Ho - 1) * s + 3 - H - pt)), w, None, s, 0, 1, Cc)
                  * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None])
-    o_old, s_old, _ = res[0]
+    o_old, s_old, _, h_old = res[0]
     close(from_nhwc(ops.Act(o_old, 4, Cc).torch(), B, Ho, Wo), ref, dtype, f"dw3x3 old {case}")
-    for o_new, s_new, ns in res[1:]:
+    want_h = ref.sum((2, 3)) @ wr.cpu().t()
+    for o_new, s_new, ns, h_new in res[1:]:
+        assert torch.isfinite(h_new).all() and torch.allclose(h_new, want_h, rtol=1e-4, atol=1e-4 * float(want_h.abs().max()))
         assert torch.equal(o_new, o_old), f"{int((o_new != o_old).sum())} elements differ from the LDS-strip kernel (slots {ns})"
         assert float(o_new[:, :4].abs().max()) == 0 and float(o_new[:, 4 + Cc:].abs().max()) == 0
         assert torch.isfinite(s_new).all() and torch.allclose(s_new, s_old, rtol=1e-5, atol=1e-5 * float(s_old.abs().max()))
