@@ -32,7 +32,7 @@ struct DwrP {
   const float* in; const float* w; const float* scale; const float* shift; float* out; float* partial;
   const float* w_red; float* hpart; int RD;      // squeeze-excite reduce FC [RD][C] and its partial dot products [B][nps * ncb][RD], or null
   int in_ld, out_ld, B, H, W, C, pad_t, pad_l, Ho, Wo, act;
-  int R, nruns, CV, ncb, npx, nps;      // output rows per run, runs, C / 4, ceil(CV / 8), Wo * nruns, ceil(npx / 8)
+  int R, nruns, CV, ncb, npx, nps;      // output rows per run, runs, C / 4, ceil(CV / 8), Wo * nruns, ceil(ceil(npx / 8) / 4) = SLOTS (workgroups per image and channel block)
   unsigned img_bytes, oimg_bytes;       // extent of one image of `in` / `out` in bytes (< 2^30)
   FastDiv dWo, dnps, dncb;
 };
@@ -40,14 +40,18 @@ struct DwrP {
 constexpr unsigned DWR_OOB = 0x40000000u;     // added to a byte offset: beyond every image (< 2^30 bytes), also when added twice
 
 template <int STRIDE, int ACT>
-__global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
+__global__ __launch_bounds__(256) void dw3x3_rows_kernel(DwrP p) {
   constexpr int NB = STRIDE == 1 ? 4 : 5;       // ring of input rows: output row i reads rows S i .. S i + 2, rows S i + 3 .. are in flight
-  const int lane = threadIdx.x;
-  // task = (image, 8-vector channel block, group of 8 pixel slots); XCD-aware: neighbouring groups / blocks share lines in one L2
+  const int lane = threadIdx.x & 63;
+  const int wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // task = (image, 8-vector channel block, FOUR groups of 8 pixel slots: one per wave); XCD-aware: neighbouring tasks share lines in one L2.
+  // The four waves never meet before the channel sums at the very end (one barrier): they exist to cut the number of partial-sum slots
+  // the squeeze-excite tail has to add (cfp_se_gate_fold / fold2 walk them serially) by four.
   unsigned t = (unsigned)xcd_remap(blockIdx.x, gridDim.x);
-  unsigned psg, cb, b;
-  fd_rowcol(t, p.dnps, t, psg);
+  unsigned psg4, cb, b;
+  fd_rowcol(t, p.dnps, t, psg4);
   fd_rowcol(t, p.dncb, b, cb);
+  const unsigned psg = psg4 * 4 + (unsigned)wv_id;
   const int cvl = lane & 7, pxl = lane >> 3;
   const int cv = (int)cb * 8 + cvl;
   const int ps = (int)psg * 8 + pxl;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
   f32x4 rb[NB][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) ldrow(r, rb[r]);
-  const int R = p.R;
+  const int R = (int)psg * 8 < p.npx ? p.R : 0;      // a wave past the last pixel slot (the workgroup's ragged tail) only joins the final barrier
   {
     for (int i0 = 0; i0 < R; i0 += NB) {
 #pragma unroll
@@ -126,7 +130,8 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
   }
 
   if (p.partial == nullptr && p.hpart == nullptr) return;
-  // sum over the wave's 8 pixel slots (lane bits 3-5) in a fixed order; lanes 0-7 hold the result
+  // sum over the wave's 8 pixel slots (lane bits 3-5) in a fixed order, then over the four waves through LDS (wave order): wave 0 holds the
+  // workgroup's 32 channel sums in lanes 0-7 (and in every lane with the same cvl)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v = csum[e];
@@ -135,10 +140,15 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
     v += __shfl_xor(v, 32, 64);
     csum[e] = v;
   }
-  if (p.partial != nullptr && pxl == 0 && cv < p.CV) *reinterpret_cast<f32x4*>(p.partial + ((long long)b * p.nps + psg) * p.C + c) = csum;
+  __shared__ f32x4 wsum[4][8];
+  if (lane < 8) wsum[wv_id][lane] = csum;
+  __syncthreads();
+  if (wv_id != 0) return;
+  csum = (wsum[0][cvl] + wsum[1][cvl]) + (wsum[2][cvl] + wsum[3][cvl]);
+  if (p.partial != nullptr && pxl == 0 && cv < p.CV) *reinterpret_cast<f32x4*>(p.partial + ((long long)b * p.nps + psg4) * p.C + c) = csum;
   if (p.hpart == nullptr) return;
-  // squeeze-excite: the reduce FC is linear in the channel sums, so the wave applies it to its own 32 channels (lane = hidden unit r <= 64):
-  // hpart[b][psg * ncb + cb][r] = sum_c w_red[r][c] * sum[c]; cfp_se_gate_fold2 adds the parts in index order.  Dead channels hold 0.
+  // squeeze-excite: the reduce FC is linear in the channel sums, so the workgroup applies it to its own 32 channels (lane = hidden unit
+  // r <= 64): hpart[b][slot * ncb + cb][r] = sum_c w_red[r][c] * sum[c]; cfp_se_gate_fold2 adds the parts in index order.  Dead channels hold 0.
   float dot = 0.f;
   const bool r_ok = lane < p.RD;
 #pragma unroll
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(64) void dw3x3_rows_kernel(DwrP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) dot = fmaf(wq[e], lane_value(csum[e], l), dot);
   }
-  if (r_ok) p.hpart[(((long long)b * p.nps + psg) * p.ncb + cb) * p.RD + lane] = dot;
+  if (r_ok) p.hpart[(((long long)b * p.nps + psg4) * p.ncb + cb) * p.RD + lane] = dot;
 }
 
 }  // namespace
@@ -168,19 +178,24 @@ static bool dwr_plan(int B, int H, int W, int Ho, int Wo, int C, int stride, int
     if (g_dwr_force_R && R != std::min(g_dwr_force_R, Ho)) continue;
     const int nruns = cdiv(Ho, R);
     if (!g_dwr_force_R && cdiv(Ho, nruns) != R) continue;                // the shortest run length for this run count
-    const long long npx = (long long)Wo * nruns, nps = (npx + 7) / 8;
+    const long long npx = (long long)Wo * nruns, nps = (npx + 7) / 8;      // pixel-slot groups = live waves per image and channel block
     const long long waves = (long long)B * ncb * nps;
+    // A time model in microseconds, fitted on tools/dw_bench_f32.py --sweep-r at batch 1 / 8 / 128 (profiles/r5a_dw_f32_sweep.txt):
+    //   bytes: halo rows cost what first reads cost (a neighbouring run is rarely in flight nearby); ~5.5 TB/s while the chip is full;
+    //   chain: a lane's R row steps are serial (~0.25 us each: load -> 36 FMAs -> store), once per resident round of 4 096 waves;
+    //   tail:  every slot is one more partial vector the squeeze-excite kernel adds serially (~10 ns each).
     const double halo = (double)((R - 1) * stride + 3) / (R * stride);  // input rows read per input row used
     const double lanes = (double)(nps * 8) / npx;
     const double rows = (double)(nruns * R) / Ho;                       // ragged last run (its lanes idle through the tail rows)
-    // fitted on tools/dw_bench_f32.py --sweep-r (profiles/r5a_dw_f32_sweep.txt): the optimum sits at ~2 000 - 2 800 waves (one resident round:
-    // 122 VGPRs = 4 waves per SIMD = 4 096 per chip) and halo rows cost what first reads cost (a neighbouring run is rarely in flight nearby)
-    const double fill = waves >= 2048 ? 1.0 : 2048.0 / (double)waves;
-    const double cst = halo * lanes * rows * fill;
+    const double in_b = 4.0 * B * H * W * C, out_b = 4.0 * B * Ho * Wo * C;
+    const double t_mem = (in_b * halo + out_b) * lanes * rows / 5.5e6;
+    const double t_chain = std::max(1.0, (double)waves / 4096.0) * R * 0.25;
+    const double t_tail = 0.01 * (double)((nps + 3) / 4) * ncb;
+    const double cst = t_mem + t_chain + t_tail;
     if (cst < bc) { bc = cst; best = R; }
   }
   if (best == 0) return false;
-  d.R = best; d.nruns = cdiv(Ho, best); d.npx = Wo * d.nruns; d.nps = cdiv(d.npx, 8); d.ncb = ncb;
+  d.R = best; d.nruns = cdiv(Ho, best); d.npx = Wo * d.nruns; d.nps = cdiv(cdiv(d.npx, 8), 4); d.ncb = ncb;      // nps = workgroups (4 waves) per image and channel block
   return (long long)B * ncb * d.nps < (1ll << 31);
 }
 
@@ -212,10 +227,10 @@ int cfp_dwr_launch(const void* in, int in_ld, const void* w, const float* scale,
   p.img_bytes = (unsigned)(((long long)(H * W - 1) * in_ld + C) * 4);
   p.oimg_bytes = (unsigned)(((long long)(Ho * Wo - 1) * out_ld + C) * 4);
   p.dWo = make_fastdiv((unsigned)Wo); p.dnps = make_fastdiv((unsigned)d.nps); p.dncb = make_fastdiv((unsigned)d.ncb);
-  const long long waves = (long long)B * d.ncb * d.nps;
+  const long long wgs = (long long)B * d.ncb * d.nps;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the activation is a template argument (one register budget per variant: erff's temporaries would set it for all of them otherwise)
-#define DWR(ST, AC) hipLaunchKernelGGL((dw3x3_rows_kernel<ST, AC>), dim3((unsigned)waves), dim3(64), 0, s, p)
+#define DWR(ST, AC) hipLaunchKernelGGL((dw3x3_rows_kernel<ST, AC>), dim3((unsigned)wgs), dim3(256), 0, s, p)
   if (act == CFP_ACT_SILU) { if (stride == 1) DWR(1, CFP_ACT_SILU); else DWR(2, CFP_ACT_SILU); }
   else if (act == CFP_ACT_RELU) { if (stride == 1) DWR(1, CFP_ACT_RELU); else DWR(2, CFP_ACT_RELU); }
   else { if (stride == 1) DWR(1, CFP_ACT_NONE); else DWR(2, CFP_ACT_NONE); }

@@ -144,9 +144,11 @@ class Engine:
         # The float32 depthwise kernel leaves the same partial dot products, so the default f16x3 mode can take this path too.  Measured:
         # one graph at a time it is faster at every batch (3.69 vs 3.87 ms at batch 1, 4.03 vs 4.26 at 2, 4.91 vs 5.05 at 4, 7.08 vs 7.17 at 8:
         # one launch fewer per block on the critical path), with four batches in flight it is neutral to slightly slower (4.63 vs 4.59 ms at
-        # batch 8).  So the f16x3 engine takes it outside the in-flight plan (`se2_x3`; CFP_SE2_X3=0 never, =1 always).
+        # batch 8) -- with the round-1 LDS-strip kernel.  Round 5: dw3x3_rows_kernel (csrc/dw3x3_rows.hip) takes the dot products in its
+        # tail at no visible cost, and with four batches in flight the path is now ahead too (4.47 vs 4.51 ms at batch 8): always on
+        # (`se2_x3`; CFP_SE2_X3=0 never, =auto outside the in-flight plan only).
         self.se2 = dtype in (torch.bfloat16, torch.float16) and os.environ.get("CFP_SE2", "1") == "1"
-        self.se2_x3 = os.environ.get("CFP_SE2_X3", "auto") if self.x3 else "0"
+        self.se2_x3 = os.environ.get("CFP_SE2_X3", "1") if self.x3 else "0"
         # DIAGNOSTIC ONLY (tools/precision_family.py --acts): "name:dtype,..." rounds the named encoder tensors of a float32 engine to a
         # 16-bit format in place right after they are produced, to attribute the 16-bit error to single tensors.  Never set in product use.
         self._dbg_round = {}
