@@ -6,6 +6,7 @@ buffers.  torch is used for device memory and the stream only.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -226,6 +227,10 @@ def pack_w_x3(w2d: torch.Tensor) -> torch.Tensor:
     rows, k = w2d.shape
     out = torch.empty(rows, (k + 31) // 32 * 64, dtype=torch.float16, device=w2d.device)
     hip.call("cfp_pack_w_x3", w2d.data_ptr(), out.data_ptr(), rows, k, _s())
+    if os.environ.get("CFP_X3_DIAG_TWO_TERM", "0") == "1":
+        # DIAGNOSTIC ONLY (tools/x3_two_term_probe.py, VERDICT r4 task 1b): zero the lo halves of the STATIC weights, i.e. the accuracy of a
+        # two-term product A_hi W_hi + A_lo W_hi (weights as ONE half) measured with the three-term kernels.  Never set in product use.
+        out.view(rows, -1, 2, 32)[:, :, 1, :] = 0
     return out
 
 
