@@ -602,6 +602,53 @@ def training_kernel_times(tr, inp, target):
     return agg
 
 
+XGMI_LINK_GBPS = 153.0        # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links per GPU, fully connected 8-GPU mesh)
+
+
+def allreduce_plan(tr, inp, target, measure_window: bool):
+    """What the data-parallel exchange of one training step moves and what it can hide behind (VERDICT r4 task 7): the per-bucket payloads
+    of the flat float32 gradient in the order they are reduced, the overlap window (duration of the RGB-encoder backward, the second graph
+    of the split step, measured here on one GPU), and two wire-time models per world size -- so that `allreduce_ms` of a 2 / 4 / 8-GPU
+    run can be judged at first sight.  No collective runs here."""
+    from cfpnet_amd import train_ops  # noqa: F401
+    flat = tr.flat
+    bucket_elems = 8 * 1024 * 1024
+    groups, payload = [], 0
+    for gi, what in ((1, "10x lr group (head, decoder, fusion blocks, ToF encoder): final after the first graph, reduced on the communication stream BESIDE the RGB-encoder backward"),
+                     (0, "1x lr group (RGB encoder): reduced after the second graph, exposed")):
+        lo, hi = flat.group_range[gi]
+        groups.append({"group": what, "elements": int(hi - lo), "MB": (hi - lo) * 4 / 1e6,
+                       "buckets_MB": [round((b1 - b0) * 4 / 1e6, 2) for b0, b1 in flat.buckets(bucket_elems, lo, hi)]})
+        payload += (hi - lo) * 4
+    out = {"dtype": "float32", "payload_MB": payload / 1e6, "groups_in_reduction_order": groups,
+           "dead_tail_excluded_elements": int(flat.total - flat.live) if hasattr(flat, "total") else None}
+    models = {}
+    for n in (2, 4, 8):
+        ring = 2.0 * (n - 1) / n * payload / (XGMI_LINK_GBPS * 1e9) * 1e3          # every rank sends 2 (N-1)/N x payload over ONE link (ring neighbours)
+        mesh = 2.0 * payload / n / (XGMI_LINK_GBPS * 1e9) * 1e3                     # direct reduce-scatter + all-gather: payload / N per link and phase, N-1 links in parallel
+        models[str(n)] = {"ring_ms_at_one_link": ring, "direct_rs_ag_ms_on_the_mesh": mesh}
+    out["wire_time_models_ms"] = {"link_GBps": XGMI_LINK_GBPS, "by_world_size": models,
+                                  "what": "lower bounds from bytes / link rate only (no latency, no protocol overhead); RCCL's default for 8 fully "
+                                          "connected GPUs is a ring per channel over several links, so the measured figure should fall between the two"}
+    if measure_window:
+        if True:                                      # (the trainer is discarded right after this: its single-graph capture is replaced)
+            tr.capture(inp, target, split=True)
+            for _ in range(2):
+                tr._graph.replay(); tr._graph2.replay()
+            ts = []
+            for _ in range(5):
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record(); tr._graph.replay(); e1.record(); tr._graph2.replay(); e2.record()
+                torch.cuda.synchronize()
+                ts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+            ts.sort(key=lambda t: t[1])
+            first, second = ts[len(ts) // 2]
+            out["overlap_window"] = {"first_graph_ms": first, "rgb_encoder_backward_ms": second,
+                                     "what": "the 10x group's all-reduce (first entry above) has `rgb_encoder_backward_ms` to hide behind; the 1x group's is exposed",
+                                     "hidden_if_10x_allreduce_ms_below": second}
+    return out
+
+
 def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 1, warmup: int = 2, fidelity: bool = False, dtype=None):
     """BASELINE.json configs[2..3] shape: 416x544 crops, 6x6 zones of 64 px, `batch` samples per GPU, 16-bit activations with
     float32 master parameters; one step = training forward + SILog + backward (+ gradient all-reduce) + AdamW/OneCycle, replayed as
@@ -685,6 +732,10 @@ def training_step_rate(batch: int, dev, steps: int = 6, dist=None, world: int = 
                                  "protocol": "one instrumented EAGER step after the timed region: HIP events around every C-ABI call on the launch stream; "
                                              "algorithmic FLOPs 2 M N K of the forward / data-gradient / weight-gradient GEMMs, 16-bit operand bytes"}
     if dtype == torch.float16:
+        try:
+            extra["allreduce_plan"] = allreduce_plan(tr, inp, target, measure_window=dist is None)
+        except Exception as e:                        # a diagnostic appendix must never take the line down
+            extra["allreduce_plan"] = {"error": repr(e)}
         extra["overflow_guard"] = {"skipped_steps": tr.opt.skipped_steps(),
                                    "what": "a step whose gradient norm is not finite is skipped on the device (cfp_grad_clip_factor / cfp_adamw_step)"}
     loss_last = float(loss)
@@ -720,7 +771,7 @@ def main():
                               "warmup": a.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic", "config": r["config"],
                               "loss_first_step": r["loss_first_step"],
-                              **{k: r[k] for k in ("allreduce_ms", "overlap_frac", "ms_per_step_sequential_allreduce", "ms_per_step_no_allreduce", "allreduce") if k in r}}))
+                              **{k: r[k] for k in ("allreduce_ms", "overlap_frac", "ms_per_step_sequential_allreduce", "ms_per_step_no_allreduce", "allreduce", "allreduce_plan") if k in r}}))
         if dist:
             dist.barrier()
             dist.destroy_process_group()
