@@ -187,7 +187,8 @@ static bool dwr_plan(int B, int H, int W, int Ho, int Wo, int C, int stride, int
     const double halo = (double)((R - 1) * stride + 3) / (R * stride);  // input rows read per input row used
     const double lanes = (double)(nps * 8) / npx;
     const double rows = (double)(nruns * R) / Ho;                       // ragged last run (its lanes idle through the tail rows)
-    const double in_b = 4.0 * B * H * W * C, out_b = 4.0 * B * Ho * Wo * C;
+    const double in_b = 4.0 * B * (Ho * stride) * (Wo * stride) * C, out_b = 4.0 * B * Ho * Wo * C;      // from the OUTPUT extent only: cfp_dwr_slots (asked before
+                                                                                                         // the launch, without H / W) must see the same plan
     const double t_mem = (in_b * halo + out_b) * lanes * rows / 5.5e6;
     const double t_chain = std::max(1.0, (double)waves / 4096.0) * R * 0.25;
     const double t_tail = 0.01 * (double)((nps + 3) / 4) * ncb;
@@ -197,6 +198,12 @@ static bool dwr_plan(int B, int H, int W, int Ho, int Wo, int C, int stride, int
   if (best == 0) return false;
   d.R = best; d.nruns = cdiv(Ho, best); d.npx = Wo * d.nruns; d.nps = cdiv(cdiv(d.npx, 8), 4); d.ncb = ncb;      // nps = workgroups (4 waves) per image and channel block
   return (long long)B * ncb * d.nps < (1ll << 31);
+}
+
+int cfp_dwr_launch_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int in_ld, int out_ld) {
+  DwrPlan d;
+  if (!g_dwr_mode || !dwr_plan(B, H, W, Ho, Wo, C, stride, in_ld, out_ld, d)) return 0;
+  return d.nps;
 }
 
 void cfp_dwr_debug_set(int key, int value) { if (key == 10) g_dwr_mode = value; else if (key == 11) g_dwr_force_R = value; }

@@ -842,6 +842,7 @@ int cfp_dwr_launch(const void* in, int in_ld, const void* w, const float* scale,
                    const float* w_red, int RD, float* hpart, int B, int H, int W, int C, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, cfp_stream_t stream, const char* who);
 int cfp_dwr_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int* ncb);
 void cfp_dwr_debug_set(int key, int value);
+int cfp_dwr_launch_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int in_ld, int out_ld);
 
 namespace {
 // Work decomposition of the depthwise 3x3 kernel: CVB channel vectors and R output rows per workgroup.
@@ -995,6 +996,11 @@ extern "C" int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, in
     if (n > 0) return n;
   }
   return dw_plan(B, Ho, Wo, C, stride, vec_elems(dtype), is16(dtype) && C % 16 == 0 && !g_dw_valu).nstrips;
+}
+
+extern "C" int cfp_dwconv3x3_launch_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int in_ld, int out_ld, int dtype) {
+  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (stride != 1 && stride != 2) || dtype != CFP_F32) return 0;
+  return cfp_dwr_launch_slots(B, H, W, Ho, Wo, C, stride, in_ld, out_ld);
 }
 
 extern "C" int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,

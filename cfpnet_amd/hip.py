@@ -37,6 +37,7 @@ SIGNATURES = {
     "cfp_conv2d_variant": (_i, [_i, _i]),
     "cfp_dwconv3x3_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i] + [_i] * 11 + [_p]),
     "cfp_dwconv3x3_strips": (_i, [_i] * 6),
+    "cfp_dwconv3x3_launch_slots": (_i, [_i] * 10),
     "cfp_dwconv3x3_sum_nhwc": (_i, [_p, _i, _p, _p, _p, _p, _i, _p] + [_i] * 11 + [_p]),
     "cfp_se_fold": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "cfp_se_gate_fold": (_i, [_p, _i, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

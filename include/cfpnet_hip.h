@@ -132,6 +132,10 @@ int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* sc
  * pass: cfp_se_hidden(partial, nsplit = strips, ...) consumes it directly.  Strip order and the
  * in-strip reduction order are fixed: the sums are run-to-run deterministic. */
 int cfp_dwconv3x3_strips(int B, int Ho, int Wo, int C, int stride, int dtype);
+/* The number of slots the float32-storage LAUNCH will write for these full arguments (0: it does not take the shape and the older kernel's
+ * own count applies).  Host-side only, no GPU work: tests/test_abi.py sweeps shapes and checks that it equals cfp_dwconv3x3_strips, which is
+ * asked WITHOUT the input extent -- a mismatch would be an out-of-bounds write into `partial` (found and fixed in round 5). */
+int cfp_dwconv3x3_launch_slots(int B, int H, int W, int Ho, int Wo, int C, int stride, int in_ld, int out_ld, int dtype);
 int cfp_dwconv3x3_sum_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                            void* out, int out_ld, float* partial, int B, int H, int W, int C, int stride,
                            int pad_t, int pad_l, int Ho, int Wo, int act, int dtype, cfp_stream_t stream);

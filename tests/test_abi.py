@@ -98,3 +98,25 @@ def test_deltar_container_on_cpu():
     with pytest.raises(NotImplementedError):
         args.attention_layer = ["hist2image", "bogus"]
         make_model(args)
+
+
+def test_float32_depthwise_slot_count_is_the_same_with_and_without_the_input_extent():
+    """Round 5 bug: `cfp_dwconv3x3_strips` (asked before the launch, without H / W) and the launch's own plan used slightly different byte
+    counts in their time model, chose different run lengths at batch 4 and the kernel wrote more `partial` slots than the caller had
+    allocated (a GPU memory fault in tools/probes/x3_b4_check.py).  The plan now depends on the output extent only; this sweep pins it for
+    every encoder shape x batch 1..32 x both paddings of a SAME-padded input, and for odd sizes."""
+    from cfpnet_amd import hip
+    lib = hip.load()
+    n = 0
+    for (H, W, C, s) in [(60, 80, 224, 2), (30, 40, 448, 1), (30, 40, 672, 1), (30, 40, 816, 1), (30, 40, 816, 2), (15, 20, 1392, 1),
+                         (52, 68, 224, 2), (26, 34, 672, 1), (13, 17, 1392, 1), (80, 120, 224, 2), (40, 60, 816, 1), (20, 30, 1392, 1),
+                         (7, 5, 16, 1), (33, 130, 48, 2), (17, 3, 40, 1), (1, 1, 8, 1)]:
+        Ho, Wo = -(-H // s), -(-W // s)
+        for B in list(range(1, 33)) + [48, 64, 128, 256]:
+            want = lib.cfp_dwconv3x3_strips(B, Ho, Wo, C, s, hip.F32)
+            for (h, w) in ((H, W), (Ho * s, Wo * s), ((Ho - 1) * s + 1, (Wo - 1) * s + 1)):
+                for ld in (C, C + 12):
+                    got = lib.cfp_dwconv3x3_launch_slots(B, h, w, Ho, Wo, C, s, ld, ld, hip.F32)
+                    assert got == want and got > 0, (B, H, W, C, s, h, w, ld, got, want)
+                    n += 1
+    assert n > 3000
