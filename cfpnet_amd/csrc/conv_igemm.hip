@@ -462,7 +462,7 @@ int pick_ln_variant(int Cout, long long M) {   // the tile must span exactly Cou
 
 // Plan of the f16x3 kernels (float32 storage, conv_igemm_x3.hip): the gen-2 rules on the equivalent 16-bit problem.  A K-step of 32
 // channels moves the bytes and takes the LDS reads of a 64-channel 16-bit step, so the rules see twice the K.
-static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split, bool tput) {
+static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split, bool tput, bool piw_split = true) {
   Plan2 pl = plan2(M, N, 2 * (cdiv(K, 32) * 32), rpb, B, allow_split, false, tput);
   // short-K, many-row problems (the rules' "first-generation" answer) and the direct 3x3 kernel have no f16x3 form: row-heavy tiles
   if (pl.gen1 || pl.direct >= 0) pl.variant = N <= 16 ? 10 : N <= 32 ? 16 : N <= 64 ? 14 : K <= 64 ? 16 : 1;
@@ -478,6 +478,14 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
   // (300 x 1392 x 232: 7.7 vs 10.5 us)
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 2400 && K >= 2000 && N >= 128 && (pl.variant == 15 || pl.variant == 13)) pl.variant = 19;
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 512 && N >= 512 && K <= 512) pl.variant = 17;
+  // per-image weights (the squeeze-excite-folded project GEMMs) on a handful of row tiles with a long K -- single images: 300 x 232 x 1392 is
+  // 20 tiles of 44 serial K-steps at ~0.8 us each (18.2 us, profiles/r4_conv_bench_x3_b1_alone.txt) on 20 of 256 CUs.  K splits instead of the
+  // two K groups (round 5; the caller passes the slab workspace, cfp_conv2d_plan with rows_per_batch > 0 tells it the split count)
+  if (rpb > 0 && !tput && piw_split && pl.splits <= 1) {
+    const long long tiles = (long long)B * cdiv(rpb, 64) * cdiv(N, 64);
+    const int nks = cdiv(K, 32);
+    if (tiles <= 64 && nks >= 20) { pl.variant = 4; pl.splits = nks >= 40 ? 8 : 4; }
+  }
   if (g_x3_ad && pl.splits <= 1) pl.variant = x3_ad_of(pl.variant);
   return pl;
 }
@@ -611,8 +619,12 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (g_force_variant >= 400 && g_force_variant - 400 < igemm_x3_num_variants()) pl.variant = g_force_variant - 400;
     if (g_force_splits >= 1) pl.splits = g_force_splits;
     if (pl.splits > 1 && pl.variant >= 19) pl.variant = 4;
-    if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * cdiv(p.K, 32) * 64; pl.splits = 1; }
-    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) pl.splits = 1;
+    if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * cdiv(p.K, 32) * 64; }
+    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) {
+      pl.splits = 1;
+      if (rpb > 0) pl = plan_x3(p.M, Cout, p.K, rpb, B, false, tput, false);      // no workspace: the un-split plan of this problem (K groups)
+      pl.splits = 1;
+    }
     // LayerNorm over Cout in the epilogue when a four-row-wave tile spans exactly Cout channels; otherwise as a second kernel
     int ln_v = -1;
     if (ln_gamma && rpb == 0 && g_x3_ln_fused) ln_v = Cout == 128 ? (p.M >= 30000 ? 26 : 27) : Cout == 64 ? (p.M >= 100000 ? 14 : 13) : Cout == 32 ? 16 : Cout == 16 ? 11 : -1;

@@ -466,7 +466,7 @@ class Engine:
                     ops.se_gate_fold2(hpart, K, 1.0 / (ho * wo), self.P[q + ".se.br"], self.P[q + ".se.we_t"], self.P[q + ".se.be"],
                                       self.P[q + ".pwl.w32"], wb, B, b.cout, b.mid, b.se_rd, x3=self.x3)
                     ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
-                               res, None, per_image_weights=True)
+                               res, self._piw_ws(plan, bi, B, ho * wo, b.cout, b.mid), per_image_weights=True)
                     x, h, w = out, ho, wo
                     if bi in spec.ENC_TAPS:
                         tap_acts.append(out)
@@ -492,7 +492,7 @@ class Engine:
                 ops.se_gate_fold(part, ns, 1.0 / (ho * wo), self.P[q + ".se.wr"], self.P[q + ".se.br"], self.P[q + ".se.we_t"],
                                  self.P[q + ".se.be"], self.P[q + (".pwl.w32" if self.x3 else ".pwl.w")], wb, B, b.cout, b.mid, b.se_rd)
                 ops.conv2d(mid2, wb, self.P[q + ".pwl.s"], self.P[q + ".pwl.t"], out, B, ho, wo, 1, 1, 1, 0, 0, ho, wo, hip.ACT_NONE,
-                           res, None, per_image_weights=True)
+                           res, self._piw_ws(plan, bi, B, ho * wo, b.cout, b.mid), per_image_weights=True)
             self._dbg(f"enc{bi}", out)
             x, h, w = out, ho, wo
             if bi in spec.ENC_TAPS:
@@ -579,6 +579,14 @@ class Engine:
         hid = self._act(plan, f"{tag}.hid", rows_q, 2 * D)
         self._lin(p + ".mlp0", xb, hid, rows_q, hip.ACT_RELU)
         self._lin(p + ".mlp2", hid, out, rows_q, residual=x, ln=(self.P[p + ".norm2.g"], self.P[p + ".norm2.b"], 1e-5))
+
+    def _piw_ws(self, plan, bi: int, B: int, hw: int, cout: int, k: int):
+        """Split-K slab workspace of a per-image-weight project GEMM in the f16x3 mode, when the kernel plan wants one (single images: a few
+        row tiles x a long K; cfp_conv2d_plan with rows_per_batch = hw), else None."""
+        if not self.x3:
+            return None
+        _, sp = ops.conv2d_plan(B * hw, cout, k, hip.F32X3, hw, B, 1, 1)
+        return self._f32(plan, f"enc{bi}.piw_ws", sp * B * hw * cout) if sp > 1 else None
 
     def _fusion(self, plan, name: str, x: Act, feat1: Act, zone_valid: torch.Tensor, geo: FusionGeometry, B, H, W, out: Act,
                 pos_offset, taps):

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 import re
-from typing import Dict, Iterable, Tuple
+from typing import Dict, Iterable, Optional, Tuple
 
 import numpy as np
 
@@ -161,13 +161,15 @@ def make_torch_state_dict(manifest, family: str = "uniform"):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in make_state_dict(manifest, family).items()}
 
 
-def trained_like_state_dict(layer_names, steps: int = 300, batch: int = 4, device="cuda:0", lr: float = 3e-4, seed: int = 7, dtype=None):
+def trained_like_state_dict(layer_names, steps: int = 300, batch: int = 4, device="cuda:0", lr: float = 3e-4, seed: int = 7, dtype=None,
+                            loss_log: Optional[list] = None):
     """The closest stand-in for the authors' `best.pt` (/root/reference/README.md:22) that can be made offline: the reference's own
     initialisation (the `kaiming` family) after `steps` real optimisation steps of `trainer.Trainer` (train.py:104-135: training forward,
     SILog, backward, AdamW / OneCycle) on synthetic 416x544 crops whose target depth FOLLOWS the ToF zones (zone means of the histogram
     samples, bilinearly spread over the crop) -- so the network learns depth completion from its inputs: a confident (peaked) 256-way head,
     BatchNorm running statistics that are real moving averages, weights that have left their initial distribution.  Runs on the GPU
-    (there is no CPU training path); returns a reference-layout state dict on the CPU."""
+    (there is no CPU training path); returns a reference-layout state dict on the CPU.  `dtype`: the Trainer's storage mode (default float32);
+    `loss_log`: receives the SILog value of every step."""
     import torch
     import torch.nn.functional as F
     from . import spec, synthetic
@@ -188,6 +190,8 @@ def trained_like_state_dict(layer_names, steps: int = 300, batch: int = 4, devic
         torch.manual_seed(seed)
         for i in range(steps):
             loss, _, _ = tr.step(*data[i % len(data)])
+            if loss_log is not None:                 # (one host sync per step: the convergence A/B of tests/test_train_step_gpu.py)
+                loss_log.append(float(loss))
     torch.cuda.synchronize()
     out = tr.state_dict()
     out["__loss__"] = float(loss)

@@ -356,7 +356,9 @@ def _flat(gs, keys):
 
 
 # bounds = measured on MI355X with margin: (loss rel, pred rel-L1, full-gradient cosine, share of tensors whose rms is within 10 %)
-_SHARD_BOUNDS = {torch.float32: (2e-5, 2e-5, 0.9995, 0.99), torch.float16: (2e-3, 1e-2, 0.97, 0.8), torch.bfloat16: (1e-2, 6e-2, 0.80, 0.6)}
+# round 5: the 16-bit bounds sit just under what is MEASURED on the benched shard (bench line `training.fidelity_vs_f32_same_batch`,
+# r5a: fp16 cosine 0.9798 / loss 4.9e-5, bf16 0.8868 / 6.4e-4) instead of far below it; how a 16-bit run OPTIMISES is the convergence test below
+_SHARD_BOUNDS = {torch.float32: (2e-5, 2e-5, 0.9995, 0.99), torch.float16: (5e-4, 1e-2, 0.975, 0.8), torch.bfloat16: (3e-3, 6e-2, 0.87, 0.6)}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
@@ -397,3 +399,24 @@ def test_config2_shard_b16_416x544_training_step_vs_oracle(dtype):
             assert torch.allclose(net.buf[k].double().cpu(), v, rtol=2e-3, atol=1e-5), k
     del net
     torch.cuda.empty_cache()
+
+
+def test_sixteen_bit_training_converges_like_float32_over_300_steps():
+    """VERDICT r4 task 4: a gradient cosine says how one step differs, not whether a 16-bit run OPTIMISES like the float32 one the reference
+    trains with (train.py:119-135, no autocast).  300 real optimisation steps (Trainer: training forward, SILog, backward, AdamW / OneCycle;
+    weights.trained_like_state_dict) from the reference's own initialisation on the same six batches in the same order, positional windows
+    from the same generator seed -- in float32, fp16 (the training headline) and bf16 (the type BASELINE.json names).  The SILog curve,
+    averaged over the 30 steps before step 100 / 200 / 300, must stay within 3 % (fp16) of the float32 run's; bf16 is reported and held to 10 %."""
+    layers = spec.COMBINE1_LAYERS
+    logs = {}
+    for name, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+        log = []
+        weights.trained_like_state_dict(layers, steps=300, dtype=dt, loss_log=log)
+        assert len(log) == 300 and all(np.isfinite(log))
+        logs[name] = {k: float(np.mean(log[k - 30:k])) for k in (100, 200, 300)}
+        logs[name]["first"] = log[0]
+    print("SILog, mean of the 30 steps before step 100 / 200 / 300:", logs)
+    assert logs["f32"][300] < 0.8 * logs["f32"]["first"]                 # the float32 run really optimises
+    for k in (100, 200, 300):
+        assert abs(logs["f16"][k] - logs["f32"][k]) <= 0.03 * logs["f32"][k], (k, logs)
+        assert abs(logs["bf16"][k] - logs["f32"][k]) <= 0.10 * logs["f32"][k], (k, logs)
