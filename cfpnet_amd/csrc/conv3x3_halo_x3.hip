@@ -254,7 +254,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
 // chunk c's ninth tap.  LDS: two chunk buffers + two weight stages (16 x 16 pixels, 128 output channels: 104 + 32 KB), so the tile can be
 // 256 pixels at ANY depth and the weights are re-read once per 256 pixels instead of once per 128: head conv 1.9 GB through the L2 -> LDS
 // path instead of the implicit GEMM's 5.7 GB.
-template <int NT, int WN>
+//
+// UP = true (round 5; cfp_upsample_cat_conv3x3 in float32 storage -- decoder.py:51-58 UpSampleBN's first conv): the input is the CONCATENATION
+// [bilinear upsample (align_corners=True) of the low-resolution tensor p.up_src (p.up_C channels, a multiple of 32) | skip tensor p.in
+// (p.Cin - p.up_C channels, a multiple of 4)], neither of which is materialised: chunks below p.up_C / 32 are BLENDED in the loader (four
+// taps per piece, cfp_resize_bilinear's own expression in float32, then split like any other chunk), the chunks behind them come from the
+// skip tensor with the channels past its end read as zeros.  The weight operand is packed over that padded channel axis
+// ([Cout][9][up_C + 32 ceil(Cskip / 32)], ops.pack_w_x3_cat).  Removes the resize launch, the write + read of the upsampled tensor
+// (157 MB at up4, batch 8) and the nine-fold tap re-fetch of the implicit GEMM these layers ran before (Cin = 80 / 168 / 312 / 392 is not a
+// multiple of 32).
+template <int NT, int WN, bool UP = false>
 __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P hp) {
   constexpr int WM = 4 / WN;
   constexpr int TH = 4 * WM;
@@ -290,7 +299,10 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   const float* __restrict__ in = reinterpret_cast<const float*>(p.in) + (long long)b * p.H * p.W * p.in_ld;
   const f16_t* __restrict__ wt = reinterpret_cast<const f16_t*>(p.w);
   const void* zsrc = reinterpret_cast<const void*>(g_zero16hx);
-  const int NC = p.Cin >> 5;                               // 32-channel chunks
+  const int NC0 = UP ? (p.up_C >> 5) : 0;                  // blended chunks (UP)
+  const int c_skip = UP ? p.Cin - p.up_C : p.Cin;          // channels of `in` (UP: the skip tensor; any multiple of 4, zero-padded to chunks)
+  const int NC = NC0 + ((c_skip + 31) >> 5);               // 32-channel chunks
+  const float* __restrict__ low = UP ? reinterpret_cast<const float*>(p.up_src) + (long long)b * p.up_H * p.up_W * p.up_ld : nullptr;
   const int nit = 9 * NC;
   const int wrow = nit * 64;
 
@@ -322,31 +334,75 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
     const int hy = px / HC, hx = px - hy * HC;
     const int y = y0 - p.pad_t + hy, x = x0 - p.pad_l + hx;
     const bool ok = i < HPIX * 8 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-    src_off[n] = ok ? (y * p.W + x) * p.in_ld + q * 4 : 0;       // one image < 2^31 elements (host check); invalid pieces read the image's first quad
+    src_off[n] = ok ? (y * p.W + x) * p.in_ld + (UP ? 0 : q * 4) : 0;       // one image < 2^31 elements (host check); invalid pieces read the image's first quad
     if (ok) src_okmask |= 1u << n;
     dst_off[n] = i < HPIX * 8 ? px * PPC + q * 8 : -1;
   }
-  f32x4 hv[NLD];
-  // EVERY wave issues exactly NLD loads per chunk (clamped address, value selected afterwards): the counted `s_waitcnt vmcnt(NLD)` below, which
-  // lets them stay in flight behind the weight DMA, is only right if the count is exact -- a wave whose last pieces lie outside the halo must
-  // not skip the instruction
-  auto load_chunk = [&](int c) {
+  // UP: this thread's pieces in the low-resolution source: top-left tap offset, the +1 steps (0 at the last row / column) and the two
+  // interpolation weights -- cfp_resize_bilinear's own arithmetic (src = scale * dst_index, truncation, 1 - l)
+  int up_off[UP ? NLD : 1], up_dxo[UP ? NLD : 1], up_dyo[UP ? NLD : 1];
+  float up_ly[UP ? NLD : 1], up_lx[UP ? NLD : 1];
+  if constexpr (UP) {
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
-      const float* src = in + src_off[n] + c * 32;
+      const int i = tid + n * 256;
+      const int px = i >> 3, q = i & 7;
+      const int hy = px / HC, hx = px - hy * HC;
+      const int y = min(max(y0 - p.pad_t + hy, 0), p.H - 1), x = min(max(x0 - p.pad_l + hx, 0), p.W - 1);      // (pieces outside the image are zeroed by src_okmask)
+      const float fy = p.up_sy * (float)y, fx = p.up_sx * (float)x;
+      const int ys = (int)fy, xs = (int)fx;
+      up_ly[n] = fy - (float)ys; up_lx[n] = fx - (float)xs;
+      up_dyo[n] = (ys < p.up_H - 1 ? 1 : 0) * p.up_W * p.up_ld;
+      up_dxo[n] = (xs < p.up_W - 1 ? 1 : 0) * p.up_ld;
+      up_off[n] = (ys * p.up_W + xs) * p.up_ld + q * 4;
+    }
+  }
+  f32x4 hv[NLD][UP ? 4 : 1];
+  // EVERY wave issues the same number of loads per chunk (clamped address, value selected afterwards): a wave whose last pieces lie outside
+  // the halo must not skip the instruction
+  auto load_chunk = [&](int c) {
+    if (UP && c < NC0) {                                     // wave-uniform: a blended chunk -- four taps per piece
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const float* s00 = low + up_off[UP ? n : 0] + c * 32;
+        asm volatile("" : "+v"(s00));
+        hv[n][0] = *reinterpret_cast<const f32x4*>(s00);
+        if constexpr (UP) {
+          hv[n][1] = *reinterpret_cast<const f32x4*>(s00 + up_dxo[n]);
+          hv[n][2] = *reinterpret_cast<const f32x4*>(s00 + up_dyo[n]);
+          hv[n][3] = *reinterpret_cast<const f32x4*>(s00 + up_dyo[n] + up_dxo[n]);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      // UP: src_off is the pixel only; the piece's four channels of the skip tensor, clamped (channels past its end are zeroed in store_chunk)
+      const float* src = UP ? in + src_off[n] + min((c - NC0) * 32 + ((tid + n * 256) & 7) * 4, c_skip - 4) : in + src_off[n] + c * 32;
       asm volatile("" : "+v"(src));                          // keep the load unconditional (no exec-masked skip)
-      hv[n] = *reinterpret_cast<const f32x4*>(src);
+      hv[n][0] = *reinterpret_cast<const f32x4*>(src);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int c) {
     unsigned char* d = sX + buf * CBUF;
+    const bool blended = UP && c < NC0;                      // wave-uniform
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
       if (dst_off[n] < 0) continue;
-      const bool okn = (src_okmask >> n) & 1u;
+      bool okn = (src_okmask >> n) & 1u;
+      f32x4 v = hv[n][0];
+      if constexpr (UP) {
+        if (blended) {
+          const float ly1 = up_ly[n], lx1 = up_lx[n], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * hv[n][0][e] + lx1 * hv[n][1][e]) + ly1 * (lx0 * hv[n][2][e] + lx1 * hv[n][3][e]);
+        } else {
+          okn = okn && (c - NC0) * 32 + ((tid + n * 256) & 7) * 4 < c_skip;
+        }
+      }
       f16x4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float v = okn ? hv[n][e] : 0.f; hi[e] = f2h(v); lo[e] = (f16_t)(v - (float)hi[e]); }
+      for (int e = 0; e < 4; ++e) { const float x = okn ? v[e] : 0.f; hi[e] = f2h(x); lo[e] = (f16_t)(x - (float)hi[e]); }
       *reinterpret_cast<f16x4*>(d + dst_off[n]) = hi;
       *reinterpret_cast<f16x4*>(d + LO + dst_off[n]) = lo;
     }
@@ -354,7 +410,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
 
   issue_w(0, 0, 0);
   load_chunk(0);
-  store_chunk(0);
+  store_chunk(0, 0);
 
   f32x4 acc[4][NT];
 #pragma unroll
@@ -401,7 +457,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xhi, acc[g][j], 0, 0, 0);
         }
       }
-      if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1);      // (every wave is past chunk c - 1: the buffer is free)
+      if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1);      // (every wave is past chunk c - 1: the buffer is free)
     }
   }
 
@@ -434,19 +490,22 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   });
 }
 
-template <int NT, int WN>
+template <int NT, int WN, bool UP = false>
 int launch_cx(const ConvP& p, hipStream_t s) {
   constexpr int TH = 4 * (4 / WN);
   constexpr int NPAD = NT * WN * 16;
   HaloX3P hp;
   hp.n_blocks = cdiv(p.Cout, NPAD);
   hp.QPP = p.Cin / 4; hp.dq = make_fastdiv((unsigned)hp.QPP); hp.PP = 80; hp.LO = (TH + 2) * 18 * 80;
-  if ((long long)p.H * p.W * p.in_ld >= (1ll << 31) || p.Cin % 32 != 0) return -1;
+  if ((long long)p.H * p.W * p.in_ld >= (1ll << 31)) return -1;
+  if (!UP && p.Cin % 32 != 0) return -1;
+  if (UP && (p.up_src == nullptr || p.up_C % 32 != 0 || p.up_C <= 0 || (p.Cin - p.up_C) % 4 != 0 || p.Cin - p.up_C < 4 ||
+             (long long)p.up_H * p.up_W * p.up_ld >= (1ll << 31) || p.H < 2 || p.W < 2)) return -1;
   hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
   const size_t lds = (size_t)2 * NPAD * 128 + (size_t)2 * 2 * hp.LO;
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
-  auto k = conv3x3_chunk_x3_kernel<NT, WN>;
+  auto k = conv3x3_chunk_x3_kernel<NT, WN, UP>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);
@@ -555,6 +614,10 @@ int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
     case 23: return launch_cx<4, 2>(p, s);      // <= 128, 8 x 16 pixels
     case 24: return launch_cx<2, 2>(p, s);      // <= 64, 8 x 16 pixels
     case 25: return launch_cx<8, 2>(p, s);      // <= 256, 8 x 16 pixels
+    // two sources (cfp_upsample_cat_conv3x3): 8 x 16 pixel tiles (six pieces per thread and chunk: 96 registers of taps in flight)
+    case 40: return launch_cx<1, 2, true>(p, s);      // <= 32 output channels per workgroup
+    case 41: return launch_cx<2, 2, true>(p, s);      // <= 64
+    case 42: return launch_cx<4, 2, true>(p, s);      // <= 128
     default: return -3;
   }
 }

@@ -763,7 +763,31 @@ extern "C" int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int
                                         const void* w, const float* scale, const float* shift, void* out, int out_ld, int B, int H, int W,
                                         int Cout, int act, int dtype, cfp_stream_t stream) {
   CFP_REQUIRE(low && skip && w && out, CFP_EINVAL, "cfp_upsample_cat_conv3x3: null pointer");
-  CFP_REQUIRE(is16(dtype), CFP_ESHAPE, "cfp_upsample_cat_conv3x3: 16-bit storage types only");
+  if (dtype == CFP_F32X3) {
+    // float32 tensors, f16x3 matrix math (round 5): the chunk-pipelined kernel with two sources (conv3x3_halo_x3.hip, UP = true).  `w` is the
+    // pre-split operand packed over the PADDED channel axis [Cout][9][Cup + 32 ceil(Cskip / 32)] (ops.pack_w_x3_cat)
+    CFP_REQUIRE(B > 0 && H > 1 && W > 1 && Hs > 0 && Ws > 0 && Cup > 0 && Cup % 32 == 0 && Cskip >= 4 && Cskip % 4 == 0 && Cout % 4 == 0 && Cout > 0 &&
+                    low_ld % 4 == 0 && low_ld >= Cup && skip_ld % 4 == 0 && skip_ld >= Cskip && out_ld % 4 == 0 && out_ld >= Cout, CFP_ESHAPE,
+                "cfp_upsample_cat_conv3x3 (f32x3): need Cup % 32 == 0, Cskip % 4 == 0 and 16-byte channel vectors");
+    CFP_REQUIRE(aligned16(low) && aligned16(skip) && aligned16(w) && aligned16(out) && aligned16(scale) && aligned16(shift), CFP_EINVAL,
+                "cfp_upsample_cat_conv3x3: pointers must be 16-byte aligned");
+    CFP_REQUIRE(((long long)H * W) * skip_ld < (1ll << 31) - 65536 && ((long long)Hs * Ws) * low_ld < (1ll << 31) - 65536 && (long long)B * H * W < (1ll << 31),
+                CFP_ESHAPE, "cfp_upsample_cat_conv3x3: tensor too large for 32-bit offsets");
+    ConvP p{};
+    p.in = skip; p.w = w; p.out = out; p.res = nullptr; p.scale = scale; p.shift = shift;
+    p.in_ld = skip_ld; p.out_ld = out_ld; p.res_ld = 0;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cup + Cskip; p.Ho = H; p.Wo = W; p.Cout = Cout;
+    p.KH = 3; p.KW = 3; p.stride = 1; p.pad_t = 1; p.pad_l = 1;
+    p.M = B * H * W; p.K = 9 * (Cup + cdiv(Cskip, 32) * 32); p.act = act; p.dil = 1;
+    p.up_src = low; p.up_ld = low_ld; p.up_C = Cup; p.up_H = Hs; p.up_W = Ws;
+    p.up_sy = (float)(Hs - 1) / (float)(H - 1);        // cfp_resize_bilinear's own expression
+    p.up_sx = (float)(Ws - 1) / (float)(W - 1);
+    const int v = g_force_variant >= 540 && g_force_variant <= 542 ? g_force_variant - 500 : (Cout <= 32 ? 40 : Cout <= 64 ? 41 : 42);
+    int rc = conv3x3_halo_x3_launch(v, p, reinterpret_cast<hipStream_t>(stream));
+    CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_upsample_cat_conv3x3 (f32x3): kernel launch failed");
+    return cfp_check_launch("cfp_upsample_cat_conv3x3");
+  }
+  CFP_REQUIRE(is16(dtype), CFP_ESHAPE, "cfp_upsample_cat_conv3x3: bf16 / f16 storage or CFP_F32X3");
   CFP_REQUIRE(B > 0 && H > 1 && W > 1 && Hs > 0 && Ws > 0 && Cup > 0 && Cup % 64 == 0 && Cskip > 0 && Cskip % 8 == 0 && Cout % 8 == 0 &&
                   low_ld % 8 == 0 && low_ld >= Cup && skip_ld % 8 == 0 && skip_ld >= Cskip && out_ld % 8 == 0 && out_ld >= Cout, CFP_ESHAPE,
               "cfp_upsample_cat_conv3x3: need Cup % 64 == 0 and 16-byte channel vectors");

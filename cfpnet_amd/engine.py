@@ -157,6 +157,10 @@ class Engine:
             self._dbg_round[n] = {"f16": torch.float16, "bf16": torch.bfloat16}[d]
         # decoder stages whose bilinear upsample + skip concat run inside the first conv's loader (cfp_upsample_cat_conv3x3); digits 1-4
         self.up_fused = os.environ.get("CFP_UP_FUSED", "4")
+        # f16x3 mode: decoder stages whose first conv takes the two-source chunk kernel (cfp_upsample_cat_conv3x3 with CFP_F32X3, round 5).  Built,
+        # parity-tested and MEASURED SLOWER than resize + implicit GEMM at every stage (tools/up_bench_x3.py, batch 8, four copies in flight: up1
+        # 107 vs 79 us, up2 137 vs 129, up3 219 vs 164, up4 358 vs 225; whole step 4.71 vs 4.68 ms): OFF by default, CFP_UP_FUSED_X3=1234 enables it.
+        self.up_fused_x3 = os.environ.get("CFP_UP_FUSED_X3", "")
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
@@ -304,6 +308,12 @@ class Engine:
         for i in (1, 2, 3, 4):
             q = f"{d}.up{i}._net"
             self._conv(sd, f"{d}.up{i}.a", q + ".0.weight", q + ".0.bias", bn=q + ".1")
+            if self.x3 and str(i) in self.up_fused_x3:
+                # the same weights packed over the PADDED concatenation axis [upsampled decoder channels | skip channels -> next multiple of 32]:
+                # the operand of cfp_upsample_cat_conv3x3 in the f16x3 mode (two-source chunk kernel: no resize launch, no concatenation)
+                wfull = sd[q + ".0.weight"].detach().float()                  # [Cout, Cup + Cskip, 3, 3]
+                cup = wfull.shape[1] - spec.DEC_ENC_CH[i]
+                self.P[f"{d}.up{i}.a.wcat"] = ops.pack_w_x3_cat(self._dev(wfull.permute(0, 2, 3, 1).contiguous()), cup)
             self._conv(sd, f"{d}.up{i}.b", q + ".3.weight", q + ".3.bias", bn=q + ".4")
         for n in ("conv3", "conv2", "conv1", "conv0"):
             self._conv(sd, f"{d}.{n}", f"{d}.{n}.weight", f"{d}.{n}.bias")
@@ -1067,7 +1077,13 @@ class Engine:
             t1 = self._act(plan, f"up{i}.a", M, c[i])
             # the fused kernel's own preconditions (cfp_upsample_cat_conv3x3 returns CFP_ESHAPE otherwise): 32-bit byte offsets, H, W > 1
             fits = hd > 1 and wd > 1 and B * hd * wd * cat[i].ld * 2 < 2 ** 31 - 65536 and hs_ * ws_ * src.ld * 2 < 2 ** 31 - 65536
-            if self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None and fits:
+            if self.x3 and str(i) in self.up_fused_x3 and src.C % 32 == 0 and taps is None and hd > 1 and wd > 1:
+                # round 5: the two-source chunk kernel (conv3x3_halo_x3.hip, UP): bilinear blend in the halo loader, skip channels from the
+                # concatenation buffer's slice; the upsampled tensor is never written
+                n = f"decoder.up{i}.a"
+                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".wcat"], self.P[n + ".s"], self.P[n + ".t"],
+                                         t1, B, hd, wd, hip.ACT_LRELU, x3=True)
+            elif self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None and fits:
                 # cfp_upsample_cat_conv3x3: bilinear + concat computed inside the conv's halo loader (bit-identical to the pair below)
                 n = f"decoder.up{i}.a"
                 ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".w"], self.P[n + ".s"], self.P[n + ".t"],

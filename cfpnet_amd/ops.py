@@ -411,11 +411,29 @@ def copy_rows(x: Act, out: Act, rows):
     hip.call("cfp_copy_rows", x.ptr, x.ld, out.ptr, out.ld, rows, x.C, x.dt, _s())
 
 
-def upsample_cat_conv3x3(low: Act, Hs, Ws, skip: Act, w, scale, shift, out: Act, B, H, W, act):
-    """bilinear (align_corners) upsample of `low` to H x W + concat with `skip` + conv3x3 + BN + activation in one launch (16-bit modes)."""
+def upsample_cat_conv3x3(low: Act, Hs, Ws, skip: Act, w, scale, shift, out: Act, B, H, W, act, x3: bool = False):
+    """bilinear (align_corners) upsample of `low` to H x W + concat with `skip` + conv3x3 + BN + activation in one launch.  16-bit modes:
+    `w` [Cout, 9 * (Cup + Cskip)] in the storage type; `x3` (float32 tensors, f16x3 matrix math): `w` = pack_w_x3_cat's operand."""
+    if x3:
+        assert low.dt == skip.dt == out.dt == hip.F32 and w.dtype == torch.float16 and w.shape[-1] == 9 * (low.C + (skip.C + 31) // 32 * 32) * 2
+        hip.call("cfp_upsample_cat_conv3x3", low.ptr, low.ld, Hs, Ws, low.C, skip.ptr, skip.ld, skip.C, w.data_ptr(),
+                 hip.ptr(scale), hip.ptr(shift), out.ptr, out.ld, B, H, W, out.C, act, hip.F32X3, _s())
+        return
     assert w.shape[-1] == 9 * (low.C + skip.C) and low.dt == skip.dt == out.dt
     hip.call("cfp_upsample_cat_conv3x3", low.ptr, low.ld, Hs, Ws, low.C, skip.ptr, skip.ld, skip.C, w.data_ptr(),
              hip.ptr(scale), hip.ptr(shift), out.ptr, out.ld, B, H, W, out.C, act, out.dt, _s())
+
+
+def pack_w_x3_cat(w: torch.Tensor, cup: int) -> torch.Tensor:
+    """[Cout, 3, 3, Cup + Cskip] float32 on the GPU (the concatenation's channel order, decoder.py:56-57) -> the f16x3 operand of
+    cfp_upsample_cat_conv3x3: the same weights over the PADDED channel axis [Cup | Cskip -> next multiple of 32] (zero weights on the padding;
+    Cup % 32 == 0), per tap, through cfp_pack_w_x3."""
+    co, kh, kw, cin = w.shape
+    assert kh == 3 and kw == 3 and cup % 32 == 0 and 0 < cup < cin
+    csk = cin - cup
+    pad = (csk + 31) // 32 * 32 - csk
+    wp = torch.nn.functional.pad(w, (0, pad)) if pad else w
+    return pack_w_x3(wp.reshape(co, 9 * (cup + csk + pad)).contiguous())
 
 
 def copy_rows2(x0: Act, out0: Act, x1: Act, out1: Act, rows):

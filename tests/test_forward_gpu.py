@@ -303,6 +303,23 @@ def test_optional_kernel_paths_keep_parity(env, monkeypatch):
     assert r < TOL_F16
 
 
+def test_optional_two_source_chunk_kernel_keeps_parity_in_the_default_mode(monkeypatch):
+    """CFP_UP_FUSED_X3=1234 (measured slower, off by default): every decoder stage's first conv through cfp_upsample_cat_conv3x3 in the f16x3
+    mode -- no resize launch, no materialised upsampled tensor -- stays inside the gate against the CPU oracle and within 1e-5 of the default
+    plan's depth map."""
+    layers, sd, inp = _full_case(2, 480, 640, 8, 56, 21, 0.2)
+    e0, p0, pr0 = O.forward(sd, inp, layer_names=layers)
+    ref = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True).forward(inp)[1].clone()
+    monkeypatch.setenv("CFP_UP_FUSED_X3", "1234")
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True)
+    assert "decoder.up4.a.wcat" in eng.P
+    p1 = eng.forward(inp)[1]
+    torch.cuda.synchronize()
+    r = rel_l1(p1.cpu().numpy(), p0.numpy())
+    print(f"two-source chunk kernel at up1-4: pred relL1 vs oracle {r:.3e}, vs the default plan {rel_l1(p1.cpu().numpy(), ref.cpu().numpy()):.3e}")
+    assert r < TOL_F32 and rel_l1(p1.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+
+
 def test_forward_is_deterministic_and_batch_independent():
     """Size-independent properties: same input -> identical bits; a sample's result does not depend
     on what else is in the batch (all-valid zones, so the batch-reduced geometry is shared) beyond

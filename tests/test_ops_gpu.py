@@ -326,6 +326,42 @@ def test_conv2d_x3_dynamic_range_limit_is_what_the_docs_say():
             _x3_close(got.cpu(), y, f"x3 range {xscale}", tol=tol)
 
 
+@pytest.mark.parametrize("case", [(2, 15, 20, 30, 40, 64, 16, 32), (1, 8, 10, 16, 20, 128, 40, 64), (2, 5, 7, 10, 14, 256, 56, 128),
+                                  (1, 4, 5, 8, 10, 256, 136, 256), (1, 7, 9, 13, 21, 32, 8, 16), (1, 3, 3, 9, 33, 64, 4, 96), (3, 6, 6, 12, 12, 32, 36, 32)])
+def test_upsample_cat_conv3x3_x3(case):
+    """cfp_upsample_cat_conv3x3 in the default numerics (float32 tensors, f16x3 matrix math; round 5, conv3x3_chunk_x3_kernel<.., UP>): bilinear
+    upsample (align_corners=True) of the low-resolution tensor + concatenation with the skip tensor + conv3x3 + folded BatchNorm + LeakyReLU
+    (decoder.py:51-58) in ONE launch against float64 torch, and against the pair it replaces (cfp_resize_bilinear + the f16x3 conv on the
+    materialised concatenation).  Skip channel counts that are not multiples of 32 (zero-padded chunks), output sizes that are not multiples
+    of the 8 x 16 pixel tile, the skip tensor as a column slice of a wider buffer, several channel blocks per tile (Cout = 256)."""
+    B, Hs, Ws, H, W, Cup, Csk, Cout = case
+    low = rnd(B, Cup, Hs, Ws, seed=1)
+    skip = rnd(B, Csk, H, W, seed=2)
+    w = rnd(Cout, Cup + Csk, 3, 3, seed=3, scale=1.0 / math.sqrt(9 * (Cup + Csk)))
+    scale, shift = rnd(Cout, seed=4).abs() + 0.5, rnd(Cout, seed=5)
+    up = F.interpolate(low.double(), size=(H, W), mode="bilinear", align_corners=True)
+    ref = F.conv2d(torch.cat([up, skip.double()], 1), w.double(), None, 1, 1)
+    ref = F.leaky_relu(ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None], 0.01)
+    la = to_act(nhwc(low), torch.float32, ld=Cup + 8, c0=4)
+    cat = ops.new_act(B * H * W, Cup + Csk, torch.float32, DEV, zero=True)       # the concatenation buffer: the skip lives in its right slice
+    cat.buf[:, Cup:] = nhwc(skip).to(DEV)
+    sk = cat.slice(Cup, Csk)
+    wcat = ops.pack_w_x3_cat(w.permute(0, 2, 3, 1).contiguous().to(DEV), Cup)
+    out = ops.new_act(B * H * W, Cout, torch.float32, DEV, ld=Cout + 4)
+    ops.upsample_cat_conv3x3(la, Hs, Ws, sk, wcat, scale.to(DEV), shift.to(DEV), out, B, H, W, hip.ACT_LRELU, x3=True)
+    torch.cuda.synchronize()
+    got = from_nhwc(out.torch(), B, H, W)
+    _x3_close(got, ref, f"upsample+cat+conv3x3 x3 {case}")
+    # the pair it replaces
+    ops.resize_bilinear(la, Hs, Ws, (0, 0, Hs, Ws), cat.slice(0, Cup), H, W, (0, 0, H, W), B)
+    w32 = w.permute(0, 2, 3, 1).reshape(Cout, 9 * (Cup + Csk)).contiguous().to(DEV)
+    out2 = ops.new_act(B * H * W, Cout, torch.float32, DEV)
+    ops.conv2d(cat, ops.pack_w_x3(w32), scale.to(DEV), shift.to(DEV), out2, B, H, W, 3, 3, 1, 1, 1, H, W, hip.ACT_LRELU)
+    torch.cuda.synchronize()
+    _x3_close(from_nhwc(out2.torch(), B, H, W), ref, f"resize + conv x3 {case}")
+    _x3_close(got, from_nhwc(out2.torch(), B, H, W).double(), f"fused vs pair {case}", tol=2e-6)
+
+
 def test_conv2d_x3_per_image_weights_and_layernorm():
     """Per-image pre-split weights (the squeeze-excite fold) and the LayerNorm that follows as a second kernel."""
     B, HW, Cin, Cout = 3, 300, 232, 128
