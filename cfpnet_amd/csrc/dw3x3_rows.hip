@@ -185,7 +185,8 @@ static bool dwr_plan(int B, int H, int W, int Ho, int Wo, int C, int stride, int
     //   chain: a lane's R row steps are serial (~0.25 us each: load -> 36 FMAs -> store), once per resident round of 4 096 waves;
     //   tail:  every slot is one more partial vector the squeeze-excite kernel adds serially (~10 ns each).
     const double halo = (double)((R - 1) * stride + 3) / (R * stride);  // input rows read per input row used
-    const double lanes = (double)(nps * 8) / npx;
+    const double lanes = (double)(((nps + 3) / 4) * 32) / npx;         // idle lanes AND idle waves of the four-wave workgroups: they hold registers
+                                                                         // (122 VGPRs: 16 waves per CU) that would otherwise keep loads in flight
     const double rows = (double)(nruns * R) / Ho;                       // ragged last run (its lanes idle through the tail rows)
     const double in_b = 4.0 * B * (Ho * stride) * (Wo * stride) * C, out_b = 4.0 * B * Ho * Wo * C;      // from the OUTPUT extent only: cfp_dwr_slots (asked before
                                                                                                          // the launch, without H / W) must see the same plan
