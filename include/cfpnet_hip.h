@@ -121,7 +121,9 @@ int cfp_debug_set(int key, int value);
 
 /* Depthwise 3x3 convolution, stride 1/2, explicit (TF-"SAME", possibly asymmetric) padding, fused
  * BatchNorm scale/shift + activation.  w packed [9][C].  HBM-bandwidth-bound.
- * Replaces timm InvertedResidual.conv_dw + bn2 + SiLU (encoder.py:66-69, 24 convs). */
+ * Replaces timm InvertedResidual.conv_dw + bn2 + SiLU (encoder.py:66-69, 24 convs).
+ * Kernels: float32 storage -> dw3x3_rows_kernel (round 5: register-sliding rows, no LDS; csrc/dw3x3_rows.hip; SiLU / ReLU / none), 16-bit storage with
+ * C % 16 == 0 -> dw3x3_slide_kernel (diagonal-weight MFMA, csrc/dw3x3_slide.hip), otherwise the LDS-strip kernel of csrc/dwconv.hip. */
 int cfp_dwconv3x3_nhwc(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                        void* out, int out_ld, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                        int Ho, int Wo, int act, int dtype, cfp_stream_t stream);
@@ -298,7 +300,11 @@ int cfp_add_rowtable(const void* in, int in_ld, const float* table, void* out, i
  * skip [B,H,W,skip_ld] (Cskip channels), w [Cout][3][3][Cup + Cskip] (the concatenation's channel order), out [B,H,W,out_ld].
  * The upsampled tensor and the concatenation are never materialised: the direct 3x3 kernel computes the upsampled channel chunks into its
  * LDS halo tile (four taps blended in float32, rounded to `dtype` like a stored tensor) and fetches the skip chunks.  Bit-identical to
- * cfp_resize_bilinear + cfp_conv2d_nhwc.  bf16 / f16, Cup % 64 == 0, Cskip % 8 == 0, Cout % 8 == 0. */
+ * cfp_resize_bilinear + cfp_conv2d_nhwc.  bf16 / f16, Cup % 64 == 0, Cskip % 8 == 0, Cout % 8 == 0.
+ * dtype = CFP_F32X3 (round 5): float32 tensors, f16x3 matrix math -- the chunk-pipelined kernel with two sources (conv3x3_halo_x3.hip); `w` is then
+ * the pre-split operand of cfp_pack_w_x3 over the PADDED channel axis [Cout][9][Cup + 32 * ceil(Cskip / 32)] (zero weights on the padding);
+ * Cup % 32 == 0, Cskip % 4 == 0, Cout % 4 == 0.  Equal to the pair it replaces to float32 round-off (another summation order); measured slower than
+ * that pair at every decoder stage (profiles/r5_up_bench_x3.txt), so the engine takes it only under CFP_UP_FUSED_X3. */
 int cfp_upsample_cat_conv3x3(const void* low, int low_ld, int Hs, int Ws, int Cup, const void* skip, int skip_ld, int Cskip,
                              const void* w, const float* scale, const float* shift, void* out, int out_ld, int B, int H, int W,
                              int Cout, int act, int dtype, cfp_stream_t stream);
