@@ -153,6 +153,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first "
             f"(`python -c 'import __graft_entry__ as g; g.build()'` or `make -C cfpnet_amd/csrc`). "
             "There is no CPU fallback for the product path.")
+    # torch FIRST: its wheel carries its own libamdhip64; the kernels must run in the HIP runtime that owns the tensors they are handed.  Loaded the
+    # other way round (library, then torch -- `build()` followed by `smoke()` in one process) the process ends up with two runtimes and the first
+    # kernel launch fails with "no ROCm-capable device is detected" (seen on the GPU box in round 5).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the .so does not export it
