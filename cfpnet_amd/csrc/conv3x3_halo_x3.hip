@@ -432,8 +432,10 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores / fragment reads of the previous step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (it + 1 < nit) { const int t1 = tap == 8 ? 0 : tap + 1; issue_w(tap == 8 ? c + 1 : c, t1, (it + 1) & 1); }
+      // timing probes (cfp_debug_set key 16; results are garbage): 1 = no weight DMA after the prologue, 2 = no fragment reads / MFMAs
+      if (it + 1 < nit && !(p.probe & 1)) { const int t1 = tap == 8 ? 0 : tap + 1; issue_w(tap == 8 ? c + 1 : c, t1, (it + 1) & 1); }
       if (tap == 7 && c + 1 < NC) load_chunk(c + 1);       // lands during this step's MFMAs; stored after the next (last) tap
+      if (p.probe & 2) { if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1); continue; }
       const unsigned char* cW = sW + (it & 1) * WSTAGE + (wn * NT * 16) * 128;
       f16x8 whi[NT], wlo[NT];
 #pragma unroll
