@@ -263,7 +263,19 @@ __global__ __launch_bounds__(256) void conv3x3_halo_x3_kernel(ConvP p, HaloX3P h
 // ([Cout][9][up_C + 32 ceil(Cskip / 32)], ops.pack_w_x3_cat).  Removes the resize launch, the write + read of the upsampled tensor
 // (157 MB at up4, batch 8) and the nine-fold tap re-fetch of the implicit GEMM these layers ran before (Cin = 80 / 168 / 312 / 392 is not a
 // multiple of 32).
-template <int NT, int WN, bool UP = false>
+//
+// NSTW = 3 (round 5): three weight stages with COUNTED waits.  The weights of K-step `it` are issued TWO steps ahead, so at the top of a step the
+// stage it needs is strictly older than everything issued during the previous step (the next stage's DMA and, after tap 7, the next chunk's halo
+// loads -- whichever side of the DMA builtin the compiler puts those plain loads): "all but the newest NB (+ NLD) operations have landed" is exact.
+// With two stages the weights of a step were issued ONE step before it and the wait had to be a full one (the probe of tools/probes/
+// chunk_x3_probe.py: 75 of the head conv's 645 us are exposed weight-DMA latency).
+//
+// SB = true (round 5): ONE chunk buffer instead of two.  The probe of the three-stage variants showed what bounds these kernels: <2,2> at 74 KB (two
+// workgroups per CU) runs the head conv in 678 us, the same tile at 82 KB (one per CU) in 1 037 -- a workgroup's load / split / store, MFMA and
+// output phases serialise, and only a SECOND resident workgroup fills them.  The 128-channel 8 x 16 pixel tile <4,2> needs 90 KB with two chunk
+// buffers; with one it is 61 KB = two per CU, at the price of one more barrier per chunk (the next chunk is stored after everybody has left
+// the current one) -- which the other workgroup covers.
+template <int NT, int WN, bool UP = false, int NSTW = 2, bool SB = false>
 __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P hp) {
   constexpr int WM = 4 / WN;
   constexpr int TH = 4 * WM;
@@ -278,8 +290,10 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   constexpr int CBUF = 2 * LO;                             // one chunk buffer
   constexpr int NLD = (HPIX * 8 + 255) / 256;              // 16-byte float32 pieces per thread and chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(NSTW == 2 || NSTW == 3, "weight stages");
+  static_assert(NB + NLD * (UP ? 4 : 1) <= 63, "vmcnt field");
   unsigned char* sW = smem;
-  unsigned char* sX = smem + 2 * WSTAGE;
+  unsigned char* sX = smem + NSTW * WSTAGE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -409,6 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   };
 
   issue_w(0, 0, 0);
+  if (NSTW == 3 && nit > 1) issue_w(0, 1, 1);              // (nit = 9 NC >= 9: K-step 1 is tap 1 of chunk 0)
   load_chunk(0);
   store_chunk(0, 0);
 
@@ -422,21 +437,44 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
 
   int it = 0;
+  int rbuf = 0;                                            // weight stage of the current step (it % NSTW)
+  constexpr int NLDV = NLD * (UP ? 4 : 1);                 // vector-memory loads of one load_chunk (blended chunks: four taps per piece)
   for (int c = 0; c < NC; ++c) {
-    const unsigned char* xc = sX + (c & 1) * CBUF + xrow;
+    const unsigned char* xc = sX + (SB ? 0 : (c & 1)) * CBUF + xrow;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap, ++it) {
-      // the weights of this step were issued one step ago.  (No counted wait here: the halo loads of the next chunk, issued at tap 7, are
-      // plain register loads the compiler may order either side of the DMA builtin, so "leave NLD in flight" would not be exact.)
-      wait_vmcnt<0>();
+      if constexpr (SB) {
+        if (tap == 0 && c > 0) {                           // single buffer: everybody has left chunk c - 1 -> store chunk c (loaded at tap 7), meet again
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          store_chunk(0, c);
+        }
+      }
+      if constexpr (NSTW == 2) {
+        // the weights of this step were issued one step ago.  (No counted wait here: the halo loads of the next chunk, issued at tap 7, are
+        // plain register loads the compiler may order either side of the DMA builtin, so "leave NLD in flight" would not be exact.)
+        wait_vmcnt<0>();
+      } else {
+        // three stages: everything issued during the previous step may stay in flight -- the next step's weights (NB DMA instructions, when
+        // there is a next step) and, at tap 8, the next chunk's halo loads (NLDV; a skip chunk of a two-source kernel issues fewer: UP keeps
+        // the full wait there)
+        if (it + 1 >= nit) wait_vmcnt<0>();
+        else if (tap == 8 && c + 1 < NC) { if (UP) wait_vmcnt<0>(); else wait_vmcnt<NB + NLDV>(); }
+        else wait_vmcnt<NB>();
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's halo stores / fragment reads of the previous step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // timing probes (cfp_debug_set key 16; results are garbage): 1 = no weight DMA after the prologue, 2 = no fragment reads / MFMAs
-      if (it + 1 < nit && !(p.probe & 1)) { const int t1 = tap == 8 ? 0 : tap + 1; issue_w(tap == 8 ? c + 1 : c, t1, (it + 1) & 1); }
+      if (it + NSTW - 1 < nit && !(p.probe & 1)) {
+        const int tn = tap + NSTW - 1;                     // K-step it + NSTW - 1 = (chunk, tap) of the stage everybody has just finished reading
+        issue_w(tn >= 9 ? c + 1 : c, tn >= 9 ? tn - 9 : tn, NSTW == 2 ? ((it + 1) & 1) : (rbuf == 0 ? 2 : rbuf - 1));
+      }
       if (tap == 7 && c + 1 < NC) load_chunk(c + 1);       // lands during this step's MFMAs; stored after the next (last) tap
-      if (p.probe & 2) { if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1); continue; }
-      const unsigned char* cW = sW + (it & 1) * WSTAGE + (wn * NT * 16) * 128;
+      if (p.probe & 2) { if (!SB && tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1); rbuf = rbuf + 1 == NSTW ? 0 : rbuf + 1; continue; }
+      const unsigned char* cW = sW + rbuf * WSTAGE + (wn * NT * 16) * 128;
+      rbuf = rbuf + 1 == NSTW ? 0 : rbuf + 1;
       f16x8 whi[NT], wlo[NT];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -459,7 +497,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[j], xhi, acc[g][j], 0, 0, 0);
         }
       }
-      if (tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1);      // (every wave is past chunk c - 1: the buffer is free)
+      if (!SB && tap == 8 && c + 1 < NC) store_chunk((c + 1) & 1, c + 1);      // (every wave is past chunk c - 1: the buffer is free)
     }
   }
 
@@ -492,7 +530,7 @@ __global__ __launch_bounds__(256) void conv3x3_chunk_x3_kernel(ConvP p, HaloX3P 
   });
 }
 
-template <int NT, int WN, bool UP = false>
+template <int NT, int WN, bool UP = false, int NSTW = 2, bool SB = false>
 int launch_cx(const ConvP& p, hipStream_t s) {
   constexpr int TH = 4 * (4 / WN);
   constexpr int NPAD = NT * WN * 16;
@@ -505,9 +543,9 @@ int launch_cx(const ConvP& p, hipStream_t s) {
              (long long)p.up_H * p.up_W * p.up_ld >= (1ll << 31) || p.H < 2 || p.W < 2)) return -1;
   hp.tiles_x = cdiv(p.Wo, 16); hp.tiles_y = cdiv(p.Ho, TH);
   const long long tiles = (long long)p.B * hp.tiles_x * hp.tiles_y * hp.n_blocks;
-  const size_t lds = (size_t)2 * NPAD * 128 + (size_t)2 * 2 * hp.LO;
+  const size_t lds = (size_t)NSTW * NPAD * 128 + (size_t)(SB ? 1 : 2) * 2 * hp.LO;
   if (lds > 160 * 1024 || tiles >= (1ll << 31)) return -1;
-  auto k = conv3x3_chunk_x3_kernel<NT, WN, UP>;
+  auto k = conv3x3_chunk_x3_kernel<NT, WN, UP, NSTW, SB>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, s, p, hp);
@@ -616,6 +654,19 @@ int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
     case 23: return launch_cx<4, 2>(p, s);      // <= 128, 8 x 16 pixels
     case 24: return launch_cx<2, 2>(p, s);      // <= 64, 8 x 16 pixels
     case 25: return launch_cx<8, 2>(p, s);      // <= 256, 8 x 16 pixels
+    // three weight stages with counted waits (round 5)
+    case 30: return launch_cx<2, 1, false, 3>(p, s);
+    case 31: return launch_cx<4, 1, false, 3>(p, s);
+    case 32: return launch_cx<8, 1, false, 3>(p, s);
+    case 33: return launch_cx<4, 2, false, 3>(p, s);
+    case 34: return launch_cx<2, 2, false, 3>(p, s);
+    case 35: return launch_cx<8, 2, false, 3>(p, s);
+    // one chunk buffer: two workgroups per CU for the 128-channel tile (round 5)
+    case 36: return launch_cx<4, 2, false, 2, true>(p, s);      // <= 128 channels, 8 x 16 pixels, 61 KB
+    case 37: return launch_cx<8, 2, false, 2, true>(p, s);      // <= 256 channels, 8 x 16 pixels, 93 KB (one per CU; for comparison)
+    case 38: return launch_cx<4, 1, false, 2, true>(p, s);      // <= 64 channels, 16 x 16 pixels, 68 KB
+    case 39: return launch_cx<4, 2, false, 3, true>(p, s);      // 36 with three weight stages: 77 KB, still two per CU
+    case 43: return launch_cx<4, 1, false, 3, true>(p, s);      // 38 with three weight stages: 76 KB
     // two sources (cfp_upsample_cat_conv3x3): 8 x 16 pixel tiles (six pieces per thread and chunk: 96 registers of taps in flight)
     case 40: return launch_cx<1, 2, true>(p, s);      // <= 32 output channels per workgroup
     case 41: return launch_cx<2, 2, true>(p, s);      // <= 64

@@ -329,6 +329,21 @@ int g_halo_x3 = 1;              // cfp_debug_set key 24: 0 = the f16x3 3x3 convo
 // (95-124 KB through registers) nothing overlaps, where the implicit GEMM pipelines its operand stream over K.
 // alone (one graph at a time) the halo kernel already wins at half the pixels (batch 1: 19200 px x 160 x 360 19.3 vs 24.2 us, profiles/r4_conv_bench_x3_b1_alone.txt)
 static bool halo_x3_wins(long long M, int Cin, int Cout, bool tput) { return M >= (tput ? 30000 : 15000) && Cin <= 56; }
+// Deep inputs (Cin % 32 == 0, >= 64): which tile of the chunk-pipelined kernel, or -1 = the implicit GEMM.  Round 5: the single-chunk-buffer tiles
+// (36: 128 channels x 8 x 16 pixels, 61 KB; 38: 64 channels x 16 x 16 pixels, 68 KB) hold TWO workgroups per CU, whose load / split / MFMA / store
+// phases cover each other -- tools/probes/chunk_x3_inflight.py, us per call with four copies side by side (alone):
+//   614400 px 128 -> 128 (head conv)  464 (490) against 529 (577) for the 256-pixel double-buffered tile 22;  76800 px (batch 1): 62 (84) vs 79 (95)
+//   153600 px  64 -> 64   35 (54) vs 44 (54) for tile 24;   64 -> 32: 30 (46) vs 40 (51);   64 -> 128: 68 (74) vs 88 (96, implicit GEMM)
+//    38400 px 128 -> 128  32 (59) vs 47 (80, implicit GEMM); 256 -> 128: 61 (92) vs 88 (143); 128 -> 64: 16 (42) vs 21 (38): in flight only
+//     9600 px 256 -> 256  35 (72) vs 45 (73, implicit GEMM); 128 / 256 -> 128: the implicit GEMM stays ahead (12.4 / 22.4 vs 13.7 / 23.7)
+static int chunk_x3_variant(long long M, int Cin, int Cout, bool tput) {
+  if (Cin % 32 != 0 || Cin < 64) return -1;
+  if (Cout > 128) return (tput && M >= 9000) ? 36 : -1;
+  if (Cout > 64) return M >= 30000 ? 36 : -1;
+  if (M >= 100000) return 38;
+  if (M >= 30000) return tput ? 38 : 24;
+  return -1;
+}
 static bool halo_wins_s2(long long M, int Cout) { return g_halo == 2 || (g_halo == 1 && g_halo_s2 && M >= 30000 && Cout <= 160); }
 static bool halo_wins(long long M, int Cout, bool tput) {
   if (g_halo == 2) return true;
@@ -336,6 +351,7 @@ static bool halo_wins(long long M, int Cout, bool tput) {
   return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
                          (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
+void cfp_dwl3_debug_set(int value);          // dwlarge_x3.hip: key 30 = 1: the 32 x 32 pixel tile for k = 31 (two workgroups per CU)
 void cfp_dwl_wgrad_debug_set(int value);     // train_misc2.hip: key 23 = 1 keeps the VALU kernels for the large depthwise weight gradient
 void cfp_wgrad_debug_set(int value);         // conv_bwd.hip: key 22 = workgroups a small weight-gradient launch aims for (sets the slab count)
 void cfp_bn_debug_set(int key, int value);   // bn_train.hip: 20 / 21 = workgroup targets of the column reductions / elementwise sweeps
@@ -344,6 +360,7 @@ void cfp_dw_debug_set(int key, int value);   // dwconv.hip: key 3 = channel vect
 extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: cfp_dw_debug_set(key, value); return CFP_OK;
+    case 30: cfp_dwl3_debug_set(value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
     case 29: g_x3_ad = value; return CFP_OK;
@@ -494,7 +511,7 @@ extern "C" int cfp_conv2d_plan(int M, int Cout, int K, int KH, int stride, int d
                                int* splits) {
   if (dtype == CFP_F32X3) {
     const int cin3 = K / 9;
-    const bool chunk3 = cin3 % 32 == 0 && cin3 >= 64 && M >= 30000 && (Cout <= 64 || (Cout == 128 && M >= 60000));
+    const bool chunk3 = chunk_x3_variant(M, cin3, Cout, g_tput != 0) >= 0;
     if (KH == 3 && stride == 1 && K % 9 == 0 && cin3 % 8 == 0 && rows_per_batch <= 0 && g_halo_x3 && g_force_variant < 0 &&
         (chunk3 || halo_x3_wins(M, cin3, Cout, g_tput != 0))) {
       if (variant) *variant = 500;          // conv3x3_halo_x3.hip (the tile is chosen from Cout and the LDS the halo takes)
@@ -607,7 +624,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     // deep inputs (Cin % 32 == 0, >= 64): the chunk-pipelined form where it measured ahead of the implicit GEMM with four copies side by side
     // (tools/conv_bench_x3.py --halo --inflight 4: 153600 px 64 -> 64 ch 43.6 vs 49.4 us, 38400 px 128 -> 64 20.4 vs 22.0, head conv 556 vs 565)
     // (batch 1: the head conv, 76800 px, 84 us through chunk tile 24 against 118 us through the 128 x 128 implicit GEMM)
-    const int chunk_v = (g_halo_x3 && Cin % 32 == 0 && Cin >= 64 && p.M >= 30000) ? (Cout <= 64 ? 24 : (Cout == 128 && p.M >= 300000) ? 22 : (Cout == 128 && p.M >= 60000) ? 24 : -1) : -1;
+    const int chunk_v = g_halo_x3 ? chunk_x3_variant(p.M, Cin, Cout, tput) : -1;
     if (!per_image_weights && !ln_gamma && conv3x3_halo_x3_takes(p) &&
         (g_force_variant >= 500 || (g_force_variant < 0 && g_halo_x3 && (chunk_v >= 0 || halo_x3_wins(p.M, Cin, Cout, tput))))) {
       const int hv = g_force_variant >= 500 && g_force_variant < 599 ? g_force_variant - 500 : chunk_v;

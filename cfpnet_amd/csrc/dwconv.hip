@@ -1124,6 +1124,8 @@ extern "C" int cfp_dwconv_large_mfma_nhwc(const void* in, int in_ld, const void*
   CFP_REQUIRE((long long)B * cdiv(H, 32) * cdiv(W, 32) * (C / 8) < (1ll << 31), CFP_ESHAPE, "cfp_dwconv_large_mfma_nhwc: grid too large");
   (void)0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // (k = 31 as 32 x 32 pixel tiles -- 79 KB of LDS, two workgroups per CU -- is the f16x3 kernel's default since round 5; in 16-bit storage the whole
+  // step measured 2.219 vs 2.199 ms with four batches in flight, i.e. no gain: the 64 x 32 tile stays here)
 #define DWL(HH) (k == 31 ? launch_dwlarge_mfma<HH, 31, 64, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s) \
                : k == 15 ? launch_dwlarge_mfma<HH, 15, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s) \
                          : launch_dwlarge_mfma<HH, 7, 32, 32>(in, in_ld, toeplitz, scale, shift, out, out_ld, B, H, W, C, act, s))

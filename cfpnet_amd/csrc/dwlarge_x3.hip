@@ -172,8 +172,13 @@ hipError_t launch_dwlarge_x3(const void* in, int in_ld, const void* tb, long lon
 
 // cfp_dwconv_large_mfma_nhwc for dtype CFP_F32X3 (dwconv.hip dispatches here): float32 in / out, `toeplitz` = [hi table | lo table] of halves,
 // each cfp_dwconv_large_toeplitz_elems(C, k) long.
+int g_dwl3_small31 = 1;      // default since round 5: 74.6 vs 113.2 us alone, 70.3 vs 90.5 with four copies (tools/probes/dwl3_tile_probe.py), bit-identical
+void cfp_dwl3_debug_set(int value) { g_dwl3_small31 = value; }
 hipError_t dwlarge_x3_launch(const void* in, int in_ld, const void* toeplitz, long long table_elems, const float* scale, const float* shift, void* out,
                              int out_ld, int B, int H, int W, int C, int k, int act, hipStream_t s) {
+  // k = 31: the 64 x 32 pixel tile takes 120 KB of LDS (one workgroup per CU: staging, products and the output pass of a workgroup serialise),
+  // the 32 x 32 tile 79 KB (two per CU) at 1.3x the halo rows per output row -- cfp_debug_set(30, v): 0 = 64 x 32, 1 = 32 x 32
+  if (k == 31 && g_dwl3_small31) return launch_dwlarge_x3<31, 32, 32>(in, in_ld, toeplitz, table_elems, scale, shift, out, out_ld, B, H, W, C, act, s);
   if (k == 31) return launch_dwlarge_x3<31, 64, 32>(in, in_ld, toeplitz, table_elems, scale, shift, out, out_ld, B, H, W, C, act, s);
   if (k == 15) return launch_dwlarge_x3<15, 32, 32>(in, in_ld, toeplitz, table_elems, scale, shift, out, out_ld, B, H, W, C, act, s);
   return launch_dwlarge_x3<7, 32, 32>(in, in_ld, toeplitz, table_elems, scale, shift, out, out_ld, B, H, W, C, act, s);

@@ -1,6 +1,7 @@
 """Kernel-level numerics: every HIP entry point against a plain PyTorch fp32 reference of the
 same op (CPU), in f32 (tight) and bf16 (storage-rounding) tolerances.  Runs on the GPU box."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -442,10 +443,12 @@ X3_CHUNK_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [20, 21, 22, 23, 24, 25])
+@pytest.mark.parametrize("variant", [20, 21, 22, 23, 24, 25, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 43])
 def test_conv3x3_chunk_x3_every_variant(variant):
     """The chunk-pipelined f16x3 3x3 kernel for deep inputs (Cin % 32 == 0: the halo by 32-channel chunks, double buffered, K loop chunk-major):
-    every tile forced through the debug knob (500 + v) against a float64 reference and the f16x3 implicit GEMM."""
+    every tile forced through the debug knob (500 + v) against a float64 reference and the f16x3 implicit GEMM.  Variants 30-35 (round 5) =
+    20-25 with three weight stages and counted waits: the same products in the same order -> bit-identical to 20-25, ten launches in a row;
+    36-38 = one chunk buffer (two workgroups per CU for the 128-channel tile): bit-identical to 23 / 25 / 21."""
     lib = hip.load()
     try:
         for case in X3_CHUNK_CASES:
@@ -463,6 +466,14 @@ def test_conv3x3_chunk_x3_every_variant(variant):
             ops.conv2d(xa, wx, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
             torch.cuda.synchronize()
             assert float((out2.torch() - out.torch()).abs().max()) <= 2e-6 * float(ref.abs().max())
+            if variant >= 30:
+                lib.cfp_debug_set(0, 500 + ({36: 23, 37: 25, 38: 21, 39: 23, 43: 21}.get(variant, variant - 10)))
+                ops.conv2d(xa, wx, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+                lib.cfp_debug_set(0, 500 + variant)
+                for _ in range(10):
+                    ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
+                    torch.cuda.synchronize()
+                    assert torch.equal(out.torch(), out2.torch()), (variant, case)
     finally:
         lib.cfp_debug_set(0, -1)
 
@@ -793,6 +804,16 @@ def test_dwconv_large_x3_toeplitz(case):
     torch.cuda.synchronize()
     _x3_close(from_nhwc(out.torch(), B, H, W), ref, f"dwlarge x3 {case}")
     assert float(out.buf[:, :4].abs().max()) == 0 and float(out.buf[:, 4 + Cc:].abs().max()) == 0
+    if k == 31:       # the other tile of k = 31 (cfp_debug_set(30, .): 64 x 32 / 32 x 32 pixels): same products per output -> same bits
+        lib = hip.load()
+        first = out.torch().clone()
+        try:
+            lib.cfp_debug_set(30, 0 if int(os.environ.get("CFP_DWL3_DEFAULT", "1")) else 1)
+            ops.dwconv_large_mfma(to_act(nhwc(x), torch.float32, ld=Cc + 16, c0=8), tb, scale.to(DEV), shift.to(DEV), out, B, H, W, k, hip.ACT_RELU)
+            torch.cuda.synchronize()
+            assert torch.equal(out.torch(), first)
+        finally:
+            lib.cfp_debug_set(30, int(os.environ.get("CFP_DWL3_DEFAULT", "1")))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -8,7 +8,9 @@ from cfpnet_amd import hip, ops
 from _gtime import graph_time_us
 lib = hip.load()
 DEV = "cuda:0"
-for (B, H, W, Cin, Cout, force) in ((8, 240, 320, 128, 128, 522), (8, 240, 320, 128, 128, 524), (8, 120, 160, 64, 64, 524)):
+for (B, H, W, Cin, Cout, force) in ((8, 240, 320, 128, 128, 522), (8, 240, 320, 128, 128, 523), (8, 240, 320, 128, 128, 536), (8, 240, 320, 128, 128, 524),
+                                    (8, 120, 160, 64, 64, 524), (8, 120, 160, 64, 64, 538), (8, 120, 160, 64, 64, 521), (8, 60, 80, 128, 64, 524), (8, 60, 80, 128, 64, 538),
+                                    (8, 60, 80, 128, 128, 523), (8, 60, 80, 128, 128, 536), (1, 240, 320, 128, 128, 524), (1, 240, 320, 128, 128, 536)):
     x = ops.Act(torch.randn(B * H * W, Cin, device=DEV), 0, Cin)
     w = torch.randn(Cout, 9 * Cin, device=DEV) / (3 * Cin ** 0.5)
     wx = ops.pack_w_x3(w)
