@@ -161,6 +161,7 @@ class Engine:
         # parity-tested and MEASURED SLOWER than resize + implicit GEMM at every stage (tools/up_bench_x3.py, batch 8, four copies in flight: up1
         # 107 vs 79 us, up2 137 vs 129, up3 219 vs 164, up4 358 vs 225; whole step 4.71 vs 4.68 ms): OFF by default, CFP_UP_FUSED_X3=1234 enables it.
         self.up_fused_x3 = os.environ.get("CFP_UP_FUSED_X3", "")
+        self.cat_pad = os.environ.get("CFP_CAT_PAD", "1") == "1" and not self.up_fused_x3      # f16x3: zero-padded concatenation buffers (see _pack: decoder.up*.a)
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
@@ -307,6 +308,13 @@ class Engine:
         self._conv(sd, d + ".conv4", d + ".conv4.weight", d + ".conv4.bias")
         for i in (1, 2, 3, 4):
             q = f"{d}.up{i}._net"
+            if self.x3 and self.cat_pad:
+                # f16x3 mode (round 5): the concatenation buffer [upsampled | skip] is padded with zero channels to a multiple of 32 (80 / 168 / 312 /
+                # 392 -> 96 / 192 / 320 / 416) and the weights with zero columns, so that the first conv of the stage is a Cin % 32 == 0 problem for
+                # the chunk-pipelined 3x3 kernel (two workgroups per CU) instead of an im2col implicit GEMM that fetches its input once per tap
+                wfull = sd[q + ".0.weight"]
+                cpad = (wfull.shape[1] + 31) // 32 * 32
+                self.P[f"{d}.up{i}.a.wpad"] = self._pack_conv(torch.nn.functional.pad(wfull.detach().float(), (0, 0, 0, 0, 0, cpad - wfull.shape[1])))
             self._conv(sd, f"{d}.up{i}.a", q + ".0.weight", q + ".0.bias", bn=q + ".1")
             if self.x3 and str(i) in self.up_fused_x3:
                 # the same weights packed over the PADDED concatenation axis [upsampled decoder channels | skip channels -> next multiple of 32]:
@@ -1033,11 +1041,13 @@ class Engine:
         wsz = [W // 2, W // 4, W // 8, W // 16, W // 32]
         e, c = spec.DEC_ENC_CH, spec.DEC_CH
         # concatenation buffers: [upsampled decoder features | encoder skip]
+        cp = (lambda n: (n + 31) // 32 * 32) if (self.x3 and self.cat_pad) else (lambda n: n)      # f16x3: zero channels up to a multiple of 32, never written
+        zc = self.x3 and self.cat_pad
         cat = [None,
-               self._act(plan, "cat1", B * hs[3] * wsz[3], c[0] + e[1]),
-               self._act(plan, "cat2", B * hs[2] * wsz[2], c[1] + e[2]),
-               self._act(plan, "cat3", B * hs[1] * wsz[1], c[2] + e[3]),
-               self._act(plan, "cat4", B * hs[0] * wsz[0], c[3] + e[4])]
+               self._act(plan, "cat1", B * hs[3] * wsz[3], cp(c[0] + e[1]), zero=zc),
+               self._act(plan, "cat2", B * hs[2] * wsz[2], cp(c[1] + e[2]), zero=zc),
+               self._act(plan, "cat3", B * hs[1] * wsz[1], cp(c[2] + e[3]), zero=zc),
+               self._act(plan, "cat4", B * hs[0] * wsz[0], cp(c[3] + e[4]), zero=zc)]
         b4 = self._act(plan, "tap4", B * hs[4] * wsz[4], e[0])
         plan["tap_dst"] = [cat[4].slice(c[3], e[4]), cat[3].slice(c[2], e[3]), cat[2].slice(c[1], e[2]),
                            cat[1].slice(c[0], e[1]), b4]
@@ -1081,16 +1091,23 @@ class Engine:
                 # round 5: the two-source chunk kernel (conv3x3_halo_x3.hip, UP): bilinear blend in the halo loader, skip channels from the
                 # concatenation buffer's slice; the upsampled tensor is never written
                 n = f"decoder.up{i}.a"
-                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".wcat"], self.P[n + ".s"], self.P[n + ".t"],
+                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, e[i]), self.P[n + ".wcat"], self.P[n + ".s"], self.P[n + ".t"],
                                          t1, B, hd, wd, hip.ACT_LRELU, x3=True)
             elif self.half and str(i) in self.up_fused and src.C % 64 == 0 and taps is None and fits:
                 # cfp_upsample_cat_conv3x3: bilinear + concat computed inside the conv's halo loader (bit-identical to the pair below)
                 n = f"decoder.up{i}.a"
-                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, cat[i].C - src.C), self.P[n + ".w"], self.P[n + ".s"], self.P[n + ".t"],
+                ops.upsample_cat_conv3x3(src, hs_, ws_, cat[i].slice(src.C, e[i]), self.P[n + ".w"], self.P[n + ".s"], self.P[n + ".t"],
                                          t1, B, hd, wd, hip.ACT_LRELU)
             else:
                 ops.resize_bilinear(src, hs_, ws_, (0, 0, hs_, ws_), cat[i].slice(0, src.C), hd, wd, (0, 0, hd, wd), B)
-                self._cv(f"decoder.up{i}.a", cat[i], t1, B, hd, wd, 3, act=hip.ACT_LRELU)
+                n = f"decoder.up{i}.a"
+                if (n + ".wpad") in self.P and M >= 30000:
+                    # many pixels: the zero-padded concatenation (Cin % 32 == 0) through the chunk-pipelined kernel; few pixels (single images
+                    # below the 1/2 scale): the unpadded columns of the same buffer through the implicit GEMM as before
+                    ops.conv2d(cat[i], self.P[n + ".wpad"], self.P[n + ".s"], self.P[n + ".t"], t1, B, hd, wd, 3, 3, 1, 1, 1, hd, wd, hip.ACT_LRELU,
+                               None, self._ws(M, t1.C, 9 * cat[i].C))
+                else:
+                    self._cv(n, cat[i].slice(0, src.C + e[i]), t1, B, hd, wd, 3, act=hip.ACT_LRELU)
             t2 = self._act(plan, f"up{i}.b", M, c[i])
             self._cv(f"decoder.up{i}.b", t1, t2, B, hd, wd, 3, act=hip.ACT_LRELU)
             return t2
