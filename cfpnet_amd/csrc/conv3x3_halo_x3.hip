@@ -666,6 +666,9 @@ int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
     case 37: return launch_cx<8, 2, false, 2, true>(p, s);      // <= 256 channels, 8 x 16 pixels, 93 KB (one per CU; for comparison)
     case 38: return launch_cx<4, 1, false, 2, true>(p, s);      // <= 64 channels, 16 x 16 pixels, 68 KB
     case 39: return launch_cx<4, 2, false, 3, true>(p, s);      // 36 with three weight stages: 77 KB, still two per CU
+    case 44: return launch_cx<2, 2, false, 2, true>(p, s);      // <= 64 channels, 8 x 16 pixels, 45 KB: three per CU
+    case 45: return launch_cx<1, 2, false, 2, true>(p, s);      // <= 32 channels, 8 x 16 pixels, 37 KB: four per CU
+    case 46: return launch_cx<2, 1, false, 2, true>(p, s);      // <= 32 channels, 16 x 16 pixels, 60 KB: two per CU
     case 43: return launch_cx<4, 1, false, 3, true>(p, s);      // 38 with three weight stages: 76 KB
     // two sources (cfp_upsample_cat_conv3x3): 8 x 16 pixel tiles (six pieces per thread and chunk: 96 registers of taps in flight)
     case 40: return launch_cx<1, 2, true>(p, s);      // <= 32 output channels per workgroup

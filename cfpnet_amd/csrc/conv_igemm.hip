@@ -340,6 +340,8 @@ static int chunk_x3_variant(long long M, int Cin, int Cout, bool tput) {
   if (Cin % 32 != 0 || Cin < 64) return -1;
   if (Cout > 128) return (tput && M >= 9000) ? 36 : -1;
   if (Cout > 64) return M >= 30000 ? 36 : -1;
+  if (Cout <= 32) return M >= 30000 ? 45 : -1;      // 32 channels x 8 x 16 pixels, 37 KB (four per CU): 614400 px 96 -> 32 (up4's first conv on the padded
+                                                    // concatenation) 127 (136) vs 174 (187) for the 64-channel tile 38; 153600 px 64 -> 32: 20 (35) vs 30 (45)
   if (M >= 100000) return 38;
   if (M >= 30000) return tput ? 38 : 24;
   return -1;

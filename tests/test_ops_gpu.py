@@ -443,7 +443,7 @@ X3_CHUNK_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [20, 21, 22, 23, 24, 25, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 43])
+@pytest.mark.parametrize("variant", [20, 21, 22, 23, 24, 25, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 43, 44, 45, 46])
 def test_conv3x3_chunk_x3_every_variant(variant):
     """The chunk-pipelined f16x3 3x3 kernel for deep inputs (Cin % 32 == 0: the halo by 32-channel chunks, double buffered, K loop chunk-major):
     every tile forced through the debug knob (500 + v) against a float64 reference and the f16x3 implicit GEMM.  Variants 30-35 (round 5) =
@@ -467,7 +467,7 @@ def test_conv3x3_chunk_x3_every_variant(variant):
             torch.cuda.synchronize()
             assert float((out2.torch() - out.torch()).abs().max()) <= 2e-6 * float(ref.abs().max())
             if variant >= 30:
-                lib.cfp_debug_set(0, 500 + ({36: 23, 37: 25, 38: 21, 39: 23, 43: 21}.get(variant, variant - 10)))
+                lib.cfp_debug_set(0, 500 + ({36: 23, 37: 25, 38: 21, 39: 23, 43: 21, 44: 24, 45: 24, 46: 20}.get(variant, variant - 10)))
                 ops.conv2d(xa, wx, scale, shift, out2, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, None)
                 lib.cfp_debug_set(0, 500 + variant)
                 for _ in range(10):

@@ -10,8 +10,8 @@ lib = hip.load()
 DEV = "cuda:0"
 ST = concurrent_streams(DEV, want=4)
 ops.PLAN_IN_FLIGHT = True
-for (B, H, W, Cin, Cout, forces) in ((8, 240, 320, 128, 128, (536, 539, -1)), (8, 120, 160, 64, 64, (538, 543, -1)), (8, 60, 80, 128, 128, (536, 539, -1)),
-                                     (8, 60, 80, 256, 128, (536, 539, -1)), (8, 30, 40, 256, 256, (536, 539, -1)), (8, 60, 80, 128, 64, (538, 543, -1)), (1, 240, 320, 128, 128, (536, 539, -1))):
+for (B, H, W, Cin, Cout, forces) in ((8, 240, 320, 96, 32, (538, 544, 545, 546, -1)), (8, 120, 160, 192, 64, (538, 544, -1)), (8, 120, 160, 64, 64, (538, 544, -1)), (8, 120, 160, 64, 32, (538, 544, 545, 546, -1)),
+                                     (8, 60, 80, 128, 64, (538, 544, -1)), (8, 60, 80, 64, 64, (538, 544, -1)), (8, 60, 80, 320, 128, (536, -1)), (8, 30, 40, 416, 256, (536, -1)), (1, 240, 320, 96, 32, (524, 538, 544, 545, -1)), (1, 120, 160, 192, 64, (538, 544, -1))):
     x = ops.Act(torch.randn(B * H * W, Cin, device=DEV), 0, Cin)
     w = torch.randn(Cout, 9 * Cin, device=DEV) / (3 * Cin ** 0.5)
     wx = ops.pack_w_x3(w)
