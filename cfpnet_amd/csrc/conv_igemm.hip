@@ -611,6 +611,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
   const bool w2 = (per_image_weights & CFP_CONV_W2) != 0;
   const bool x3 = (per_image_weights & CFP_CONV_X3) != 0;
   const bool tput = (per_image_weights & CFP_CONV_IN_FLIGHT) != 0 || g_tput != 0;
+  const bool tickets = (per_image_weights & CFP_CONV_WS_TICKETS) != 0;
   per_image_weights &= CFP_CONV_PER_IMAGE;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 
@@ -639,7 +640,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (g_force_splits >= 1) pl.splits = g_force_splits;
     if (pl.splits > 1 && pl.variant >= 19) pl.variant = 4;
     if (rpb > 0) { p.rows_per_batch = rpb; p.w_bstride = (long long)Cout * cdiv(p.K, 32) * 64; }
-    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float))) {
+    if (pl.splits > 1 && (!ws || ws_bytes < (size_t)pl.splits * p.M * Cout * sizeof(float) + (tickets ? CFP_CONV_TICKET_BYTES : 0))) {
       pl.splits = 1;
       if (rpb > 0) pl = plan_x3(p.M, Cout, p.K, rpb, B, false, tput, false);      // no workspace: the un-split plan of this problem (K groups)
       pl.splits = 1;
@@ -653,12 +654,24 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     } else if (ln_gamma) {
       p.res = nullptr;      // the residual is added after the LayerNorm kernel
     }
-    int rc = igemm_x3_launch(pl.variant, p, (float*)ws, pl.splits, s);
+    // CFP_CONV_WS_TICKETS: the first CFP_CONV_TICKET_BYTES of `ws` are the caller's zeroed ticket area and the slabs follow -- the last workgroup
+    // to reach an output tile finishes it (sum in split order + epilogue), no second launch
+    unsigned* tk = nullptr;
+    float* slabs = (float*)ws;
+    if (tickets && pl.splits > 1) {
+      int bm, bn, st;
+      igemm_x3_variant_shape(pl.variant, &bm, &bn, &st);
+      const long long tiles = (rpb > 0 ? (long long)B * cdiv(rpb, bm) : cdiv(p.M, bm)) * cdiv(Cout, bn);
+      if (tiles <= CFP_TICKET_SLOTS && (long long)pl.splits * p.M * Cout * 4 < (1ll << 31) - 16) {      // (the slabs sit behind one buffer descriptor)
+        tk = (unsigned*)ws; slabs = (float*)((char*)ws + CFP_CONV_TICKET_BYTES);
+      }
+    }
+    int rc = igemm_x3_launch(pl.variant, p, slabs, pl.splits, s, tk);
     CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: f16x3 kernel launch failed");
-    if (pl.splits > 1) {
+    if (pl.splits > 1 && !tk) {
       long long total = (long long)p.M * (Cout / 4);
       int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)ws, pl.splits, p);
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)slabs, pl.splits, p);
     }
     int e = cfp_check_launch("cfp_conv2d_nhwc");
     if (e != CFP_OK || !ln_gamma || ln_v >= 0) return e;

@@ -480,7 +480,7 @@ __device__ __forceinline__ void x3_mainloop_ad(const ConvP& p, const f16_t* __re
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1, bool AD = false>
-__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __restrict__ slabs, int splits) {
+__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* slabs, int splits, unsigned* tickets) {
   static_assert(WM * WN == 4, "four waves per group");
   static_assert(!AD || (WM == 4 && WN == 1 && KG == 1 && !SPLITK && STAGES == 2), "A-direct: 4 x 1 waves, two stages, whole K");
   static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
@@ -550,16 +550,81 @@ __global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* __re
   }
 
   if constexpr (SPLITK) {
-    float* slab = slabs + (long long)sp * p.M * p.Cout;
+    if (tickets == nullptr) {                   // the finishing sum is a second launch (splitk_reduce_kernel)
+      float* slab = slabs + (long long)sp * p.M * p.Cout;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m = m0 + a_row0 + i * 16 + fr;
+          const int n = n0 + b_row0 + j * 16 + fq * 4;
+          if (m < m_end && n < p.Cout) *reinterpret_cast<f32x4*>(slab + (long long)m * p.Cout + n) = acc[i][j];
+        }
+      return;
+    }
+    // Ticketed finish: the workgroup that arrives LAST at its output tile sums the slabs -- every one read back from memory in split order, so the
+    // value is splitk_reduce_kernel's bit for bit whichever workgroup that is -- and runs the epilogue below.
+    // Visibility across the eight XCDs (private L2s) WITHOUT fences: a device-scope release fence is buffer_wbl2 -- a walk over the whole L2 per
+    // wave, measured +23 us per launch with 1 280 waves -- so the slab traffic itself is device-coherent instead: stores and loads carry the
+    // sc1 scope bit (write-through to memory / never served from a stale L2 line), every wave waits for its stores to be acknowledged
+    // (vmcnt 0) before the barrier, and only then is the ticket taken (a device-scope atomic).
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    constexpr int SC1 = 16;                     // cache-policy bit of the buffer intrinsics: sc1 = agent (device) scope on gfx940+
+    const long long slab_elems = (long long)p.M * p.Cout;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, (int)(slab_elems * splits * 4), 0x00020000);     // host: < 2^31 bytes
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int m = m0 + a_row0 + i * 16 + fr;
         const int n = n0 + b_row0 + j * 16 + fq * 4;
-        if (m < m_end && n < p.Cout) *reinterpret_cast<f32x4*>(slab + (long long)m * p.Cout + n) = acc[i][j];
+        if (m < m_end && n < p.Cout)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[i][j]), rs, (int)((sp * slab_elems + (long long)m * p.Cout + n) * 4), 0, SC1);
       }
-  } else {
+    wait_vmcnt<0>();
+    __syncthreads();
+    int* s_last = reinterpret_cast<int*>(smem);       // (the operand stages are free after the barrier; a static __shared__ would push the
+    if (tid == 0) {                                   //  kernel past the 160 KB the dynamic allocation may ask for)
+      const unsigned t = __hip_atomic_fetch_add(tickets + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = t == (unsigned)(splits - 1);
+      if (*s_last) __hip_atomic_store(tickets + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // handed back zeroed for the next launch
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    // U splits' loads are issued together (each is a trip to memory: one at a time would be a chain of `splits` latencies), added in split order
+    constexpr int U = TM * TN >= 16 ? 1 : TM * TN >= 8 ? 2 : 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q0 = 0; q0 < splits; q0 += U) {
+      f32x4 x[U][TM][TN];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int m = m0 + a_row0 + i * 16 + fr;
+            const int n = n0 + b_row0 + j * 16 + fq * 4;
+            const bool ok = m < m_end && n < p.Cout && q0 + u < splits;
+            // (a refused element reads past the descriptor's range: zeros, and its sum is never stored)
+            const long long off = ok ? ((q0 + u) * slab_elems + (long long)m * p.Cout + n) * 4 : 0x7ffffff0ll;
+            x[u][i][j] = __builtin_bit_cast(f32x4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, SC1));
+          }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (q0 + u < splits) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][r] += x[u][i][j][r];
+        }
+    }
+  }
+  {
     float* __restrict__ out = reinterpret_cast<float*>(p.out);
     const float* __restrict__ res = reinterpret_cast<const float*>(p.res);
     if constexpr (WN == 1 && KG == 1) {
@@ -651,7 +716,7 @@ constexpr Cfg kCfg[] = {
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1, bool AD = false>
-int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
+int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s, unsigned* tickets) {
   const size_t lds = AD ? (size_t)STAGES * BN * 128 : (size_t)KG * STAGES * (BM + BN) * 128;
   if (lds > 160 * 1024) return -1;
   if ((KG == 2 || AD) && splits > 1) return -4;
@@ -662,12 +727,13 @@ int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s) {
     auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG, AD>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1);
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1, (unsigned*)nullptr);
   } else if constexpr (KG == 1 && !AD) {
     auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, p, slabs, splits);
+    if (tickets && tiles > CFP_TICKET_SLOTS) return -6;
+    hipLaunchKernelGGL(k, dim3((unsigned)(tiles * splits)), dim3(256), lds, s, p, slabs, splits, tickets);
   }
   return 0;
 }
@@ -768,42 +834,42 @@ int igemm_x3_num_variants() { return kNumCfg; }
 void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages) { *bm = kCfg[v].bm; *bn = kCfg[v].bn; *stages = kCfg[v].stages; }
 
 // Launch variant v (conv_igemm2.hip's ids).  Returns 0, or a negative value if the variant cannot run this problem.
-int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s) {
+int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s, unsigned* tickets) {
   switch (v) {
-    case 0: return launch_x3<128, 128, 2, 2, 3>(p, slabs, splits, s);
-    case 1: return launch_x3<128, 128, 2, 2, 2>(p, slabs, splits, s);
-    case 2: return launch_x3<128, 64, 4, 1, 3>(p, slabs, splits, s);
-    case 3: return launch_x3<128, 64, 4, 1, 4>(p, slabs, splits, s);
-    case 4: return launch_x3<64, 64, 4, 1, 3>(p, slabs, splits, s);
-    case 5: return launch_x3<64, 64, 4, 1, 4>(p, slabs, splits, s);
-    case 6: return launch_x3<256, 32, 4, 1, 3>(p, slabs, splits, s);
-    case 7: return launch_x3<256, 32, 4, 1, 2>(p, slabs, splits, s);
-    case 8: return launch_x3<128, 32, 4, 1, 3>(p, slabs, splits, s);
-    case 9: return launch_x3<128, 32, 4, 1, 4>(p, slabs, splits, s);
-    case 10: return launch_x3<256, 16, 4, 1, 2>(p, slabs, splits, s);
-    case 11: return launch_x3<128, 16, 4, 1, 4>(p, slabs, splits, s);
-    case 12: return launch_x3<64, 128, 2, 2, 3>(p, slabs, splits, s);
-    case 13: return launch_x3<64, 64, 4, 1, 2>(p, slabs, splits, s);
-    case 14: return launch_x3<128, 64, 4, 1, 2>(p, slabs, splits, s);
-    case 15: return launch_x3<64, 128, 2, 2, 2>(p, slabs, splits, s);
-    case 16: return launch_x3<128, 32, 4, 1, 2>(p, slabs, splits, s);
-    case 17: return launch_x3<32, 64, 1, 4, 3>(p, slabs, splits, s);
-    case 18: return launch_x3<32, 128, 1, 4, 3>(p, slabs, splits, s);
-    case 19: return launch_x3<64, 64, 4, 1, 2, 2>(p, slabs, splits, s);
-    case 20: return launch_x3<64, 64, 4, 1, 3, 2>(p, slabs, splits, s);
-    case 21: return launch_x3<64, 128, 2, 2, 2, 2>(p, slabs, splits, s);
-    case 22: return launch_x3<256, 128, 2, 2, 2>(p, slabs, splits, s);
-    case 23: return launch_x3<256, 64, 4, 1, 2>(p, slabs, splits, s);
-    case 24: return launch_x3<64, 64, 2, 2, 2>(p, slabs, splits, s);
-    case 25: return launch_x3<128, 64, 2, 2, 2>(p, slabs, splits, s);
-    case 26: return launch_x3<128, 128, 4, 1, 2>(p, slabs, splits, s);
-    case 27: return launch_x3<64, 128, 4, 1, 2>(p, slabs, splits, s);
-    case 28: return launch_x3<128, 128, 4, 1, 2, 1, true>(p, slabs, splits, s);
-    case 29: return launch_x3<128, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
-    case 30: return launch_x3<64, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
-    case 31: return launch_x3<256, 64, 4, 1, 2, 1, true>(p, slabs, splits, s);
-    case 32: return launch_x3<128, 32, 4, 1, 2, 1, true>(p, slabs, splits, s);
-    case 33: return launch_x3<256, 128, 4, 1, 2, 1, true>(p, slabs, splits, s);
+    case 0: return launch_x3<128, 128, 2, 2, 3>(p, slabs, splits, s, tickets);
+    case 1: return launch_x3<128, 128, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 2: return launch_x3<128, 64, 4, 1, 3>(p, slabs, splits, s, tickets);
+    case 3: return launch_x3<128, 64, 4, 1, 4>(p, slabs, splits, s, tickets);
+    case 4: return launch_x3<64, 64, 4, 1, 3>(p, slabs, splits, s, tickets);
+    case 5: return launch_x3<64, 64, 4, 1, 4>(p, slabs, splits, s, tickets);
+    case 6: return launch_x3<256, 32, 4, 1, 3>(p, slabs, splits, s, tickets);
+    case 7: return launch_x3<256, 32, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 8: return launch_x3<128, 32, 4, 1, 3>(p, slabs, splits, s, tickets);
+    case 9: return launch_x3<128, 32, 4, 1, 4>(p, slabs, splits, s, tickets);
+    case 10: return launch_x3<256, 16, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 11: return launch_x3<128, 16, 4, 1, 4>(p, slabs, splits, s, tickets);
+    case 12: return launch_x3<64, 128, 2, 2, 3>(p, slabs, splits, s, tickets);
+    case 13: return launch_x3<64, 64, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 14: return launch_x3<128, 64, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 15: return launch_x3<64, 128, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 16: return launch_x3<128, 32, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 17: return launch_x3<32, 64, 1, 4, 3>(p, slabs, splits, s, tickets);
+    case 18: return launch_x3<32, 128, 1, 4, 3>(p, slabs, splits, s, tickets);
+    case 19: return launch_x3<64, 64, 4, 1, 2, 2>(p, slabs, splits, s, tickets);
+    case 20: return launch_x3<64, 64, 4, 1, 3, 2>(p, slabs, splits, s, tickets);
+    case 21: return launch_x3<64, 128, 2, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 22: return launch_x3<256, 128, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 23: return launch_x3<256, 64, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 24: return launch_x3<64, 64, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 25: return launch_x3<128, 64, 2, 2, 2>(p, slabs, splits, s, tickets);
+    case 26: return launch_x3<128, 128, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 27: return launch_x3<64, 128, 4, 1, 2>(p, slabs, splits, s, tickets);
+    case 28: return launch_x3<128, 128, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 29: return launch_x3<128, 64, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 30: return launch_x3<64, 64, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 31: return launch_x3<256, 64, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 32: return launch_x3<128, 32, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 33: return launch_x3<256, 128, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
     default: return -3;
   }
 }

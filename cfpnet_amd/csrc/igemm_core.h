@@ -44,7 +44,8 @@ int igemm2_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s
 // conv_igemm_x3.hip (float32 storage, f16x3 matrix math; `p.w` = the packed operand of cfp_pack_w_x3)
 int igemm_x3_num_variants();
 void igemm_x3_variant_shape(int v, int* bm, int* bn, int* stages);
-int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s);
+constexpr int CFP_TICKET_SLOTS = 1024;       // output tiles a ticketed split-K launch may have (CFP_CONV_TICKET_BYTES / 4, cfpnet_hip.h)
+int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t s, unsigned* tickets = nullptr);
 int bin_head_x3_launch(const void* x, int x_ld, const void* w, const float* bias, const float* centers, float* prob, float* pred, int B, int HW,
                        int Cin, hipStream_t s);
 

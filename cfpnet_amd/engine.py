@@ -120,6 +120,9 @@ class Engine:
         assert not x3 or dtype == torch.float32, "x3 is a matrix-math mode of float32 storage"
         self.x3 = bool(x3)
         self.cdt = hip.F32X3 if self.x3 else ops.DT[dtype]          # planning dtype (cfp_conv2d_ws_bytes)
+        # ticketed split-K (CFP_CONV_WS_TICKETS: the last workgroup at a tile finishes it, no reduce launch) is bit-identical and measured EQUAL at
+        # batch 1 (3.20 vs 3.18 ms: the memory round trip + ticket it adds to the GEMM is as long as the launch it removes): off
+        self.tickets = self.x3 and os.environ.get("CFP_SPLITK_TICKETS", "0") == "1"
         self.zone_sample_num = zone_sample_num
         # depth head: conv3x3 -> conv_out -> softmax -> expectation as ONE kernel (csrc/head_fused.hip) in the 16-bit modes;
         # head_hilo = (conv_out weights as hi + lo planes, ram fed to conv_out as hi + lo): the logits then carry neither the
@@ -417,11 +420,17 @@ class Engine:
         need = ops.conv2d_ws_bytes(M, Cout, K, self.cdt)
         if need == 0:
             return None
+        if self.tickets:
+            need += hip.CONV_TICKET_BYTES
         ws = self._lane_ws.get(self._lane)
         if ws is None or ws.numel() * 4 < need:
             if self._capturing:
                 raise RuntimeError("split-K workspace must be sized by a warm-up forward before graph capture")
-            ws = self._lane_ws[self._lane] = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            if self.tickets:      # f16x3: ticketed split-K (the last workgroup at a tile finishes it: no reduce launch)
+                ws = ops.ticket_ws(need - hip.CONV_TICKET_BYTES, self.device)
+            else:
+                ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+            self._lane_ws[self._lane] = ws
         return ws
 
     def _dbg(self, name: str, a: Act):
@@ -604,7 +613,14 @@ class Engine:
         if not self.x3:
             return None
         _, sp = ops.conv2d_plan(B * hw, cout, k, hip.F32X3, hw, B, 1, 1)
-        return self._f32(plan, f"enc{bi}.piw_ws", sp * B * hw * cout) if sp > 1 else None
+        if sp <= 1:
+            return None
+        if not self.tickets:
+            return self._f32(plan, f"enc{bi}.piw_ws", sp * B * hw * cout)
+        bufs, key = plan["bufs"], f"enc{bi}.piw_ws"
+        if key not in bufs:
+            bufs[key] = ops.ticket_ws(sp * B * hw * cout * 4, self.device)
+        return bufs[key]
 
     def _fusion(self, plan, name: str, x: Act, feat1: Act, zone_valid: torch.Tensor, geo: FusionGeometry, B, H, W, out: Act,
                 pos_offset, taps):

@@ -18,7 +18,8 @@ F32X3 = 3      # float32 storage + f16x3 matrix math: a planning / packing dtype
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SILU, ACT_GELU, ACT_SIGMOID = range(6)
 TOF_SAMPLE_UNIFORM, TOF_SAMPLE_ICDF = 0, 1
 HEAD_WOUT_HILO, HEAD_RAM_HILO = 1, 2
-CONV_PER_IMAGE, CONV_W2, CONV_IN_FLIGHT, CONV_X3 = 1, 2, 4, 8
+CONV_PER_IMAGE, CONV_W2, CONV_IN_FLIGHT, CONV_X3, CONV_WS_TICKETS = 1, 2, 4, 8, 16
+CONV_TICKET_BYTES = 4096     # CFP_CONV_TICKET_BYTES
 
 _p, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 

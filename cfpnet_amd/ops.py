@@ -57,6 +57,14 @@ def _s():
     return hip.current_stream()
 
 
+def ticket_ws(slab_bytes: int, device) -> torch.Tensor:
+    """Split-K workspace with the ticket area of CFP_CONV_WS_TICKETS in front: [CONV_TICKET_BYTES of zeros | slabs].  The kernels hand the area
+    back zeroed after every launch, so it is zeroed exactly once, here."""
+    ws = torch.zeros((hip.CONV_TICKET_BYTES + slab_bytes + 3) // 4, dtype=torch.float32, device=device)
+    ws.cfp_tickets = True
+    return ws
+
+
 def conv2d_ws_bytes(M: int, Cout: int, K: int, dt: int) -> int:
     return int(hip.load().cfp_conv2d_ws_bytes(M, Cout, K, dt))
 
@@ -68,7 +76,9 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
            act=hip.ACT_NONE, residual: Optional[Act] = None, ws: Optional[torch.Tensor] = None, ln=None,
            per_image_weights: bool = False):
     """`ln = (gamma, beta, eps)` fuses a LayerNorm over the output channels (residual added after it);
-    `per_image_weights`: w is [B, Cout, K] and image b uses w[b]."""
+    `per_image_weights`: w is [B, Cout, K] and image b uses w[b]; a `ws` made by ticket_ws() starts with the zeroed ticket area
+    (CFP_CONV_WS_TICKETS: a split-K layer then finishes in its own launch)."""
+    tickets = getattr(ws, "cfp_tickets", False)
     assert x.rows >= B * H * W and out.rows >= B * Ho * Wo
     K = KH * KW * x.C
     wshape = (B, out.C, K) if per_image_weights else (out.C, K)
@@ -82,7 +92,8 @@ def conv2d(x: Act, w: torch.Tensor, scale, shift, out: Act, B, H, W, KH, KW, str
              residual.ptr if residual else 0, residual.ld if residual else 0, out.ptr, out.ld,
              B, H, W, x.C, out.C, KH, KW, stride, pad_t, pad_l, Ho, Wo, act, x.dt,
              hip.ptr(g), hip.ptr(b), float(eps),
-             int(per_image_weights) | (hip.CONV_W2 if w2 else 0) | (hip.CONV_IN_FLIGHT if PLAN_IN_FLIGHT else 0) | (hip.CONV_X3 if x3 else 0),
+             int(per_image_weights) | (hip.CONV_W2 if w2 else 0) | (hip.CONV_IN_FLIGHT if PLAN_IN_FLIGHT else 0) | (hip.CONV_X3 if x3 else 0) |
+             (hip.CONV_WS_TICKETS if tickets and ws is not None else 0),
              hip.ptr(ws), ws.numel() * ws.element_size() if ws is not None else 0, _s())
 
 

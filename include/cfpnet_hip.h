@@ -78,9 +78,15 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
  *     with CFP_CONV_PER_IMAGE: B such matrices, as cfp_se_gate_fold writes them for dtype CFP_F32X3).  This is the mode whose results
  *     stay inside the reference tolerance (1e-3 relative L1 on the depth map, /root/reference/src/models/deltar.py:34-67 in float32)
  *     for every weight family -- the default of the drop-in boundary. */
-enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2, CFP_CONV_IN_FLIGHT = 4, CFP_CONV_X3 = 8 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument.
+enum { CFP_CONV_PER_IMAGE = 1, CFP_CONV_W2 = 2, CFP_CONV_IN_FLIGHT = 4, CFP_CONV_X3 = 8, CFP_CONV_WS_TICKETS = 16 };   /* bits of cfp_conv2d_nhwc_ex's `per_image_weights` argument.
  * CFP_CONV_IN_FLIGHT: a hint -- this launch will run beside launches of other batches (several captured forwards in flight): the tile is then
- * chosen for the resources it holds rather than for its own latency (larger tiles).  Results do not depend on it: every tile walks K in the same order. */
+ * chosen for the resources it holds rather than for its own latency (larger tiles).  Results do not depend on it: every tile walks K in the same order.
+ * CFP_CONV_WS_TICKETS (CFP_CONV_X3 launches): the first CFP_CONV_TICKET_BYTES of `ws` are a TICKET AREA -- all zero when the workspace is first handed
+ * over, and left all zero by every launch -- and the split-K slabs follow it (ws_bytes >= CFP_CONV_TICKET_BYTES + cfp_conv2d_ws_bytes(...)).  When K is
+ * split, the workgroup that reaches an output tile last then finishes it (slabs summed in split order, scale / shift / act / residual), instead of a
+ * second launch doing so: one kernel less per split layer, the same bits.  Launches that share a workspace must be ordered (one stream), as they must
+ * for the slabs. */
+#define CFP_CONV_TICKET_BYTES 4096
 int cfp_conv2d_nhwc_ex(const void* in, int in_ld, const void* w, const float* scale, const float* shift,
                        const void* residual, int res_ld, void* out, int out_ld,
                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,

@@ -234,6 +234,67 @@ def test_conv2d_x3_every_tile_variant(variant):
         lib.cfp_debug_set(1, -1)
 
 
+@pytest.mark.parametrize("variant", [4, 13, 14, 12, 17, 0])
+def test_conv2d_x3_ticketed_split_k_is_bit_identical_to_the_reduce_launch(variant):
+    """CFP_CONV_WS_TICKETS: the last workgroup at an output tile sums the slabs (in split order, from memory) and runs the epilogue -- EQUAL to
+    the two-launch form (slabs + splitk_reduce_kernel) for 2 .. 8 splits, ragged tiles, residual + activation; the ticket area comes back zeroed,
+    also after several launches on one workspace (a captured graph replays it)."""
+    lib = hip.load()
+    cases = [(1, 15, 20, 1824, 304, 1, 1, (0, 0, 0, 0)), (2, 8, 8, 136, 816, 1, 1, (0, 0, 0, 0)), (1, 9, 11, 72, 40, 3, 1, (1, 1, 1, 1)),
+             (1, 30, 40, 960, 176, 1, 1, (0, 0, 0, 0)), (3, 7, 9, 96, 64, 3, 1, (1, 1, 1, 1)), (1, 1, 515, 128, 128, 1, 1, (0, 0, 0, 0))]
+    try:
+        lib.cfp_debug_set(0, 400 + variant)
+        for case in cases:
+            B, H, W, Cin, Cout, k, s, pads = case
+            ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
+            for splits in (2, 3, 8):
+                lib.cfp_debug_set(1, splits)
+                slab_bytes = splits * B * Ho * Wo * Cout * 4
+                plain = torch.empty(slab_bytes // 4, device=DEV)
+                tws = ops.ticket_ws(slab_bytes, DEV)
+                x0 = xa.buf.clone()
+                for it in range(3):      # the same workspace with DIFFERENT data every time: a slab line left in some L2 by the launch before would show
+                    xa.buf.copy_(x0 * (1.0 + 0.37 * it))
+                    got = []
+                    for ws in (plain, tws):
+                        out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
+                        out = ops.Act(out.buf, 16, Cout)
+                        ops.conv2d(xa, wx, scale, shift, out, B, H, W, k, k, s, pads[0], pads[1], Ho, Wo, hip.ACT_SILU, ra, ws)
+                        torch.cuda.synchronize()
+                        got.append(out.buf.clone())
+                    assert int(tws[: hip.CONV_TICKET_BYTES // 4].view(torch.int32).abs().max()) == 0, (variant, case, splits)
+                    assert torch.equal(got[0], got[1]), (variant, case, splits, it)
+                    if it == 0:
+                        _x3_close(from_nhwc(ops.Act(got[1], 16, Cout).torch(), B, Ho, Wo), ref, f"x3 ticketed v{variant} splits {splits} {case}")
+                xa.buf.copy_(x0)
+        # per-image weights (the project GEMM of a squeeze-excite block on single images: the layer the engine splits)
+        lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
+        B, hw, K, Cout = 2, 300, 1824, 304
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B * hw, K, generator=g).to(DEV)
+        x0 = x.clone()
+        w = (torch.randn(B, Cout, K, generator=g) / K ** 0.5).to(DEV)
+        wx = torch.stack([ops.pack_w_x3(w[b]) for b in range(B)]).contiguous()
+        sc, sh = torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV)
+        _, sp = ops.conv2d_plan(B * hw, Cout, K, hip.F32X3, hw, B, 1, 1)
+        assert sp > 1, "the plan is expected to split this per-image GEMM"
+        xa = ops.Act(x, 0, K)
+        got = []
+        for ws in (torch.empty(sp * B * hw * Cout, device=DEV), ops.ticket_ws(sp * B * hw * Cout * 4, DEV)):
+            out = ops.new_act(B * hw, Cout, torch.float32, DEV)
+            for it in range(3):      # back to back on one stream, the last launch on the original data
+                x.copy_(x0 * (2.0 - it if it < 2 else 1.0))
+                ops.conv2d(xa, wx, sc, sh, out, B, hw, 1, 1, 1, 1, 0, 0, hw, 1, hip.ACT_NONE, None, ws, per_image_weights=True)
+            torch.cuda.synchronize()
+            got.append(out.torch().clone())
+        assert torch.equal(got[0], got[1])
+        want = torch.stack([x[b * hw:(b + 1) * hw].double() @ w[b].double().t() for b in range(B)]).reshape(B * hw, Cout) * sc.double() + sh.double()
+        assert float((got[1].double() - want).abs().max() / want.abs().max()) < 2e-5
+    finally:
+        lib.cfp_debug_set(0, -1)
+        lib.cfp_debug_set(1, -1)
+
+
 @pytest.mark.parametrize("pair", [(28, 26), (29, 14), (30, 13), (31, 23), (32, 16)])
 def test_conv2d_x3_a_direct_loop_is_bit_identical_to_the_staged_loop(pair):
     """The A-direct K loop (A values global -> registers, only the W tile through LDS) against the staged loop of the same tile: same
