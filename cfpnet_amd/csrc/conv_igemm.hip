@@ -308,6 +308,8 @@ int g_tput = 0;                 // cfp_debug_set key 17 (tools): 1 = every call 
                                 // prefers larger tiles than the isolated sweep the default plan is fitted on
 int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
 int g_x3_ad = 0;                // cfp_debug_set key 29: f16x3 implicit GEMMs with four row waves take their A-direct form (A values global -> registers)
+int g_x3_occ = 1;            // cfp_debug_set key 32: 0 = in-flight plans keep the unconstrained instantiations of the 64 x 64 / 128 x 32 / 64 x 128 tiles
+static int x3_occ_of(int v) { return v == 13 ? 34 : v == 16 ? 35 : v == 15 ? 36 : v; }
 static int x3_ad_of(int v) { return v == 26 ? 28 : v == 14 ? 29 : v == 13 ? 30 : v == 23 ? 31 : v == 16 ? 32 : v; }
 int g_small_s2 = 1;             // cfp_debug_set key 15: 0 = three-stage 64x64 tiles for the small GEMMs (the round-2 plan)
 int g_up_halo = 1;              // cfp_debug_set key 14: cfp_upsample_cat_conv3x3 through the halo kernel: 0 never, 1 where planned, 2 wherever it can run
@@ -363,6 +365,7 @@ extern "C" int cfp_debug_set(int key, int value) {
   switch (key) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: cfp_dw_debug_set(key, value); return CFP_OK;
     case 30: cfp_dwl3_debug_set(value); return CFP_OK;
+    case 32: g_x3_occ = value; return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
     case 29: g_x3_ad = value; return CFP_OK;
@@ -506,6 +509,7 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
     if (tiles <= 64 && nks >= 20) { pl.variant = 4; pl.splits = nks >= 40 ? 8 : 4; }
   }
   if (g_x3_ad && pl.splits <= 1) pl.variant = x3_ad_of(pl.variant);
+  if (tput && g_x3_occ && pl.splits <= 1) pl.variant = x3_occ_of(pl.variant);      // one more resident workgroup per CU (conv_igemm_x3.hip, OCC)
   return pl;
 }
 

@@ -479,8 +479,15 @@ __device__ __forceinline__ void x3_mainloop_ad(const ConvP& p, const f16_t* __re
   wait_vmcnt<0>();
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1, bool AD = false>
-__global__ __launch_bounds__(256 * KG) void igemm_x3_kernel(ConvP p, float* slabs, int splits, unsigned* tickets) {
+// OCC > 0: waves per SIMD the register allocation must leave room for (second argument of __launch_bounds__).  Left alone the compiler lands a
+// few registers past a step of the occupancy ladder (512 / waves, in eights): 134 VGPRs for the 64 x 64 and 128 x 32 tiles (3 waves where 128 is
+// 4), 178 for 64 x 128 (2 where 168 is 3).  Squeezed, they spill 3 ... 10 registers to scratch.  Measured on one box (tools/mode_bench.py, float32
+// storage): with four batches in flight the extra resident workgroup per CU wins (4.200 vs 4.259 ms per batch of 8: these GEMMs spend half their
+// wave-cycles waiting on K loops of 4 ... 20 steps); a single graph LOSES (6.56 vs 6.42 ms, batch 1 3.22 vs 3.18: too few workgroups to fill
+// the slots, and each is a little slower).  So these are separate instantiations (variant ids 34 - 36) that the plan picks under the
+// CFP_CONV_IN_FLIGHT hint only.  128 x 64 at 168 registers spills 18 and measured slower either way: no such variant.
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLITK, int KG = 1, bool AD = false, int OCC = 0>
+__global__ __launch_bounds__(256 * KG, (OCC > 0 ? OCC : 1)) void igemm_x3_kernel(ConvP p, float* slabs, int splits, unsigned* tickets) {
   static_assert(WM * WN == 4, "four waves per group");
   static_assert(!AD || (WM == 4 && WN == 1 && KG == 1 && !SPLITK && STAGES == 2), "A-direct: 4 x 1 waves, two stages, whole K");
   static_assert(KG == 1 || (KG == 2 && !SPLITK), "K groups are the in-workgroup alternative to split-K");
@@ -712,23 +719,25 @@ constexpr Cfg kCfg[] = {
     {256, 128, 2}, {256, 64, 2}, {64, 64, 2}, {128, 64, 2}, {128, 128, 2}, {64, 128, 2},
     // A-direct (ids >= 28): 4 x 1 waves, the A values go global -> registers, only the W tile through LDS
     {128, 128, 2, 1, true}, {128, 64, 2, 1, true}, {64, 64, 2, 1, true}, {256, 64, 2, 1, true}, {128, 32, 2, 1, true}, {256, 128, 2, 1, true},
+    // ids 34-36: ids 13 / 16 / 15 compiled for 4 / 4 / 3 waves per SIMD (in-flight plans; the same arithmetic in the same order)
+    {64, 64, 2}, {128, 32, 2}, {64, 128, 2},
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1, bool AD = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int KG = 1, bool AD = false, int OCC = 0>
 int launch_x3(const ConvP& p, float* slabs, int splits, hipStream_t s, unsigned* tickets) {
   const size_t lds = AD ? (size_t)STAGES * BN * 128 : (size_t)KG * STAGES * (BM + BN) * 128;
   if (lds > 160 * 1024) return -1;
-  if ((KG == 2 || AD) && splits > 1) return -4;
+  if ((KG == 2 || AD || OCC > 0) && splits > 1) return -4;
   if (AD && p.Cin < 8) return -5;
   long long tiles_m = p.rows_per_batch > 0 ? (long long)p.B * cdiv(p.rows_per_batch, BM) : cdiv(p.M, BM);
   long long tiles = tiles_m * cdiv(p.Cout, BN);
   if (splits <= 1) {
-    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG, AD>;
+    auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, false, KG, AD, OCC>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256 * KG), lds, s, p, slabs, 1, (unsigned*)nullptr);
-  } else if constexpr (KG == 1 && !AD) {
+  } else if constexpr (KG == 1 && !AD && OCC == 0) {
     auto k = igemm_x3_kernel<BM, BN, WM, WN, STAGES, true>;
     static bool attr = false;
     if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2; attr = true; }
@@ -870,6 +879,9 @@ int igemm_x3_launch(int v, const ConvP& p, float* slabs, int splits, hipStream_t
     case 31: return launch_x3<256, 64, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
     case 32: return launch_x3<128, 32, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
     case 33: return launch_x3<256, 128, 4, 1, 2, 1, true>(p, slabs, splits, s, tickets);
+    case 34: return launch_x3<64, 64, 4, 1, 2, 1, false, 4>(p, slabs, splits, s, tickets);
+    case 35: return launch_x3<128, 32, 4, 1, 2, 1, false, 4>(p, slabs, splits, s, tickets);
+    case 36: return launch_x3<64, 128, 2, 2, 2, 1, false, 3>(p, slabs, splits, s, tickets);
     default: return -3;
   }
 }

@@ -116,8 +116,10 @@ GEN2_TILES = [(128, 128, 3), (128, 128, 2), (128, 64, 3), (128, 64, 4), (64, 64,
               (128, 32, 3), (128, 32, 4), (256, 16, 2), (128, 16, 4), (64, 128, 3), (64, 64, 2), (128, 64, 2), (64, 128, 2), (128, 32, 2),
               (32, 64, 3), (32, 128, 3), (64, 64, 2), (64, 64, 3), (64, 128, 2)]      # 19-21: eight waves, two K groups
 X3_ONLY_TILES = [(256, 128, 2), (256, 64, 2), (64, 64, 2), (128, 64, 2), (128, 128, 2), (64, 128, 2),      # conv_igemm_x3.hip ids 22-27
-                 (128, 128, 2), (128, 64, 2), (64, 64, 2), (256, 64, 2), (128, 32, 2), (256, 128, 2)]     # 28-33: A-direct (A values global -> registers)
+                 (128, 128, 2), (128, 64, 2), (64, 64, 2), (256, 64, 2), (128, 32, 2), (256, 128, 2),     # 28-33: A-direct (A values global -> registers)
+                 (64, 64, 2), (128, 32, 2), (64, 128, 2)]      # 34-36: ids 13 / 16 / 15 compiled for one more resident workgroup per CU (in-flight plans)
 X3_ADIRECT = range(28, 34)
+X3_OCC = range(34, 37)
 GEN1_TILES = [(256, 16), (256, 32), (128, 64), (128, 128)]
 # (tile rows, BN) of direct 3x3 variant v (conv3x3_direct.hip kCfg3); pixel tile = rows x 16
 DIRECT3_TILES = [(8, 128), (8, 64), (16, 64), (16, 32), (8, 32), (16, 16)]
@@ -129,7 +131,7 @@ def conv2d_kernel_name(variant: int, splits: int, dt: int) -> str:
         n = "conv3x3_halo_x3"
     elif variant >= 400:
         bm, bn, st = (GEN2_TILES + X3_ONLY_TILES)[variant - 400]
-        n = f"igemm_x3<{bm}x{bn},s{st}" + (",kg2>" if 19 <= variant - 400 <= 21 else ",ad>" if variant - 400 in X3_ADIRECT else ">")
+        n = f"igemm_x3<{bm}x{bn},s{st}" + (",kg2>" if 19 <= variant - 400 <= 21 else ",ad>" if variant - 400 in X3_ADIRECT else ",occ>" if variant - 400 in X3_OCC else ">")
     elif variant >= 300:
         n = f"conv3x3_halo<{t}>"
     elif variant >= 200:

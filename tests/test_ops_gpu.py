@@ -211,7 +211,7 @@ def test_conv2d_x3(case):
         assert float(out.buf[:, :16].abs().max()) == 0 and float(out.buf[:, 16 + Cout:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("variant", list(range(34)))      # 0-21: conv_igemm2.hip's ids, 22-27: f16x3 only, 28-33: f16x3 A-direct
+@pytest.mark.parametrize("variant", list(range(37)))      # 0-21: conv_igemm2.hip's ids, 22-27: f16x3 only, 28-33: f16x3 A-direct, 34-36: occupancy builds
 def test_conv2d_x3_every_tile_variant(variant):
     """Every f16x3 tile configuration on every conv case, forced through the debug knob (400 + v), un-split and with 4 K-splits."""
     lib = hip.load()
@@ -220,7 +220,7 @@ def test_conv2d_x3_every_tile_variant(variant):
         for case in CONV_CASES:
             B, H, W, Cin, Cout, k, s, pads = case
             ref, xa, w32, wx, scale, shift, ra, Ho, Wo = _x3_problem(case)
-            for splits in ((1,) if (variant in GEN2_KGROUPS or variant in ops.X3_ADIRECT) else (1, 4)):
+            for splits in ((1,) if (variant in GEN2_KGROUPS or variant in ops.X3_ADIRECT or variant in ops.X3_OCC) else (1, 4)):
                 lib.cfp_debug_set(1, splits)
                 out = ops.new_act(B * Ho * Wo, Cout, torch.float32, DEV, ld=Cout + 24, zero=True)
                 out = ops.Act(out.buf, 16, Cout)
@@ -295,9 +295,10 @@ def test_conv2d_x3_ticketed_split_k_is_bit_identical_to_the_reduce_launch(varian
         lib.cfp_debug_set(1, -1)
 
 
-@pytest.mark.parametrize("pair", [(28, 26), (29, 14), (30, 13), (31, 23), (32, 16)])
+@pytest.mark.parametrize("pair", [(28, 26), (29, 14), (30, 13), (31, 23), (32, 16), (34, 13), (35, 16), (36, 15)])
 def test_conv2d_x3_a_direct_loop_is_bit_identical_to_the_staged_loop(pair):
-    """The A-direct K loop (A values global -> registers, only the W tile through LDS) against the staged loop of the same tile: same
+    """The A-direct K loop (A values global -> registers, only the W tile through LDS) against the staged loop of the same tile -- and the
+    occupancy builds (ids 34-36: the same source under a register budget) against theirs: same
     products in the same order, so the float32 results must be EQUAL -- K lengths of 1, 2, 3, 4 and many K-steps, 1x1 and 3x3 (taps that
     straddle K-steps: Cin = 8, 40, 392), stride 2, ragged row and channel tails."""
     ad, staged = pair

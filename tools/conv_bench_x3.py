@@ -57,7 +57,7 @@ def timeit(args, reps):
     return graph_time_us(fn, calls=max(4, reps // 2), replays=4)
 
 
-NV = 34
+NV = 37
 VLIST = [int(x) for x in a.only.split(",")] if a.only else list(range(NV))
 rows, tot_auto, tot_best = [], 0.0, 0.0
 for key, (args, cnt) in uniq.items():
