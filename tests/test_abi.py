@@ -120,3 +120,35 @@ def test_float32_depthwise_slot_count_is_the_same_with_and_without_the_input_ext
                     assert got == want and got > 0, (B, H, W, C, s, h, w, ld, got, want)
                     n += 1
     assert n > 3000
+
+
+def test_f16x3_plan_picks_the_occupancy_builds_only_for_in_flight_launches():
+    """The 64x64 / 128x32 / 64x128 f16x3 tiles exist a second time under a register budget (variant ids 34-36: one more resident workgroup per
+    CU; faster with several batches in flight, slower alone).  The plan must hand them out under the in-flight hint only, never for split-K
+    or per-image split plans, and every other variant must be unchanged by the hint's occupancy rule (cfp_debug_set key 32 switches it off)."""
+    import ctypes
+    from cfpnet_amd import hip
+    lib = hip.load()
+
+    def plan(M, N, K, rpb=0, B=1):
+        v, s = ctypes.c_int(0), ctypes.c_int(0)
+        lib.cfp_conv2d_plan(M, N, K, 1, 1, hip.F32X3, rpb, B, ctypes.byref(v), ctypes.byref(s))
+        return v.value, s.value
+
+    shapes = [(9600, 816, 136), (2400, 1392, 232), (9600, 448, 112), (153600, 96, 32), (38400, 64, 128), (153600, 40, 160), (9600, 512, 128),
+              (240, 256, 128), (2400, 232, 1392), (300, 304, 1824), (614400, 128, 64)]
+    try:
+        alone = [plan(*s) for s in shapes]
+        assert not any(400 + 34 <= v <= 400 + 36 for v, _ in alone), alone
+        lib.cfp_debug_set(17, 1)                       # plan as for several batches in flight
+        flight = [plan(*s) for s in shapes]
+        lib.cfp_debug_set(32, 0)
+        flight_plain = [plan(*s) for s in shapes]
+        lib.cfp_debug_set(32, 1)
+        occ = {13: 34, 16: 35, 15: 36}
+        assert any(400 + 34 <= v <= 400 + 36 for v, _ in flight), flight
+        for (v1, s1), (v0, s0) in zip(flight, flight_plain):
+            assert s1 == s0 and (v1 == v0 or (s0 <= 1 and v1 - 400 == occ.get(v0 - 400))), (flight, flight_plain)
+    finally:
+        lib.cfp_debug_set(17, 0)
+        lib.cfp_debug_set(32, 1)
