@@ -44,8 +44,13 @@ struct TailX3P {
 // One GEMM of the chain for this wave's 16 rows: acc[j] += A[16 x 32 nks] * W[N x ..]^T over the K-steps [ks0, ks0 + nks) of the weight rows
 // (N = NT * 16 rows starting at W, `wrow` halves per row).  `arow(ks)` returns the wave-private float32 row pointer (lane's row fr) of the
 // A operand's 32 channels of K-step ks.  All four waves of the workgroup must call it together (they share the weight stages).
-constexpr int TAIL_STAGES = 3;
-template <int NT, int BSTAGE, bool ZERO, typename AF>
+// Weight stages per kernel: three (two K-steps of DMA in flight) unless one fewer lets ANOTHER WORKGROUP share the CU -- these kernels run
+// their phases (projection, attention apply, GEMM chain, LayerNorms) behind barriers, so a co-resident workgroup is what fills the gaps (the
+// lesson of DESIGN.md 4.5): the LoFTR tail at D = 32 is 43 KB with three stages (three per CU) and 39 KB with two (four per CU; its GEMMs
+// are one or two K-steps long anyway); the LKPM tail at D = 64 is 61 KB -> 53 KB (two -> three per CU).
+template <int D> constexpr int tail_nst_loftr() { return D == 32 ? 2 : 3; }
+template <int D> constexpr int tail_nst_lkpm() { return D == 64 ? 2 : 3; }
+template <int NT, int BSTAGE, bool ZERO, int NST, typename AF>
 __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __restrict__ W, int wrow, int ks0, int nks, AF arow, unsigned char* sB,
                                              int wave, int lane) {
   constexpr int N = NT * 16;
@@ -81,17 +86,19 @@ __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __re
   // next stage has been issued behind it, and they complete in order; the last step waits for everything.  Issuing the first stages of the
   // NEXT GEMM of the chain right after a K loop (under the LayerNorm / attention / GELU work between the GEMMs) was built too and measured
   // no gain (3.42 ms; it costs a barrier per GEMM) -- not kept.
+  constexpr int AHEAD = NST - 1;              // K-steps of DMA in flight beside the one being computed
+  static_assert(NST == 2 || NST == 3, "wait ladder below");
   issue(ks0, 0);
-  if (nks > 1) issue(ks0 + 1, 1);
+  if (AHEAD > 1 && nks > 1) issue(ks0 + 1, 1);
   const int pc0 = ((fq) ^ (fr & 7)) * 16, pc1 = ((4 + fq) ^ (fr & 7)) * 16;
   for (int i = 0; i < nks; ++i) {
-    if (i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");
+    if (AHEAD > 1 && i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBW) : "memory");      // (the loads of step i + 1 may still fly)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (i + 2 < nks) issue(ks0 + i + 2, (i + 2) % TAIL_STAGES);      // stage (i - 1) % 3: everybody has read it (barrier above)
-    const unsigned char* cB = sB + (i % TAIL_STAGES) * BSTAGE;
+    if (i + AHEAD < nks) issue(ks0 + i + AHEAD, (i + AHEAD) % NST);      // the stage of step i - 1: everybody has read it (barrier above)
+    const unsigned char* cB = sB + (i % NST) * BSTAGE;
     const float* ar = arow(ks0 + i);
     const f32x4 x0 = *reinterpret_cast<const f32x4*>(ar + 4 * fq);
     const f32x4 x1 = *reinterpret_cast<const f32x4*>(ar + 16 + 4 * fq);
@@ -146,8 +153,9 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
+  constexpr int NST = tail_nst_loftr<D>();
   unsigned char* sB = smem;
-  float* tMsg = reinterpret_cast<float*>(smem + TAIL_STAGES * BSTAGE + wave * WAVE_LDS);
+  float* tMsg = reinterpret_cast<float*>(smem + NST * BSTAGE + wave * WAVE_LDS);
   float* tX = tMsg + TILE;
   float* tH = tX + TILE;
   const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   const bool own_q = p.wq != nullptr;
   if (own_q) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true>(acc, p.wq, wrow1, 0, D / 32, [&](int ks) { return tX + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.wq, wrow1, 0, D / 32, [&](int ks) { return tX + fr * PA + ks * 32; }, sB, wave, lane);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   // ---- merge + norm1 -----------------------------------------------------------------------------------------------------------------
   {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true>(acc, p.wm, wrow1, 0, D / 32, [&](int ks) { return tMsg + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.wm, wrow1, 0, D / 32, [&](int ks) { return tMsg + fr * PA + ks * 32; }, sB, wave, lane);
     tail_layernorm_x3<NT>(acc, p.g1, p.b1, p.ln_eps, fr);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of msg are complete
 #pragma unroll
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true>(acc, p.w0 + (long long)half * D * wrow2, wrow2, 0, 2 * D / 32,
+    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.w0 + (long long)half * D * wrow2, wrow2, 0, 2 * D / 32,
                                    [&](int ks) { return ks * 32 < D ? tX + fr * PA + ks * 32 : tMsg + fr * PA + (ks * 32 - D); }, sB, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (second half) this wave's mlp.2 reads of the previous half are complete
 #pragma unroll
@@ -246,9 +254,9 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
       for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PA + j * 16 + fr] = fmaxf(acc[j][r], 0.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (half == 0)
-      tail_gemm_x3<NT, BSTAGE, true>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, true, NST>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
     else
-      tail_gemm_x3<NT, BSTAGE, false>(acc2, p.w2, wrow2, D / 32, D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - D); }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, false, NST>(acc2, p.w2, wrow2, D / 32, D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - D); }, sB, wave, lane);
   }
   tail_layernorm_x3<NT>(acc2, p.g2, p.b2, p.ln_eps, fr);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
 
 template <int D, int HEADS>
 int launch_tail_x3(const TailX3P& p, hipStream_t s) {
-  constexpr size_t lds = TAIL_STAGES * (D * 128) + 4 * (3 * 16 * (D + 8) * 4);
+  constexpr size_t lds = tail_nst_loftr<D>() * (D * 128) + 4 * (3 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = loftr_tail_x3_kernel<D, HEADS>;
   static bool attr = false;
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   unsigned char* sB = smem;
-  float* tA = reinterpret_cast<float*>(smem + TAIL_STAGES * BSTAGE + wave * WAVE_LDS);
+  constexpr int NST = tail_nst_lkpm<D>();
+  float* tA = reinterpret_cast<float*>(smem + NST * BSTAGE + wave * WAVE_LDS);
   float* tH = tA + TILE;
   const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
   constexpr int XCH = D / 4;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true>(acc, p.w1 + (long long)part * D * wrow1, wrow1, 0, D / 32, [&](int ks) { return tA + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.w1 + (long long)part * D * wrow1, wrow1, 0, D / 32, [&](int ks) { return tA + fr * PA + ks * 32; }, sB, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's pwconv2 reads of the previous quarter are complete
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -358,9 +367,9 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (part == 0)
-      tail_gemm_x3<NT, BSTAGE, true>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, true, NST>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
     else
-      tail_gemm_x3<NT, BSTAGE, false>(acc2, p.w2, wrow2, part * (D / 32), D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - part * D); }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, false, NST>(acc2, p.w2, wrow2, part * (D / 32), D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - part * D); }, sB, wave, lane);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
 
 template <int D>
 int launch_lkpm_x3(const LkpmX3P& p, hipStream_t s) {
-  constexpr size_t lds = TAIL_STAGES * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
+  constexpr size_t lds = tail_nst_lkpm<D>() * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = lkpm_tail_x3_kernel<D>;
   static bool attr = false;
