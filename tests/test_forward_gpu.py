@@ -49,6 +49,33 @@ def _full_case(B, H, W, zn, zpx, seed, drop):
     return layers, sd, inp
 
 
+@pytest.mark.parametrize("case", ["no_zone_valid", "one_image_without_zones"])
+def test_batches_without_a_single_valid_tof_zone_vs_oracle(case):
+    """The reference's edge of the ToF path: `mask` all False (every histogram dropped: fusion.py:120-131 then propagates nothing and the
+    depth comes from the RGB path alone) for the whole batch, and for one image of a batch whose other image has all 64 zones -- the
+    batch-reduced zone geometry is shared, the validity is per image.  Default numerics (f32x3), every image inside the 1e-3 gate."""
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers))
+    if case == "no_zone_valid":
+        inp = synthetic.make_inputs(2, 480, 640, 8, 56, seed=5, drop_hist=1.0)
+        assert int(inp["additional"]["mask"].sum()) == 0
+    else:
+        inp = synthetic.make_inputs(2, 480, 640, 8, 56, seed=6)
+        inp["additional"]["mask"][0] = False
+        inp["additional"]["hist_data"][0] = 0
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    e0, p0, pr0 = O.forward(sd, inp, layer_names=layers)
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True)
+    e1, p1, pr1 = eng.forward(inp)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(pr1).all())
+    for b in range(2):
+        r = rel_l1(p1[b].cpu().numpy(), p0[b].numpy())
+        print(f"  {case} image {b}: pred relL1 vs oracle = {r:.3e}")
+        assert r < 1e-3, (case, b, r)
+    assert torch.allclose(e1.cpu(), e0, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,H,W,zn,zpx,drop", [(1, 480, 640, 8, 56, 0.0), (2, 480, 640, 8, 56, 0.34), (1, 416, 544, 6, 64, 0.2)])
 def test_full_model_vs_oracle_f32(B, H, W, zn, zpx, drop):
     layers, sd, inp = _full_case(B, H, W, zn, zpx, 7 + B, drop)
