@@ -626,6 +626,7 @@ int conv3x3_halo_x3_launch(int v, const ConvP& p, hipStream_t s) {
     // 8 x 16 pixel tiles (153600 px x 32 ch: 17.2 vs 19.6 us in flight); 224 channels as two 128-channel blocks (33 vs 39 us)
     if (c <= 32 && px < 300000 && conv3x3_halo_x3_lds(7, p)) best = 7;
     if (c > 160 && c <= 256 && conv3x3_halo_x3_lds(4, p)) best = 4;
+    if (c > 128 && c <= 160 && px < 30000 && conv3x3_halo_x3_lds(3, p)) best = 3;      // a single image's 19200 px x 160: three 64-channel blocks, 19.7 vs 24.3 us (one 160-channel block)
     for (int i = 0; i < 5 && best < 0; ++i)
       if (c <= cap16[i] && conv3x3_halo_x3_lds(cands16[i], p) && conv3x3_halo_x3_lds(cands16[i], p) <= 80 * 1024) best = cands16[i];
     for (int i = 0; i < 5 && best < 0; ++i)

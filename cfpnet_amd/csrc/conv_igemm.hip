@@ -338,11 +338,22 @@ static bool halo_x3_wins(long long M, int Cin, int Cout, bool tput) { return M >
 //   153600 px  64 -> 64   35 (54) vs 44 (54) for tile 24;   64 -> 32: 30 (46) vs 40 (51);   64 -> 128: 68 (74) vs 88 (96, implicit GEMM)
 //    38400 px 128 -> 128  32 (59) vs 47 (80, implicit GEMM); 256 -> 128: 61 (92) vs 88 (143); 128 -> 64: 16 (42) vs 21 (38): in flight only
 //     9600 px 256 -> 256  35 (72) vs 45 (73, implicit GEMM); 128 / 256 -> 128: the implicit GEMM stays ahead (12.4 / 22.4 vs 13.7 / 23.7)
+// Round 5, late (tools/conv_bench_x3.py --halo with the single-buffer tiles in the sweep, batch 1 alone and batch 8 with four copies in flight):
+//   * ONE input chunk (Cin = 32) is a problem for these tiles too: 32 -> 32 through tile 45 beats the whole-depth halo kernel (614400 px 50.5 vs 56.7 us in
+//     flight, 76800 px alone 14.0 vs 14.6), and a single image's 32 -> 128 (the head's conv0, 76800 px) runs 28.4 us through tile 44 against 34.1;
+//   * a single graph's 65 ... 128 output channels below 200 000 pixels: tile 44 (64 channels x 8 x 16 pixels, two channel blocks) instead of 36 --
+//     the head conv of one image is 600 workgroups of tile 36 on 512 slots (two rounds for 1.17 rounds of work); 1 200 half-size ones: 74.7 vs 82.5 us;
+//   * 32 output channels alone: tile 45 from 15 000 pixels (19200 px 64 -> 32: 14.5 vs 16.1 us through the implicit GEMM).
 static int chunk_x3_variant(long long M, int Cin, int Cout, bool tput) {
-  if (Cin % 32 != 0 || Cin < 64) return -1;
+  if (Cin % 32 != 0) return -1;
+  if (Cin == 32) {
+    if (Cout <= 32) return M >= 30000 ? 45 : -1;
+    if (Cout > 64 && Cout <= 128 && !tput) return (M >= 30000 && M < 200000) ? 44 : -1;
+    return -1;
+  }
   if (Cout > 128) return (tput && M >= 9000) ? 36 : -1;
-  if (Cout > 64) return M >= 30000 ? 36 : -1;
-  if (Cout <= 32) return M >= 30000 ? 45 : -1;      // 32 channels x 8 x 16 pixels, 37 KB (four per CU): 614400 px 96 -> 32 (up4's first conv on the padded
+  if (Cout > 64) return M >= 30000 ? ((!tput && M < 200000) ? 44 : 36) : -1;
+  if (Cout <= 32) return M >= (tput ? 30000 : 15000) ? 45 : -1;      // 32 channels x 8 x 16 pixels, 37 KB (four per CU): 614400 px 96 -> 32 (up4's first conv on the padded
                                                     // concatenation) 127 (136) vs 174 (187) for the 64-channel tile 38; 153600 px 64 -> 32: 20 (35) vs 30 (45)
   if (M >= 100000) return 38;
   if (M >= 30000) return tput ? 38 : 24;

@@ -81,7 +81,7 @@ for key, (args, cnt) in uniq.items():
         lib.cfp_debug_set(0, -1); lib.cfp_debug_set(1, -1)
     if KH == 3 and st == 1 and Cin % 8 == 0 and not piw and not ln and not a.only:      # conv3x3_halo_x3.hip: every tile + the implicit GEMM's plan without it
         lib.cfp_debug_set(1, 1)
-        for v in list(range(10)) + [99] + ([20, 21, 22, 23, 24, 25] if Cin % 32 == 0 else []):
+        for v in list(range(10)) + [99] + ([20, 21, 22, 23, 24, 25, 36, 37, 38, 44, 45, 46] if Cin % 32 == 0 else []):
             lib.cfp_debug_set(0, 500 + v)
             try:
                 t = timeit(args, max(5, a.reps // 2))
