@@ -308,6 +308,7 @@ int g_tput = 0;                 // cfp_debug_set key 17 (tools): 1 = every call 
                                 // prefers larger tiles than the isolated sweep the default plan is fitted on
 int g_probe = 0;                // cfp_debug_set key 16: ConvP.probe
 int g_x3_ad = 0;                // cfp_debug_set key 29: f16x3 implicit GEMMs with four row waves take their A-direct form (A values global -> registers)
+int g_x3_small_m = 4800, g_x3_small_k = 1 << 30;      // cfp_debug_set keys 33 / 34: single-image plans take the 32 x 64 tile up to this many rows / this K
 int g_x3_occ = 1;            // cfp_debug_set key 32: 0 = in-flight plans keep the unconstrained instantiations of the 64 x 64 / 128 x 32 / 64 x 128 tiles
 static int x3_occ_of(int v) { return v == 13 ? 34 : v == 16 ? 35 : v == 15 ? 36 : v; }
 static int x3_ad_of(int v) { return v == 26 ? 28 : v == 14 ? 29 : v == 13 ? 30 : v == 23 ? 31 : v == 16 ? 32 : v; }
@@ -366,6 +367,7 @@ static bool halo_wins(long long M, int Cout, bool tput) {
   return g_halo == 1 && ((M >= 300000 && (Cout <= 32 || Cout == 128)) || (M >= 100000 && Cout > 128 && Cout <= 160) ||
                          (M >= 30000 && Cout > 160 && Cout <= 256));          // 38400 px x 224 ch (two 128-channel blocks): 19.8 / 22.9
 }
+void cfp_tail_x3_debug_set(int value);      // loftr_tail_x3.hip: key 35 = waves per workgroup of the fused tails (0 = by the row count)
 void cfp_dwl3_debug_set(int value);          // dwlarge_x3.hip: key 30 = 1: the 32 x 32 pixel tile for k = 31 (two workgroups per CU)
 void cfp_dwl_wgrad_debug_set(int value);     // train_misc2.hip: key 23 = 1 keeps the VALU kernels for the large depthwise weight gradient
 void cfp_wgrad_debug_set(int value);         // conv_bwd.hip: key 22 = workgroups a small weight-gradient launch aims for (sets the slab count)
@@ -377,6 +379,9 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: case 11: cfp_dw_debug_set(key, value); return CFP_OK;
     case 30: cfp_dwl3_debug_set(value); return CFP_OK;
     case 32: g_x3_occ = value; return CFP_OK;
+    case 33: g_x3_small_m = value; return CFP_OK;
+    case 34: g_x3_small_k = value; return CFP_OK;
+    case 35: cfp_tail_x3_debug_set(value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
     case 29: g_x3_ad = value; return CFP_OK;
@@ -511,6 +516,12 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
   // (300 x 1392 x 232: 7.7 vs 10.5 us)
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 2400 && K >= 2000 && N >= 128 && (pl.variant == 15 || pl.variant == 13)) pl.variant = 19;
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 512 && N >= 512 && K <= 512) pl.variant = 17;
+  // round 5, late (full sweep of a single image's launches, tools/conv_bench_x3.py --batch 1): up to 4 800 rows the 32 x 64 tile (twice the workgroups,
+  // four column waves) is ahead of 64 x 64 on every short-K layer (4800 x 56 x 224: 7.3 vs 8.6 us, 1200 x 512 x 128: 7.8 vs 9.4, 4800 x 256 x 64: 8.0 vs
+  // 9.4; whole forward, same box: 3.03 vs 3.15 ms -- far more than the isolated launches predict); at 19 200 rows it is level or behind.  The 12 x 12 / 9 x 9 / 6 x 6 patch convolutions of the global attention (30 ... 130 rows, K ~ 5 000,
+  // eight K splits): 16.8 / 17.9 / 16.8 us against 17.9 / 19.8 / 18.0 through 64-row tiles that are mostly padding
+  if (!tput && pl.splits <= 1 && pl.variant == 13 && M <= g_x3_small_m && K <= g_x3_small_k) pl.variant = 17;
+  if (!tput && rpb == 0 && pl.splits >= 4 && M <= 160 && (pl.variant == 4 || pl.variant == 13)) pl.variant = 17;
   // per-image weights (the squeeze-excite-folded project GEMMs) on a handful of row tiles with a long K -- single images: 300 x 232 x 1392 is
   // 20 tiles of 44 serial K-steps at ~0.8 us each (18.2 us, profiles/r4_conv_bench_x3_b1_alone.txt) on 20 of 256 CUs.  K splits instead of the
   // two K groups (round 5; the caller passes the slab workspace, cfp_conv2d_plan with rows_per_batch > 0 tells it the split count)

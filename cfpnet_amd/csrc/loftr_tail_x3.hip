@@ -50,12 +50,12 @@ struct TailX3P {
 // are one or two K-steps long anyway); the LKPM tail at D = 64 is 61 KB -> 53 KB (two -> three per CU).
 template <int D> constexpr int tail_nst_loftr() { return D == 32 ? 2 : 3; }
 template <int D> constexpr int tail_nst_lkpm() { return D == 64 ? 2 : 3; }
-template <int NT, int BSTAGE, bool ZERO, int NST, typename AF>
+template <int NT, int BSTAGE, bool ZERO, int NST, int WAVES, typename AF>
 __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __restrict__ W, int wrow, int ks0, int nks, AF arow, unsigned char* sB,
                                              int wave, int lane) {
   constexpr int N = NT * 16;
   constexpr int NBG = N / 8;                  // 8-row DMA groups of a weight stage
-  constexpr int NBW = (NBG + 3) / 4;
+  constexpr int NBW = (NBG + WAVES - 1) / WAVES;      // LDS-DMA instructions per wave and stage
   static_assert(N * 128 <= BSTAGE, "weight stage");
   const int fr = lane & 15, fq = lane >> 4;
   const int rsub = lane >> 3;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void tail_gemm_x3(f32x4 (&acc)[NT], const f16_t* __re
   auto issue = [&](int ks, int st) {
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
-      const int g = (j * 4 + wave) % NBG;
+      const int g = (j * WAVES + wave) % NBG;
       const int n = g * 8 + rsub;
       glds16(W + (long long)n * wrow + (ks * 8 + lc) * 8, sB + st * BSTAGE + g * 1024);      // rows are zero-padded to whole K-steps
     }
@@ -140,8 +140,13 @@ __device__ __forceinline__ void tail_layernorm_x3(f32x4 (&acc)[NT], const float*
   }
 }
 
-template <int D, int HEADS>
-__global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
+// WAVES (1, 2 or 4) waves of 16 token rows per workgroup.  Every wave reads the WHOLE weight tile of a K-step from LDS (16 KB at D = 128), so four
+// waves share one LDS pipe for four times the bytes: the GEMM phases of the four-wave kernel are LDS-read bound (64 KB per step at 128 B / clk
+// against 24 MFMAs per wave).  Few token rows (a single image: 19 four-wave workgroups at D = 128 on 256 CUs) therefore run as MORE, NARROWER
+// workgroups -- each streams all the weights from L2 itself, which is cheap while the chip is mostly idle -- and many rows keep four waves
+// (the weight stream is then shared by 64 rows).  Same arithmetic per row in every layout.
+template <int D, int HEADS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void loftr_tail_x3_kernel(TailX3P p) {
   constexpr int d = D / HEADS;
   constexpr int NT = D / 16;
   constexpr int PA = D + 8;                                // row pitch in floats: (D + 8) / 4 = 2 (mod 4) sixteen-byte slots
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   float* tMsg = reinterpret_cast<float*>(smem + NST * BSTAGE + wave * WAVE_LDS);
   float* tX = tMsg + TILE;
   float* tH = tX + TILE;
-  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+  const long long row0 = (long long)blockIdx.x * (16 * WAVES) + wave * 16;
   constexpr int wrow1 = (D / 32) * 64, wrow2 = (2 * D / 32) * 64;      // halves per packed weight row for K = D and K = 2 D
 
   // ---- x tile -> LDS (16-byte vectors) ------------------------------------------------------------------------------------------
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   const bool own_q = p.wq != nullptr;
   if (own_q) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.wq, wrow1, 0, D / 32, [&](int ks) { return tX + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc, p.wq, wrow1, 0, D / 32, [&](int ks) { return tX + fr * PA + ks * 32; }, sB, wave, lane);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   // ---- merge + norm1 -----------------------------------------------------------------------------------------------------------------
   {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.wm, wrow1, 0, D / 32, [&](int ks) { return tMsg + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc, p.wm, wrow1, 0, D / 32, [&](int ks) { return tMsg + fr * PA + ks * 32; }, sB, wave, lane);
     tail_layernorm_x3<NT>(acc, p.g1, p.b1, p.ln_eps, fr);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's reads of msg are complete
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.w0 + (long long)half * D * wrow2, wrow2, 0, 2 * D / 32,
+    tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc, p.w0 + (long long)half * D * wrow2, wrow2, 0, 2 * D / 32,
                                    [&](int ks) { return ks * 32 < D ? tX + fr * PA + ks * 32 : tMsg + fr * PA + (ks * 32 - D); }, sB, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (second half) this wave's mlp.2 reads of the previous half are complete
 #pragma unroll
@@ -254,9 +259,9 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
       for (int r = 0; r < 4; ++r) tH[(fq * 4 + r) * PA + j * 16 + fr] = fmaxf(acc[j][r], 0.f);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (half == 0)
-      tail_gemm_x3<NT, BSTAGE, true, NST>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
     else
-      tail_gemm_x3<NT, BSTAGE, false, NST>(acc2, p.w2, wrow2, D / 32, D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - D); }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, false, NST, WAVES>(acc2, p.w2, wrow2, D / 32, D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - D); }, sB, wave, lane);
   }
   tail_layernorm_x3<NT>(acc2, p.g2, p.b2, p.ln_eps, fr);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -275,15 +280,27 @@ __global__ __launch_bounds__(256) void loftr_tail_x3_kernel(TailX3P p) {
   }
 }
 
-template <int D, int HEADS>
-int launch_tail_x3(const TailX3P& p, hipStream_t s) {
-  constexpr size_t lds = tail_nst_loftr<D>() * (D * 128) + 4 * (3 * 16 * (D + 8) * 4);
+int g_tail_waves = 0;      // cfp_debug_set key 35: 0 = by the row count, else 1 / 2 / 4 waves per workgroup (A/B)
+// waves per workgroup for `rows` token rows: few rows -> narrow workgroups (see the kernel)
+inline int tail_waves(long long rows) {
+  if (g_tail_waves == 1 || g_tail_waves == 2 || g_tail_waves == 4) return g_tail_waves;
+  return rows <= 4800 ? 1 : rows < 8192 ? 2 : 4;      // (a batch of 8 at D = 128, 9 600 rows, measured slower with two waves: 6.50 vs 6.32 ms per forward)
+}
+
+template <int D, int HEADS, int WAVES>
+int launch_tail_x3w(const TailX3P& p, hipStream_t s) {
+  constexpr size_t lds = tail_nst_loftr<D>() * (D * 128) + WAVES * (3 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = loftr_tail_x3_kernel<D, HEADS>;
+  auto k = loftr_tail_x3_kernel<D, HEADS, WAVES>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
-  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 16 * WAVES)), dim3(64 * WAVES), lds, s, p);
   return 0;
+}
+template <int D, int HEADS>
+int launch_tail_x3(const TailX3P& p, hipStream_t s) {
+  const int w = tail_waves(p.rows);
+  return w == 1 ? launch_tail_x3w<D, HEADS, 1>(p, s) : w == 2 ? launch_tail_x3w<D, HEADS, 2>(p, s) : launch_tail_x3w<D, HEADS, 4>(p, s);
 }
 
 // ---- LKPM tail (Block14.forward after the depthwise conv, convnext.py:48-58): LayerNorm(1e-6) -> pwconv1 (D -> 4 D) -> GELU -> pwconv2
@@ -297,8 +314,8 @@ struct LkpmX3P {
   float ln_eps;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
+template <int D, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void lkpm_tail_x3_kernel(LkpmX3P p) {
   constexpr int NT = D / 16;
   constexpr int PA = D + 8;
   constexpr int TILE = 16 * PA;
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
   constexpr int NST = tail_nst_lkpm<D>();
   float* tA = reinterpret_cast<float*>(smem + NST * BSTAGE + wave * WAVE_LDS);
   float* tH = tA + TILE;
-  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+  const long long row0 = (long long)blockIdx.x * (16 * WAVES) + wave * 16;
   constexpr int XCH = D / 4;
   constexpr int wrow1 = (D / 32) * 64, wrow2 = (4 * D / 32) * 64;
 
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
     f32x4 acc[NT];
-    tail_gemm_x3<NT, BSTAGE, true, NST>(acc, p.w1 + (long long)part * D * wrow1, wrow1, 0, D / 32, [&](int ks) { return tA + fr * PA + ks * 32; }, sB, wave, lane);
+    tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc, p.w1 + (long long)part * D * wrow1, wrow1, 0, D / 32, [&](int ks) { return tA + fr * PA + ks * 32; }, sB, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's pwconv2 reads of the previous quarter are complete
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -367,9 +384,9 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (part == 0)
-      tail_gemm_x3<NT, BSTAGE, true, NST>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, true, NST, WAVES>(acc2, p.w2, wrow2, 0, D / 32, [&](int ks) { return tH + fr * PA + ks * 32; }, sB, wave, lane);
     else
-      tail_gemm_x3<NT, BSTAGE, false, NST>(acc2, p.w2, wrow2, part * (D / 32), D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - part * D); }, sB, wave, lane);
+      tail_gemm_x3<NT, BSTAGE, false, NST, WAVES>(acc2, p.w2, wrow2, part * (D / 32), D / 32, [&](int ks) { return tH + fr * PA + (ks * 32 - part * D); }, sB, wave, lane);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -392,18 +409,25 @@ __global__ __launch_bounds__(256) void lkpm_tail_x3_kernel(LkpmX3P p) {
   }
 }
 
-template <int D>
-int launch_lkpm_x3(const LkpmX3P& p, hipStream_t s) {
-  constexpr size_t lds = tail_nst_lkpm<D>() * (D * 128) + 4 * (2 * 16 * (D + 8) * 4);
+template <int D, int WAVES>
+int launch_lkpm_x3w(const LkpmX3P& p, hipStream_t s) {
+  constexpr size_t lds = tail_nst_lkpm<D>() * (D * 128) + WAVES * (2 * 16 * (D + 8) * 4);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = lkpm_tail_x3_kernel<D>;
+  auto k = lkpm_tail_x3_kernel<D, WAVES>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
-  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 16 * WAVES)), dim3(64 * WAVES), lds, s, p);
   return 0;
+}
+template <int D>
+int launch_lkpm_x3(const LkpmX3P& p, hipStream_t s) {
+  const int w = tail_waves(p.rows);
+  return w == 1 ? launch_lkpm_x3w<D, 1>(p, s) : w == 2 ? launch_lkpm_x3w<D, 2>(p, s) : launch_lkpm_x3w<D, 4>(p, s);
 }
 
 }  // namespace
+
+void cfp_tail_x3_debug_set(int value) { g_tail_waves = value; }
 
 // cfp_lkpm_tail for dtype CFP_F32X3 (loftr_tail.hip dispatches here)
 int lkpm_tail_x3_launch(const void* t, int t_ld, const void* xin, int x_ld, void* out, int out_ld, const void* w1, const float* b1, const void* w2,
