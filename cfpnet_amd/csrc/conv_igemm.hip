@@ -515,6 +515,12 @@ static Plan2 plan_x3(long long M, int N, int K, int rpb, int B, bool allow_split
   // tile halves the serial chain (1200 x 256 x 3528: 43.7 vs 77.5 us, x 2304: 30.4 vs 49.7); a few hundred rows x many channels -> 32-row tiles
   // (300 x 1392 x 232: 7.7 vs 10.5 us)
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 2400 && K >= 2000 && N >= 128 && (pl.variant == 15 || pl.variant == 13)) pl.variant = 19;
+  // round 5, late: REAL K splits measured against the two K groups (tools/probes/splitk_b1_probe.py -- the sweep tool's forced splits had silently
+  // run un-split for want of a workspace): 1200 x 256 x 3528 22.3 us (eight splits + the reduce launch) vs 42.2, 1200 x 256 x 2304 20.4 (four) vs 27.5,
+  // 4800 x 128 x 2808 29.5 (four) vs 32.8; from 1 152 deep down the K groups stay ahead (4800 x 128 x 1152: 17.1 vs 20.0)
+  if (!tput && rpb == 0 && allow_split && pl.splits <= 1 && K >= 2000 && (M <= 1200 || (M <= 4800 && K >= 2500))) {
+    pl.variant = 13; pl.splits = (M <= 1200 && K >= 3000) ? 8 : 4;
+  }
   if (!tput && rpb == 0 && pl.splits <= 1 && M <= 512 && N >= 512 && K <= 512) pl.variant = 17;
   // round 5, late (full sweep of a single image's launches, tools/conv_bench_x3.py --batch 1): up to 4 800 rows the 32 x 64 tile (twice the workgroups,
   // four column waves) is ahead of 64 x 64 on every short-K layer (4800 x 56 x 224: 7.3 vs 8.6 us, 1200 x 512 x 128: 7.8 vs 9.4, 4800 x 256 x 64: 8.0 vs
