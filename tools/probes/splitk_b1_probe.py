@@ -10,7 +10,8 @@ from _gtime import graph_time_us
 DEV = "cuda:0"
 lib = hip.load()
 CASES = [(1, 30, 40, 392, 256, 3), (1, 60, 80, 312, 128, 3), (1, 30, 40, 256, 256, 3), (1, 60, 80, 128, 64, 3), (1, 60, 80, 128, 128, 3), (1, 60, 80, 64, 64, 3),
-         (1, 30, 40, 128, 128, 3), (1, 30, 40, 512, 128, 1), (1, 15, 20, 1392, 232, 1)]
+         (1, 30, 40, 128, 128, 3), (1, 30, 40, 512, 128, 1), (1, 15, 20, 1392, 232, 1),
+         (1, 120, 160, 168, 64, 3), (1, 120, 160, 64, 64, 3), (1, 60, 80, 40, 160, 3), (1, 60, 80, 56, 224, 3)]
 for B, H, W, Cin, Cout, k in CASES:
     M, K = B * H * W, k * k * Cin
     x = ops.Act(torch.randn(M, Cin, device=DEV), 0, Cin)
