@@ -766,6 +766,8 @@ extern "C" int cfp_se_gate_fold(const float* partial, int nsplit, float inv_hw, 
   return cfp_check_launch("cfp_se_gate_fold");
 }
 
+int g_fold_zcap = 16;     // cfp_debug_set key 37: most row splits of the project weights per 128-channel slab (binds for single images only: 8 -> 16 measured 2.960 -> 2.948 ms, inside the noise but never behind)
+void cfp_fold_debug_set(int v) { g_fold_zcap = v; }
 extern "C" int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const float* b_reduce, const float* w_expand_t, const float* b_expand,
                                  const float* w_proj, void* w_out, int B, int Cout, int C, int R, int dtype, cfp_stream_t stream) {
   const int x3 = dtype == CFP_F32X3 ? 1 : 0;
@@ -777,7 +779,7 @@ extern "C" int cfp_se_gate_fold2(const float* hpart, int K, float inv_hw, const 
               "cfp_se_gate_fold2: need C % 8 == 0, R <= 64");
   const int slabs = cdiv(C, 128);
   int Z = cdiv(384, slabs * B);                       // enough workgroups to fill 256 CUs; each recomputes the (cheap) phases A and B
-  if (Z > 8) Z = 8;
+  if (Z > g_fold_zcap) Z = g_fold_zcap;
   if (Z > Cout) Z = Cout;
   if (Z < 1) Z = 1;
   const int rows_per_z = cdiv(Cout, Z);
