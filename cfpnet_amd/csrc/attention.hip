@@ -161,47 +161,54 @@ struct ApP {
   FastDiv fheads, fwq, fhq, fqth, fqtw;      // (token, head) index arithmetic without 64-bit divisions (five per element in the first version)
 };
 
-template <typename T, int D>
+// JS lanes share one (token, head): lane js computes the D / JS outputs js * D / JS ... (and the normaliser, redundantly).  With one lane per
+// (token, head) a d = 32 head is a chain of 1 024 dependent-latency FMAs fed by 256 sixteen-byte loads, and a single image has 4 800 such lanes --
+// 19 workgroups, 24 us; eight lanes each shorten the chain eightfold and fill eight times the CUs.  Every output is the same sum in the same order.
+template <typename T, int D, int JS>
 __global__ __launch_bounds__(256) void attn_apply_kernel(ApP p) {
+  constexpr int DJ = D / JS;
   const T* __restrict__ Q = reinterpret_cast<const T*>(p.q);
   T* __restrict__ O = reinterpret_cast<T*>(p.out);
-  const unsigned total = (unsigned)p.NB * p.Hq * p.Wq * p.heads;      // < 2^31: host check
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+  const unsigned total = (unsigned)p.NB * p.Hq * p.Wq * p.heads * JS;      // < 2^31: host check
+  for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < total; i0 += gridDim.x * 256u) {
+    const unsigned i = i0 / JS;
+    const int js = (int)(i0 - i * JS);
     unsigned toku, hu, tu, xu, bu, yu;
     fd_rowcol(i, p.fheads, toku, hu);
     fd_rowcol(toku, p.fwq, tu, xu);
     fd_rowcol(tu, p.fhq, bu, yu);
     const int h = (int)hu, x = (int)xu, y = (int)yu, b = (int)bu;
     const long long tok = toku;
-    T* op = O + tok * p.out_ld + h * D;
-    float o[D];
+    T* op = O + tok * p.out_ld + h * D + js * DJ;
+    float o[DJ];
     if (y >= p.ey0 && y < p.ey1 && x >= p.ex0 && x < p.ex1) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) o[j] = 0.f;
+      for (int j = 0; j < DJ; ++j) o[j] = 0.f;
     } else {
       const long long g = ((long long)b * p.ggy + fd_div((unsigned)y, p.fqth)) * p.ggx + fd_div((unsigned)x, p.fqtw);
-      const float* kv = p.kv + (g * p.heads + h) * D * D;
+      const float* kv = p.kv + (g * p.heads + h) * D * D + js * DJ;
       const float* ks = p.ksum + (g * p.heads + h) * D;
       const T* qp = Q + tok * p.q_ld + h * D;
       float z = 0.f;
 #pragma unroll
-      for (int j = 0; j < D; ++j) o[j] = 0.f;
+      for (int j = 0; j < DJ; ++j) o[j] = 0.f;
 #pragma unroll
       for (int ii = 0; ii < D; ++ii) {
         const float qv = elu1(to_f32<T>(qp[ii]));
         z = fmaf(qv, ks[ii], z);
 #pragma unroll
-        for (int j = 0; j < D; ++j) o[j] = fmaf(qv, kv[ii * D + j], o[j]);
+        for (int j = 0; j < DJ; ++j) o[j] = fmaf(qv, kv[ii * D + j], o[j]);
       }
       const float zi = 1.f / (z + p.eps);
 #pragma unroll
-      for (int j = 0; j < D; ++j) o[j] = o[j] * zi * p.v_length;
+      for (int j = 0; j < DJ; ++j) o[j] = o[j] * zi * p.v_length;
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j) op[j] = from_f32<T>(o[j]);
+    for (int j = 0; j < DJ; ++j) op[j] = from_f32<T>(o[j]);
   }
 }
 
+int g_ap_split_below = 65536;      // cfp_debug_set key 38: (token, head) pairs below which the outputs of a pair are split over several lanes
 int g_kv_target_waves = 2048;      // cfp_debug_set key 19 (A/B)
 int pick_nsplit(int S, long long groups_heads) {
   // enough waves to cover the chip, at least ~64 keys per wave
@@ -216,6 +223,7 @@ int pick_nsplit(int S, long long groups_heads) {
 }  // namespace
 
 void cfp_attn_debug_set(int value) { g_kv_target_waves = value; }
+void cfp_attn_apply_debug_set(int value) { g_ap_split_below = value; }
 
 extern "C" size_t cfp_attn_kv_ws_floats(int NB, int Hk, int Wk, int th, int tw, int heads, int d) {
   if (NB <= 0 || Hk <= 0 || Wk <= 0 || th <= 0 || tw <= 0 || heads <= 0 || d <= 0) return 0;
@@ -275,11 +283,16 @@ extern "C" int cfp_attn_apply(const void* q, int q_ld, const float* kv, const fl
   CFP_REQUIRE(total < (1ll << 31), CFP_ESHAPE, "cfp_attn_apply: too many (token, head) pairs");
   p.fheads = make_fastdiv((unsigned)heads); p.fwq = make_fastdiv((unsigned)Wq); p.fhq = make_fastdiv((unsigned)Hq);
   p.fqth = make_fastdiv((unsigned)qth); p.fqtw = make_fastdiv((unsigned)qtw);
-  int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const int js = total < g_ap_split_below ? (d >= 32 ? 8 : d >= 16 ? 4 : d >= 8 ? 2 : 1) : 1;
+  CFP_REQUIRE(total * js < (1ll << 31), CFP_ESHAPE, "cfp_attn_apply: too many lanes");
+  const long long lanes = total * js;
+  int blocks = (int)((lanes + 255) / 256 > 8192 ? 8192 : (lanes + 255) / 256);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define AP_LAUNCH(T, D) hipLaunchKernelGGL((attn_apply_kernel<T, D>), dim3(blocks), dim3(256), 0, s, p)
-#define AP_SWITCH(T) switch (d) { case 4: AP_LAUNCH(T, 4); break; case 8: AP_LAUNCH(T, 8); break; \
-                                  case 16: AP_LAUNCH(T, 16); break; default: AP_LAUNCH(T, 32); break; }
+#define AP_LAUNCH(T, D, JS) hipLaunchKernelGGL((attn_apply_kernel<T, D, JS>), dim3(blocks), dim3(256), 0, s, p)
+#define AP_SWITCH(T) switch (d) { case 4: AP_LAUNCH(T, 4, 1); break; \
+                                  case 8: if (js > 1) AP_LAUNCH(T, 8, 2); else AP_LAUNCH(T, 8, 1); break; \
+                                  case 16: if (js > 1) AP_LAUNCH(T, 16, 4); else AP_LAUNCH(T, 16, 1); break; \
+                                  default: if (js > 1) AP_LAUNCH(T, 32, 8); else AP_LAUNCH(T, 32, 1); break; }
   if (dtype == CFP_BF16) { AP_SWITCH(bf16_t) } else if (dtype == CFP_F16) { AP_SWITCH(f16_t) } else { AP_SWITCH(float) }
 #undef AP_SWITCH
 #undef AP_LAUNCH
