@@ -192,6 +192,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         else v[e] = act_c<decltype(A)::value>(v[e] * sc + sh);
       }
     });
+    if constexpr (sizeof(T) == 4) {
+      if (p.ln_gamma != nullptr) {
+        // LayerNorm over the Cout channels of the row, fused into the finishing sum (round 5: the global attention's patch conv is a split-K
+        // GEMM followed by nn.LayerNorm -- twins.py sr + norm).  A row is CV = Cout / 4 consecutive lanes (host: a power of two <= 64 and
+        // Cout a multiple of 4), all in one wave and all in this iteration together; two-pass statistics as cfp_layernorm.
+        float sum = (v[0] + v[1]) + (v[2] + v[3]);
+        for (int o = 1; o < CV; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)p.Cout;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { v[e] -= mean; q = fmaf(v[e], v[e], q); }
+        for (int o = 1; o < CV; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q / (float)p.Cout + p.ln_eps);
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = v[e] * rstd * p.ln_gamma[n + e] + p.ln_beta[n + e];
+      }
+    }
     if (res) {
       float r[VE];
       Vec<T>::load(res + m * p.res_ld + n, r);
@@ -684,7 +701,12 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     // LayerNorm over Cout in the epilogue when a four-row-wave tile spans exactly Cout channels; otherwise as a second kernel
     int ln_v = -1;
     if (ln_gamma && rpb == 0 && g_x3_ln_fused) ln_v = Cout == 128 ? (p.M >= 30000 ? 26 : 27) : Cout == 64 ? (p.M >= 100000 ? 14 : 13) : Cout == 32 ? 16 : Cout == 16 ? 11 : -1;
-    if (ln_v >= 0) {
+    // ... or, when K is split, inside the finishing sum (splitk_reduce_kernel): a row must be a power-of-two group of lanes of one wave
+    const int cv4 = Cout / 4;
+    const bool ln_in_reduce = ln_gamma && pl.splits > 1 && !tickets && Cout % 4 == 0 && cv4 <= 64 && (cv4 & (cv4 - 1)) == 0 && g_x3_ln_fused;
+    if (ln_in_reduce) {
+      p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;      // (the split GEMM ignores them: it only writes slabs)
+    } else if (ln_v >= 0) {
       CFP_REQUIRE(aligned16(ln_gamma) && aligned16(ln_beta), CFP_EINVAL, "cfp_conv2d_nhwc: LayerNorm parameters must be 16-byte aligned");
       pl.variant = g_x3_ad ? x3_ad_of(ln_v) : ln_v; pl.splits = 1; p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;
     } else if (ln_gamma) {
@@ -710,7 +732,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
       hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)slabs, pl.splits, p);
     }
     int e = cfp_check_launch("cfp_conv2d_nhwc");
-    if (e != CFP_OK || !ln_gamma || ln_v >= 0) return e;
+    if (e != CFP_OK || !ln_gamma || ln_v >= 0 || ln_in_reduce) return e;
     return cfp_layernorm(out, out_ld, ln_gamma, ln_beta, ln_eps, residual, res_ld, out, out_ld, p.M, Cout, dtype, stream);
   }
 

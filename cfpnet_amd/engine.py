@@ -167,6 +167,7 @@ class Engine:
         self.cat_pad = os.environ.get("CFP_CAT_PAD", "1") == "1" and not self.up_fused_x3      # f16x3: zero-padded concatenation buffers (see _pack: decoder.up*.a)
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
+        self.sr_ln_fused = os.environ.get("CFP_SR_LN_FUSED", "1") == "1"      # f16x3: the global attention's LayerNorm inside its patch conv (0: a launch of its own)
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
         self.head_hilo = (hl[0] == "1", hl[1] == "1")
@@ -679,11 +680,17 @@ class Engine:
                             dict(NB=B, Hq=H, Wq=W, qth=ws, qtw=ws))
                 cur ^= 1
                 hk, wk = gsa_keys(H, W, ws)
-                kraw = self._act(plan, f"{name}.gsa.kraw", B * hk * wk, D)
-                ops.conv2d(tok[cur].slice(0, D), self.P[l + ".gsa.sr.w"], self.P[l + ".gsa.sr.s"], self.P[l + ".gsa.sr.t"], kraw,
-                           B, H, W, ws, ws, ws, 0, 0, hk, wk, ws=self._ws(B * hk * wk, D, ws * ws * D))
                 keys = self._act(plan, f"{name}.gsa.keys", B * hk * wk, D)
-                ops.layernorm(kraw, self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5, keys, B * hk * wk)
+                if self.x3 and self.sr_ln_fused:
+                    # f16x3: nn.LayerNorm goes into the patch conv -- into the finishing sum of its K splits, or the GEMM epilogue when K is not split
+                    ops.conv2d(tok[cur].slice(0, D), self.P[l + ".gsa.sr.w"], self.P[l + ".gsa.sr.s"], self.P[l + ".gsa.sr.t"], keys,
+                               B, H, W, ws, ws, ws, 0, 0, hk, wk, ws=self._ws(B * hk * wk, D, ws * ws * D),
+                               ln=(self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5))
+                else:
+                    kraw = self._act(plan, f"{name}.gsa.kraw", B * hk * wk, D)
+                    ops.conv2d(tok[cur].slice(0, D), self.P[l + ".gsa.sr.w"], self.P[l + ".gsa.sr.s"], self.P[l + ".gsa.sr.t"], kraw,
+                               B, H, W, ws, ws, ws, 0, 0, hk, wk, ws=self._ws(B * hk * wk, D, ws * ws * D))
+                    ops.layernorm(kraw, self.P[l + ".gsa.norm.g"], self.P[l + ".gsa.norm.b"], 1e-5, keys, B * hk * wk)
                 S = hk * wk
                 self._loftr(plan, f"{name}.gsa", l + ".gsa.encoder_layer", tok[cur], M, keys, B * S, spec.TWINS_HEADS,
                             final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D),

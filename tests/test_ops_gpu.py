@@ -425,6 +425,41 @@ def test_upsample_cat_conv3x3_x3(case):
     _x3_close(got, from_nhwc(out2.torch(), B, H, W).double(), f"fused vs pair {case}", tol=2e-6)
 
 
+@pytest.mark.parametrize("Co", [128, 64, 32])
+def test_conv2d_x3_layernorm_inside_the_split_k_reduce(Co):
+    """The global attention's patch convolution (twins.py: sr conv with kernel = stride = the window, then nn.LayerNorm) in the default numerics:
+    a few rows x K of thousands, so K is split -- and the LayerNorm (+ residual after it) runs inside the finishing sum of the splits instead of a
+    launch of its own.  Against float64, for the automatic plan and forced 2 / 4 / 8 splits, ragged row counts, a padded output pitch."""
+    lib = hip.load()
+    for (B, H, W, k) in ((1, 36, 48, 12), (2, 27, 45, 9), (1, 30, 40, 6)):
+        Cin = Co
+        Ho, Wo = H // k, W // k
+        x = rnd(B, Cin, H, W, seed=21)
+        w = rnd(Co, Cin, k, k, seed=22, scale=1.0 / math.sqrt(Cin * k * k))
+        sc, sh = rnd(Co, seed=23).abs() + 0.5, rnd(Co, seed=24)
+        g, bt = rnd(Co, seed=25).abs() + 0.5, rnd(Co, seed=26)
+        res = rnd(B * Ho * Wo, Co, seed=27)
+        y = F.conv2d(x.double(), w.double(), None, k).permute(0, 2, 3, 1).reshape(-1, Co) * sc.double() + sh.double()
+        ref = F.layer_norm(y, (Co,), g.double(), bt.double(), 1e-5) + res.double()
+        xa = to_act(nhwc(x), torch.float32)
+        wx = ops.pack_w_x3(w.permute(0, 2, 3, 1).reshape(Co, k * k * Cin).contiguous().to(DEV))
+        M = B * Ho * Wo
+        try:
+            for splits in (-1, 2, 4, 8):
+                lib.cfp_debug_set(1, splits)
+                _, sp = ops.conv2d_plan(M, Co, k * k * Cin, hip.F32X3, 0, B, k, k)
+                ws = torch.empty(8 * M * Co, device=DEV)
+                out = ops.new_act(M, Co, torch.float32, DEV, ld=Co + 8, zero=True)
+                ops.conv2d(xa, wx, sc.to(DEV), sh.to(DEV), out, B, H, W, k, k, k, 0, 0, Ho, Wo, hip.ACT_NONE, to_act(res, torch.float32), ws,
+                           ln=(g.to(DEV), bt.to(DEV), 1e-5))
+                torch.cuda.synchronize()
+                assert splits > 0 or sp > 1, "the automatic plan is expected to split this problem"
+                _x3_close(out.torch().cpu(), ref, f"x3 sr conv + LayerNorm in the reduce (Cout {Co}, {B}x{H}x{W} k{k}, splits {splits})", tol=2e-5)
+                assert float(out.buf[:, Co:].abs().max()) == 0
+        finally:
+            lib.cfp_debug_set(1, -1)
+
+
 def test_conv2d_x3_per_image_weights_and_layernorm():
     """Per-image pre-split weights (the squeeze-excite fold) and the LayerNorm that follows as a second kernel."""
     B, HW, Cin, Cout = 3, 300, 232, 128
