@@ -167,6 +167,7 @@ class Engine:
         self.cat_pad = os.environ.get("CFP_CAT_PAD", "1") == "1" and not self.up_fused_x3      # f16x3: zero-padded concatenation buffers (see _pack: decoder.up*.a)
         self.lkpm_fused = os.environ.get("CFP_LKPM_FUSED", "1") != "0"      # LKPM's LayerNorm + MLP + residual as one kernel (cfp_lkpm_tail)
         self.tail_q = os.environ.get("CFP_TAIL_Q", "1") == "1"          # q projection inside the fused LoFTR tail
+        self.lkpm_min_rows = int(os.environ.get("CFP_LKPM_MIN_ROWS", "30000"))      # token rows from which the LKPM tail runs fused
         self.sr_ln_fused = os.environ.get("CFP_SR_LN_FUSED", "1") == "1"      # f16x3: the global attention's LayerNorm inside its patch conv (0: a launch of its own)
         self.head_fused = os.environ.get("CFP_HEAD_FUSED", "1") != "0"
         hl = os.environ.get("CFP_HEAD_HILO", "00")
@@ -727,7 +728,7 @@ class Engine:
                 else:
                     ops.dwconv_large(xin.slice(0, D), self.P[k + ".dw.w"], self.P[k + ".dw.s"], self.P[k + ".dw.t"], t1, B, H, W, lk, hip.ACT_RELU)
                 lk_dst = final_dst if final_dst is not None else tok[cur ^ 1].slice(0, D)
-                if ((self.half and not self.weights2) or (self.x3 and os.environ.get("CFP_X3_TAIL", "1") != "0")) and self.lkpm_fused and D in (32, 64, 128) and M >= 30000:
+                if ((self.half and not self.weights2) or (self.x3 and os.environ.get("CFP_X3_TAIL", "1") != "0")) and self.lkpm_fused and D in (32, 64, 128) and M >= self.lkpm_min_rows:
                     # LayerNorm -> pwconv1 -> GELU -> pwconv2 -> + input in one kernel: the 4D-wide hidden tensor stays in LDS.
                     # Measured at batch 8 (tools/small_kernel_bench.py): 24 vs 49 us at the 1/4 scale, 29 vs 34 us at 1/8, 30 vs 25 us at
                     # 1/16 (9 600 rows = 150 workgroups: too few to hide the chain's latency) -> only the many-row scales take it
