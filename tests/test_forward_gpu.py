@@ -293,6 +293,33 @@ def test_f32x3_meets_the_gate_on_every_image_of_every_weight_family(family):
     print(f"f32x3 {family}: worst image of 16 = {worst:.3e}")
 
 
+@pytest.mark.parametrize("family", ["uniform", "kaiming_peaked"])
+def test_f32x3_single_image_plans_meet_the_gate(family):
+    """A SINGLE image takes plans of its own in the default mode (round 5: 32 x 64 GEMM tiles up to 4 800 rows, real K splits for the long-K
+    low-resolution convs, the head conv through the 64-channel chunk tile, one-wave workgroups in the fused tails, attention outputs split over
+    lanes, LayerNorm inside the split-K reduce) that no batch-8 test reaches: 480x640 and a 416x544 crop with a positional window, eager and
+    through the captured graph, against the CPU oracle, inside the 1e-3 gate."""
+    layers = spec.COMBINE1_LAYERS
+    sd = weights.make_torch_state_dict(spec.model_manifest(layers), family=family)
+    if family != "uniform":
+        sd = calibrate_bn(sd, layers)
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    eng = Engine(sd, layer_names=layers, dtype=torch.float32, x3=True)
+    for (H, W, zn, zpx, drop, offs) in ((480, 640, 8, 56, 0.2, None), (416, 544, 6, 64, 0.0, {"cross_atten3": (2, 3), "cross_atten2": (4, 7), "cross_atten1": (9, 11)})):
+        inp = synthetic.make_inputs(1, H, W, zn, zpx, seed=77, drop_hist=drop)
+        _, p0, pr0 = O.forward(sd, inp, layer_names=layers, pos_offsets=offs)
+        dinp = synthetic.to_device(inp, "cuda:0")
+        _, p1, pr1 = eng.forward(dinp, pos_offsets=offs)
+        torch.cuda.synchronize()
+        r = rel_l1(p1.cpu().numpy(), p0.numpy())
+        print(f"f32x3 single image {family} {H}x{W}: eager rel-L1 {r:.3e}")
+        assert r <= TOL_F32 and bool(torch.isfinite(pr1).all()), (family, H, W, r)
+        eng.capture(dinp, pos_offsets=offs)
+        _, p2, _ = eng.replay(dinp)
+        torch.cuda.synchronize()
+        assert torch.equal(p1, p2), "the captured graph must reproduce the eager forward bit for bit"
+
+
 def test_ill_conditioned_network_is_reported_not_gated():
     """The reference's initialisation with a CONFIDENT head (conv_out x 6: a peaked 256-way softmax like a trained model's): the float32
     engine with nothing but its INPUT IMAGE rounded once to fp16 already differs from itself by > 1e-3 -- no 16-bit storage format can
