@@ -386,6 +386,7 @@ static bool halo_wins(long long M, int Cout, bool tput) {
 }
 void cfp_tail_x3_debug_set(int value);      // loftr_tail_x3.hip: key 35 = waves per workgroup of the fused tails (0 = by the row count)
 void cfp_fold_debug_set(int v);
+void cfp_tail16_debug_set(int value);
 void cfp_attn_apply_debug_set(int value);
 void cfp_dwl3_debug_set(int value);          // dwlarge_x3.hip: key 30 = 1: the 32 x 32 pixel tile for k = 31 (two workgroups per CU)
 void cfp_dwl_wgrad_debug_set(int value);     // train_misc2.hip: key 23 = 1 keeps the VALU kernels for the large depthwise weight gradient
@@ -403,6 +404,7 @@ extern "C" int cfp_debug_set(int key, int value) {
     case 35: cfp_tail_x3_debug_set(value); return CFP_OK;
     case 37: cfp_fold_debug_set(value); return CFP_OK;
     case 38: cfp_attn_apply_debug_set(value); return CFP_OK;
+    case 39: cfp_tail16_debug_set(value); return CFP_OK;
     case 17: g_tput = value; return CFP_OK;
     case 16: g_probe = (g_probe & 16) | value; return CFP_OK;
     case 29: g_x3_ad = value; return CFP_OK;

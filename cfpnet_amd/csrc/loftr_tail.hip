@@ -40,12 +40,12 @@ template <typename H> struct TailP {
 // One GEMM of the chain for this wave's 16 rows: acc[j] += A[16 x K] * W[N x K]^T, N = NT * 16.
 // `afrag(k)` returns the lane's A fragment for columns [k, k + 32) of the wave-private operand.
 // All four waves of the workgroup must call it together (they share the weight slabs).
-template <typename H, int NT, int BSTAGE, typename AF>
+template <typename H, int NT, int BSTAGE, int WAVES, typename AF>
 __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict__ W, int K, AF afrag, unsigned char* sB,
                                           int wave, int lane) {
   constexpr int N = NT * 16;
   constexpr int NBG = N / 8;                  // 8-row DMA groups of a weight slab
-  constexpr int NBW = (NBG + 3) / 4;
+  constexpr int NBW = (NBG + WAVES - 1) / WAVES;      // LDS-DMA instructions per wave and slab
   // weight slabs of THIS GEMM are N * 128 bytes; the region holds 2 * BSTAGE bytes (two slabs of the widest GEMM, N = 2 D): the N = D GEMMs
   // fit three of theirs in it and keep two K-steps of DMA in flight (round 4: a K-step is a few MFMAs against a ~0.7-1 us round trip of
   // its weight tile from L2; counted wait as in loftr_tail_x3.hip)
@@ -61,7 +61,7 @@ __device__ __forceinline__ void tail_gemm(f32x4 (&acc)[NT], const H* __restrict_
     const bool kok = kk < K;
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
-      const int g = (j * 4 + wave) % NBG;
+      const int g = (j * WAVES + wave) % NBG;
       const int n = g * 8 + rsub;
       glds16(kok ? W + (long long)n * K + kk : zsrc, sB + st * SST + g * 1024);
     }
@@ -126,8 +126,10 @@ __device__ __forceinline__ void tail_layernorm(f32x4 (&acc)[NT], const float* __
   }
 }
 
-template <typename H, int D, int HEADS>
-__global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
+// WAVES waves of 16 token rows per workgroup: 4, or 1 / 2 for few token rows (a single image), as loftr_tail_x3.hip (round 5) -- narrower
+// workgroups fill more of an otherwise idle chip and shorten each one's chain; same arithmetic per row.
+template <typename H, int D, int HEADS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void loftr_tail_kernel(TailP<H> p) {
   constexpr int d = D / HEADS;
   constexpr int PA = D + 8, PH = 2 * D + 8;               // row pitches (elements): +16 bytes
   constexpr int WAVE_LDS = (2 * PA + PH) * 16 * 2;         // msg/y1 | x | h tiles of one wave
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   H* tMsg = reinterpret_cast<H*>(smem + 2 * BSTAGE + wave * WAVE_LDS);
   H* tX = tMsg + 16 * PA;
   H* tH = tX + 16 * PA;
-  const long long row0 = (long long)blockIdx.x * 64 + wave * 16;
+  const long long row0 = (long long)blockIdx.x * (16 * WAVES) + wave * 16;
 
   // ---- x tile -> LDS (16-byte vectors) -----------------------------------------------------------
   constexpr int XCH = D / 8;                               // 16-byte chunks per row
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   if (own_q) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     f32x4 acc[D / 16];
-    tail_gemm<H, D / 16, BSTAGE>(acc, p.wq, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tX + fr * PA + k + fq * 8); }, sB, wave, lane);
+    tail_gemm<H, D / 16, BSTAGE, WAVES>(acc, p.wq, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tX + fr * PA + k + fq * 8); }, sB, wave, lane);
 #pragma unroll
     for (int j = 0; j < D / 16; ++j)
 #pragma unroll
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   // ---- merge + norm1 -------------------------------------------------------------------------------
   {
     f32x4 acc[D / 16];
-    tail_gemm<H, D / 16, BSTAGE>(acc, p.wm, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tMsg + fr * PA + k + fq * 8); }, sB, wave, lane);
+    tail_gemm<H, D / 16, BSTAGE, WAVES>(acc, p.wm, D, [&](int k) { return *reinterpret_cast<const s16x8*>(tMsg + fr * PA + k + fq * 8); }, sB, wave, lane);
     tail_layernorm<H, D / 16>(acc, p.g1, p.b1, p.ln_eps, fr);
 #pragma unroll
     for (int j = 0; j < D / 16; ++j)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   // ---- mlp.0: [x | y1] (K = 2D) -> 2D, ReLU ---------------------------------------------------------
   {
     f32x4 acc[2 * D / 16];
-    tail_gemm<H, 2 * D / 16, BSTAGE>(acc, p.w0, 2 * D, [&](int k) {
+    tail_gemm<H, 2 * D / 16, BSTAGE, WAVES>(acc, p.w0, 2 * D, [&](int k) {
       const H* src = k < D ? tX + fr * PA + k : tMsg + fr * PA + (k - D);
       return *reinterpret_cast<const s16x8*>(src + fq * 8);
     }, sB, wave, lane);
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   // ---- mlp.2 (K = 2D) -> D, norm2, + x ---------------------------------------------------------------
   {
     f32x4 acc[D / 16];
-    tail_gemm<H, D / 16, BSTAGE>(acc, p.w2, 2 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
+    tail_gemm<H, D / 16, BSTAGE, WAVES>(acc, p.w2, 2 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
     tail_layernorm<H, D / 16>(acc, p.g2, p.b2, p.ln_eps, fr);
 #pragma unroll
     for (int j = 0; j < D / 16; ++j)
@@ -270,15 +272,21 @@ __global__ __launch_bounds__(256) void loftr_tail_kernel(TailP<H> p) {
   }
 }
 
-template <typename H, int D, int HEADS>
-int launch_tail(const TailP<H>& p, hipStream_t s) {
-  constexpr size_t lds = 2 * (2 * D * 128) + 4 * ((2 * (D + 8) + 2 * D + 8) * 16 * 2);
+int g_tail16_waves = 0;      // cfp_debug_set key 39: 0 = by the row count, else 1 / 2 / 4 waves per workgroup (A/B)
+template <typename H, int D, int HEADS, int WAVES>
+int launch_tail_w(const TailP<H>& p, hipStream_t s) {
+  constexpr size_t lds = 2 * (2 * D * 128) + WAVES * ((2 * (D + 8) + 2 * D + 8) * 16 * 2);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto k = loftr_tail_kernel<H, D, HEADS>;
+  auto k = loftr_tail_kernel<H, D, HEADS, WAVES>;
   static bool attr = false;
   if (!attr) { if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1; attr = true; }
-  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 64)), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)cdiv(p.rows, 16 * WAVES)), dim3(64 * WAVES), lds, s, p);
   return 0;
+}
+template <typename H, int D, int HEADS>
+int launch_tail(const TailP<H>& p, hipStream_t s) {
+  const int w = (g_tail16_waves == 1 || g_tail16_waves == 2 || g_tail16_waves == 4) ? g_tail16_waves : p.rows <= 4800 ? 1 : p.rows < 8192 ? 2 : 4;
+  return w == 1 ? launch_tail_w<H, D, HEADS, 1>(p, s) : w == 2 ? launch_tail_w<H, D, HEADS, 2>(p, s) : launch_tail_w<H, D, HEADS, 4>(p, s);
 }
 
 // ---- LKPM tail (Block14.forward after the depthwise conv, convnext.py:48-58): LayerNorm(1e-6) -> pwconv1 (D -> 4D) -> GELU ->
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_kernel(LkpmP<H> p) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     f32x4 acc[2 * D / 16];
-    tail_gemm<H, 2 * D / 16, BSTAGE>(acc, p.w1 + (long long)half * 2 * D * D, D,
+    tail_gemm<H, 2 * D / 16, BSTAGE, 4>(acc, p.w1 + (long long)half * 2 * D * D, D,
                                      [&](int k) { return *reinterpret_cast<const s16x8*>(tA + fr * PA + k + fq * 8); }, sB, wave, lane);
 #pragma unroll
     for (int j = 0; j < 2 * D / 16; ++j) {
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void lkpm_tail_kernel(LkpmP<H> p) {
   float* tF = reinterpret_cast<float*>(tH);
   {
     f32x4 acc[D / 16];
-    tail_gemm<H, D / 16, BSTAGE>(acc, p.w2, 4 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
+    tail_gemm<H, D / 16, BSTAGE, 4>(acc, p.w2, 4 * D, [&](int k) { return *reinterpret_cast<const s16x8*>(tH + fr * PH + k + fq * 8); }, sB, wave, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tH are complete (tail_gemm consumed them)
 #pragma unroll
     for (int j = 0; j < D / 16; ++j) {
@@ -403,6 +411,8 @@ int launch_lkpm(const LkpmP<H>& p, hipStream_t s) {
 }
 
 }  // namespace
+
+void cfp_tail16_debug_set(int value) { g_tail16_waves = value; }
 
 int loftr_tail_x3_launch(const void* q, int q_ld, const float* kv, const float* ksum, const void* x, int x_ld, void* out, int out_ld,
                          const void* w_q, const void* w_merge, const void* w_mlp0, const void* w_mlp2, const float* ln1_g, const float* ln1_b,

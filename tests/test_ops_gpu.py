@@ -1431,6 +1431,52 @@ def test_loftr_tail_x3(D, heads, NB, Hq, Wq, qth, qtw):
         assert float(out.buf[:, :D].abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,heads", [(128, 8), (128, 4), (64, 8), (32, 4)])
+def test_fused_tails_give_the_same_bits_with_one_two_and_four_waves_per_workgroup(D, heads, dtype):
+    """Round 5: the fused LoFTR / LKPM tails run as 1-, 2- or 4-wave workgroups (16 token rows per wave) by the row count -- narrow workgroups for
+    a single image, four waves from 8 192 rows.  A wave's rows never meet another wave's, so the three layouts must agree bit for bit
+    (cfp_debug_set keys 35 / 39 force the layout); row counts that leave ragged last workgroups in every layout."""
+    lib = hip.load()
+    x3 = dtype == torch.float32
+    g = torch.Generator().manual_seed(11)
+    NB, Hq, Wq, qt = 1, 37, 29, 6
+    rows, d = NB * Hq * Wq, D // heads
+    G = NB * (-(-Hq // qt)) * (-(-Wq // qt))
+    x = ops.new_act(rows, D, dtype, DEV); x.buf.copy_(torch.randn(rows, D, generator=g).to(dtype))
+    kv = (torch.randn(G * heads, d, d, generator=g) * 0.3).to(DEV); ks = (torch.rand(G * heads, d, generator=g) + 0.5).to(DEV)
+    mk = (lambda n, k: ops.pack_w_x3((torch.randn(n, k, generator=g) / k ** 0.5).to(DEV))) if x3 else (lambda n, k: (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(DEV))
+    wq, wm, w0, w2 = mk(D, D), mk(D, D), mk(2 * D, 2 * D), mk(D, 2 * D)
+    ln1 = (torch.rand(D, generator=g).to(DEV) + 0.5, torch.randn(D, generator=g).to(DEV), 1e-5)
+    ln2 = (torch.rand(D, generator=g).to(DEV) + 0.5, torch.randn(D, generator=g).to(DEV), 1e-5)
+    key = 35 if x3 else 39
+    got = []
+    try:
+        for w in (4, 2, 1, 0):
+            lib.cfp_debug_set(key, w)
+            out = ops.new_act(rows, D, dtype, DEV, zero=True)
+            ops.loftr_tail(None, kv, ks, x, out, wq, wm, w0, w2, ln1[:2], ln2[:2], NB, Hq, Wq, qt, qt, float(qt * qt), heads)
+            torch.cuda.synchronize()
+            got.append(out.buf.clone())
+            assert bool(torch.isfinite(got[-1].float()).all())
+        if x3 and D in (32, 64, 128):
+            t = ops.new_act(rows, D, dtype, DEV); t.buf.copy_(torch.randn(rows, D, generator=g))
+            w1, w2l = mk(4 * D, D), mk(D, 4 * D)
+            b1, b2 = torch.randn(4 * D, generator=g).to(DEV) * 0.1, torch.randn(D, generator=g).to(DEV) * 0.1
+            lk = []
+            for w in (4, 2, 1):
+                lib.cfp_debug_set(key, w)
+                out = ops.new_act(rows, D, dtype, DEV, zero=True)
+                ops.lkpm_tail(t, x, out, w1, b1, w2l, b2, ln1[0], ln1[1], rows)
+                torch.cuda.synchronize()
+                lk.append(out.buf.clone())
+            assert torch.equal(lk[0], lk[1]) and torch.equal(lk[0], lk[2])
+    finally:
+        lib.cfp_debug_set(key, 0)
+    for o in got[1:]:
+        assert torch.equal(got[0], o), (D, heads, dtype)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_fused_tails_are_bit_stable_at_d32(dtype):
     """D = 32 makes every GEMM of the fused tails one or two K-steps long: straight-line code in which the hand-over of the shared weight
