@@ -705,7 +705,7 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
     if (ln_gamma && rpb == 0 && g_x3_ln_fused) ln_v = Cout == 128 ? (p.M >= 30000 ? 26 : 27) : Cout == 64 ? (p.M >= 100000 ? 14 : 13) : Cout == 32 ? 16 : Cout == 16 ? 11 : -1;
     // ... or, when K is split, inside the finishing sum (splitk_reduce_kernel): a row must be a power-of-two group of lanes of one wave
     const int cv4 = Cout / 4;
-    const bool ln_in_reduce = ln_gamma && pl.splits > 1 && !tickets && Cout % 4 == 0 && cv4 <= 64 && (cv4 & (cv4 - 1)) == 0 && g_x3_ln_fused;
+    const bool ln_in_reduce = ln_gamma && pl.splits > 1 && Cout % 4 == 0 && cv4 <= 64 && (cv4 & (cv4 - 1)) == 0 && g_x3_ln_fused;
     if (ln_in_reduce) {
       p.ln_gamma = ln_gamma; p.ln_beta = ln_beta;      // (the split GEMM ignores them: it only writes slabs)
     } else if (ln_v >= 0) {
@@ -722,9 +722,9 @@ static int conv2d_impl(const void* in, int in_ld, const void* w, const float* sc
       int bm, bn, st;
       igemm_x3_variant_shape(pl.variant, &bm, &bn, &st);
       const long long tiles = (rpb > 0 ? (long long)B * cdiv(rpb, bm) : cdiv(p.M, bm)) * cdiv(Cout, bn);
-      if (tiles <= CFP_TICKET_SLOTS && (long long)pl.splits * p.M * Cout * 4 < (1ll << 31) - 16) {      // (the slabs sit behind one buffer descriptor)
-        tk = (unsigned*)ws; slabs = (float*)((char*)ws + CFP_CONV_TICKET_BYTES);
-      }
+      slabs = (float*)((char*)ws + CFP_CONV_TICKET_BYTES);      // the ticket area is never slab space, whether this launch takes tickets or not
+      // (a LayerNorm that rides in the finishing sum keeps the reduce launch: the ticketed finish has no row-wide statistics)
+      if (!ln_in_reduce && tiles <= CFP_TICKET_SLOTS && (long long)pl.splits * p.M * Cout * 4 < (1ll << 31) - 16) tk = (unsigned*)ws;      // (slabs behind one buffer descriptor)
     }
     int rc = igemm_x3_launch(pl.variant, p, slabs, pl.splits, s, tk);
     CFP_REQUIRE(rc == 0, CFP_EHIP, "cfp_conv2d_nhwc: f16x3 kernel launch failed");

@@ -121,7 +121,8 @@ class Engine:
         self.x3 = bool(x3)
         self.cdt = hip.F32X3 if self.x3 else ops.DT[dtype]          # planning dtype (cfp_conv2d_ws_bytes)
         # ticketed split-K (CFP_CONV_WS_TICKETS: the last workgroup at a tile finishes it, no reduce launch) is bit-identical and measured EQUAL at
-        # batch 1 (3.20 vs 3.18 ms: the memory round trip + ticket it adds to the GEMM is as long as the launch it removes): off
+        # batch 1 (3.20 vs 3.18 ms: the memory round trip + ticket it adds to the GEMM is as long as the launch it removes; with the
+        # end-of-round single-image plans 2.91 vs 2.86): off
         self.tickets = self.x3 and os.environ.get("CFP_SPLITK_TICKETS", "0") == "1"
         self.zone_sample_num = zone_sample_num
         # depth head: conv3x3 -> conv_out -> softmax -> expectation as ONE kernel (csrc/head_fused.hip) in the 16-bit modes;

@@ -448,14 +448,17 @@ def test_conv2d_x3_layernorm_inside_the_split_k_reduce(Co):
             for splits in (-1, 2, 4, 8):
                 lib.cfp_debug_set(1, splits)
                 _, sp = ops.conv2d_plan(M, Co, k * k * Cin, hip.F32X3, 0, B, k, k)
-                ws = torch.empty(8 * M * Co, device=DEV)
-                out = ops.new_act(M, Co, torch.float32, DEV, ld=Co + 8, zero=True)
-                ops.conv2d(xa, wx, sc.to(DEV), sh.to(DEV), out, B, H, W, k, k, k, 0, 0, Ho, Wo, hip.ACT_NONE, to_act(res, torch.float32), ws,
-                           ln=(g.to(DEV), bt.to(DEV), 1e-5))
-                torch.cuda.synchronize()
-                assert splits > 0 or sp > 1, "the automatic plan is expected to split this problem"
-                _x3_close(out.torch().cpu(), ref, f"x3 sr conv + LayerNorm in the reduce (Cout {Co}, {B}x{H}x{W} k{k}, splits {splits})", tol=2e-5)
-                assert float(out.buf[:, Co:].abs().max()) == 0
+                # a plain workspace, and one with the ticket area in front (CFP_CONV_WS_TICKETS): the LayerNorm keeps the reduce launch, the area stays zero
+                for ws in (torch.empty(8 * M * Co, device=DEV), ops.ticket_ws(8 * M * Co * 4, DEV)):
+                    out = ops.new_act(M, Co, torch.float32, DEV, ld=Co + 8, zero=True)
+                    ops.conv2d(xa, wx, sc.to(DEV), sh.to(DEV), out, B, H, W, k, k, k, 0, 0, Ho, Wo, hip.ACT_NONE, to_act(res, torch.float32), ws,
+                               ln=(g.to(DEV), bt.to(DEV), 1e-5))
+                    torch.cuda.synchronize()
+                    assert splits > 0 or sp > 1, "the automatic plan is expected to split this problem"
+                    _x3_close(out.torch().cpu(), ref, f"x3 sr conv + LayerNorm in the reduce (Cout {Co}, {B}x{H}x{W} k{k}, splits {splits})", tol=2e-5)
+                    assert float(out.buf[:, Co:].abs().max()) == 0
+                    if getattr(ws, "cfp_tickets", False):
+                        assert int(ws[: hip.CONV_TICKET_BYTES // 4].view(torch.int32).abs().max()) == 0
         finally:
             lib.cfp_debug_set(1, -1)
 
