@@ -62,7 +62,8 @@ int cfp_conv2d_nhwc(const void* in, int in_ld, const void* w, const float* scale
  *         out = LN(act(conv * scale + shift)) * gamma + beta + residual
  *     (transformer.py:63,68-70: merge -> norm1, mlp -> norm2 -> + x).  Fused into the GEMM
  *     epilogue when a tile spans exactly Cout channels (bf16, Cout in {16,32,64,128}), otherwise
- *     run as a second kernel on `out` in place.
+ *     run as a second kernel on `out` in place.  CFP_CONV_X3 launches whose K is split run it inside
+ *     the finishing sum of the splits (Cout / 4 a power of two <= 64; round 5).
  *   - per_image_weights != 0: `w` holds B weight matrices [B][Cout][K]; image b of the batch uses
  *     matrix b.  Used for the squeeze-excite gate folded into the project conv of the encoder's
  *     inverted-residual blocks (x * gate[b,:]) @ W^T == x @ (W * gate[b,:])^T, see cfp_se_fold.
